@@ -1,0 +1,167 @@
+"""NumPy restatement of the BERT encoder forward/backward used by
+``HFBertEncoder`` / ``BiBertEncoder`` / ``Reranker``.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).
+
+Spec followed (file:line under /root/reference):
+  * embeddings: word + token_type(0) + position(0..S-1) -> LayerNorm(eps 1e-12)
+    LEAD/modeling_bert.py:181-240
+  * self-attention: QKV linears, QK^T / sqrt(d) + (1-mask)*finfo.min, softmax, PV
+    LEAD/modeling_bert.py:243-374
+  * attention output / FFN output: LN(dense(x) + residual)
+    LEAD/modeling_bert.py:377-388, 455-466
+  * intermediate: erf-GELU(dense(x))     LEAD/modeling_bert.py:440-452
+  * pooler output multiplied by 0 and [CLS] slice of last hidden returned
+    SimANS/model/models.py:77-82  (so pooler grads are exact zeros)
+Dropout is OFF (reference parity is taken in eval()-semantics with grads on,
+SURVEY 8c).  Works on the padded [n,S] layout exactly like the reference; the
+GPU product uses a packed (varlen) layout, so agreement is a real check.
+"""
+import numpy as np
+from scipy.special import erf
+
+SQRT1_2 = 0.7071067811865476
+INV_SQRT_2PI = 0.3989422804014327
+
+
+def _ln_fwd(x, g, b, eps):
+    mu = x.mean(-1, keepdims=True)
+    xc = x - mu
+    var = (xc * xc).mean(-1, keepdims=True)
+    rstd = 1.0 / np.sqrt(var + eps)
+    xhat = xc * rstd
+    return xhat * g + b, (xhat, rstd)
+
+
+def _ln_bwd(dy, cache, g):
+    xhat, rstd = cache
+    dg = (dy * xhat).reshape(-1, xhat.shape[-1]).sum(0)
+    db = dy.reshape(-1, xhat.shape[-1]).sum(0)
+    dxh = dy * g
+    dx = rstd * (dxh - dxh.mean(-1, keepdims=True) - xhat * (dxh * xhat).mean(-1, keepdims=True))
+    return dx, dg, db
+
+
+def gelu(u):
+    return 0.5 * u * (1.0 + erf(u * SQRT1_2))
+
+
+def gelu_grad(u):
+    return 0.5 * (1.0 + erf(u * SQRT1_2)) + u * np.exp(-0.5 * u * u) * INV_SQRT_2PI
+
+
+def bert_forward(P, ids, mask, heads, eps=1e-12, dtype=np.float64, keep=True, prefix=""):
+    """Returns (seq [n,S,H], cls [n,H], caches).  ``P``: HF-keyed dict."""
+    g = lambda k: np.asarray(P[prefix + k], dtype=dtype)
+    n, S = ids.shape
+    H = g("embeddings.word_embeddings.weight").shape[1]
+    d = H // heads
+    fmin = float(np.finfo(np.float32).min)
+    emb = (g("embeddings.word_embeddings.weight")[ids]
+           + g("embeddings.position_embeddings.weight")[None, :S]
+           + g("embeddings.token_type_embeddings.weight")[0][None, None])
+    x, ln0 = _ln_fwd(emb, g("embeddings.LayerNorm.weight"), g("embeddings.LayerNorm.bias"), eps)
+    bias = ((1.0 - mask.astype(dtype)) * fmin)[:, None, None, :]          # [n,1,1,S]
+    caches = {"ln0": ln0, "layers": []} if keep else None
+    L = 0
+    while (prefix + "encoder.layer.%d.attention.self.query.weight" % L) in P:
+        L += 1
+    for i in range(L):
+        p = "encoder.layer.%d." % i
+        def lin(t, name):
+            return t @ g(p + name + ".weight").T + g(p + name + ".bias")
+        q = lin(x, "attention.self.query").reshape(n, S, heads, d).transpose(0, 2, 1, 3)
+        k = lin(x, "attention.self.key").reshape(n, S, heads, d).transpose(0, 2, 1, 3)
+        v = lin(x, "attention.self.value").reshape(n, S, heads, d).transpose(0, 2, 1, 3)
+        s = (q @ k.transpose(0, 1, 3, 2)) / np.sqrt(d) + bias
+        s = s - s.max(-1, keepdims=True)
+        e = np.exp(s)
+        pr = e / e.sum(-1, keepdims=True)
+        ctx = (pr @ v).transpose(0, 2, 1, 3).reshape(n, S, H)
+        a = lin(ctx, "attention.output.dense")
+        x1, ln1 = _ln_fwd(a + x, g(p + "attention.output.LayerNorm.weight"),
+                          g(p + "attention.output.LayerNorm.bias"), eps)
+        u = lin(x1, "intermediate.dense")
+        h = gelu(u)
+        y = lin(h, "output.dense")
+        x2, ln2 = _ln_fwd(y + x1, g(p + "output.LayerNorm.weight"), g(p + "output.LayerNorm.bias"), eps)
+        if keep:
+            caches["layers"].append(dict(x=x, q=q, k=k, v=v, pr=pr, ctx=ctx, ln1=ln1, x1=x1, u=u, h=h, ln2=ln2))
+        x = x2
+    return x, x[:, 0, :].copy(), caches
+
+
+def bert_backward(P, ids, mask, heads, caches, d_cls, d_seq=None, dtype=np.float64, prefix=""):
+    """Gradients of sum(cls*d_cls) (+ sum(seq*d_seq)) w.r.t. every parameter.
+    Pad positions receive zero upstream gradient (they never reach the loss in
+    the reference either: only [CLS] is used, and real tokens do not attend to
+    pad keys)."""
+    g = lambda k: np.asarray(P[prefix + k], dtype=dtype)
+    n, S = ids.shape
+    H = g("embeddings.word_embeddings.weight").shape[1]
+    d = H // heads
+    G = {}
+    dx = np.zeros((n, S, H), dtype=dtype)
+    dx[:, 0, :] += d_cls
+    if d_seq is not None:
+        dx += d_seq
+    L = len(caches["layers"])
+    flat = lambda t: t.reshape(-1, t.shape[-1])
+
+    def lin_bwd(dy, x_in, name, p):
+        G[prefix + p + name + ".weight"] = flat(dy).T @ flat(x_in)
+        G[prefix + p + name + ".bias"] = flat(dy).sum(0)
+        return dy @ g(p + name + ".weight")
+
+    for i in reversed(range(L)):
+        p = "encoder.layer.%d." % i
+        c = caches["layers"][i]
+        dz, dg_, db_ = _ln_bwd(dx, c["ln2"], g(p + "output.LayerNorm.weight"))
+        G[prefix + p + "output.LayerNorm.weight"], G[prefix + p + "output.LayerNorm.bias"] = dg_, db_
+        dh = lin_bwd(dz, c["h"], "output.dense", p)
+        du = dh * gelu_grad(c["u"])
+        dx1 = dz + lin_bwd(du, c["x1"], "intermediate.dense", p)
+        dz1, dg_, db_ = _ln_bwd(dx1, c["ln1"], g(p + "attention.output.LayerNorm.weight"))
+        G[prefix + p + "attention.output.LayerNorm.weight"] = dg_
+        G[prefix + p + "attention.output.LayerNorm.bias"] = db_
+        dctx = lin_bwd(dz1, c["ctx"], "attention.output.dense", p)
+        dctx = dctx.reshape(n, S, heads, d).transpose(0, 2, 1, 3)
+        dpr = dctx @ c["v"].transpose(0, 1, 3, 2)
+        dv = c["pr"].transpose(0, 1, 3, 2) @ dctx
+        ds = c["pr"] * (dpr - (dpr * c["pr"]).sum(-1, keepdims=True))
+        ds = ds / np.sqrt(d)
+        dq = ds @ c["k"]
+        dk = ds.transpose(0, 1, 3, 2) @ c["q"]
+        back = lambda t: t.transpose(0, 2, 1, 3).reshape(n, S, H)
+        dxa = (lin_bwd(back(dq), c["x"], "attention.self.query", p)
+               + lin_bwd(back(dk), c["x"], "attention.self.key", p)
+               + lin_bwd(back(dv), c["x"], "attention.self.value", p))
+        dx = dz1 + dxa
+    demb, dg_, db_ = _ln_bwd(dx, caches["ln0"], g("embeddings.LayerNorm.weight"))
+    G[prefix + "embeddings.LayerNorm.weight"], G[prefix + "embeddings.LayerNorm.bias"] = dg_, db_
+    # only real tokens contribute in the product (packed layout); in the padded
+    # reference pad rows have zero upstream grad as well when only CLS is used.
+    demb = demb * mask[..., None].astype(dtype) if d_seq is None else demb
+    gw = np.zeros_like(g("embeddings.word_embeddings.weight"))
+    np.add.at(gw, ids.reshape(-1), flat(demb))
+    G[prefix + "embeddings.word_embeddings.weight"] = gw
+    gp = np.zeros_like(g("embeddings.position_embeddings.weight"))
+    gp[:S] = demb.sum(0)
+    G[prefix + "embeddings.position_embeddings.weight"] = gp
+    gt = np.zeros_like(g("embeddings.token_type_embeddings.weight"))
+    gt[0] = flat(demb).sum(0)
+    G[prefix + "embeddings.token_type_embeddings.weight"] = gt
+    G[prefix + "pooler.dense.weight"] = np.zeros_like(g("pooler.dense.weight"))
+    G[prefix + "pooler.dense.bias"] = np.zeros_like(g("pooler.dense.bias"))
+    return G
+
+
+def reranker_forward(P, ids3, mask3, heads, dtype=np.float64, keep=True):
+    """Reranker.forward (SimANS/model/models.py:647-659): [N,M,L] -> logits [N,M]."""
+    N, M, Lq = ids3.shape
+    seq, cls, caches = bert_forward(P, ids3.reshape(N * M, Lq), mask3.reshape(N * M, Lq), heads,
+                                    dtype=dtype, keep=keep, prefix="encoder.")
+    w = np.asarray(P["qa_classifier.weight"], dtype=dtype)
+    b = np.asarray(P["qa_classifier.bias"], dtype=dtype)
+    logits = (cls @ w.T + b).reshape(N, M)
+    return logits, cls, caches

@@ -1,0 +1,432 @@
+"""Generate tests/golden/* by running the IMPORTED REFERENCE in the build container.
+
+TEST INFRASTRUCTURE.  Needs /root/reference (not present on the GPU box); only
+the data files it writes travel.  Run:  python -m oracle.make_golden
+
+What is imported from the reference and driven with synthetic inputs:
+  SimANS/model/models.py        HFBertEncoder, BiBertEncoder, Reranker, BiEncoderNllLoss
+  SimANS/utils/MARCO_until_new.py  Rocketqa_v2Dataset (sampler + collate)
+  SimANS/utils/util_wiki.py        TraditionDataset   (sampler + collate)
+  PROD/ProD_KD/model/models.py  CrossBERTKDLoss, BiEncoderKDLoss
+and the literal step bodies co_training_marco_train.py:198-217 /
+co_training_wiki_train.py:198-228 (the scripts themselves are not importable:
+faiss / apex / transformers.AdamW are absent).
+
+Each golden is also asserted against the NumPy oracle here, so a drift between
+oracle and reference is caught at generation time, and again (oracle vs file)
+by tests/test_oracle_golden.py on any box.
+"""
+import importlib.util
+import json
+import os
+import random
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+from . import bert as obert
+from . import losses as oloss
+from . import sampler as osamp
+from .weights import BertCfg, TINY, make_bert_params, make_batch, normal
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _ref_models():
+    sys.path.insert(0, os.path.join(REF, "SimANS"))
+    return _load("ref_simans_models", os.path.join(REF, "SimANS/model/models.py"))
+
+
+def _hf_dir(tmp, cfg, params, tag):
+    """Write config.json + weights so that HFBertEncoder.init_encoder(args) can from_pretrained it."""
+    from transformers import BertConfig
+    d = os.path.join(tmp, tag)
+    hf = BertConfig(vocab_size=cfg.vocab, hidden_size=cfg.hidden, num_hidden_layers=cfg.layers,
+                    num_attention_heads=cfg.heads, intermediate_size=cfg.inter,
+                    max_position_embeddings=cfg.max_pos, type_vocab_size=cfg.type_vocab,
+                    layer_norm_eps=cfg.eps, hidden_act="gelu")
+    m = RM.HFBertEncoder(hf)
+    sd = {k: torch.from_numpy(np.asarray(v, dtype=np.float32)) for k, v in params.items()}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not [k for k in missing if "position_ids" not in k], missing
+    assert not unexpected, unexpected
+    m.save_pretrained(d)
+    return d
+
+
+def _no_dropout(m):
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    m.eval()
+    return m
+
+
+def _grads(model):
+    return {k: p.grad.detach().numpy().astype(np.float64) for k, p in model.named_parameters()
+            if p.grad is not None}
+
+
+def _cmp(tag, a, b, tol):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    err = np.abs(a - b).max() if a.size else 0.0
+    ref = max(1.0, np.abs(b).max()) if b.size else 1.0
+    print("   %-42s max|diff| %.3e  (scale %.3e)" % (tag, err, ref))
+    assert err <= tol * ref, (tag, err, tol * ref)
+
+
+def gen_encoder_step(tmp, cfg_kw, tag, B, N, q_len, p_len, ce_len, seeds, full_grads, tol, std=0.02):
+    """Config-1 shaped retriever step of co_training_marco_train.py / co_training_wiki_train.py."""
+    cfg = BertCfg(**cfg_kw)
+    Pq = make_bert_params(cfg, seeds[0], std=std)
+    Pc = make_bert_params(cfg, seeds[1], std=std)
+    Pt = make_bert_params(cfg, seeds[2], std=std)
+    args = types.SimpleNamespace(model_type=_hf_dir(tmp, cfg, Pq, tag + "_q"), gradient_checkpointing=False,
+                                 share_weight=False)
+    model = RM.BiBertEncoder(args)
+    # ctx tower gets its own weights
+    sd = {k: torch.from_numpy(v) for k, v in Pc.items()}
+    model.ctx_model.load_state_dict(sd, strict=False)
+    _no_dropout(model)
+    teacher = RM.Reranker(RM.HFBertEncoder.init_encoder(
+        types.SimpleNamespace(gradient_checkpointing=False), model_type=_hf_dir(tmp, cfg, Pt, tag + "_t")), cfg.hidden)
+    wcls = normal(seeds[2], "qa_classifier.weight", (1, cfg.hidden), 0.05).astype(np.float32)
+    bcls = normal(seeds[2], "qa_classifier.bias", (1,), 0.05).astype(np.float32)
+    with torch.no_grad():
+        teacher.qa_classifier.weight.copy_(torch.from_numpy(wcls))
+        teacher.qa_classifier.bias.copy_(torch.from_numpy(bcls))
+    _no_dropout(teacher)
+
+    P = B * (1 + N)
+    q_ids, q_mask, _ = make_batch(seeds[0] + 100, B, q_len, cfg.vocab, 9, 3, 4)
+    c_ids, c_mask, _ = make_batch(seeds[1] + 100, P, p_len, cfg.vocab, 80, 25, 16)
+    t_ids, t_mask, _ = make_batch(seeds[2] + 100, P, ce_len, cfg.vocab, 90, 25, 20)
+    t_ids3, t_mask3 = t_ids.reshape(B, 1 + N, ce_len), t_mask.reshape(B, 1 + N, ce_len)
+    tt = lambda a: torch.from_numpy(a)
+
+    # fp32 run of the imported reference (as shipped) -- kept for the record
+    with torch.no_grad():
+        q32, c32 = model(query_ids=tt(q_ids), attention_mask_q=tt(q_mask), input_ids_a=tt(c_ids), attention_mask_a=tt(c_mask))
+        z32 = teacher(input_ids=tt(t_ids3), attention_mask=tt(t_mask3))
+    # golden = the same imported modules in float64 (removes fp32 cancellation noise from grads)
+    model.double(); teacher.double()
+
+    # --- literal step body, co_training_marco_train.py:198-217 (L1) -----------------
+    model.zero_grad()
+    local_q, local_ctx = model(query_ids=tt(q_ids), attention_mask_q=tt(q_mask),
+                               input_ids_a=tt(c_ids), attention_mask_a=tt(c_mask))
+    ctx3 = local_ctx.reshape(local_q.size(0), local_ctx.size(0) // local_q.size(0), -1)
+    sim = torch.einsum("bh,bdh->bd", local_q, ctx3)
+    p_s = torch.nn.functional.softmax(sim, dim=1)
+    with torch.no_grad():
+        z = teacher(input_ids=tt(t_ids3), attention_mask=tt(t_mask3))
+        p_t = torch.nn.functional.softmax(z / 1.0, dim=1)
+    loss = torch.nn.KLDivLoss(reduction="batchmean")((p_s + 1e-7).log(), p_t)
+    loss.backward()
+    G = _grads(model)
+
+    out = dict(q_ids=q_ids, q_mask=q_mask, c_ids=c_ids, c_mask=c_mask, t_ids=t_ids3, t_mask=t_mask3,
+               qa_w=wcls, qa_b=bcls,
+               q_emb_fp32=q32.numpy(), ctx_emb_fp32=c32.numpy(), teacher_logits_fp32=z32.numpy(), std=np.float64(std),
+               q_emb=local_q.detach().numpy(), ctx_emb=local_ctx.detach().numpy(),
+               sim=sim.detach().numpy(), teacher_logits=z.numpy(), loss_kl=np.float64(loss.item()),
+               cfg=json.dumps(cfg.as_dict()), seeds=np.asarray(seeds), shape=np.asarray([B, N, q_len, p_len, ce_len]))
+
+    # --- oracle agreement (fp64) ------------------------------------------------------
+    print(" [%s] oracle vs imported reference" % tag)
+    _, oq, cq = obert.bert_forward(Pq, q_ids, q_mask, cfg.heads)
+    _, oc, cc = obert.bert_forward(Pc, c_ids, c_mask, cfg.heads)
+    Pt2 = {"encoder." + k: v for k, v in Pt.items()}
+    Pt2["qa_classifier.weight"], Pt2["qa_classifier.bias"] = wcls, bcls
+    oz, _, _ = obert.reranker_forward(Pt2, t_ids3, t_mask3, cfg.heads, keep=False)
+    _cmp("q_emb (vs fp32 reference)", oq, out["q_emb_fp32"], 2e-5)
+    _cmp("ctx_emb (vs fp32 reference)", oc, out["ctx_emb_fp32"], 2e-5)
+    _cmp("teacher_logits (vs fp32 reference)", oz, out["teacher_logits_fp32"], 2e-5)
+    _cmp("q_emb", oq, out["q_emb"], tol)
+    _cmp("ctx_emb", oc, out["ctx_emb"], tol)
+    _cmp("teacher_logits", oz, out["teacher_logits"], tol)
+    osim = oloss.sim_block(oq, oc)
+    _cmp("sim", osim, out["sim"], tol)
+    ol, od, ods = oloss.kl_distill(osim, oz)
+    _cmp("loss_kl", ol, out["loss_kl"], tol)
+    dq, dc = oloss.sim_block_bwd(oq, oc, ods)
+    Gq = obert.bert_backward(Pq, q_ids, q_mask, cfg.heads, cq, dq)
+    Gc = obert.bert_backward(Pc, c_ids, c_mask, cfg.heads, cc, dc)
+    worst = 0.0
+    for pre, Go in (("question_model.", Gq), ("ctx_model.", Gc)):
+        for k, g in Go.items():
+            r = G[pre + k]
+            scale = max(np.abs(r).max(), 1e-6)
+            worst = max(worst, np.abs(g - r).max() / scale)
+    print("   %-42s worst rel-to-max grad diff %.3e" % ("all %d parameter grads" % (len(Gq) + len(Gc)), worst))
+    assert worst < 1e3 * tol, worst
+
+    # --- NQ/TQ loss on the same embeddings, co_training_wiki_train.py:198-228 (L2) ----
+    for lam in (0.0, 0.5):
+        model.zero_grad()
+        lq, lc = model(query_ids=tt(q_ids), attention_mask_q=tt(q_mask), input_ids_a=tt(c_ids), attention_mask_a=tt(c_mask))
+        rs = torch.einsum("bh,bdh->bd", lq, lc.reshape(lq.size(0), lc.size(0) // lq.size(0), -1))
+        rp = torch.nn.functional.softmax(rs, dim=1)
+        with torch.no_grad():
+            probs = torch.nn.functional.softmax(z / 1.0, dim=1)
+            pos = z[:, :1]
+            reward_logits = torch.stack((pos.expand(z.size()), z), -1)
+            reward = torch.log(torch.nn.functional.softmax(reward_logits, dim=2)[:, :, 0] + 1e-7)
+        normal_loss = (-probs * torch.log(rp + 1e-7)).sum() / rp.size(0)
+        adv_loss = (reward * torch.log(rp + 1e-7)).sum()
+        l2 = lam * adv_loss + (1 - lam) * normal_loss
+        out["loss_wiki_lam%g" % lam] = np.float64(l2.item())
+        o2, _, _, _ = oloss.wiki_normal_adv(osim, oz, 1.0, lam)
+        _cmp("loss_wiki lam=%g" % lam, o2, l2.item(), tol)
+
+    # --- gradients kept in the fixture ---------------------------------------------------
+    if full_grads:
+        for k, g in G.items():
+            out["grad." + k] = g
+    else:
+        # BERT-base: norms of every grad + a few slices
+        names = sorted(G.keys())
+        out["grad_names"] = np.asarray(names)
+        out["grad_norms"] = np.asarray([np.sqrt((G[k] ** 2).sum()) for k in names])
+        for k in ("question_model.encoder.layer.0.attention.self.query.weight",
+                  "ctx_model.encoder.layer.11.output.dense.weight",
+                  "ctx_model.encoder.layer.5.intermediate.dense.weight"):
+            out["gslice." + k] = G[k][:8, :64]
+        for k in ("ctx_model.embeddings.LayerNorm.weight", "question_model.encoder.layer.11.output.LayerNorm.bias",
+                  "ctx_model.encoder.layer.3.attention.self.key.bias"):
+            out["gslice." + k] = G[k]
+    np.savez_compressed(os.path.join(OUT, "step_%s.npz" % tag), **out)
+
+
+def gen_losses():
+    """Loss classes driven on random [B,1+N] / [Q,C] tensors with torch autograd."""
+    PR = _load("ref_prod_models", os.path.join(REF, "PROD/ProD_KD/model/models.py"))
+    rs = np.random.RandomState(7)
+    out = {}
+    B, D, H = 6, 16, 32
+    s = rs.randn(B, D) * 3.0
+    z = rs.randn(B, D) * 2.0
+    sf = rs.randn(B, D) * 3.0
+    out.update(s=s, z=z, s_frozen=sf)
+    T = torch.tensor
+
+    def run(fn, *xs):
+        ts = [T(x, dtype=torch.float64, requires_grad=True) for x in xs]
+        l = fn(*ts)
+        l.backward()
+        return l.item(), [t.grad.numpy() for t in ts]
+
+    # L1 (with and without scale_simmila, temperature_distill 1 and 2, grad_accum 2)
+    for tag, temp, scale, ga in (("a", 1.0, 1.0, 1), ("b", 2.0, 1.0 / np.sqrt(768.0), 2)):
+        def f(st):
+            p = torch.nn.functional.softmax(st * scale, dim=1)
+            pt = torch.nn.functional.softmax(T(z) / temp, dim=1)
+            return torch.nn.KLDivLoss(reduction="batchmean")((p + 1e-7).log(), pt) / ga
+        l, (g,) = run(f, s)
+        out["L1%s_loss" % tag], out["L1%s_ds" % tag] = l, g
+        ol, _, ods = oloss.kl_distill(s, z, temp, scale, ga)
+        _cmp("L1%s loss" % tag, ol, l, 1e-12); _cmp("L1%s ds" % tag, ods, g, 1e-12)
+    # L3 CrossBERTKDLoss (KD_softmax), without and with LwF
+    a = types.SimpleNamespace(KD_type="KD_softmax", TEMPERATURE=4.0, CE_WEIGHT=0.1, KD_WEIGHT=0.9, LwF_WEIGHT=1.0)
+    q = rs.randn(B, H); c = rs.randn(B * D, H); qo = rs.randn(B, H); co = rs.randn(B * D, H)
+    out.update(q=q, c=c, qo=qo, co=co)
+    import warnings
+    warnings.simplefilter("ignore")
+    for lwf in (False, True):
+        def f(qt, ct):
+            l, corr = PR.CrossBERTKDLoss().calc(a, qt, ct, T(z), LwF=lwf, ori_q_vector=T(qo), ori_ctx_vectors=T(co))
+            f.corr = int(corr)
+            return l
+        l, (gq, gc) = run(f, q, c)
+        key = "L3lwf" if lwf else "L3"
+        out[key + "_loss"], out[key + "_dq"], out[key + "_dc"], out[key + "_correct"] = l, gq, gc, f.corr
+        sim = oloss.sim_block(q, c)
+        ol, _, _, corr, ods = oloss.cross_kd(sim, z, 4.0, 0.1, 0.9, oloss.sim_block(qo, co) if lwf else None, 1.0)
+        odq, odc = oloss.sim_block_bwd(q, c, ods)
+        _cmp(key + " loss", ol, l, 1e-12); _cmp(key + " dq", odq, gq, 1e-12); _cmp(key + " dc", odc, gc, 1e-12)
+        assert corr == f.corr
+    # M2 BiEncoderNllLoss (SimANS copy)
+    Q, C = 5, 20
+    q2 = rs.randn(Q, H); c2 = rs.randn(C, H); pos = [0, 4, 8, 12, 16]
+    out.update(q2=q2, c2=c2, pos=np.asarray(pos))
+    def f(qt, ct):
+        l, corr = RM.BiEncoderNllLoss().calc(qt, ct, pos)
+        f.corr = int(corr)
+        return l
+    l, (gq, gc) = run(f, q2, c2)
+    out.update(M2_loss=l, M2_dq=gq, M2_dc=gc, M2_correct=f.corr)
+    ol, corr, odq, odc, _ = oloss.nll_inbatch(q2, c2, pos)
+    _cmp("M2 loss", ol, l, 1e-12); _cmp("M2 dq", odq, gq, 1e-12); _cmp("M2 dc", odc, gc, 1e-12)
+    assert corr == f.corr
+    # L4 BiEncoderKDLoss
+    qT = rs.randn(Q, H); cT = rs.randn(C, H)
+    out.update(qT=qT, cT=cT)
+    def f(qt, ct):
+        l, corr = PR.BiEncoderKDLoss().calc(a, qt, ct, T(qT), T(cT), pos)
+        f.corr = int(corr)
+        return l
+    l, (gq, gc) = run(f, q2, c2)
+    out.update(L4_loss=l, L4_dq=gq, L4_dc=gc, L4_correct=f.corr)
+    ol, _, _, corr, odq, odc = oloss.bi_kd(q2, c2, qT, cT, pos, 4.0, 0.1, 0.9)
+    _cmp("L4 loss", ol, l, 1e-12); _cmp("L4 dq", odq, gq, 1e-12); _cmp("L4 dc", odc, gc, 1e-12)
+    # L6 teacher CE
+    def f(zt):
+        return torch.nn.CrossEntropyLoss()(zt, torch.zeros(B, dtype=torch.long))
+    l, (g,) = run(f, z)
+    out.update(L6_loss=l, L6_dz=g)
+    ol, odz = oloss.teacher_ce(z)
+    _cmp("L6 loss", ol, l, 1e-12); _cmp("L6 dz", odz, g, 1e-12)
+    # distributed gather semantics (train_DE_model_marco.py:224-278), simulated W=2 in-process
+    W, Bq, Np = 2, 3, 4
+    qr = [rs.randn(Bq, H) for _ in range(W)]
+    cr = [rs.randn(Bq * Np, H) for _ in range(W)]
+    for r in range(W):
+        lq = T(qr[r], dtype=torch.float64, requires_grad=True)
+        lc = T(cr[r], dtype=torch.float64, requires_grad=True)
+        gq_, gc_, posi, tot = [], [], [], 0
+        for i in range(W):
+            if i != r:
+                gq_.append(T(qr[i])); gc_.append(T(cr[i]))
+            else:
+                gq_.append(lq); gc_.append(lc)
+            posi += [v + tot for v in [j * Np for j in range(Bq)]]
+            tot += cr[i].shape[0]
+        l, corr = RM.BiEncoderNllLoss().calc(torch.cat(gq_, 0), torch.cat(gc_, 0), posi)
+        l.backward()
+        out["dist_q%d" % r], out["dist_c%d" % r] = qr[r], cr[r]
+        out["dist_loss%d" % r], out["dist_dq%d" % r], out["dist_dc%d" % r] = l.item(), lq.grad.numpy(), lc.grad.numpy()
+        ol, _, odq, odc = oloss.nll_inbatch_distributed(qr, cr, r)
+        _cmp("dist loss r%d" % r, ol, l.item(), 1e-12); _cmp("dist dq r%d" % r, odq, lq.grad.numpy(), 1e-12)
+        _cmp("dist dc r%d" % r, odc, lc.grad.numpy(), 1e-12)
+    np.savez_compressed(os.path.join(OUT, "losses.npz"), **out)
+
+
+class _StubTok:
+    """Minimal tokenizer: passage text is its pid as a decimal string; encodes to [101, 1000+pid, 102]."""
+    sep_token_id, pad_token_id = 102, 0
+
+    def encode(self, text, text_pair=None, add_special_tokens=True, max_length=None, truncation=True,
+               pad_to_max_length=False):
+        body = text_pair if text_pair is not None else text
+        try:
+            v = 1000 + int(str(body).strip())
+        except ValueError:
+            v = 999
+        return [101, v, 102] if add_special_tokens else [v]
+
+
+def gen_sampler(tmp):
+    MU = _load("ref_marco_until_new", os.path.join(REF, "SimANS/utils/MARCO_until_new.py"))
+    rs = np.random.RandomState(11)
+    n_q, C, N = 12, 40, 15
+    para = os.path.join(tmp, "corpus")
+    os.makedirs(para, exist_ok=True)
+    with open(os.path.join(para, "para.txt"), "w") as f, open(os.path.join(para, "para.title.txt"), "w") as g:
+        for pid in range(5000):
+            f.write("%d\t%d\n" % (pid, pid)); g.write("%d\t-\n" % pid)
+    rows, meta = [], []
+    for qi in range(n_q):
+        s_pos = float(np.round(70 + 20 * rs.rand(), 4))
+        if qi == 3:
+            s_pos = 0.0                       # positive not retrieved -> fallback branch
+        pids = rs.choice(np.arange(1, 5000), size=C + 1, replace=False)
+        scores = np.sort(np.round((s_pos if s_pos else 80.0) - np.abs(rs.randn(C)) * 1.5, 4))[::-1]
+        pos = "%d %s" % (pids[0], repr(s_pos))
+        neg = ",".join("%d %s" % (p, repr(float(s))) for p, s in zip(pids[1:], scores))
+        rows.append("%d\tq%d\t%s\t%s" % (qi, qi, pos, neg))
+        meta.append(dict(s_pos=s_pos, cand=[int(p) for p in pids[1:]], scores=[float(s) for s in scores]))
+    tsv = os.path.join(tmp, "train.tsv")
+    with open(tsv, "w") as f:
+        f.write("\n".join(rows) + "\n")
+    ds = MU.Rocketqa_v2Dataset(tsv, _StubTok(), num_hard_negatives=N, corpus_path=para)
+    random.seed(1234)
+    picked = []
+    for i in range(n_q):
+        qtok, ctx, ce = ds[i]
+        picked.append([int(v) - 1000 for v in ctx[1:, 1].tolist()])
+    # oracle literal replay with the same seed
+    random.seed(1234)
+    for i in range(n_q):
+        m = meta[i]
+        random.choice([0])                                     # the reference's random.choice(pos_pairs_list)
+        _, negs = osamp.reference_draw(random, m["cand"], m["scores"], m["s_pos"], N, osamp.LAPLACE, tau=3.0)
+        assert negs == picked[i], (i, negs, picked[i])
+        w = osamp.weights(m["scores"], m["s_pos"], osamp.LAPLACE, tau=3.0)
+        m["weights_laplace"] = w
+        m["weights_gauss_nq"] = osamp.weights(m["scores"], m["s_pos"], osamp.GAUSS, a=0.5, b=1.0)
+        m["picked"] = picked[i]
+    print(" [sampler] literal replay == imported Rocketqa_v2Dataset for %d queries (seed 1234)" % n_q)
+    # collate shape check of the reference
+    coll = MU.Rocketqa_v2Dataset.get_collate_fn(None)
+    random.seed(5)
+    batch = coll([ds[i] for i in range(4)])
+    shapes = dict(q=list(batch["student"][0].shape), ctx=list(batch["student"][2].shape),
+                  ce=list(batch["teacher"][0].shape), pos=batch["student"][4])
+    # TraditionDataset (NQ/TQ gaussian form)
+    UW = _load("ref_util_wiki", os.path.join(REF, "SimANS/utils/util_wiki.py"))
+    data = []
+    for qi in range(6):
+        m = meta[qi]
+        sp = m["s_pos"] if m["s_pos"] else 75.0
+        data.append(dict(question="q %d" % qi, answers=["a"],
+                         positive_ctxs=[dict(text="%d" % (9000 + qi), title="-", score=sp, passage_id=9000 + qi)],
+                         hard_negative_ctxs=[dict(text="%d" % p, title="-", score=s, passage_id=p)
+                                             for p, s in zip(m["cand"], m["scores"])]))
+    js = os.path.join(tmp, "nq.json")
+    with open(js, "w") as f:
+        json.dump(data, f)
+    td = UW.TraditionDataset(js, _StubTok(), num_hard_negatives=N, a=0.5, b=1.0)
+    random.seed(77)
+    wiki_picked = []
+    for i in range(6):
+        _, ctx_tok, _, _, _ = td[i]
+        wiki_picked.append([t[1] - 1000 for t in ctx_tok[1:]])
+    # literal replay
+    random.seed(77)
+    for i in range(6):
+        m = meta[i]
+        sp = m["s_pos"] if m["s_pos"] else 75.0
+        order = list(range(len(m["cand"])))
+        random.shuffle(order)
+        cand = [m["cand"][j] for j in order]
+        sc = [m["scores"][j] for j in order]
+        union, _ = osamp.reference_draw(random, cand, sc, sp, N, osamp.GAUSS, a=0.5, b=1.0)
+        sel = [c for c in cand if c in union][0:N]
+        assert sel == wiki_picked[i], (i, sel, wiki_picked[i])
+    print(" [sampler] literal replay == imported TraditionDataset for 6 queries (seed 77)")
+    with open(os.path.join(OUT, "sampler_ref.json"), "w") as f:
+        json.dump(dict(N=N, tau=3.0, queries=meta, collate_shapes=shapes, wiki_picked=wiki_picked,
+                       wiki_seed=77, marco_seed=1234), f)
+
+
+def main():
+    global RM
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    RM = _ref_models()
+    with tempfile.TemporaryDirectory() as tmp:
+        gen_losses()
+        gen_sampler(tmp)
+        gen_encoder_step(tmp, TINY, "tiny", B=4, N=3, q_len=32, p_len=128, ce_len=160,
+                         seeds=(1234, 1235, 1236), full_grads=True, tol=1e-11, std=0.08)
+        if "--no-base" not in sys.argv:
+            gen_encoder_step(tmp, {}, "base_cfg1", B=4, N=1, q_len=32, p_len=128, ce_len=160,
+                             seeds=(1234, 1235, 1236), full_grads=False, tol=1e-10)
+    print("golden vectors written to", OUT)
+
+
+if __name__ == "__main__":
+    main()

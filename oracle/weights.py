@@ -1,0 +1,131 @@
+"""Framework-independent seeded weight / batch generator (oracle side).
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  The product has its own copy of
+the same integer recipe in ``simxns_amd/utils/synth.py``; the two are checked
+against each other in tests/test_synth.py so fixtures never depend on a
+torch / numpy RNG stream.
+
+Recipe: splitmix64(counter) -> two 53-bit uniforms -> Box-Muller normal.
+Init distribution follows the reference's ``init_weights``
+(SimANS/model/models.py:452-465: Linear/Embedding ~ N(0, 0.02), LayerNorm
+gamma=1 beta=0, biases 0), which is also HF BertModel's.
+"""
+import numpy as np
+
+_M = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x):
+    x = x.astype(np.uint64)
+    with np.errstate(over="ignore"):
+        z = x + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def _fnv1a64(name):
+    h = 0xCBF29CE484222325
+    for ch in name.encode("utf8"):
+        h ^= ch
+        h = (h * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def uniform01(seed, name, n):
+    """n doubles in [0,1), stream keyed by (seed, name)."""
+    base = (_fnv1a64(name) ^ ((seed * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)) & 0xFFFFFFFFFFFFFFFF
+    with np.errstate(over="ignore"):
+        ctr = np.arange(n, dtype=np.uint64) + np.uint64(base)
+    h = _splitmix64(ctr)
+    return (h >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def normal(seed, name, shape, std=1.0):
+    n = int(np.prod(shape))
+    u1 = 1.0 - uniform01(seed, name + "#a", n)          # (0,1]
+    u2 = uniform01(seed, name + "#b", n)
+    z = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+    return (z * std).reshape(shape)
+
+
+def randint(seed, name, lo, hi, shape):
+    """integers in [lo, hi)"""
+    n = int(np.prod(shape))
+    u = uniform01(seed, name, n)
+    return (lo + np.floor(u * (hi - lo))).astype(np.int64).reshape(shape)
+
+
+class BertCfg:
+    def __init__(self, vocab=30522, hidden=768, layers=12, heads=12, inter=3072,
+                 max_pos=512, type_vocab=2, eps=1e-12):
+        self.vocab, self.hidden, self.layers, self.heads = vocab, hidden, layers, heads
+        self.inter, self.max_pos, self.type_vocab, self.eps = inter, max_pos, type_vocab, eps
+
+    def as_dict(self):
+        return dict(vocab=self.vocab, hidden=self.hidden, layers=self.layers, heads=self.heads,
+                    inter=self.inter, max_pos=self.max_pos, type_vocab=self.type_vocab, eps=self.eps)
+
+
+TINY = dict(vocab=1000, hidden=64, layers=2, heads=4, inter=128, max_pos=192)
+BASE = dict()
+
+
+def bert_param_shapes(cfg):
+    """HF BertModel state_dict key schema, in registration order."""
+    H, F = cfg.hidden, cfg.inter
+    out = [("embeddings.word_embeddings.weight", (cfg.vocab, H)),
+           ("embeddings.position_embeddings.weight", (cfg.max_pos, H)),
+           ("embeddings.token_type_embeddings.weight", (cfg.type_vocab, H)),
+           ("embeddings.LayerNorm.weight", (H,)),
+           ("embeddings.LayerNorm.bias", (H,))]
+    for i in range(cfg.layers):
+        p = "encoder.layer.%d." % i
+        out += [(p + "attention.self.query.weight", (H, H)), (p + "attention.self.query.bias", (H,)),
+                (p + "attention.self.key.weight", (H, H)), (p + "attention.self.key.bias", (H,)),
+                (p + "attention.self.value.weight", (H, H)), (p + "attention.self.value.bias", (H,)),
+                (p + "attention.output.dense.weight", (H, H)), (p + "attention.output.dense.bias", (H,)),
+                (p + "attention.output.LayerNorm.weight", (H,)), (p + "attention.output.LayerNorm.bias", (H,)),
+                (p + "intermediate.dense.weight", (F, H)), (p + "intermediate.dense.bias", (F,)),
+                (p + "output.dense.weight", (H, F)), (p + "output.dense.bias", (H,)),
+                (p + "output.LayerNorm.weight", (H,)), (p + "output.LayerNorm.bias", (H,))]
+    out += [("pooler.dense.weight", (H, H)), ("pooler.dense.bias", (H,))]
+    return out
+
+
+def make_bert_params(cfg, seed, dtype=np.float32, perturb=True, std=0.02):
+    """Seeded parameters.  With ``perturb`` the LayerNorm gains / all biases get
+    small non-trivial values (N(1,0.05) / N(0,0.02)) so that parity tests
+    exercise gamma/beta/bias paths; perturb=False is the exact HF init.  ``std`` is the
+    Linear/Embedding init scale (0.02 = HF; the tiny fixtures use 0.08 so that [CLS]
+    vectors of different inputs differ enough for well-conditioned gradients)."""
+    params = {}
+    for name, shape in bert_param_shapes(cfg):
+        if name.endswith("LayerNorm.weight"):
+            w = 1.0 + (normal(seed, name, shape, 0.05) if perturb else 0.0) * np.ones(shape)
+        elif name.endswith(".bias"):
+            w = normal(seed, name, shape, 0.02) if perturb else np.zeros(shape)
+        else:
+            w = normal(seed, name, shape, std)
+        params[name] = np.ascontiguousarray(w, dtype=dtype)
+    return params
+
+
+def make_batch(seed, n, S, vocab, len_mean, len_std, len_min, full=False):
+    """Synthetic token batch per SURVEY 8d: ids ~ U{lo..vocab-1}, [CLS]=101 first,
+    [SEP]=102 last real token, pad=0, right padded.  Returns (ids[n,S] int64,
+    mask[n,S] int64, lens[n])."""
+    lo = 1000 if vocab > 2000 else 110
+    ids = randint(seed, "ids", lo, vocab, (n, S))
+    if full:
+        lens = np.full((n,), S, dtype=np.int64)
+    else:
+        z = normal(seed, "lens", (n,), 1.0)
+        lens = np.clip(np.rint(len_mean + len_std * z), len_min, S).astype(np.int64)
+    pos = np.arange(S)[None, :]
+    mask = (pos < lens[:, None]).astype(np.int64)
+    ids = ids * mask
+    ids[:, 0] = 101
+    ids[np.arange(n), lens - 1] = 102
+    return ids, mask, lens

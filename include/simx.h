@@ -1,0 +1,211 @@
+/*
+ * simx.h -- C ABI of libsimx_hip.so, the MI355X (gfx950) engine behind the
+ * SimANS/co_training bi-encoder hot path.
+ *
+ * The reference (microsoft/SimXNS) has no FFI layer: its boundary is the Python
+ * module API (SimANS/model/models.py, utils/dpr_utils.py).  This header is the
+ * C-level boundary a maintainer binds instead (ctypes stub: simxns_amd/_lib.py;
+ * see INTEGRATION.md).  Each entry point names the reference lines it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch allocator),
+ *     unless the name ends in _host;
+ *   - no allocation and no stream synchronisation inside; scratch memory is passed
+ *     in (size from the matching *_bytes query);
+ *   - `stream` is a hipStream_t;
+ *   - return value: SIMX_OK (0) or a negative SIMX_ERR_*; simx_last_error() gives
+ *     the thread-local message;
+ *   - dtype selects the activation / GEMM-operand type: SIMX_F32 (parity mode, exact
+ *     f32 arithmetic) or SIMX_BF16 (bf16 operands, f32 accumulate, f32 statistics).
+ *     Parameters, gradients, LayerNorm statistics, embeddings handed to the loss and
+ *     all loss arithmetic are f32 in both modes.
+ *   - packed ("varlen") token layout: the T real tokens of nseq sequences are
+ *     stored back to back; cu_seqlens[nseq+1] holds the prefix sums (int32).
+ */
+#ifndef SIMX_H
+#define SIMX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* simx_stream_t;
+
+enum { SIMX_OK = 0, SIMX_ERR_BAD_SHAPE = -1, SIMX_ERR_BAD_DTYPE = -2, SIMX_ERR_WORKSPACE = -3,
+       SIMX_ERR_HIP = -4, SIMX_ERR_UNSUPPORTED = -5 };
+enum { SIMX_F32 = 0, SIMX_BF16 = 1 };
+
+int simx_version(void);
+const char* simx_last_error(void);
+
+/* ------------------------------------------------------------------ GEMMs
+ * The dense layers of BertSelfAttention / BertSelfOutput / BertIntermediate /
+ * BertOutput (LEAD/modeling_bert.py:285-310, 385, 450, 463) and their backward. */
+enum { SIMX_EPI_NONE = 0,   /* C = acc (+bias) (+residual)                              */
+       SIMX_EPI_GELU = 1,   /* C = acc + bias (pre-activation), C2 = gelu_erf(C)        */
+       SIMX_EPI_DGELU = 2   /* C = (acc (+residual)) * gelu_erf'(aux)                   */ };
+
+/* C[M,N] = A[M,K] . B[N,K]^T  (both operands K-contiguous; nn.Linear: B = weight [out,in]).
+ * bias: f32 [N] or NULL; residual/aux/C/C2: same dtype as A, row strides in elements. */
+int simx_gemm_nt(simx_stream_t stream, int dtype, int M, int N, int K,
+                 const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                 const float* bias, const void* residual, int ldr, int epilogue,
+                 const void* aux, int ldaux, void* C2, int ldc2);
+
+/* C[M,N] (f32) (+)= A[K,M]^T . B[K,N]   (weight gradient: A = dY [T,out], B = X [T,in]).
+ * Split over K into f32 slabs in `ws`, reduced deterministically. */
+size_t simx_gemm_tn_workspace_bytes(int M, int N, int K);
+int simx_gemm_tn(simx_stream_t stream, int dtype, int M, int N, int K,
+                 const void* A, int lda, const void* B, int ldb, float* C, int ldc,
+                 int accumulate, void* ws, size_t ws_bytes);
+
+/* out[N] (f32) (+)= column sums of x[T,N]  (bias gradients). */
+int simx_colsum(simx_stream_t stream, int dtype, int T, int N, const void* x, int ldx,
+                float* out, int accumulate);
+
+/* f32 master weight [rows,cols] -> bf16 copy and (optional) bf16 transposed copy [cols,rows]. */
+int simx_cast_weight(simx_stream_t stream, const float* w, int rows, int cols, void* w_bf16, void* wT_bf16);
+/* same with a selectable output dtype (either output may be NULL). */
+int simx_transpose_cast(simx_stream_t stream, int out_dtype, const float* w, int rows, int cols, void* out, void* outT);
+/* plain f32 GEMM with arbitrary element strides: C[m,n] (+)= sum_k A[m*a_rs + k*a_cs] * B[k*b_ks + n*b_ns]
+ * (k-ordered f32 FMA chain; the all-pairs score matrix of M2 and its two backward products). */
+int simx_gemm_f32_strided(simx_stream_t stream, int M, int N, int K, const float* A, long a_rs, long a_cs,
+                          const float* B, long b_ks, long b_ns, float* C, int ldc, int accumulate);
+
+/* --------------------------------------------------------- embeddings + LayerNorm
+ * BertEmbeddings (LEAD/modeling_bert.py:181-240): LN(word[ids] + pos[pos_ids] + type[0]). */
+int simx_embed_ln_fwd(simx_stream_t stream, int dtype, int T, int H,
+                      const int32_t* ids, const int32_t* pos_ids,
+                      const float* word, const float* posw, const float* typew,
+                      const float* gamma, const float* beta, float eps, void* out);
+/* accumulates into dword/dpos/dtype0/dgamma/dbeta (f32, atomics). */
+int simx_embed_ln_bwd(simx_stream_t stream, int dtype, int T, int H,
+                      const int32_t* ids, const int32_t* pos_ids,
+                      const float* word, const float* posw, const float* typew,
+                      const float* gamma, float eps, const void* dy,
+                      float* dword, float* dpos, float* dtype0, float* dgamma, float* dbeta);
+
+/* y = LN(z) ; z already holds dense(x)+bias+residual (BertSelfOutput / BertOutput,
+ * LEAD/modeling_bert.py:384-388, 462-466). */
+int simx_ln_fwd(simx_stream_t stream, int dtype, int T, int H, const void* z,
+                const float* gamma, const float* beta, float eps, void* y);
+/* dz = LN'(z) . dy ; dgamma/dbeta/dbias (colsum of dz, may be NULL) accumulate (f32 atomics). */
+int simx_ln_bwd(simx_stream_t stream, int dtype, int T, int H, const void* z,
+                const float* gamma, float eps, const void* dy, void* dz,
+                float* dgamma, float* dbeta, float* dbias);
+
+/* ------------------------------------------------------------ self-attention
+ * BertSelfAttention core (LEAD/modeling_bert.py:318-374): softmax(QK^T/sqrt(d)) V per head,
+ * keys restricted to the sequence's own real tokens (== the additive finfo.min mask).
+ * qkv [T,3H] rows = [q | k | v]; ctx [T,H]; lse [heads,T] f32 (log-sum-exp of scaled scores). */
+int simx_mha_fwd(simx_stream_t stream, int dtype, int nseq, int heads, int head_dim,
+                 const int32_t* cu_seqlens, int max_len, int T,
+                 const void* qkv, void* ctx, float* lse);
+int simx_mha_bwd(simx_stream_t stream, int dtype, int nseq, int heads, int head_dim,
+                 const int32_t* cu_seqlens, int max_len, int T,
+                 const void* qkv, const void* ctx, const float* lse, const void* dctx, void* dqkv);
+
+/* [CLS] slice sequence_output[:,0,:] (SimANS/model/models.py:81) -> f32 [nseq,H], and its adjoint
+ * (writes dcls into the first row of each sequence of dx, zero elsewhere). */
+int simx_cls_gather(simx_stream_t stream, int dtype, int nseq, int H, const int32_t* cu_seqlens,
+                    const void* x, float* cls);
+int simx_cls_scatter(simx_stream_t stream, int dtype, int nseq, int H, int T, const int32_t* cu_seqlens,
+                     const float* dcls, void* dx);
+
+/* ------------------------------------------------- whole-encoder driver (native runtime)
+ * HFBertEncoder.forward (SimANS/model/models.py:77-82 -> HF BertModel.forward, spec
+ * LEAD/modeling_bert.py:916-1038) and its backward, sequenced in C++ over the kernels above.
+ * Parameters live in ONE f32 buffer in the canonical layout described by
+ * simx_bert_param_offset(); gradients in a buffer of the same layout (accumulated). */
+typedef struct simx_bert_cfg {
+  int32_t dtype, layers, hidden, heads, inter, vocab, max_pos, type_vocab;
+  float eps;
+} simx_bert_cfg;
+
+enum { SIMX_P_WORD = 0, SIMX_P_POS, SIMX_P_TYPE, SIMX_P_EMB_LN_G, SIMX_P_EMB_LN_B,   /* layer = -1 */
+       SIMX_P_WQKV, SIMX_P_BQKV, SIMX_P_WO, SIMX_P_BO, SIMX_P_LN1_G, SIMX_P_LN1_B,
+       SIMX_P_W1, SIMX_P_B1, SIMX_P_W2, SIMX_P_B2, SIMX_P_LN2_G, SIMX_P_LN2_B,        /* layer = 0..L-1 */
+       SIMX_P_POOL_W, SIMX_P_POOL_B,                                                   /* layer = L */
+       SIMX_P_END };
+size_t simx_bert_param_count(const simx_bert_cfg* cfg);
+/* element offset of tensor `which` of `layer` inside the flat buffer; (size_t)-1 on bad input */
+size_t simx_bert_param_offset(const simx_bert_cfg* cfg, int layer, int which);
+size_t simx_bert_wcache_bytes(const simx_bert_cfg* cfg);               /* bf16 weight + transposed copies */
+size_t simx_bert_act_bytes(const simx_bert_cfg* cfg, int T, int nseq, int save_for_bwd);
+size_t simx_bert_bwd_scratch_bytes(const simx_bert_cfg* cfg, int T, int nseq);
+int simx_bert_cast_weights(simx_stream_t stream, const simx_bert_cfg* cfg, const float* params, void* wcache);
+/* cls_out f32 [nseq,hidden]; hidden_out (may be NULL) receives the packed last hidden state [T,hidden]
+ * in the activation dtype. */
+int simx_bert_fwd(simx_stream_t stream, const simx_bert_cfg* cfg, const float* params, const void* wcache,
+                  const int32_t* ids, const int32_t* pos_ids, const int32_t* cu_seqlens,
+                  int nseq, int T, int max_len, void* act, size_t act_bytes, int save_for_bwd,
+                  float* cls_out, void* hidden_out);
+int simx_bert_bwd(simx_stream_t stream, const simx_bert_cfg* cfg, const float* params, const void* wcache,
+                  const int32_t* ids, const int32_t* pos_ids, const int32_t* cu_seqlens,
+                  int nseq, int T, int max_len, const void* act, size_t act_bytes,
+                  const float* dcls, float* grads, void* scratch, size_t scratch_bytes);
+
+/* -------------------------------------------------- similarity + losses (f32)
+ * M1 local similarity einsum("bh,bdh->bd") (co_training_marco_train.py:199-202) fused with the
+ * step loss and its closed-form backward:
+ *   SIMX_LOSS_KL    L1  KLDiv(batchmean)(log(softmax(s*scale)+1e-7), softmax(z/temp))  co_training_marco_train.py:203-217
+ *   SIMX_LOSS_WIKI  L2  adv_lambda*adv + (1-adv_lambda)*normal                            co_training_wiki_train.py:203-228
+ *   SIMX_LOSS_CEKD  L3  ce_w*NLL(target 0) + kd_w*T^2*KL(softmax(z/T)||softmax(s/T))    PROD/ProD_KD/model/models.py:668-781
+ *   SIMX_LOSS_CE    L6  CrossEntropy(target 0) on s itself                                co_training_marco_train.py:228-236
+ * q [B,H], ctx [B*D,H], teacher [B,D] (ignored for CE) ; outputs: sim [B,D], losses[4] =
+ * {loss, aux0, aux1, correct_count}, dq [B,H], dctx [B*D,H] (gradients already divided by grad_accum).
+ * If q == NULL the D logits are read from `sim` directly (no similarity, dctx receives ds [B,D]). */
+enum { SIMX_LOSS_KL = 0, SIMX_LOSS_WIKI = 1, SIMX_LOSS_CEKD = 2, SIMX_LOSS_CE = 3 };
+typedef struct simx_loss_params {
+  int32_t kind;
+  float scale;          /* 1 or 1/sqrt(H) (--scale_simmila) */
+  float temperature;    /* temperature_distill / temperature_normal / TEMPERATURE */
+  float adv_lambda;     /* L2 */
+  float ce_w, kd_w;     /* L3 */
+  float grad_accum;     /* loss and grads divided by this */
+} simx_loss_params;
+int simx_sim_loss_fwd_bwd(simx_stream_t stream, int B, int D, int H,
+                          const float* q, const float* ctx, const float* teacher,
+                          const simx_loss_params* lp_host, float* sim, float* losses,
+                          float* dq, float* dctx);
+
+/* M2: dot_product_scores + BiEncoderNllLoss.calc (SimANS/model/models.py:468-505, 564-572) with the
+ * multi-GPU semantics of caculate_cont_loss (PROD/ProD_base/train_DE_model_marco.py:224-278):
+ * q [Q,H], ctx [C,H] are the rank-ordered global concatenations; gradients are produced only for
+ * rows [q_lo,q_lo+q_n) of q and [c_lo,c_lo+c_n) of ctx (the local slots).  scores [Q,C] f32 scratch.
+ * losses[4] = {loss, 0, 0, correct_count}; loss_scale multiplies loss and grads (1 = none). */
+int simx_scores_nll_fwd_bwd(simx_stream_t stream, int Q, int C, int H,
+                            const float* q, const float* ctx, const int32_t* pos_idx,
+                            float loss_scale, int q_lo, int q_n, int c_lo, int c_n,
+                            float* scores, float* row_stats, float* losses, float* dq_local, float* dctx_local);
+
+/* -------------------------------------------------------------- SimANS sampler
+ * S1+S2 (SimANS/utils/MARCO_until_new.py:174-202, util_wiki.py:609-639, MARCO_until_Doc.py:110-148).
+ * scores [nq,C] f64 candidate scores (rank order), pos_score [nq] f64.  form 0: exp(-|s-s+|*tau);
+ * form 1: exp(-(s-s+ +b)^2*a).  pos_score == 0 -> last N candidates.  One wavefront per query,
+ * rounds of N with-replacement inverse-CDF draws (Philox4x32-10 keyed by seed, counter
+ * (query, round, draw/2, offset)), dedupe, zero the chosen weights, repeat until >= N.
+ * neg_idx [nq,N] candidate indices (draw order), union_idx [nq,2N] / union_cnt [nq] the pre-truncation
+ * union (may be NULL), weights_out [nq,C] f64 (may be NULL). */
+int simx_simans_sample(simx_stream_t stream, int nq, int C, int N,
+                       const double* scores, const double* pos_score,
+                       int form, double a, double b, double tau,
+                       uint64_t seed, uint32_t offset,
+                       int32_t* neg_idx, int32_t* union_idx, int32_t* union_cnt, double* weights_out);
+
+/* ------------------------------------------------------------------ optimiser
+ * clip_grad_norm_ + transformers.AdamW + zero_grad (co_training_marco_train.py:57-69, 246-254;
+ * update rule SURVEY App. C).  sqnorm: device scalar accumulator (zero it first). */
+int simx_sqnorm_accum(simx_stream_t stream, const float* g, size_t n, float* sqnorm);
+/* p,m,v updated in place; g is read, scaled by min(1, max_norm/(sqrt(*sqnorm)+1e-6)) * grad_scale
+ * (max_norm <= 0 or sqnorm == NULL: no clipping), and zeroed afterwards when zero_grad != 0. */
+int simx_adamw_step(simx_stream_t stream, float* p, float* g, float* m, float* v, size_t n,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                    const float* sqnorm, float max_norm, float grad_scale, int zero_grad);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIMX_H */

@@ -1,0 +1,110 @@
+"""ctypes binding of libsimx_hip.so (C ABI declared in include/simx.h).
+
+This is the reference-side stub a maintainer adds: torch supplies
+device pointers (`tensor.data_ptr()`) and the current HIP stream; everything else is
+plain C.  There is NO fallback: if the shared library is missing the import of any
+op fails loudly (the product path must never run on a CPU / eager substitute).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsimx_hip.so")
+
+SIMX_F32, SIMX_BF16 = 0, 1
+EPI_NONE, EPI_GELU, EPI_DGELU = 0, 1, 2
+LOSS_KL, LOSS_WIKI, LOSS_CEKD, LOSS_CE = 0, 1, 2, 3
+(P_WORD, P_POS, P_TYPE, P_EMB_LN_G, P_EMB_LN_B, P_WQKV, P_BQKV, P_WO, P_BO, P_LN1_G, P_LN1_B,
+ P_W1, P_B1, P_W2, P_B2, P_LN2_G, P_LN2_B, P_POOL_W, P_POOL_B) = range(19)
+
+
+class SimxError(RuntimeError):
+    pass
+
+
+class BertCfg(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("layers", C.c_int32), ("hidden", C.c_int32), ("heads", C.c_int32),
+                ("inter", C.c_int32), ("vocab", C.c_int32), ("max_pos", C.c_int32), ("type_vocab", C.c_int32),
+                ("eps", C.c_float)]
+
+
+class LossParams(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("scale", C.c_float), ("temperature", C.c_float), ("adv_lambda", C.c_float),
+                ("ce_w", C.c_float), ("kd_w", C.c_float), ("grad_accum", C.c_float)]
+
+
+_p, _i, _f, _d, _z, _l = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t, C.c_long
+_cfgp, _lpp = C.POINTER(BertCfg), C.POINTER(LossParams)
+
+# name -> (restype, argtypes); every symbol of include/simx.h
+SIGNATURES = {
+    "simx_version": (_i, []),
+    "simx_last_error": (C.c_char_p, []),
+    "simx_gemm_nt": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _i, _i, _p, _i, _p, _i]),
+    "simx_gemm_tn_workspace_bytes": (_z, [_i, _i, _i]),
+    "simx_gemm_tn": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p, _z]),
+    "simx_colsum": (_i, [_p, _i, _i, _i, _p, _i, _p, _i]),
+    "simx_cast_weight": (_i, [_p, _p, _i, _i, _p, _p]),
+    "simx_transpose_cast": (_i, [_p, _i, _p, _i, _i, _p, _p]),
+    "simx_gemm_f32_strided": (_i, [_p, _i, _i, _i, _p, _l, _l, _p, _l, _l, _p, _i, _i]),
+    "simx_embed_ln_fwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _p]),
+    "simx_embed_ln_bwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p]),
+    "simx_ln_fwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _f, _p]),
+    "simx_ln_bwd": (_i, [_p, _i, _i, _i, _p, _p, _f, _p, _p, _p, _p, _p]),
+    "simx_mha_fwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p]),
+    "simx_mha_bwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p]),
+    "simx_cls_gather": (_i, [_p, _i, _i, _i, _p, _p, _p]),
+    "simx_cls_scatter": (_i, [_p, _i, _i, _i, _i, _p, _p, _p]),
+    "simx_bert_param_count": (_z, [_cfgp]),
+    "simx_bert_param_offset": (_z, [_cfgp, _i, _i]),
+    "simx_bert_wcache_bytes": (_z, [_cfgp]),
+    "simx_bert_act_bytes": (_z, [_cfgp, _i, _i, _i]),
+    "simx_bert_bwd_scratch_bytes": (_z, [_cfgp, _i, _i]),
+    "simx_bert_cast_weights": (_i, [_p, _cfgp, _p, _p]),
+    "simx_bert_fwd": (_i, [_p, _cfgp, _p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _i, _p, _p]),
+    "simx_bert_bwd": (_i, [_p, _cfgp, _p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p, _p, _p, _z]),
+    "simx_sim_loss_fwd_bwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _lpp, _p, _p, _p, _p]),
+    "simx_scores_nll_fwd_bwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _f, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "simx_simans_sample": (_i, [_p, _i, _i, _i, _p, _p, _i, _d, _d, _d, C.c_uint64, C.c_uint32, _p, _p, _p, _p]),
+    "simx_sqnorm_accum": (_i, [_p, _p, _z, _p]),
+    "simx_adamw_step": (_i, [_p, _p, _p, _p, _p, _z, _f, _f, _f, _f, _f, _i, _p, _f, _f, _i]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises SimxError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SimxError("libsimx_hip.so not found at %s -- build it with simxns_amd/csrc/build.sh "
+                        "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError = header/library drift: let it surface
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().simx_last_error().decode("utf8", "replace")
+        raise SimxError("%s failed (%d): %s" % (what or "simx call", rc, msg))
+
+
+def call(name, *args):
+    """Call an int-returning entry point and raise on a non-zero status."""
+    check(getattr(load(), name)(*args), name)
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Build libsimx_hip.so for gfx950 (in-tree; the .so travels with the snapshot to the GPU box).
+set -e
+cd "$(dirname "$0")"
+OUT=../libsimx_hip.so
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
+OBJS=""
+for f in gemm attention layernorm loss sampler optim encoder; do
+  if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ common.h -nt $f.o ] || [ ../../include/simx.h -nt $f.o ]; then
+    echo "hipcc $f.hip"
+    hipcc $FLAGS -c $f.hip -o $f.o &
+  fi
+  OBJS="$OBJS $f.o"
+done
+wait
+hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $OUT
+echo "built $OUT"

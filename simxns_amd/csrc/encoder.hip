@@ -1,0 +1,284 @@
+// Native runtime: the whole-encoder forward / backward driver and library plumbing.
+// Sequences the gfx950 kernels for HFBertEncoder.forward (SimANS/model/models.py:77-82 -> HF
+// BertModel.forward, spec LEAD/modeling_bert.py:916-1038) and its backward on the packed token
+// layout.  No allocation, no synchronisation: every buffer is carved from caller-provided memory.
+//
+// HBM layout (all 256-B aligned):
+//   params / grads : one f32 buffer each, canonical order (simx_bert_param_offset)
+//   wcache         : per layer  Wqkv, Wqkv^T, Wo, Wo^T, W1, W1^T, W2, W2^T   (bf16; f32 mode keeps only
+//                    the transposes, in f32) -- rebuilt once per optimiser step
+//   act            : x0 | per layer { qkv[T,3H] ctx[T,H] lse[heads,T](f32) z1[T,H] x1[T,H] u[T,F] h[T,F]
+//                    z2[T,H] xout[T,H] }   -- everything backward needs is KEPT (288 GB HBM: no recompute)
+//   bwd scratch    : bufA[T,H] bufB[T,H] du[T,F] dqkv[T,3H] | split-K slabs of the wgrad GEMMs
+#include <stdarg.h>
+#include <string.h>
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+void simx_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* simx_last_error(void) { return g_err; }
+extern "C" int simx_version(void) { return 100; }
+
+extern "C" int simx_transpose_cast(simx_stream_t stream, int out_dtype, const float* w, int rows, int cols, void* out, void* outT);
+
+// ------------------------------------------------------------------------------------------ layouts
+static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+static inline size_t esz(int dtype) { return dtype == SIMX_F32 ? 4 : 2; }
+
+static bool cfg_ok(const simx_bert_cfg* c) {
+  return c && (c->dtype == SIMX_F32 || c->dtype == SIMX_BF16) && c->layers > 0 && c->hidden > 0 && c->heads > 0 &&
+         c->hidden % c->heads == 0 && c->hidden % 4 == 0 && c->inter > 0 && c->inter % 4 == 0 && c->vocab > 0 &&
+         c->max_pos > 0 && c->type_vocab > 0 && c->hidden <= 1024;
+}
+
+static size_t layer_param_count(const simx_bert_cfg* c) {
+  const size_t H = c->hidden, F = c->inter;
+  return 3 * H * H + 3 * H + H * H + H + 2 * H + F * H + F + H * F + H + 2 * H;
+}
+
+extern "C" size_t simx_bert_param_count(const simx_bert_cfg* c) {
+  if (!cfg_ok(c)) return 0;
+  const size_t H = c->hidden;
+  return (size_t)c->vocab * H + (size_t)c->max_pos * H + (size_t)c->type_vocab * H + 2 * H +
+         (size_t)c->layers * layer_param_count(c) + H * H + H;
+}
+
+extern "C" size_t simx_bert_param_offset(const simx_bert_cfg* c, int layer, int which) {
+  if (!cfg_ok(c)) return (size_t)-1;
+  const size_t H = c->hidden, F = c->inter;
+  const size_t emb = (size_t)c->vocab * H + (size_t)c->max_pos * H + (size_t)c->type_vocab * H + 2 * H;
+  if (layer == -1) {
+    switch (which) {
+      case SIMX_P_WORD: return 0;
+      case SIMX_P_POS: return (size_t)c->vocab * H;
+      case SIMX_P_TYPE: return (size_t)c->vocab * H + (size_t)c->max_pos * H;
+      case SIMX_P_EMB_LN_G: return emb - 2 * H;
+      case SIMX_P_EMB_LN_B: return emb - H;
+      default: return (size_t)-1;
+    }
+  }
+  if (layer >= 0 && layer < c->layers) {
+    size_t o = emb + (size_t)layer * layer_param_count(c);
+    const size_t sizes[12] = {3 * H * H, 3 * H, H * H, H, H, H, F * H, F, H * F, H, H, H};
+    if (which < SIMX_P_WQKV || which > SIMX_P_LN2_B) return (size_t)-1;
+    for (int i = 0; i < which - SIMX_P_WQKV; ++i) o += sizes[i];
+    return o;
+  }
+  if (layer == c->layers) {
+    const size_t o = emb + (size_t)c->layers * layer_param_count(c);
+    if (which == SIMX_P_POOL_W) return o;
+    if (which == SIMX_P_POOL_B) return o + H * H;
+  }
+  return (size_t)-1;
+}
+
+struct WLayer { const char *wqkv, *wqkvT, *wo, *woT, *w1, *w1T, *w2, *w2T; };
+static size_t wcache_layer_bytes(const simx_bert_cfg* c) {
+  const size_t H = c->hidden, F = c->inter, e = esz(c->dtype);
+  const size_t one = al(3 * H * H * e) + al(H * H * e) + 2 * al(F * H * e);
+  return c->dtype == SIMX_F32 ? one : 2 * one;
+}
+extern "C" size_t simx_bert_wcache_bytes(const simx_bert_cfg* c) {
+  return cfg_ok(c) ? (size_t)c->layers * wcache_layer_bytes(c) : 0;
+}
+static WLayer wlayer(const simx_bert_cfg* c, const float* params, const void* wcache, int l) {
+  const size_t H = c->hidden, F = c->inter, e = esz(c->dtype);
+  const char* b = (const char*)wcache + (size_t)l * wcache_layer_bytes(c);
+  WLayer w;
+  if (c->dtype == SIMX_F32) {
+    w.wqkv = (const char*)(params + simx_bert_param_offset(c, l, SIMX_P_WQKV));
+    w.wo = (const char*)(params + simx_bert_param_offset(c, l, SIMX_P_WO));
+    w.w1 = (const char*)(params + simx_bert_param_offset(c, l, SIMX_P_W1));
+    w.w2 = (const char*)(params + simx_bert_param_offset(c, l, SIMX_P_W2));
+    w.wqkvT = b; b += al(3 * H * H * e);
+    w.woT = b; b += al(H * H * e);
+    w.w1T = b; b += al(F * H * e);
+    w.w2T = b;
+  } else {
+    w.wqkv = b; b += al(3 * H * H * e);
+    w.wqkvT = b; b += al(3 * H * H * e);
+    w.wo = b; b += al(H * H * e);
+    w.woT = b; b += al(H * H * e);
+    w.w1 = b; b += al(F * H * e);
+    w.w1T = b; b += al(F * H * e);
+    w.w2 = b; b += al(F * H * e);
+    w.w2T = b;
+  }
+  return w;
+}
+
+struct ALayer { char *qkv, *ctx, *z1, *x1, *u, *h, *z2, *xout; float* lse; };
+static size_t act_layer_bytes(const simx_bert_cfg* c, size_t T) {
+  const size_t H = c->hidden, F = c->inter, e = esz(c->dtype);
+  return al(T * 3 * H * e) + 5 * al(T * H * e) + 2 * al(T * F * e) + al((size_t)c->heads * T * 4);
+}
+extern "C" size_t simx_bert_act_bytes(const simx_bert_cfg* c, int T, int nseq, int save_for_bwd) {
+  if (!cfg_ok(c) || T <= 0) return 0;
+  (void)nseq;
+  const size_t x0 = al((size_t)T * c->hidden * esz(c->dtype));
+  return x0 + (size_t)(save_for_bwd ? c->layers : 2) * act_layer_bytes(c, T);
+}
+static char* act_x0(void* act) { return (char*)act; }
+static ALayer alayer(const simx_bert_cfg* c, void* act, size_t T, int l, int save) {
+  const size_t H = c->hidden, F = c->inter, e = esz(c->dtype);
+  char* b = (char*)act + al(T * H * e) + (size_t)(save ? l : (l & 1)) * act_layer_bytes(c, T);
+  ALayer a;
+  a.qkv = b; b += al(T * 3 * H * e);
+  a.ctx = b; b += al(T * H * e);
+  a.z1 = b; b += al(T * H * e);
+  a.x1 = b; b += al(T * H * e);
+  a.z2 = b; b += al(T * H * e);
+  a.xout = b; b += al(T * H * e);
+  a.u = b; b += al(T * F * e);
+  a.h = b; b += al(T * F * e);
+  a.lse = (float*)b;
+  return a;
+}
+
+static size_t tn_ws_max(const simx_bert_cfg* c, int T) {
+  const int H = c->hidden, F = c->inter;
+  size_t m = simx_gemm_tn_workspace_bytes(3 * H, H, T);
+  size_t v = simx_gemm_tn_workspace_bytes(H, H, T); if (v > m) m = v;
+  v = simx_gemm_tn_workspace_bytes(F, H, T); if (v > m) m = v;
+  v = simx_gemm_tn_workspace_bytes(H, F, T); if (v > m) m = v;
+  return al(m);
+}
+extern "C" size_t simx_bert_bwd_scratch_bytes(const simx_bert_cfg* c, int T, int nseq) {
+  if (!cfg_ok(c) || T <= 0) return 0;
+  (void)nseq;
+  const size_t H = c->hidden, F = c->inter, e = esz(c->dtype);
+  return 2 * al((size_t)T * H * e) + al((size_t)T * F * e) + al((size_t)T * 3 * H * e) + tn_ws_max(c, T);
+}
+
+// ------------------------------------------------------------------------------------------ driver
+#define RUN(call)            \
+  do {                       \
+    int rc__ = (call);       \
+    if (rc__) return rc__;   \
+  } while (0)
+
+extern "C" int simx_bert_cast_weights(simx_stream_t stream, const simx_bert_cfg* c, const float* params, void* wcache) {
+  SIMX_REQUIRE(cfg_ok(c), SIMX_ERR_BAD_SHAPE, "bert_cast_weights: bad config");
+  SIMX_REQUIRE(params && wcache, SIMX_ERR_BAD_SHAPE, "bert_cast_weights: NULL buffer");
+  const int H = c->hidden, F = c->inter;
+  for (int l = 0; l < c->layers; ++l) {
+    const WLayer w = wlayer(c, params, wcache, l);
+    const bool f32 = c->dtype == SIMX_F32;
+    RUN(simx_transpose_cast(stream, c->dtype, params + simx_bert_param_offset(c, l, SIMX_P_WQKV), 3 * H, H,
+                            f32 ? nullptr : (void*)w.wqkv, (void*)w.wqkvT));
+    RUN(simx_transpose_cast(stream, c->dtype, params + simx_bert_param_offset(c, l, SIMX_P_WO), H, H,
+                            f32 ? nullptr : (void*)w.wo, (void*)w.woT));
+    RUN(simx_transpose_cast(stream, c->dtype, params + simx_bert_param_offset(c, l, SIMX_P_W1), F, H,
+                            f32 ? nullptr : (void*)w.w1, (void*)w.w1T));
+    RUN(simx_transpose_cast(stream, c->dtype, params + simx_bert_param_offset(c, l, SIMX_P_W2), H, F,
+                            f32 ? nullptr : (void*)w.w2, (void*)w.w2T));
+  }
+  return SIMX_OK;
+}
+
+static int check_io(const simx_bert_cfg* c, int nseq, int T, int max_len, const char* who) {
+  SIMX_REQUIRE(cfg_ok(c), SIMX_ERR_BAD_SHAPE, "%s: bad config", who);
+  SIMX_REQUIRE(nseq > 0 && T >= nseq && max_len > 0 && max_len <= c->max_pos, SIMX_ERR_BAD_SHAPE,
+               "%s: bad batch (nseq=%d T=%d max_len=%d max_pos=%d)", who, nseq, T, max_len, c->max_pos);
+  return SIMX_OK;
+}
+
+extern "C" int simx_bert_fwd(simx_stream_t stream, const simx_bert_cfg* c, const float* params, const void* wcache,
+                             const int32_t* ids, const int32_t* pos_ids, const int32_t* cu, int nseq, int T, int max_len,
+                             void* act, size_t act_bytes, int save, float* cls_out, void* hidden_out) {
+  RUN(check_io(c, nseq, T, max_len, "bert_fwd"));
+  SIMX_REQUIRE(params && wcache && ids && pos_ids && cu && act, SIMX_ERR_BAD_SHAPE, "bert_fwd: NULL buffer");
+  SIMX_REQUIRE(act_bytes >= simx_bert_act_bytes(c, T, nseq, save), SIMX_ERR_WORKSPACE, "bert_fwd: activation buffer %zu < %zu",
+               act_bytes, simx_bert_act_bytes(c, T, nseq, save));
+  const int H = c->hidden, F = c->inter, dt = c->dtype, d = H / c->heads;
+  const float* P = params;
+  auto off = [&](int l, int w) { return P + simx_bert_param_offset(c, l, w); };
+  char* x = act_x0(act);
+  RUN(simx_embed_ln_fwd(stream, dt, T, H, ids, pos_ids, off(-1, SIMX_P_WORD), off(-1, SIMX_P_POS), off(-1, SIMX_P_TYPE),
+                        off(-1, SIMX_P_EMB_LN_G), off(-1, SIMX_P_EMB_LN_B), c->eps, x));
+  for (int l = 0; l < c->layers; ++l) {
+    const WLayer w = wlayer(c, params, wcache, l);
+    const ALayer a = alayer(c, act, T, l, save);
+    RUN(simx_gemm_nt(stream, dt, T, 3 * H, H, x, H, w.wqkv, H, a.qkv, 3 * H, off(l, SIMX_P_BQKV), nullptr, 0, SIMX_EPI_NONE,
+                     nullptr, 0, nullptr, 0));
+    RUN(simx_mha_fwd(stream, dt, nseq, c->heads, d, cu, max_len, T, a.qkv, a.ctx, a.lse));
+    RUN(simx_gemm_nt(stream, dt, T, H, H, a.ctx, H, w.wo, H, a.z1, H, off(l, SIMX_P_BO), x, H, SIMX_EPI_NONE, nullptr, 0,
+                     nullptr, 0));
+    RUN(simx_ln_fwd(stream, dt, T, H, a.z1, off(l, SIMX_P_LN1_G), off(l, SIMX_P_LN1_B), c->eps, a.x1));
+    RUN(simx_gemm_nt(stream, dt, T, F, H, a.x1, H, w.w1, H, a.u, F, off(l, SIMX_P_B1), nullptr, 0, SIMX_EPI_GELU, nullptr, 0,
+                     a.h, F));
+    RUN(simx_gemm_nt(stream, dt, T, H, F, a.h, F, w.w2, F, a.z2, H, off(l, SIMX_P_B2), a.x1, H, SIMX_EPI_NONE, nullptr, 0,
+                     nullptr, 0));
+    RUN(simx_ln_fwd(stream, dt, T, H, a.z2, off(l, SIMX_P_LN2_G), off(l, SIMX_P_LN2_B), c->eps, a.xout));
+    x = a.xout;
+  }
+  if (cls_out) RUN(simx_cls_gather(stream, dt, nseq, H, cu, x, cls_out));
+  if (hidden_out) {
+    if (hipMemcpyAsync(hidden_out, x, (size_t)T * H * esz(dt), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
+      simx_set_error("bert_fwd: copy of last hidden state failed");
+      return SIMX_ERR_HIP;
+    }
+  }
+  return SIMX_OK;
+}
+
+extern "C" int simx_bert_bwd(simx_stream_t stream, const simx_bert_cfg* c, const float* params, const void* wcache,
+                             const int32_t* ids, const int32_t* pos_ids, const int32_t* cu, int nseq, int T, int max_len,
+                             const void* act, size_t act_bytes, const float* dcls, float* grads, void* scratch,
+                             size_t scratch_bytes) {
+  RUN(check_io(c, nseq, T, max_len, "bert_bwd"));
+  SIMX_REQUIRE(params && wcache && ids && pos_ids && cu && act && dcls && grads && scratch, SIMX_ERR_BAD_SHAPE,
+               "bert_bwd: NULL buffer");
+  SIMX_REQUIRE(act_bytes >= simx_bert_act_bytes(c, T, nseq, 1), SIMX_ERR_WORKSPACE, "bert_bwd: activation buffer too small");
+  SIMX_REQUIRE(scratch_bytes >= simx_bert_bwd_scratch_bytes(c, T, nseq), SIMX_ERR_WORKSPACE, "bert_bwd: scratch %zu < %zu",
+               scratch_bytes, simx_bert_bwd_scratch_bytes(c, T, nseq));
+  const int H = c->hidden, F = c->inter, dt = c->dtype, d = H / c->heads;
+  const size_t e = esz(dt);
+  auto off = [&](int l, int w) { return params + simx_bert_param_offset(c, l, w); };
+  auto goff = [&](int l, int w) { return grads + simx_bert_param_offset(c, l, w); };
+  char* bufA = (char*)scratch;
+  char* bufB = bufA + al((size_t)T * H * e);
+  char* du = bufB + al((size_t)T * H * e);
+  char* dqkv = du + al((size_t)T * F * e);
+  char* tnws = dqkv + al((size_t)T * 3 * H * e);
+  const size_t tnws_bytes = tn_ws_max(c, T);
+
+  RUN(simx_cls_scatter(stream, dt, nseq, H, T, cu, dcls, bufB));            // g_x = d(loss)/d(last hidden)
+  for (int l = c->layers - 1; l >= 0; --l) {
+    const WLayer w = wlayer(c, params, wcache, l);
+    const ALayer a = alayer(c, const_cast<void*>(act), T, l, 1);
+    const char* xin = l == 0 ? act_x0(const_cast<void*>(act)) : alayer(c, const_cast<void*>(act), T, l - 1, 1).xout;
+    // output LayerNorm : dz2, dgamma2, dbeta2, db2
+    RUN(simx_ln_bwd(stream, dt, T, H, a.z2, off(l, SIMX_P_LN2_G), c->eps, bufB, bufA, goff(l, SIMX_P_LN2_G),
+                    goff(l, SIMX_P_LN2_B), goff(l, SIMX_P_B2)));
+    // du = (dz2 . W2) * gelu'(u)
+    RUN(simx_gemm_nt(stream, dt, T, F, H, bufA, H, w.w2T, H, du, F, nullptr, nullptr, 0, SIMX_EPI_DGELU, a.u, F, nullptr, 0));
+    RUN(simx_gemm_tn(stream, dt, H, F, T, bufA, H, a.h, F, goff(l, SIMX_P_W2), F, 1, tnws, tnws_bytes));
+    // dx1 = du . W1 + dz2
+    RUN(simx_gemm_nt(stream, dt, T, H, F, du, F, w.w1T, F, bufB, H, nullptr, bufA, H, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
+    RUN(simx_gemm_tn(stream, dt, F, H, T, du, F, a.x1, H, goff(l, SIMX_P_W1), H, 1, tnws, tnws_bytes));
+    RUN(simx_colsum(stream, dt, T, F, du, F, goff(l, SIMX_P_B1), 1));
+    // attention-output LayerNorm : dz1, dgamma1, dbeta1, dbo
+    RUN(simx_ln_bwd(stream, dt, T, H, a.z1, off(l, SIMX_P_LN1_G), c->eps, bufB, bufA, goff(l, SIMX_P_LN1_G),
+                    goff(l, SIMX_P_LN1_B), goff(l, SIMX_P_BO)));
+    // dctx = dz1 . Wo
+    RUN(simx_gemm_nt(stream, dt, T, H, H, bufA, H, w.woT, H, bufB, H, nullptr, nullptr, 0, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
+    RUN(simx_gemm_tn(stream, dt, H, H, T, bufA, H, a.ctx, H, goff(l, SIMX_P_WO), H, 1, tnws, tnws_bytes));
+    RUN(simx_mha_bwd(stream, dt, nseq, c->heads, d, cu, max_len, T, a.qkv, a.ctx, a.lse, bufB, dqkv));
+    // dx = dqkv . Wqkv + dz1
+    RUN(simx_gemm_nt(stream, dt, T, H, 3 * H, dqkv, 3 * H, w.wqkvT, 3 * H, bufB, H, nullptr, bufA, H, SIMX_EPI_NONE, nullptr, 0,
+                     nullptr, 0));
+    RUN(simx_gemm_tn(stream, dt, 3 * H, H, T, dqkv, 3 * H, xin, H, goff(l, SIMX_P_WQKV), H, 1, tnws, tnws_bytes));
+    RUN(simx_colsum(stream, dt, T, 3 * H, dqkv, 3 * H, goff(l, SIMX_P_BQKV), 1));
+  }
+  RUN(simx_embed_ln_bwd(stream, dt, T, H, ids, pos_ids, off(-1, SIMX_P_WORD), off(-1, SIMX_P_POS), off(-1, SIMX_P_TYPE),
+                        off(-1, SIMX_P_EMB_LN_G), c->eps, bufB, goff(-1, SIMX_P_WORD), goff(-1, SIMX_P_POS),
+                        goff(-1, SIMX_P_TYPE), goff(-1, SIMX_P_EMB_LN_G), goff(-1, SIMX_P_EMB_LN_B)));
+  return SIMX_OK;
+}

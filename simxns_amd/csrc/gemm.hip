@@ -1,0 +1,562 @@
+// GEMMs of the BERT dense layers for gfx950.
+//
+//   simx_gemm_nt : C[M,N] = A[M,K] . B[N,K]^T      forward (x W^T) and dgrad (dY . (W^T)^T)
+//   simx_gemm_tn : C[M,N] += A[K,M]^T . B[K,N]     wgrad (dY^T X), split over K (tokens)
+//
+// bf16 path: 128x128x64 block tile, 4 waves (2x2) of 64x64, v_mfma_f32_16x16x32_bf16.
+//   * operands staged HBM -> LDS with global_load_lds (16 B per lane, lane-linear LDS image),
+//     bank conflicts removed by an XOR swizzle applied on the per-lane SOURCE address and
+//     again on the ds_read address (LDS destination stays linear);
+//   * NT: K-contiguous rows, fragments by ds_read_b128;
+//   * TN: the contraction index (tokens) is the row index of both operands, fragments by
+//     ds_read_b64_tr_b16 (hardware transpose read); the k-slot permutation this implies is
+//     applied identically to both operands so the contraction is unchanged;
+//   * the MFMA is issued with swapped operands so that each lane ends up with 4 CONSECUTIVE
+//     output columns of one row -> 8 B (bf16) / 16 B (f32) stores;
+//   * blockIdx -> tile map is XCD-aware: the 8 XCDs (private L2s) each walk a contiguous
+//     range of tiles so that the N-tiles sharing an A panel hit the same L2.
+// f32 path ("parity mode") and odd shapes: a plain LDS-tiled FMA kernel, k-ordered f32 accumulate.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------
+// generic tiled kernel (f32 parity mode, and bf16 shapes the MFMA kernels do not take)
+// ------------------------------------------------------------------------------------------
+template <typename TI, typename TO, int EPI>
+__global__ __launch_bounds__(256) void gemm_simple_kernel(
+    int M, int N, int K, const TI* __restrict__ A, long a_rs, long a_cs,
+    const TI* __restrict__ B, long b_ks, long b_ns, TO* __restrict__ C, int ldc,
+    const float* __restrict__ bias, const TI* __restrict__ res, int ldr,
+    const TI* __restrict__ aux, int ldaux, TO* __restrict__ C2, int ldc2, int accumulate) {
+  __shared__ float As[16][68];
+  __shared__ float Bs[16][68];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  float acc[4][4] = {};
+  for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int idx = tid + e * 256;
+      int mm, kk;
+      if (a_cs == 1) { kk = idx & 15; mm = idx >> 4; } else { mm = idx & 63; kk = idx >> 6; }
+      int gm = m0 + mm, gk = k0 + kk;
+      As[kk][mm] = (gm < M && gk < K) ? Elem<TI>::ld(A + (long)gm * a_rs + (long)gk * a_cs) : 0.f;
+      int nn;
+      if (b_ks == 1) { kk = idx & 15; nn = idx >> 4; } else { nn = idx & 63; kk = idx >> 6; }
+      int gn = n0 + nn; gk = k0 + kk;
+      Bs[kk][nn] = (gn < N && gk < K) ? Elem<TI>::ld(B + (long)gk * b_ks + (long)gn * b_ns) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty * 4 + i]; b[i] = Bs[kk][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = m0 + ty * 4 + i;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int n = n0 + tx * 4 + j;
+      if (n >= N) continue;
+      float v = acc[i][j];
+      if (bias) v += bias[n];
+      if (EPI == SIMX_EPI_NONE) {
+        if (res) v += Elem<TI>::ld(res + (long)m * ldr + n);
+        if (accumulate) v += Elem<TO>::ld(C + (long)m * ldc + n);
+        Elem<TO>::st(C + (long)m * ldc + n, v);
+      } else if (EPI == SIMX_EPI_GELU) {
+        Elem<TO>::st(C + (long)m * ldc + n, v);
+        Elem<TO>::st(C2 + (long)m * ldc2 + n, gelu_erf(v));
+      } else {
+        if (res) v += Elem<TI>::ld(res + (long)m * ldr + n);
+        Elem<TO>::st(C + (long)m * ldc + n, v * gelu_erf_grad(Elem<TI>::ld(aux + (long)m * ldaux + n)));
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// XCD-aware tile id: block b runs on XCD b%8 (observed placement, speed only); give every XCD
+// a contiguous range of logical tiles.  Bijective for any grid size.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int xcd_remap(int b, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, loc = b >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)lds_wave_base, 16, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------
+// bf16 NT kernel
+// ------------------------------------------------------------------------------------------
+#define NT_BM 128
+#define NT_BN 128
+#define NT_BK 64
+#define NT_STAGE_BYTES (2 * 128 * 64 * 2)   // A tile + B tile
+
+// stage one 128x64 bf16 tile (rows K-contiguous).  LDS image: row r at r*128 B, the 16-B chunk
+// c of the row stored at chunk position c ^ ((r>>1)&7).
+__device__ __forceinline__ void nt_stage_tile(const bf16_t* __restrict__ G, int ld, int row0, int nrows_total,
+                                              int k0, char* lds_tile, int wave, int lane) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = wave * 4 + j;                 // wave-instruction index: 8 rows each
+    const int r = i * 8 + (lane >> 3);
+    const int p = lane & 7;
+    const int c = p ^ ((r >> 1) & 7);
+    int gr = row0 + r;
+    gr = gr < nrows_total ? gr : nrows_total - 1;
+    glds16(G + (long)gr * ld + k0 + c * 8, lds_tile + i * 1024);
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(
+    int M, int N, int K, const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
+    bf16_t* __restrict__ C, int ldc, const float* __restrict__ bias, const bf16_t* __restrict__ res, int ldr,
+    const bf16_t* __restrict__ aux, int ldaux, bf16_t* __restrict__ C2, int ldc2, int tiles_n, int nwg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = xcd_remap(blockIdx.x, nwg);
+  const int m0 = (tile / tiles_n) * NT_BM, n0 = (tile % tiles_n) * NT_BN;
+  const int wr = wave >> 1, wc = wave & 1;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nt = K / NT_BK;
+  nt_stage_tile(A, lda, m0, M, 0, smem, wave, lane);
+  nt_stage_tile(B, ldb, n0, N, 0, smem + 16384, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int fr = lane & 15, fg = lane >> 4;
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    char* sa = smem + cur * NT_STAGE_BYTES;
+    char* sb = sa + 16384;
+    if (t + 1 < nt) {
+      char* na = smem + (cur ^ 1) * NT_STAGE_BYTES;
+      nt_stage_tile(A, lda, m0, M, (t + 1) * NT_BK, na, wave, lane);
+      nt_stage_tile(B, ldb, n0, N, (t + 1) * NT_BK, na + 16384, wave, lane);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ra = wr * 64 + i * 16 + fr;
+        af[i] = *reinterpret_cast<const bf16x8*>(sa + ra * 128 + (((ks * 4 + fg) ^ ((ra >> 1) & 7)) << 4));
+        const int rb = wc * 64 + i * 16 + fr;
+        bfr[i] = *reinterpret_cast<const bf16x8*>(sb + rb * 128 + (((ks * 4 + fg) ^ ((rb >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // epilogue: lane holds row m = ..+fr, columns n = ..+fg*4 .. +3 of each 16x16 tile
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wr * 64 + i * 16 + fr;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wc * 64 + j * 16 + fg * 4;
+      if (n >= N) continue;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (bias) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias + n);
+        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+      }
+      if (EPI == SIMX_EPI_NONE) {
+        if (res) { float r4[4]; ld4(res + (long)m * ldr + n, r4); v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3]; }
+        st4(C + (long)m * ldc + n, v);
+      } else if (EPI == SIMX_EPI_GELU) {
+        st4(C + (long)m * ldc + n, v);
+        // gelu of the bf16-ROUNDED pre-activation, so that backward (which reads C) sees the same u
+        float g4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g4[e] = gelu_erf(bf2f(f2bf(v[e])));
+        st4(C2 + (long)m * ldc2 + n, g4);
+      } else {
+        if (res) { float r4[4]; ld4(res + (long)m * ldr + n, r4); v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3]; }
+        float u4[4]; ld4(aux + (long)m * ldaux + n, u4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(u4[e]);
+        st4(C + (long)m * ldc + n, v);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// bf16 TN kernel (wgrad) : slab[split][M][N] = A[kslice,M]^T . B[kslice,N]
+// LDS image of a 64(k) x 128(col) tile: row kr at kr*256 B; the 32-B chunk q of the row stored
+// at chunk position q ^ (kr & 7).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tn_stage_tile(const bf16_t* __restrict__ G, int ld, int k0, int k_end,
+                                              int col0, int ncols_total, char* lds_tile, int wave, int lane) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = wave * 4 + j;                 // wave-instruction index: 4 k-rows each
+    const int kr = i * 4 + (lane >> 4);
+    const int p16 = lane & 15;
+    const int q = (p16 >> 1) ^ (kr & 7);
+    int gk = k0 + kr;
+    gk = gk < k_end ? gk : k_end - 1;
+    int gc = col0 + q * 16 + (p16 & 1) * 8;
+    gc = gc < ncols_total ? gc : ncols_total - 8;
+    glds16(G + (long)gk * ld + gc, lds_tile + i * 1024);
+  }
+}
+
+__device__ __forceinline__ bf16x4 lds_tr_read(uint32_t addr) {
+  bf16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(
+    int M, int N, int K, const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
+    float* __restrict__ out, long slab_stride, int ldo, int tiles_n, int tiles_mn, int k_per_split, int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int split = blockIdx.x / tiles_mn;
+  const int tile = blockIdx.x % tiles_mn;
+  const int m0 = (tile / tiles_n) * 128, n0 = (tile % tiles_n) * 128;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int kb = split * k_per_split;
+  const int ke = min(K, kb + k_per_split);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nt = (ke - kb + 63) / 64;
+  tn_stage_tile(A, lda, kb, ke, m0, M, smem, wave, lane);
+  tn_stage_tile(B, ldb, kb, ke, n0, N, smem + 16384, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int fs = lane & 15, fg = lane >> 4;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)smem;
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    char* sa = smem + cur * NT_STAGE_BYTES;
+    const int kt = kb + t * 64;
+    if (kt + 64 > ke) {
+      // ragged tail: rows >= ke-kt hold clamped copies; zero them in both tiles
+      const int valid = ke - kt;
+      for (int idx = tid; idx < 2 * 64 * 16; idx += 256) {
+        const int tl = idx >> 10, rem = idx & 1023, kr = rem >> 4, c16 = rem & 15;
+        if (kr >= valid) *reinterpret_cast<uint4*>(sa + tl * 16384 + kr * 256 + c16 * 16) = make_uint4(0, 0, 0, 0);
+      }
+      __syncthreads();
+    }
+    if (t + 1 < nt) {
+      char* na = smem + (cur ^ 1) * NT_STAGE_BYTES;
+      tn_stage_tile(A, lda, kt + 64, ke, m0, M, na, wave, lane);
+      tn_stage_tile(B, ldb, kt + 64, ke, n0, N, na + 16384, wave, lane);
+    }
+    const uint32_t a_base = lds_base + cur * NT_STAGE_BYTES;
+    const uint32_t b_base = a_base + 16384;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        bf16x4 lo, hi, lo2, hi2;
+        {
+          const int tr0 = ks * 32 + 4 * fg + (fs >> 2), tr1 = tr0 + 16;
+          const int cm = wr * 4 + i, cn = wc * 4 + i;
+          lo = lds_tr_read(a_base + tr0 * 256 + ((cm ^ (tr0 & 7)) << 5) + (fs & 3) * 8);
+          hi = lds_tr_read(a_base + tr1 * 256 + ((cm ^ (tr1 & 7)) << 5) + (fs & 3) * 8);
+          lo2 = lds_tr_read(b_base + tr0 * 256 + ((cn ^ (tr0 & 7)) << 5) + (fs & 3) * 8);
+          hi2 = lds_tr_read(b_base + tr1 * 256 + ((cn ^ (tr1 & 7)) << 5) + (fs & 3) * 8);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi), "+v"(lo2), "+v"(hi2)::"memory");
+        af[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        bfr[i] = (bf16x8){lo2[0], lo2[1], lo2[2], lo2[3], hi2[0], hi2[1], hi2[2], hi2[3]};
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  float* o = out + (long)split * slab_stride;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wr * 64 + i * 16 + fs;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wc * 64 + j * 16 + fg * 4;
+      if (n >= N) continue;
+      float4* dst = reinterpret_cast<float4*>(o + (long)m * ldo + n);
+      float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      if (accumulate) { float4 c = *dst; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
+      *dst = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int splits,
+                                                          int M, int N, float* __restrict__ C, int ldc, int accumulate) {
+  const long total4 = (long)M * N / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+    const long e = i * 4;
+    const int m = (int)(e / N), n = (int)(e % N);
+    float4 s = make_float4(0, 0, 0, 0);
+    for (int k = 0; k < splits; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(slabs + (long)k * slab_stride + e);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    float4* dst = reinterpret_cast<float4*>(C + (long)m * ldc + n);
+    if (accumulate) { const float4 c = *dst; s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w; }
+    *dst = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// column sums (bias gradients) and weight casts
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(int Trows, int N, const T* __restrict__ x, int ldx,
+                                                     float* __restrict__ out, int rows_per_block) {
+  // block = 64 columns x 4 row-lanes; grid.x over column groups, grid.y over row chunks; atomics to out
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(Trows, r0 + rows_per_block);
+  float s = 0.f;
+  if (c < N)
+    for (int r = r0 + rl; r < r1; r += 4) s += Elem<T>::ld(x + (long)r * ldx + c);
+  part[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < N) atomicAdd(out + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+template <typename TO>
+__global__ __launch_bounds__(256) void cast_weight_kernel(const float* __restrict__ w, int rows, int cols,
+                                                          TO* __restrict__ o, TO* __restrict__ ot) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    float v = 0.f;
+    if (r < rows && c < cols) { v = w[(long)r * cols + c]; if (o) Elem<TO>::st(o + (long)r * cols + c, v); }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  if (ot)
+    for (int i = ty; i < 32; i += 8) {
+      const int c = c0 + i, r = r0 + tx;
+      if (r < rows && c < cols) Elem<TO>::st(ot + (long)c * rows + r, tile[tx][i]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host entry points
+// ------------------------------------------------------------------------------------------
+template <typename TI, typename TO>
+static int launch_simple(hipStream_t s, int epi, int M, int N, int K, const TI* A, long a_rs, long a_cs,
+                         const TI* B, long b_ks, long b_ns, TO* C, int ldc, const float* bias, const TI* res, int ldr,
+                         const TI* aux, int ldaux, TO* C2, int ldc2, int accumulate) {
+  dim3 grid(cdiv(N, 64), cdiv(M, 64));
+#define L(E) hipLaunchKernelGGL((gemm_simple_kernel<TI, TO, E>), grid, dim3(256), 0, s, M, N, K, A, a_rs, a_cs, B, b_ks, \
+                                b_ns, C, ldc, bias, res, ldr, aux, ldaux, C2, ldc2, accumulate)
+  if (epi == SIMX_EPI_NONE) L(SIMX_EPI_NONE);
+  else if (epi == SIMX_EPI_GELU) L(SIMX_EPI_GELU);
+  else L(SIMX_EPI_DGELU);
+#undef L
+  SIMX_CHECK_LAUNCH("gemm_simple");
+  return SIMX_OK;
+}
+
+static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+extern "C" int simx_gemm_nt(simx_stream_t stream, int dtype, int M, int N, int K, const void* A, int lda,
+                            const void* B, int ldb, void* C, int ldc, const float* bias, const void* residual,
+                            int ldr, int epilogue, const void* aux, int ldaux, void* C2, int ldc2) {
+  hipStream_t s = (hipStream_t)stream;
+  SIMX_REQUIRE(M > 0 && N > 0 && K > 0, SIMX_ERR_BAD_SHAPE, "gemm_nt: bad shape %d %d %d", M, N, K);
+  SIMX_REQUIRE(lda >= K && ldb >= K && ldc >= N, SIMX_ERR_BAD_SHAPE, "gemm_nt: leading dims too small");
+  SIMX_REQUIRE(epilogue >= 0 && epilogue <= 2, SIMX_ERR_UNSUPPORTED, "gemm_nt: epilogue %d", epilogue);
+  SIMX_REQUIRE(epilogue != SIMX_EPI_GELU || C2, SIMX_ERR_BAD_SHAPE, "gemm_nt: GELU epilogue needs C2");
+  SIMX_REQUIRE(epilogue != SIMX_EPI_DGELU || aux, SIMX_ERR_BAD_SHAPE, "gemm_nt: DGELU epilogue needs aux");
+  if (dtype == SIMX_F32)
+    return launch_simple<float, float>(s, epilogue, M, N, K, (const float*)A, lda, 1, (const float*)B, 1, ldb,
+                                       (float*)C, ldc, bias, (const float*)residual, ldr, (const float*)aux, ldaux,
+                                       (float*)C2, ldc2, 0);
+  SIMX_REQUIRE(dtype == SIMX_BF16, SIMX_ERR_BAD_DTYPE, "gemm_nt: dtype %d", dtype);
+  const bool fast = (K % 64 == 0) && (N % 4 == 0) && (lda % 8 == 0) && (ldb % 8 == 0) && (ldc % 4 == 0) &&
+                    aligned16(A) && aligned16(B) && aligned16(C) && (!bias || aligned16(bias)) &&
+                    (!residual || (ldr % 4 == 0 && aligned16(residual))) && (!aux || (ldaux % 4 == 0 && aligned16(aux))) &&
+                    (!C2 || (ldc2 % 4 == 0 && aligned16(C2)));
+  if (!fast)
+    return launch_simple<bf16_t, bf16_t>(s, epilogue, M, N, K, (const bf16_t*)A, lda, 1, (const bf16_t*)B, 1, ldb,
+                                         (bf16_t*)C, ldc, bias, (const bf16_t*)residual, ldr, (const bf16_t*)aux,
+                                         ldaux, (bf16_t*)C2, ldc2, 0);
+  const int tiles_m = cdiv(M, NT_BM), tiles_n = cdiv(N, NT_BN), nwg = tiles_m * tiles_n;
+  const size_t lds = 2 * NT_STAGE_BYTES;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<SIMX_EPI_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<SIMX_EPI_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<SIMX_EPI_DGELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+#define L(E) hipLaunchKernelGGL((gemm_nt_bf16_kernel<E>), dim3(nwg), dim3(256), lds, s, M, N, K, (const bf16_t*)A, lda, \
+                                (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, (const bf16_t*)residual, ldr,               \
+                                (const bf16_t*)aux, ldaux, (bf16_t*)C2, ldc2, tiles_n, nwg)
+  if (epilogue == SIMX_EPI_NONE) L(SIMX_EPI_NONE);
+  else if (epilogue == SIMX_EPI_GELU) L(SIMX_EPI_GELU);
+  else L(SIMX_EPI_DGELU);
+#undef L
+  SIMX_CHECK_LAUNCH("gemm_nt_bf16");
+  return SIMX_OK;
+}
+
+static void tn_plan(int M, int N, int K, int* splits, int* k_per_split) {
+  const int tiles = cdiv(M, 128) * cdiv(N, 128);
+  int s = cdiv(1024, tiles);
+  const int max_s = cdiv(K, 512);          // at least 8 k-tiles per split
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  int kps = cdiv(cdiv(K, s), 64) * 64;
+  s = cdiv(K, kps);
+  *splits = s;
+  *k_per_split = kps;
+}
+
+extern "C" size_t simx_gemm_tn_workspace_bytes(int M, int N, int K) {
+  int s, kps;
+  tn_plan(M, N, K, &s, &kps);
+  return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+}
+
+extern "C" int simx_gemm_tn(simx_stream_t stream, int dtype, int M, int N, int K, const void* A, int lda,
+                            const void* B, int ldb, float* C, int ldc, int accumulate, void* ws, size_t ws_bytes) {
+  hipStream_t s = (hipStream_t)stream;
+  SIMX_REQUIRE(M > 0 && N > 0 && K > 0, SIMX_ERR_BAD_SHAPE, "gemm_tn: bad shape %d %d %d", M, N, K);
+  SIMX_REQUIRE(lda >= M && ldb >= N && ldc >= N, SIMX_ERR_BAD_SHAPE, "gemm_tn: leading dims too small");
+  if (dtype == SIMX_F32)
+    return launch_simple<float, float>(s, SIMX_EPI_NONE, M, N, K, (const float*)A, 1, lda, (const float*)B, ldb, 1, C,
+                                       ldc, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, accumulate);
+  SIMX_REQUIRE(dtype == SIMX_BF16, SIMX_ERR_BAD_DTYPE, "gemm_tn: dtype %d", dtype);
+  const bool fast = (M % 8 == 0) && (N % 8 == 0) && (lda % 8 == 0) && (ldb % 8 == 0) && (ldc % 4 == 0) && aligned16(A) &&
+                    aligned16(B) && aligned16(C);
+  if (!fast) {
+    // generic path: bf16 in, f32 out
+    dim3 grid(cdiv(N, 64), cdiv(M, 64));
+    hipLaunchKernelGGL((gemm_simple_kernel<bf16_t, float, SIMX_EPI_NONE>), grid, dim3(256), 0, s, M, N, K,
+                       (const bf16_t*)A, 1L, (long)lda, (const bf16_t*)B, (long)ldb, 1L, C, ldc, nullptr, nullptr, 0,
+                       nullptr, 0, nullptr, 0, accumulate);
+    SIMX_CHECK_LAUNCH("gemm_simple(tn)");
+    return SIMX_OK;
+  }
+  int splits, kps;
+  tn_plan(M, N, K, &splits, &kps);
+  const int tiles_m = cdiv(M, 128), tiles_n = cdiv(N, 128), tiles_mn = tiles_m * tiles_n;
+  const size_t lds = 2 * NT_STAGE_BYTES;
+  if (splits == 1) {
+    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(tiles_mn), dim3(256), lds, s, M, N, K, (const bf16_t*)A, lda,
+                       (const bf16_t*)B, ldb, C, 0L, ldc, tiles_n, tiles_mn, kps, accumulate);
+    SIMX_CHECK_LAUNCH("gemm_tn_bf16");
+    return SIMX_OK;
+  }
+  const size_t need = (size_t)splits * M * N * sizeof(float);
+  SIMX_REQUIRE(ws && ws_bytes >= need, SIMX_ERR_WORKSPACE, "gemm_tn: workspace %zu < %zu", ws_bytes, need);
+  SIMX_REQUIRE(aligned16(ws), SIMX_ERR_WORKSPACE, "gemm_tn: workspace not 16-B aligned");
+  hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(tiles_mn * splits), dim3(256), lds, s, M, N, K, (const bf16_t*)A, lda,
+                     (const bf16_t*)B, ldb, (float*)ws, (long)M * N, N, tiles_n, tiles_mn, kps, 0);
+  SIMX_CHECK_LAUNCH("gemm_tn_bf16");
+  const long total4 = (long)M * N / 4;
+  int blocks = (int)((total4 + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)ws, (long)M * N, splits, M, N, C,
+                     ldc, accumulate);
+  SIMX_CHECK_LAUNCH("slab_reduce");
+  return SIMX_OK;
+}
+
+extern "C" int simx_colsum(simx_stream_t stream, int dtype, int T, int N, const void* x, int ldx, float* out,
+                           int accumulate) {
+  hipStream_t s = (hipStream_t)stream;
+  SIMX_REQUIRE(T > 0 && N > 0 && ldx >= N, SIMX_ERR_BAD_SHAPE, "colsum: bad shape");
+  if (!accumulate) {
+    if (hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s) != hipSuccess) { simx_set_error("colsum: memset failed"); return SIMX_ERR_HIP; }
+  }
+  int chunks = cdiv(T, 512);
+  if (chunks > 512) chunks = 512;
+  const int rpb = cdiv(T, chunks);
+  dim3 grid(cdiv(N, 64), cdiv(T, rpb));
+  if (dtype == SIMX_F32)
+    hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, s, T, N, (const float*)x, ldx, out, rpb);
+  else if (dtype == SIMX_BF16)
+    hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(256), 0, s, T, N, (const bf16_t*)x, ldx, out, rpb);
+  else { simx_set_error("colsum: dtype %d", dtype); return SIMX_ERR_BAD_DTYPE; }
+  SIMX_CHECK_LAUNCH("colsum");
+  return SIMX_OK;
+}
+
+extern "C" int simx_transpose_cast(simx_stream_t stream, int out_dtype, const float* w, int rows, int cols, void* out,
+                                   void* outT) {
+  SIMX_REQUIRE(rows > 0 && cols > 0 && w, SIMX_ERR_BAD_SHAPE, "transpose_cast: bad shape");
+  dim3 grid(cdiv(cols, 32), cdiv(rows, 32));
+  if (out_dtype == SIMX_BF16)
+    hipLaunchKernelGGL((cast_weight_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, w, rows, cols, (bf16_t*)out, (bf16_t*)outT);
+  else if (out_dtype == SIMX_F32)
+    hipLaunchKernelGGL((cast_weight_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, w, rows, cols, (float*)out, (float*)outT);
+  else { simx_set_error("transpose_cast: dtype %d", out_dtype); return SIMX_ERR_BAD_DTYPE; }
+  SIMX_CHECK_LAUNCH("cast_weight");
+  return SIMX_OK;
+}
+
+extern "C" int simx_cast_weight(simx_stream_t stream, const float* w, int rows, int cols, void* w_bf16, void* wT_bf16) {
+  return simx_transpose_cast(stream, SIMX_BF16, w, rows, cols, w_bf16, wT_bf16);
+}
+
+extern "C" int simx_gemm_f32_strided(simx_stream_t stream, int M, int N, int K, const float* A, long a_rs, long a_cs,
+                                     const float* B, long b_ks, long b_ns, float* C, int ldc, int accumulate) {
+  SIMX_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C, SIMX_ERR_BAD_SHAPE, "gemm_f32_strided: bad arguments");
+  return launch_simple<float, float>((hipStream_t)stream, SIMX_EPI_NONE, M, N, K, A, a_rs, a_cs, B, b_ks, b_ns, C, ldc, nullptr,
+                                     nullptr, 0, nullptr, 0, nullptr, 0, accumulate);
+}

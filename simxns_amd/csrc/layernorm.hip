@@ -1,0 +1,383 @@
+// Embedding gather + LayerNorm, residual LayerNorm, [CLS] gather/scatter -- the HBM-bound row
+// kernels of the encoder (BertEmbeddings / BertSelfOutput / BertOutput, LEAD/modeling_bert.py:181-240,
+// 377-388, 455-466).  One 64-lane wavefront owns one token row (H <= 1024: the row lives in registers,
+// 4 elements per lane per step, 8/16-byte accesses), statistics in f32 with a centred second pass,
+// wave-level butterflies only (no LDS, no barriers) in the forward kernels.  Backward kernels keep
+// per-lane column partial sums (dgamma, dbeta, dbias / dtype0) across the rows a workgroup walks and
+// flush them once with f32 atomics.
+#include "common.h"
+
+#define LN_VPL 4   // 4-element vectors per lane -> H <= 64*4*4 = 1024
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int H, const T* __restrict__ z,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float eps, T* __restrict__ y) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= rows) return;
+  const T* zr = z + (long)row * H;
+  float x[LN_VPL][4];
+  float sum = 0.f;
+#pragma unroll
+  for (int v = 0; v < LN_VPL; ++v) {
+    const int c = (v * 64 + lane) * 4;
+    if (c < H) { ld4(zr + c, x[v]); sum += x[v][0] + x[v][1] + x[v][2] + x[v][3]; }
+  }
+  const float mu = wave_sum(sum) / (float)H;
+  float sq = 0.f;
+#pragma unroll
+  for (int v = 0; v < LN_VPL; ++v) {
+    const int c = (v * 64 + lane) * 4;
+    if (c < H)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { x[v][e] -= mu; sq += x[v][e] * x[v][e]; }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)H + eps);
+  T* yr = y + (long)row * H;
+#pragma unroll
+  for (int v = 0; v < LN_VPL; ++v) {
+    const int c = (v * 64 + lane) * 4;
+    if (c < H) {
+      float g[4], b[4], o[4];
+      ld4(gamma + c, g);
+      ld4(beta + c, b);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = x[v][e] * rstd * g[e] + b[e];
+      st4(yr + c, o);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void embed_ln_fwd_kernel(int rows, int H, const int* __restrict__ ids,
+                                                           const int* __restrict__ pos, const float* __restrict__ word,
+                                                           const float* __restrict__ posw, const float* __restrict__ typew,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float eps, T* __restrict__ y) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= rows) return;
+  const float* wr = word + (long)ids[row] * H;
+  const float* pr = posw + (long)pos[row] * H;
+  float x[LN_VPL][4];
+  float sum = 0.f;
+#pragma unroll
+  for (int v = 0; v < LN_VPL; ++v) {
+    const int c = (v * 64 + lane) * 4;
+    if (c < H) {
+      float a[4], b[4], t[4];
+      ld4(wr + c, a);
+      ld4(pr + c, b);
+      ld4(typew + c, t);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { x[v][e] = a[e] + b[e] + t[e]; sum += x[v][e]; }
+    }
+  }
+  const float mu = wave_sum(sum) / (float)H;
+  float sq = 0.f;
+#pragma unroll
+  for (int v = 0; v < LN_VPL; ++v) {
+    const int c = (v * 64 + lane) * 4;
+    if (c < H)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { x[v][e] -= mu; sq += x[v][e] * x[v][e]; }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)H + eps);
+  T* yr = y + (long)row * H;
+#pragma unroll
+  for (int v = 0; v < LN_VPL; ++v) {
+    const int c = (v * 64 + lane) * 4;
+    if (c < H) {
+      float g[4], b[4], o[4];
+      ld4(gamma + c, g);
+      ld4(beta + c, b);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = x[v][e] * rstd * g[e] + b[e];
+      st4(yr + c, o);
+    }
+  }
+}
+
+// shared row-backward: given centred x (in/out: becomes xhat), dy -> dz ; accumulates column partials
+__device__ __forceinline__ void ln_row_bwd(int H, int lane, float (&x)[LN_VPL][4], float (&dy)[LN_VPL][4],
+                                           const float* __restrict__ gamma, float eps, float (&dz)[LN_VPL][4],
+                                           float (&pg)[LN_VPL][4], float (&pb)[LN_VPL][4]) {
+  float sq = 0.f;
+#pragma unroll
+  for (int v = 0; v < LN_VPL; ++v)
+    if ((v * 64 + lane) * 4 < H)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sq += x[v][e] * x[v][e];
+  const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)H + eps);
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int v = 0; v < LN_VPL; ++v) {
+    const int c = (v * 64 + lane) * 4;
+    if (c < H) {
+      float g[4];
+      ld4(gamma + c, g);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        x[v][e] *= rstd;                       // xhat
+        pg[v][e] += dy[v][e] * x[v][e];
+        pb[v][e] += dy[v][e];
+        dy[v][e] *= g[e];                      // dxhat
+        s1 += dy[v][e];
+        s2 += dy[v][e] * x[v][e];
+      }
+    }
+  }
+  s1 = wave_sum(s1) / (float)H;
+  s2 = wave_sum(s2) / (float)H;
+#pragma unroll
+  for (int v = 0; v < LN_VPL; ++v)
+    if ((v * 64 + lane) * 4 < H)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dz[v][e] = rstd * (dy[v][e] - s1 - x[v][e] * s2);
+}
+
+__device__ __forceinline__ void flush_cols(int H, int lane, int w, float (&p)[LN_VPL][4], float* __restrict__ out,
+                                           float* sred /* [4][H] */) {
+  // sum the 4 waves' partials through LDS, wave 0 issues the atomics
+#pragma unroll
+  for (int v = 0; v < LN_VPL; ++v) {
+    const int c = (v * 64 + lane) * 4;
+    if (c < H)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sred[w * H + c + e] = p[v][e];
+  }
+  __syncthreads();
+  if (w == 0) {
+#pragma unroll
+    for (int v = 0; v < LN_VPL; ++v) {
+      const int c = (v * 64 + lane) * 4;
+      if (c < H)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          atomicAdd(out + c + e, sred[c + e] + sred[H + c + e] + sred[2 * H + c + e] + sred[3 * H + c + e]);
+    }
+  }
+  __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int H, int rows_per_block, const T* __restrict__ z,
+                                                     const float* __restrict__ gamma, float eps, const T* __restrict__ dyp,
+                                                     T* __restrict__ dzp, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, float* __restrict__ dbias) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sred = reinterpret_cast<float*>(smem);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float pg[LN_VPL][4] = {}, pb[LN_VPL][4] = {}, pz[LN_VPL][4] = {};
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(rows, r0 + rows_per_block);
+  for (int row = r0 + w; row < r1; row += 4) {
+    const T* zr = z + (long)row * H;
+    const T* dr = dyp + (long)row * H;
+    float x[LN_VPL][4], dy[LN_VPL][4], dz[LN_VPL][4];
+    float sum = 0.f;
+#pragma unroll
+    for (int v = 0; v < LN_VPL; ++v) {
+      const int c = (v * 64 + lane) * 4;
+      if (c < H) { ld4(zr + c, x[v]); ld4(dr + c, dy[v]); sum += x[v][0] + x[v][1] + x[v][2] + x[v][3]; }
+    }
+    const float mu = wave_sum(sum) / (float)H;
+#pragma unroll
+    for (int v = 0; v < LN_VPL; ++v)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[v][e] -= mu;
+    ln_row_bwd(H, lane, x, dy, gamma, eps, dz, pg, pb);
+    T* o = dzp + (long)row * H;
+#pragma unroll
+    for (int v = 0; v < LN_VPL; ++v) {
+      const int c = (v * 64 + lane) * 4;
+      if (c < H) {
+        st4(o + c, dz[v]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pz[v][e] += dz[v][e];
+      }
+    }
+  }
+  flush_cols(H, lane, w, pg, dgamma, sred);
+  flush_cols(H, lane, w, pb, dbeta, sred);
+  if (dbias) flush_cols(H, lane, w, pz, dbias, sred);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void embed_ln_bwd_kernel(int rows, int H, int rows_per_block, const int* __restrict__ ids,
+                                                           const int* __restrict__ pos, const float* __restrict__ word,
+                                                           const float* __restrict__ posw, const float* __restrict__ typew,
+                                                           const float* __restrict__ gamma, float eps,
+                                                           const T* __restrict__ dyp, float* __restrict__ dword,
+                                                           float* __restrict__ dpos, float* __restrict__ dtype0,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sred = reinterpret_cast<float*>(smem);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float pg[LN_VPL][4] = {}, pb[LN_VPL][4] = {}, pz[LN_VPL][4] = {};
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(rows, r0 + rows_per_block);
+  for (int row = r0 + w; row < r1; row += 4) {
+    const long wid = ids[row], pid = pos[row];
+    const float* wr = word + wid * H;
+    const float* pr = posw + pid * H;
+    const T* dr = dyp + (long)row * H;
+    float x[LN_VPL][4], dy[LN_VPL][4], dz[LN_VPL][4];
+    float sum = 0.f;
+#pragma unroll
+    for (int v = 0; v < LN_VPL; ++v) {
+      const int c = (v * 64 + lane) * 4;
+      if (c < H) {
+        float a[4], b[4], t[4];
+        ld4(wr + c, a);
+        ld4(pr + c, b);
+        ld4(typew + c, t);
+        ld4(dr + c, dy[v]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { x[v][e] = a[e] + b[e] + t[e]; sum += x[v][e]; }
+      }
+    }
+    const float mu = wave_sum(sum) / (float)H;
+#pragma unroll
+    for (int v = 0; v < LN_VPL; ++v)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[v][e] -= mu;
+    ln_row_bwd(H, lane, x, dy, gamma, eps, dz, pg, pb);
+#pragma unroll
+    for (int v = 0; v < LN_VPL; ++v) {
+      const int c = (v * 64 + lane) * 4;
+      if (c < H)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          atomicAdd(dword + wid * H + c + e, dz[v][e]);
+          atomicAdd(dpos + pid * H + c + e, dz[v][e]);
+          pz[v][e] += dz[v][e];
+        }
+    }
+  }
+  flush_cols(H, lane, w, pg, dgamma, sred);
+  flush_cols(H, lane, w, pb, dbeta, sred);
+  flush_cols(H, lane, w, pz, dtype0, sred);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cls_gather_kernel(int nseq, int H, const int* __restrict__ cu,
+                                                         const T* __restrict__ x, float* __restrict__ cls) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)nseq * H) return;
+  const int s = (int)(i / H), c = (int)(i % H);
+  cls[i] = Elem<T>::ld(x + (long)cu[s] * H + c);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cls_scatter_kernel(int nseq, int H, const int* __restrict__ cu,
+                                                          const float* __restrict__ dcls, T* __restrict__ dx) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)nseq * H) return;
+  const int s = (int)(i / H), c = (int)(i % H);
+  Elem<T>::st(dx + (long)cu[s] * H + c, dcls[i]);
+}
+
+// ------------------------------------------------------------------------------------------ host
+static int ln_check(int dtype, int T, int H, const char* who) {
+  SIMX_REQUIRE(dtype == SIMX_F32 || dtype == SIMX_BF16, SIMX_ERR_BAD_DTYPE, "%s: dtype %d", who, dtype);
+  SIMX_REQUIRE(T > 0 && H > 0, SIMX_ERR_BAD_SHAPE, "%s: bad shape T=%d H=%d", who, T, H);
+  SIMX_REQUIRE(H % 4 == 0 && H <= 64 * 4 * LN_VPL, SIMX_ERR_UNSUPPORTED, "%s: H=%d must be a multiple of 4 and <= 1024", who, H);
+  return SIMX_OK;
+}
+
+static int bwd_rows_per_block(int T) {
+  int rpb = cdiv(T, 1024);
+  if (rpb < 16) rpb = 16;
+  return cdiv(rpb, 4) * 4;
+}
+
+extern "C" int simx_ln_fwd(simx_stream_t stream, int dtype, int T, int H, const void* z, const float* gamma,
+                           const float* beta, float eps, void* y) {
+  int rc = ln_check(dtype, T, H, "ln_fwd");
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == SIMX_F32)
+    hipLaunchKernelGGL((ln_fwd_kernel<float>), dim3(cdiv(T, 4)), dim3(256), 0, s, T, H, (const float*)z, gamma, beta, eps, (float*)y);
+  else
+    hipLaunchKernelGGL((ln_fwd_kernel<bf16_t>), dim3(cdiv(T, 4)), dim3(256), 0, s, T, H, (const bf16_t*)z, gamma, beta, eps, (bf16_t*)y);
+  SIMX_CHECK_LAUNCH("ln_fwd");
+  return SIMX_OK;
+}
+
+extern "C" int simx_ln_bwd(simx_stream_t stream, int dtype, int T, int H, const void* z, const float* gamma, float eps,
+                           const void* dy, void* dz, float* dgamma, float* dbeta, float* dbias) {
+  int rc = ln_check(dtype, T, H, "ln_bwd");
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const int rpb = bwd_rows_per_block(T);
+  const size_t lds = (size_t)4 * H * sizeof(float);
+  if (dtype == SIMX_F32)
+    hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, (const float*)z, gamma, eps,
+                       (const float*)dy, (float*)dz, dgamma, dbeta, dbias);
+  else
+    hipLaunchKernelGGL((ln_bwd_kernel<bf16_t>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, (const bf16_t*)z, gamma, eps,
+                       (const bf16_t*)dy, (bf16_t*)dz, dgamma, dbeta, dbias);
+  SIMX_CHECK_LAUNCH("ln_bwd");
+  return SIMX_OK;
+}
+
+extern "C" int simx_embed_ln_fwd(simx_stream_t stream, int dtype, int T, int H, const int32_t* ids, const int32_t* pos_ids,
+                                 const float* word, const float* posw, const float* typew, const float* gamma,
+                                 const float* beta, float eps, void* out) {
+  int rc = ln_check(dtype, T, H, "embed_ln_fwd");
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == SIMX_F32)
+    hipLaunchKernelGGL((embed_ln_fwd_kernel<float>), dim3(cdiv(T, 4)), dim3(256), 0, s, T, H, ids, pos_ids, word, posw, typew,
+                       gamma, beta, eps, (float*)out);
+  else
+    hipLaunchKernelGGL((embed_ln_fwd_kernel<bf16_t>), dim3(cdiv(T, 4)), dim3(256), 0, s, T, H, ids, pos_ids, word, posw, typew,
+                       gamma, beta, eps, (bf16_t*)out);
+  SIMX_CHECK_LAUNCH("embed_ln_fwd");
+  return SIMX_OK;
+}
+
+extern "C" int simx_embed_ln_bwd(simx_stream_t stream, int dtype, int T, int H, const int32_t* ids, const int32_t* pos_ids,
+                                 const float* word, const float* posw, const float* typew, const float* gamma, float eps,
+                                 const void* dy, float* dword, float* dpos, float* dtype0, float* dgamma, float* dbeta) {
+  int rc = ln_check(dtype, T, H, "embed_ln_bwd");
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const int rpb = bwd_rows_per_block(T);
+  const size_t lds = (size_t)4 * H * sizeof(float);
+  if (dtype == SIMX_F32)
+    hipLaunchKernelGGL((embed_ln_bwd_kernel<float>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, ids, pos_ids, word, posw,
+                       typew, gamma, eps, (const float*)dy, dword, dpos, dtype0, dgamma, dbeta);
+  else
+    hipLaunchKernelGGL((embed_ln_bwd_kernel<bf16_t>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, ids, pos_ids, word, posw,
+                       typew, gamma, eps, (const bf16_t*)dy, dword, dpos, dtype0, dgamma, dbeta);
+  SIMX_CHECK_LAUNCH("embed_ln_bwd");
+  return SIMX_OK;
+}
+
+extern "C" int simx_cls_gather(simx_stream_t stream, int dtype, int nseq, int H, const int32_t* cu, const void* x, float* cls) {
+  SIMX_REQUIRE(nseq > 0 && H > 0, SIMX_ERR_BAD_SHAPE, "cls_gather: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = (int)(((long)nseq * H + 255) / 256);
+  if (dtype == SIMX_F32) hipLaunchKernelGGL((cls_gather_kernel<float>), dim3(blocks), dim3(256), 0, s, nseq, H, cu, (const float*)x, cls);
+  else if (dtype == SIMX_BF16) hipLaunchKernelGGL((cls_gather_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, nseq, H, cu, (const bf16_t*)x, cls);
+  else { simx_set_error("cls_gather: dtype %d", dtype); return SIMX_ERR_BAD_DTYPE; }
+  SIMX_CHECK_LAUNCH("cls_gather");
+  return SIMX_OK;
+}
+
+extern "C" int simx_cls_scatter(simx_stream_t stream, int dtype, int nseq, int H, int T, const int32_t* cu,
+                                const float* dcls, void* dx) {
+  SIMX_REQUIRE(nseq > 0 && H > 0 && T >= nseq, SIMX_ERR_BAD_SHAPE, "cls_scatter: bad shape");
+  SIMX_REQUIRE(dtype == SIMX_F32 || dtype == SIMX_BF16, SIMX_ERR_BAD_DTYPE, "cls_scatter: dtype %d", dtype);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t esz = dtype == SIMX_F32 ? 4 : 2;
+  if (hipMemsetAsync(dx, 0, (size_t)T * H * esz, s) != hipSuccess) { simx_set_error("cls_scatter: memset failed"); return SIMX_ERR_HIP; }
+  const int blocks = (int)(((long)nseq * H + 255) / 256);
+  if (dtype == SIMX_F32) hipLaunchKernelGGL((cls_scatter_kernel<float>), dim3(blocks), dim3(256), 0, s, nseq, H, cu, dcls, (float*)dx);
+  else hipLaunchKernelGGL((cls_scatter_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, nseq, H, cu, dcls, (bf16_t*)dx);
+  SIMX_CHECK_LAUNCH("cls_scatter");
+  return SIMX_OK;
+}

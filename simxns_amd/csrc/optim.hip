@@ -1,0 +1,87 @@
+// clip_grad_norm_ + transformers.AdamW + zero_grad as two HBM-bound passes over the flat f32 buffers
+// (SimANS/co_training/co_training_marco_train.py:57-69, 246-254; update rule SURVEY App. C).
+// Pass 1 reads g (4 B/param) for the global L2 norm; pass 2 reads p,g,m,v and writes p,m,v,(g=0):
+// 28 (+4) B/param, 16-byte accesses, no host synchronisation (the clip coefficient is computed on
+// device from the norm accumulator).
+#include "common.h"
+
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, size_t n, float* __restrict__ out) {
+  __shared__ float part[4];
+  float s = 0.f;
+  const size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(g)[i];
+    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (blockIdx.x == 0) for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) s += g[i] * g[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, size_t n, float step_size, float beta1, float beta2,
+                                                    float eps, float decay, const float* __restrict__ sqnorm, float max_norm,
+                                                    float grad_scale, int zero_grad) {
+  float coef = grad_scale;
+  if (sqnorm && max_norm > 0.f) {
+    const float total = sqrtf(*sqnorm) * grad_scale;
+    coef *= fminf(1.0f, max_norm / (total + 1e-6f));
+  }
+  const size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 pv = reinterpret_cast<float4*>(p)[i], gv = reinterpret_cast<float4*>(g)[i];
+    float4 mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+    float* pp = &pv.x; float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gg = gp[e] * coef;
+      mp[e] = beta1 * mp[e] + (1.0f - beta1) * gg;
+      vp[e] = beta2 * vp[e] + (1.0f - beta2) * gg * gg;
+      pp[e] = pp[e] - step_size * mp[e] / (sqrtf(vp[e]) + eps);
+      pp[e] = pp[e] - decay * pp[e];
+    }
+    reinterpret_cast<float4*>(p)[i] = pv;
+    reinterpret_cast<float4*>(m)[i] = mv;
+    reinterpret_cast<float4*>(v)[i] = vv;
+    if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (blockIdx.x == 0)
+    for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) {
+      const float gg = g[i] * coef;
+      m[i] = beta1 * m[i] + (1.0f - beta1) * gg;
+      v[i] = beta2 * v[i] + (1.0f - beta2) * gg * gg;
+      float pn = p[i] - step_size * m[i] / (sqrtf(v[i]) + eps);
+      p[i] = pn - decay * pn;
+      if (zero_grad) g[i] = 0.f;
+    }
+}
+
+extern "C" int simx_sqnorm_accum(simx_stream_t stream, const float* g, size_t n, float* sqnorm) {
+  SIMX_REQUIRE(g && sqnorm && n > 0, SIMX_ERR_BAD_SHAPE, "sqnorm_accum: bad arguments");
+  SIMX_REQUIRE((((uintptr_t)g) & 15) == 0, SIMX_ERR_BAD_SHAPE, "sqnorm_accum: g not 16-B aligned");
+  size_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, n, sqnorm);
+  SIMX_CHECK_LAUNCH("sqnorm");
+  return SIMX_OK;
+}
+
+extern "C" int simx_adamw_step(simx_stream_t stream, float* p, float* g, float* m, float* v, size_t n, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, int step, const float* sqnorm, float max_norm,
+                               float grad_scale, int zero_grad) {
+  SIMX_REQUIRE(p && g && m && v && n > 0 && step >= 1, SIMX_ERR_BAD_SHAPE, "adamw_step: bad arguments");
+  SIMX_REQUIRE(((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0, SIMX_ERR_BAD_SHAPE,
+               "adamw_step: buffers not 16-B aligned");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr * sqrt(bc2) / bc1);
+  size_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, step_size, beta1,
+                     beta2, eps, lr * weight_decay, sqnorm, max_norm, grad_scale, zero_grad);
+  SIMX_CHECK_LAUNCH("adamw");
+  return SIMX_OK;
+}

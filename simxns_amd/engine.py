@@ -1,0 +1,257 @@
+"""Host side of the MI355X encoder engine: owns the flat f32 parameter / gradient buffers, the
+bf16 weight cache and the per-call activation buffers, and drives the C-ABI encoder
+(simx_bert_fwd / simx_bert_bwd) from PyTorch autograd.
+
+PyTorch is plumbing here: device memory (caching allocator), the current HIP stream and the
+autograd edge between the [CLS] embeddings and the loss.  All arithmetic runs in
+libsimx_hip.so; there is no eager fallback.
+"""
+import ctypes as C
+import json
+import os
+from collections import OrderedDict
+
+import torch
+
+from . import _lib as L
+
+
+class BertConfigLite(object):
+    """The few BertConfig fields the path needs (config.json compatible with HF)."""
+
+    def __init__(self, vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                 intermediate_size=3072, max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12,
+                 hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, **kw):
+        self.vocab_size, self.hidden_size = vocab_size, hidden_size
+        self.num_hidden_layers, self.num_attention_heads = num_hidden_layers, num_attention_heads
+        self.intermediate_size, self.max_position_embeddings = intermediate_size, max_position_embeddings
+        self.type_vocab_size, self.layer_norm_eps = type_vocab_size, layer_norm_eps
+        self.hidden_dropout_prob, self.attention_probs_dropout_prob = hidden_dropout_prob, attention_probs_dropout_prob
+        self.gradient_checkpointing = kw.get("gradient_checkpointing", False)
+        self.extra = kw
+
+    @classmethod
+    def from_pretrained(cls, path):
+        f = path if path.endswith(".json") else os.path.join(path, "config.json")
+        if not os.path.exists(f):
+            known = {"bert-base-uncased": {}, "bert-large-uncased": dict(hidden_size=1024, num_hidden_layers=24,
+                     num_attention_heads=16, intermediate_size=4096)}
+            key = os.path.basename(str(path).rstrip("/"))
+            if key in known:
+                return cls(**known[key])
+            raise FileNotFoundError("no config.json under %r and not a known model name" % (path,))
+        with open(f) as fh:
+            return cls(**json.load(fh))
+
+    def to_dict(self):
+        return dict(vocab_size=self.vocab_size, hidden_size=self.hidden_size, num_hidden_layers=self.num_hidden_layers,
+                    num_attention_heads=self.num_attention_heads, intermediate_size=self.intermediate_size,
+                    max_position_embeddings=self.max_position_embeddings, type_vocab_size=self.type_vocab_size,
+                    layer_norm_eps=self.layer_norm_eps, model_type="bert")
+
+
+def _dtype_code(name):
+    if name in ("bf16", "bfloat16", torch.bfloat16):
+        return L.SIMX_BF16
+    if name in ("fp32", "float32", "f32", torch.float32):
+        return L.SIMX_F32
+    raise ValueError("compute dtype must be 'bf16' or 'fp32', got %r" % (name,))
+
+
+def hf_param_layout(cfg, ccfg):
+    """[(hf_key, flat_offset, shape)] in HF registration order (state_dict schema)."""
+    lib = L.load()
+    H, F = cfg.hidden_size, cfg.intermediate_size
+    off = lambda layer, which: lib.simx_bert_param_offset(C.byref(ccfg), layer, which)
+    out = [("embeddings.word_embeddings.weight", off(-1, L.P_WORD), (cfg.vocab_size, H)),
+           ("embeddings.position_embeddings.weight", off(-1, L.P_POS), (cfg.max_position_embeddings, H)),
+           ("embeddings.token_type_embeddings.weight", off(-1, L.P_TYPE), (cfg.type_vocab_size, H)),
+           ("embeddings.LayerNorm.weight", off(-1, L.P_EMB_LN_G), (H,)),
+           ("embeddings.LayerNorm.bias", off(-1, L.P_EMB_LN_B), (H,))]
+    for i in range(cfg.num_hidden_layers):
+        p = "encoder.layer.%d." % i
+        wq, bq = off(i, L.P_WQKV), off(i, L.P_BQKV)
+        for j, nm in enumerate(("query", "key", "value")):
+            out.append((p + "attention.self.%s.weight" % nm, wq + j * H * H, (H, H)))
+            out.append((p + "attention.self.%s.bias" % nm, bq + j * H, (H,)))
+        out += [(p + "attention.output.dense.weight", off(i, L.P_WO), (H, H)),
+                (p + "attention.output.dense.bias", off(i, L.P_BO), (H,)),
+                (p + "attention.output.LayerNorm.weight", off(i, L.P_LN1_G), (H,)),
+                (p + "attention.output.LayerNorm.bias", off(i, L.P_LN1_B), (H,)),
+                (p + "intermediate.dense.weight", off(i, L.P_W1), (F, H)),
+                (p + "intermediate.dense.bias", off(i, L.P_B1), (F,)),
+                (p + "output.dense.weight", off(i, L.P_W2), (H, F)),
+                (p + "output.dense.bias", off(i, L.P_B2), (H,)),
+                (p + "output.LayerNorm.weight", off(i, L.P_LN2_G), (H,)),
+                (p + "output.LayerNorm.bias", off(i, L.P_LN2_B), (H,))]
+    n = cfg.num_hidden_layers
+    out += [("pooler.dense.weight", off(n, L.P_POOL_W), (H, H)), ("pooler.dense.bias", off(n, L.P_POOL_B), (H,))]
+    return out
+
+
+class PackedBatch(object):
+    """Right-padded (input_ids, attention_mask) -> packed real tokens + cu_seqlens (device, int32)."""
+
+    def __init__(self, input_ids, attention_mask):
+        assert input_ids.dim() == 2 and input_ids.shape == attention_mask.shape
+        n, S = input_ids.shape
+        m = attention_mask != 0
+        lens = m.sum(1)
+        stats = torch.stack([lens.sum(), lens.max(), m[:, 0].min().to(lens.dtype)]).tolist()   # one host sync
+        self.T, self.max_len = int(stats[0]), int(stats[1])
+        if int(stats[2]) == 0:
+            raise ValueError("attention_mask[:, 0] must be 1: the [CLS] position is the embedding (models.py:81)")
+        self.nseq, self.S = n, S
+        cu = torch.zeros(n + 1, dtype=torch.int32, device=input_ids.device)
+        cu[1:] = torch.cumsum(lens, 0).to(torch.int32)
+        self.cu = cu
+        if self.T == n * S:
+            self.index = None
+            self.ids = input_ids.reshape(-1).to(torch.int32)
+            self.pos = torch.arange(S, device=input_ids.device, dtype=torch.int32).repeat(n)
+        else:
+            self.index = m.reshape(-1).nonzero(as_tuple=False).squeeze(1)
+            self.ids = input_ids.reshape(-1)[self.index].to(torch.int32)
+            self.pos = (self.index % S).to(torch.int32)
+
+    def unpack(self, packed, fill=0.0):
+        """packed [T,H] -> padded [n,S,H] (pad rows = fill)."""
+        H = packed.shape[1]
+        if self.index is None:
+            return packed.reshape(self.nseq, self.S, H)
+        out = packed.new_full((self.nseq * self.S, H), fill)
+        out[self.index] = packed
+        return out.reshape(self.nseq, self.S, H)
+
+
+class _EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, engine, pb, want_hidden):
+        cls, hidden, act = engine._run_forward(pb, True, want_hidden)
+        ctx.engine, ctx.pb, ctx.act = engine, pb, act
+        if want_hidden:
+            ctx.mark_non_differentiable(hidden)
+            return cls, hidden
+        return cls
+
+    @staticmethod
+    def backward(ctx, dcls, *unused):
+        ctx.engine._run_backward(ctx.pb, ctx.act, dcls)
+        ctx.act = None
+        return None, None, None, None
+
+
+class BertEngine(object):
+    """One BERT tower on one GPU."""
+
+    def __init__(self, cfg, compute_dtype="bf16"):
+        self.cfg = cfg
+        self.lib = L.load()
+        self.set_compute_dtype(compute_dtype)
+        self.layout = hf_param_layout(cfg, self.ccfg)
+        self.n_params = int(self.lib.simx_bert_param_count(C.byref(self.ccfg)))
+        self.flat = torch.zeros(self.n_params, dtype=torch.float32)
+        self.flat_grad = None
+        self.wcache = None
+        self._wcache_version = None
+        self._dirty = True
+        self.anchor = torch.zeros((), requires_grad=True)
+        self.grad_ready_hook = None          # called after every backward (DP all-reduce launch)
+        self.after_backward = None           # module callback: expose flat_grad as param.grad views
+
+    # ---- configuration -----------------------------------------------------------------
+    def set_compute_dtype(self, name):
+        c = self.cfg
+        self.dtype_code = _dtype_code(name)
+        self.ccfg = L.BertCfg(self.dtype_code, c.num_hidden_layers, c.hidden_size, c.num_attention_heads,
+                              c.intermediate_size, c.vocab_size, c.max_position_embeddings, c.type_vocab_size,
+                              float(c.layer_norm_eps))
+        self.wcache = None
+        self._dirty = True
+
+    @property
+    def act_torch_dtype(self):
+        return torch.bfloat16 if self.dtype_code == L.SIMX_BF16 else torch.float32
+
+    def views(self, base):
+        out = OrderedDict()
+        for name, off, shape in self.layout:
+            n = 1
+            for s in shape:
+                n *= s
+            out[name] = base[off:off + n].view(*shape)
+        return out
+
+    def to(self, device):
+        if self.flat.device != torch.device(device):
+            self.flat = self.flat.to(device)
+            if self.flat_grad is not None:
+                self.flat_grad = self.flat_grad.to(device)
+            self.wcache = None
+            self._dirty = True
+        return self
+
+    def ensure_grad(self):
+        if self.flat_grad is None or self.flat_grad.device != self.flat.device:
+            self.flat_grad = torch.zeros_like(self.flat)
+        return self.flat_grad
+
+    def mark_weights_dirty(self):
+        self._dirty = True
+
+    # ---- device work ---------------------------------------------------------------------
+    def _require_gpu(self):
+        if not self.flat.is_cuda:
+            raise L.SimxError("the encoder runs only on a HIP device: move the module to 'cuda' "
+                              "(there is no CPU fallback in the product path)")
+
+    def _refresh_wcache(self):
+        if self.wcache is not None and not self._dirty and self._wcache_version == self.flat._version:
+            return
+        nbytes = int(self.lib.simx_bert_wcache_bytes(C.byref(self.ccfg)))
+        if self.wcache is None or self.wcache.numel() != nbytes or self.wcache.device != self.flat.device:
+            self.wcache = torch.empty(nbytes, dtype=torch.uint8, device=self.flat.device)
+        L.call("simx_bert_cast_weights", L.stream_ptr(), C.byref(self.ccfg), L.ptr(self.flat), L.ptr(self.wcache))
+        self._dirty = False
+        self._wcache_version = self.flat._version
+
+    def _run_forward(self, pb, save, want_hidden):
+        self._require_gpu()
+        self._refresh_wcache()
+        dev = self.flat.device
+        H = self.cfg.hidden_size
+        nbytes = int(self.lib.simx_bert_act_bytes(C.byref(self.ccfg), pb.T, pb.nseq, 1 if save else 0))
+        act = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        cls = torch.empty(pb.nseq, H, dtype=torch.float32, device=dev)
+        hidden = torch.empty(pb.T, H, dtype=self.act_torch_dtype, device=dev) if want_hidden else None
+        L.call("simx_bert_fwd", L.stream_ptr(), C.byref(self.ccfg), L.ptr(self.flat), L.ptr(self.wcache),
+               L.ptr(pb.ids), L.ptr(pb.pos), L.ptr(pb.cu), pb.nseq, pb.T, pb.max_len, L.ptr(act), nbytes,
+               1 if save else 0, L.ptr(cls), L.ptr(hidden))
+        return cls, hidden, (act if save else None)
+
+    def _run_backward(self, pb, act, dcls):
+        g = self.ensure_grad()
+        dev = self.flat.device
+        dcls = dcls.contiguous().to(torch.float32)
+        nbytes = int(self.lib.simx_bert_bwd_scratch_bytes(C.byref(self.ccfg), pb.T, pb.nseq))
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        L.call("simx_bert_bwd", L.stream_ptr(), C.byref(self.ccfg), L.ptr(self.flat), L.ptr(self.wcache),
+               L.ptr(pb.ids), L.ptr(pb.pos), L.ptr(pb.cu), pb.nseq, pb.T, pb.max_len, L.ptr(act), act.numel(),
+               L.ptr(dcls), L.ptr(g), L.ptr(scratch), nbytes)
+        if self.after_backward is not None:
+            self.after_backward()
+        if self.grad_ready_hook is not None:
+            self.grad_ready_hook(self)
+
+    def encode(self, input_ids, attention_mask, want_hidden=False, requires_grad=None):
+        """-> cls [n,H] f32 (and the packed last hidden state + PackedBatch when want_hidden)."""
+        pb = PackedBatch(input_ids, attention_mask)
+        if requires_grad is None:
+            requires_grad = torch.is_grad_enabled()
+        if requires_grad and torch.is_grad_enabled():
+            if self.anchor.device != self.flat.device:
+                self.anchor = torch.zeros((), requires_grad=True, device=self.flat.device)
+            out = _EncoderFn.apply(self.anchor, self, pb, want_hidden)
+            return (out[0], out[1], pb) if want_hidden else out
+        cls, hidden, _ = self._run_forward(pb, False, want_hidden)
+        return (cls, hidden, pb) if want_hidden else cls

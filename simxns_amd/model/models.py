@@ -1,0 +1,246 @@
+"""Drop-in module API of SimANS/model/models.py on the MI355X engine.
+
+Same class names, constructor arguments, method signatures, return conventions and
+``state_dict`` key schema as the reference (file:line cited per symbol), so that
+``co_training_*_train.py`` and released AR2 / SimANS checkpoints work unchanged; the arithmetic
+runs in libsimx_hip.so (include/simx.h).  Out of scope: Reader/MML, *_daya,
+Cross_Encoder, Reranker_2, adv_* forward variants.
+"""
+import os
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import ops
+from ..engine import BertConfigLite, BertEngine
+
+
+class _Holder(nn.Module):
+    """Name-space node so that parameters carry HF state_dict keys."""
+
+
+class HFBertEncoder(nn.Module):
+    """SimANS/model/models.py:58-82.  forward(**kwargs) -> (sequence_output, pooled_output, None) where
+    pooled_output = sequence_output[:, 0, :] (raw last-layer [CLS], no projection; the pooler is kept in the
+    state_dict but its output is multiplied by 0 in the reference, so its gradient is exactly 0 and it is
+    never computed here)."""
+
+    def __init__(self, config, compute_dtype=None):
+        super(HFBertEncoder, self).__init__()
+        assert config.hidden_size > 0, 'Encoder hidden_size can\'t be zero'
+        self.config = config
+        self.engine = BertEngine(config, compute_dtype or os.environ.get("SIMX_DTYPE", "bf16"))
+        for name, view in self.engine.views(self.engine.flat).items():
+            parts = name.split(".")
+            mod = self
+            for p in parts[:-1]:
+                if p not in mod._modules:
+                    mod.add_module(p, _Holder())
+                mod = mod._modules[p]
+            mod.register_parameter(parts[-1], nn.Parameter(view))
+        self.engine.after_backward = self.attach_grads
+        self.init_weights()
+
+    # -- parameters live in ONE flat f32 buffer; nn.Parameters are views of it ------------------
+    def _rebind(self):
+        views = self.engine.views(self.engine.flat)
+        gviews = self.engine.views(self.engine.flat_grad) if self.engine.flat_grad is not None else None
+        for name, p in self.named_parameters():
+            p.data = views[name]
+            if gviews is not None:
+                p.grad = gviews[name]
+        self.engine.mark_weights_dirty()
+
+    def _apply(self, fn, recurse=True):
+        new_flat = fn(self.engine.flat)
+        if new_flat.dtype != torch.float32:
+            raise TypeError("master parameters stay float32; choose the compute dtype with set_compute_dtype()")
+        self.engine.flat = new_flat
+        if self.engine.flat_grad is not None:
+            self.engine.flat_grad = fn(self.engine.flat_grad)
+        self.engine.wcache = None
+        self._rebind()
+        return self
+
+    def set_compute_dtype(self, name):
+        self.engine.set_compute_dtype(name)
+        return self
+
+    def attach_grads(self):
+        """Expose the flat gradient buffer as ``param.grad`` views (done after every backward)."""
+        if self.engine.flat_grad is None:
+            return
+        gviews = self.engine.views(self.engine.flat_grad)
+        for name, p in self.named_parameters():
+            if p.grad is None or p.grad.data_ptr() != gviews[name].data_ptr():
+                p.grad = gviews[name]
+
+    def zero_grad(self, set_to_none=False):
+        if self.engine.flat_grad is not None:
+            self.engine.flat_grad.zero_()
+
+    def init_weights(self):
+        # HF BertPreTrainedModel._init_weights == reference init_weights (models.py:452-465)
+        with torch.no_grad():
+            for name, p in self.named_parameters():
+                if name.endswith("LayerNorm.weight"):
+                    p.fill_(1.0)
+                elif name.endswith(".bias"):
+                    p.zero_()
+                else:
+                    p.normal_(mean=0.0, std=0.02)
+        self.engine.mark_weights_dirty()
+
+    def _load_from_state_dict(self, *a, **k):
+        super(HFBertEncoder, self)._load_from_state_dict(*a, **k)
+        self.engine.mark_weights_dirty()
+
+    def load_numpy_state(self, state):
+        with torch.no_grad():
+            own = dict(self.named_parameters())
+            for k, v in state.items():
+                own[k].copy_(torch.from_numpy(np.asarray(v, dtype=np.float32)))
+        self.engine.mark_weights_dirty()
+
+    @classmethod
+    def init_encoder(cls, args, dropout: float = 0.1, model_type=None, compute_dtype=None):
+        """models.py:65-75.  ``model_type`` is a local directory with config.json (+ model.safetensors or
+        pytorch_model.bin) or a known name; without weights on disk the encoder is randomly initialised
+        (this image has no network)."""
+        if model_type is None:
+            model_type = args.model_type
+        cfg = BertConfigLite.from_pretrained(model_type)
+        if dropout != 0:
+            cfg.attention_probs_dropout_prob = dropout
+            cfg.hidden_dropout_prob = dropout
+        cfg.gradient_checkpointing = getattr(args, "gradient_checkpointing", False)
+        if compute_dtype is None:
+            compute_dtype = "bf16" if getattr(args, "fp16", False) or os.environ.get("SIMX_DTYPE", "bf16") == "bf16" else "fp32"
+        enc = cls(cfg, compute_dtype=compute_dtype)
+        if os.path.isdir(str(model_type)):
+            st = os.path.join(model_type, "model.safetensors")
+            pt = os.path.join(model_type, "pytorch_model.bin")
+            sd = None
+            if os.path.exists(st):
+                from safetensors.torch import load_file
+                sd = load_file(st)
+            elif os.path.exists(pt):
+                sd = torch.load(pt, map_location="cpu")
+            if sd is not None:
+                sd = {(k[5:] if k.startswith("bert.") else k): v for k, v in sd.items()}
+                enc.load_state_dict({k: v for k, v in sd.items() if k in dict(enc.named_parameters())}, strict=False)
+        return enc
+
+    def forward(self, **kwargs):
+        input_ids = kwargs.get("input_ids")
+        attention_mask = kwargs.get("attention_mask")
+        if input_ids is None:
+            raise NotImplementedError("inputs_embeds is not supported by the MI355X engine; pass input_ids")
+        tt = kwargs.get("token_type_ids")
+        if tt is not None and bool((tt != 0).any()):
+            raise NotImplementedError("token_type_ids other than 0 are not used on this path (models.py:654)")
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        cls_vec, hidden, pb = self.engine.encode(input_ids, attention_mask, want_hidden=True)
+        if self.engine.flat_grad is not None:
+            self.attach_grads()
+        seq = pb.unpack(hidden.to(torch.float32))
+        # gradient reaches the encoder through the [CLS] row only (the only row the reference path uses)
+        seq = seq.index_copy(1, torch.zeros(1, dtype=torch.long, device=seq.device), cls_vec.unsqueeze(1))
+        return seq, seq[:, 0, :], None
+
+    def embed(self, input_ids, attention_mask):
+        """Fast path used by BiBertEncoder / Reranker: [CLS] embeddings [n,H] f32 only."""
+        out = self.engine.encode(input_ids, attention_mask)
+        return out
+
+
+class BiBertEncoder(nn.Module):
+    """ Bi-Encoder model component. Encapsulates query/question and context/passage encoders.
+    (SimANS/model/models.py:85-118) """
+
+    def __init__(self, args):
+        super(BiBertEncoder, self).__init__()
+        self.question_model = HFBertEncoder.init_encoder(args)
+        if hasattr(args, 'share_weight') and args.share_weight:
+            self.ctx_model = self.question_model
+        else:
+            self.ctx_model = HFBertEncoder.init_encoder(args)
+
+    def query_emb(self, input_ids, attention_mask):
+        return self.question_model.embed(input_ids, attention_mask)
+
+    def body_emb(self, input_ids, attention_mask):
+        return self.ctx_model.embed(input_ids, attention_mask)
+
+    def forward(self, query_ids, attention_mask_q, input_ids_a=None, attention_mask_a=None, input_ids_b=None,
+                attention_mask_b=None):
+        if input_ids_b is None:
+            q_embs = self.query_emb(query_ids, attention_mask_q)
+            a_embs = self.body_emb(input_ids_a, attention_mask_a)
+            return (q_embs, a_embs)
+        # triplet form (models.py:111-118): -log_softmax([q.a, q.b])[0], mean over the batch
+        q_embs = self.query_emb(query_ids, attention_mask_q)
+        a_embs = self.body_emb(input_ids_a, attention_mask_a)
+        b_embs = self.body_emb(input_ids_b, attention_mask_b)
+        B = q_embs.shape[0]
+        ab = torch.stack([a_embs, b_embs], dim=1).reshape(2 * B, -1)
+        loss, _ = ops.pair_ce_loss(q_embs, ab)
+        return (loss,)
+
+    def zero_grad(self, set_to_none=False):
+        self.question_model.zero_grad()
+        self.ctx_model.zero_grad()
+
+
+class Reranker(nn.Module):
+    """SimANS/model/models.py:638-659: cross-encoder, Linear(H,1) on [CLS]."""
+
+    def __init__(self, encoder: nn.Module, hidden_size):
+        super(Reranker, self).__init__()
+        self.encoder = encoder
+        self.qa_classifier = nn.Linear(hidden_size, 1)
+
+    def forward(self, input_ids, attention_mask):
+        # notations: N - number of questions in a batch, M - number of passages per questions, L - sequence length
+        N, M, L = input_ids.size()
+        relevance_logits = self._forward(input_ids.view(N * M, L), attention_mask.view(N * M, L))
+        return relevance_logits.view(N, M)
+
+    def _forward(self, input_ids, attention_mask):
+        cls_vec = self.encoder.embed(input_ids, attention_mask)
+        return ops.linear_f32(cls_vec, self.qa_classifier.weight, self.qa_classifier.bias)
+
+    def zero_grad(self, set_to_none=False):
+        self.encoder.zero_grad()
+        for p in self.qa_classifier.parameters():
+            if p.grad is not None:
+                p.grad.zero_()
+
+
+class BiEncoderNllLoss(object):
+    """SimANS/model/models.py:468-514."""
+
+    def calc(self, q_vectors, ctx_vectors, positive_idx_per_question: list, hard_negative_idx_per_question: list = None,
+             loss_scale: float = None, local_q=None, local_ctx=None):
+        """-> (loss, correct_predictions_count).  ``local_q`` / ``local_ctx`` = (row_offset, rows): the rows of
+        the rank-ordered global concatenation that belong to this rank and carry gradient
+        (PROD/ProD_base/train_DE_model_marco.py:251-264); default: all rows."""
+        loss, correct = ops.inbatch_nll_loss(q_vectors, ctx_vectors, positive_idx_per_question, loss_scale,
+                                             local_q, local_ctx)
+        return loss, correct.to(torch.long)
+
+    @staticmethod
+    def get_scores(q_vector, ctx_vectors):
+        f = BiEncoderNllLoss.get_similarity_function()
+        return f(q_vector, ctx_vectors)
+
+    @staticmethod
+    def get_similarity_function():
+        return dot_product_scores
+
+
+def dot_product_scores(q_vectors, ctx_vectors):
+    """SimANS/model/models.py:564-572: q->ctx scores for every row in ctx_vector."""
+    return ops.dot_product_scores(q_vectors, ctx_vectors)

@@ -1,0 +1,213 @@
+"""torch-facing wrappers of the f32 similarity / loss / sampler / optimiser kernels.
+
+Each wrapper validates tensors, hands raw device pointers and the current HIP stream to the
+C ABI (include/simx.h) and, where a gradient exists, ties the kernel's closed-form backward
+ into autograd.  No wrapper has an eager fallback.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+
+
+def _f32c(t):
+    if not t.is_cuda:
+        raise L.SimxError("simxns_amd ops run only on a HIP device (no CPU fallback)")
+    return t.contiguous().to(torch.float32)
+
+
+# ------------------------------------------------------------------------------------------ M1 + L1/L2/L3/L6
+class _SimLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, c, teacher, lp):
+        q, c = _f32c(q), _f32c(c)
+        B, H = q.shape
+        D = c.shape[0] // B
+        assert c.shape[0] == B * D and c.shape[1] == H
+        teacher = _f32c(teacher) if teacher is not None else None
+        sim = torch.empty(B, D, dtype=torch.float32, device=q.device)
+        losses = torch.empty(4, dtype=torch.float32, device=q.device)
+        dq, dc = torch.empty_like(q), torch.empty_like(c)
+        L.call("simx_sim_loss_fwd_bwd", L.stream_ptr(), B, D, H, L.ptr(q), L.ptr(c), L.ptr(teacher), C.byref(lp),
+               L.ptr(sim), L.ptr(losses), L.ptr(dq), L.ptr(dc))
+        ctx.save_for_backward(dq, dc)
+        ctx.mark_non_differentiable(sim)
+        return losses[0], losses.detach(), sim
+
+    @staticmethod
+    def backward(ctx, g, g_all, g_sim):
+        dq, dc = ctx.saved_tensors
+        return dq * g, dc * g, None, None
+
+
+class _LogitLossFn(torch.autograd.Function):
+    """Loss on ready-made logits [B,D] (teacher CE, L6)."""
+
+    @staticmethod
+    def forward(ctx, logits, teacher, lp):
+        z = _f32c(logits).clone()
+        B, D = z.shape
+        teacher = _f32c(teacher) if teacher is not None else None
+        losses = torch.empty(4, dtype=torch.float32, device=z.device)
+        dz = torch.empty_like(z)
+        L.call("simx_sim_loss_fwd_bwd", L.stream_ptr(), B, D, 0, None, None, L.ptr(teacher), C.byref(lp), L.ptr(z),
+               L.ptr(losses), None, L.ptr(dz))
+        ctx.save_for_backward(dz)
+        return losses[0], losses.detach()
+
+    @staticmethod
+    def backward(ctx, g, g_all):
+        (dz,) = ctx.saved_tensors
+        return dz * g, None, None
+
+
+def _lp(kind, scale=1.0, temperature=1.0, adv_lambda=0.0, ce_w=0.0, kd_w=0.0, grad_accum=1.0):
+    return L.LossParams(kind, float(scale), float(temperature), float(adv_lambda), float(ce_w), float(kd_w),
+                        float(grad_accum))
+
+
+def kl_distill_loss(q, ctx_vectors, teacher_logits, temperature_distill=1.0, scale_simmila=False, grad_accum=1):
+    """co_training_marco_train.py:199-217 in one kernel.  -> (loss/grad_accum, distill_loss, student_simila)."""
+    scale = 1.0 / math.sqrt(q.shape[1]) if scale_simmila else 1.0
+    loss, allv, sim = _SimLossFn.apply(q, ctx_vectors, teacher_logits,
+                                       _lp(L.LOSS_KL, scale, temperature_distill, grad_accum=grad_accum))
+    return loss, allv[1], sim
+
+
+def wiki_normal_adv_loss(q, ctx_vectors, reranker_logits, temperature_normal=1.0, adv_lambda=0.0, scale_simmila=False,
+                         grad_accum=1):
+    """co_training_wiki_train.py:199-228.  -> (loss/grad_accum, normal_loss, adv_loss, retriever_simila)."""
+    scale = 1.0 / math.sqrt(q.shape[1]) if scale_simmila else 1.0
+    loss, allv, sim = _SimLossFn.apply(q, ctx_vectors, reranker_logits,
+                                       _lp(L.LOSS_WIKI, scale, temperature_normal, adv_lambda, grad_accum=grad_accum))
+    return loss, allv[1], allv[2], sim
+
+
+def cross_kd_loss(q, ctx_vectors, relevance_logits, temperature=4.0, ce_weight=0.1, kd_weight=0.9):
+    """PROD CrossBERTKDLoss.calc (KD_softmax).  -> (loss, correct_count, hard, soft)."""
+    loss, allv, _ = _SimLossFn.apply(q, ctx_vectors, relevance_logits,
+                                     _lp(L.LOSS_CEKD, 1.0, temperature, 0.0, ce_weight, kd_weight))
+    return loss, allv[3], allv[1], allv[2]
+
+
+def pair_ce_loss(q, ctx_vectors):
+    """-log_softmax(einsum('bh,bdh->bd'))[:,0].mean() (BiBertEncoder triplet form, models.py:111-118)."""
+    loss, allv, _ = _SimLossFn.apply(q, ctx_vectors, None, _lp(L.LOSS_CE))
+    return loss, allv[3]
+
+
+def teacher_ce_loss(relevance_logits, grad_accum=1):
+    """co_training_marco_train.py:228-236: CrossEntropy(logits, target 0).  -> (loss/grad_accum, contr_loss)."""
+    loss, allv = _LogitLossFn.apply(relevance_logits, None, _lp(L.LOSS_CE, grad_accum=grad_accum))
+    return loss, allv[1]
+
+
+# ------------------------------------------------------------------------------------------ M2
+class _NllFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, c, pos_idx, loss_scale, q_lo, q_n, c_lo, c_n):
+        q, c = _f32c(q), _f32c(c)
+        Q, H = q.shape
+        Cn = c.shape[0]
+        pos = torch.as_tensor(pos_idx, dtype=torch.int32, device=q.device).contiguous()
+        scores = torch.empty(Q, Cn, dtype=torch.float32, device=q.device)
+        losses = torch.empty(4, dtype=torch.float32, device=q.device)
+        dq = torch.zeros_like(q)
+        dc = torch.zeros_like(c)
+        L.call("simx_scores_nll_fwd_bwd", L.stream_ptr(), Q, Cn, H, L.ptr(q), L.ptr(c), L.ptr(pos),
+               float(loss_scale or 1.0), q_lo, q_n, c_lo, c_n, L.ptr(scores), None, L.ptr(losses),
+               C.c_void_p(dq.data_ptr() + q_lo * H * 4), C.c_void_p(dc.data_ptr() + c_lo * H * 4))
+        ctx.save_for_backward(dq, dc)
+        return losses[0], losses.detach()
+
+    @staticmethod
+    def backward(ctx, g, g_all):
+        dq, dc = ctx.saved_tensors
+        return dq * g, dc * g, None, None, None, None, None, None
+
+
+def inbatch_nll_loss(q_vectors, ctx_vectors, positive_idx_per_question, loss_scale=None, local_q=None, local_ctx=None):
+    """dot_product_scores + log_softmax + nll_loss(mean) + argmax count (models.py:468-505).
+    local_q / local_ctx = (lo, n): rows that carry gradient (multi-GPU gather semantics,
+    PROD/ProD_base/train_DE_model_marco.py:251-264); default all rows."""
+    q_lo, q_n = local_q if local_q is not None else (0, q_vectors.shape[0])
+    c_lo, c_n = local_ctx if local_ctx is not None else (0, ctx_vectors.shape[0])
+    loss, allv = _NllFn.apply(q_vectors, ctx_vectors, positive_idx_per_question, loss_scale, q_lo, q_n, c_lo, c_n)
+    return loss, allv[3]
+
+
+def dot_product_scores(q_vectors, ctx_vectors):
+    """q @ ctx^T on the strided f32 GEMM kernel (no grad; the training path uses inbatch_nll_loss)."""
+    q, c = _f32c(q_vectors.detach()), _f32c(ctx_vectors.detach())
+    out = torch.empty(q.shape[0], c.shape[0], dtype=torch.float32, device=q.device)
+    H = q.shape[1]
+    L.call("simx_gemm_f32_strided", L.stream_ptr(), q.shape[0], c.shape[0], H, L.ptr(q), H, 1, L.ptr(c), 1, H,
+           L.ptr(out), c.shape[0], 0)
+    return out
+
+
+# ------------------------------------------------------------------------------------------ small linear (Reranker head)
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, w = _f32c(x), _f32c(w)
+        n, H = x.shape
+        O = w.shape[0]
+        y = torch.empty(n, O, dtype=torch.float32, device=x.device)
+        L.call("simx_gemm_f32_strided", L.stream_ptr(), n, O, H, L.ptr(x), H, 1, L.ptr(w), 1, H, L.ptr(y), O, 0)
+        if b is not None:
+            y += b
+        ctx.save_for_backward(x, w)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _f32c(dy)
+        n, H = x.shape
+        O = w.shape[0]
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(w)
+        s = L.stream_ptr()
+        L.call("simx_gemm_f32_strided", s, n, H, O, L.ptr(dy), O, 1, L.ptr(w), H, 1, L.ptr(dx), H, 0)
+        L.call("simx_gemm_f32_strided", s, O, H, n, L.ptr(dy), 1, O, L.ptr(x), H, 1, L.ptr(dw), H, 0)
+        db = None
+        if ctx.has_b:
+            db = torch.empty(O, dtype=torch.float32, device=x.device)
+            L.call("simx_colsum", s, L.SIMX_F32, n, O, L.ptr(dy), O, L.ptr(db), 0)
+        return dx, dw, db
+
+
+def linear_f32(x, weight, bias=None):
+    return _LinearFn.apply(x, weight, bias)
+
+
+# ------------------------------------------------------------------------------------------ sampler
+LAPLACE, GAUSS = 0, 1
+
+
+def simans_sample(scores, pos_score, num_neg, form=LAPLACE, a=0.5, b=0.0, tau=3.0, seed=0, offset=0,
+                  return_union=False, return_weights=False):
+    """On-GPU SimANS draw.  scores [nq,C] f64 (rank order), pos_score [nq] f64 -> neg indices [nq,N] int32."""
+    if not scores.is_cuda:
+        raise L.SimxError("simans_sample runs only on a HIP device")
+    scores = scores.contiguous().to(torch.float64)
+    pos_score = pos_score.contiguous().to(torch.float64)
+    nq, Cn = scores.shape
+    dev = scores.device
+    neg = torch.empty(nq, num_neg, dtype=torch.int32, device=dev)
+    uni = torch.full((nq, 2 * num_neg), -1, dtype=torch.int32, device=dev) if return_union else None
+    cnt = torch.zeros(nq, dtype=torch.int32, device=dev) if return_union else None
+    wts = torch.empty(nq, Cn, dtype=torch.float64, device=dev) if return_weights else None
+    L.call("simx_simans_sample", L.stream_ptr(), nq, Cn, num_neg, L.ptr(scores), L.ptr(pos_score), int(form),
+           float(a), float(b), float(tau), C.c_uint64(int(seed)), C.c_uint32(int(offset)), L.ptr(neg), L.ptr(uni),
+           L.ptr(cnt), L.ptr(wts))
+    out = (neg,)
+    if return_union:
+        out += (uni, cnt)
+    if return_weights:
+        out += (wts,)
+    return out if len(out) > 1 else neg

@@ -1,0 +1,287 @@
+"""Per-kernel parity: HIP kernels (through the C ABI) vs the NumPy oracle on the same seeded inputs.
+
+bf16 kernels are compared against the oracle evaluated on the SAME bf16-rounded inputs in float64, so the
+tolerance only has to cover f32 accumulation order and the final bf16 rounding of the output
+(2^-9 relative); f32 kernels are compared at f32 round-off.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bert as obert
+from oracle import optim as ooptim
+
+pytestmark = pytest.mark.gpu
+
+
+def L():
+    from simxns_amd import _lib
+    return _lib
+
+
+def rnd(shape, seed, scale=1.0):
+    rs = np.random.RandomState(seed)
+    return (rs.randn(*shape) * scale).astype(np.float32)
+
+
+def to_dev(a, dev, bf16=False):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return t.to(torch.bfloat16) if bf16 else t
+
+
+def back(t):
+    return t.detach().to(torch.float32).cpu().numpy().astype(np.float64)
+
+
+def rounded(a, bf16):
+    """what the kernel actually sees, as float64"""
+    if not bf16:
+        return a.astype(np.float64)
+    return torch.from_numpy(a).to(torch.bfloat16).to(torch.float32).numpy().astype(np.float64)
+
+
+def assert_close(got, ref, rtol, atol, what=""):
+    err = np.abs(got - ref)
+    lim = atol + rtol * np.abs(ref)
+    bad = err > lim
+    assert not bad.any(), "%s: %d/%d out of tolerance, worst err %.3e (ref %.3e) at %s" % (
+        what, bad.sum(), bad.size, err.max(), np.abs(ref).max(), np.unravel_index(err.argmax(), err.shape))
+
+
+TOL = {False: dict(rtol=2e-5, atol=2e-5), True: dict(rtol=1.2e-2, atol=2e-2)}
+
+
+# ------------------------------------------------------------------------------------------ GEMM NT
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("M,N,K", [(200, 192, 64), (300, 768, 768), (129, 64, 128), (77, 100, 40), (1000, 3072, 768)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_nt(dev, bf16, M, N, K, epi):
+    lib = L()
+    A, B = rnd((M, K), 1, 0.5), rnd((N, K), 2, 0.5)
+    bias = rnd((N,), 3, 0.5) if epi != 2 else None
+    res = rnd((M, N), 4) if epi == 0 else None
+    aux = rnd((M, N), 5) if epi == 2 else None
+    dA, dB = to_dev(A, dev, bf16), to_dev(B, dev, bf16)
+    dbias = to_dev(bias, dev) if bias is not None else None
+    dres = to_dev(res, dev, bf16) if res is not None else None
+    daux = to_dev(aux, dev, bf16) if aux is not None else None
+    dC = torch.empty(M, N, device=dev, dtype=torch.bfloat16 if bf16 else torch.float32)
+    dC2 = torch.empty_like(dC) if epi == 1 else None
+    lib.call("simx_gemm_nt", lib.stream_ptr(), int(bf16), M, N, K, lib.ptr(dA), K, lib.ptr(dB), K, lib.ptr(dC), N,
+             lib.ptr(dbias), lib.ptr(dres), N, epi, lib.ptr(daux), N, lib.ptr(dC2), N)
+    torch.cuda.synchronize()
+    acc = rounded(A, bf16) @ rounded(B, bf16).T
+    if bias is not None:
+        acc = acc + bias.astype(np.float64)
+    t = dict(TOL[bf16])
+    t["atol"] *= max(1.0, math.sqrt(K) * 0.25)
+    if epi == 0:
+        assert_close(back(dC), acc + rounded(res, bf16), what="gemm_nt none", **t)
+    elif epi == 1:
+        u = back(dC)
+        assert_close(u, acc, what="gemm_nt gelu pre-activation", **t)
+        assert_close(back(dC2), obert.gelu(u), what="gemm_nt gelu", **TOL[bf16])
+    else:
+        assert_close(back(dC), acc * obert.gelu_grad(rounded(aux, bf16)), what="gemm_nt dgelu", **t)
+
+
+# ------------------------------------------------------------------------------------------ GEMM TN (wgrad)
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("M,N,K", [(64, 64, 200), (192, 64, 333), (768, 768, 5000), (3072, 768, 2100), (128, 256, 64), (72, 40, 130)])
+@pytest.mark.parametrize("accumulate", [0, 1])
+def test_gemm_tn(dev, bf16, M, N, K, accumulate):
+    lib = L()
+    A, B = rnd((K, M), 1, 0.5), rnd((K, N), 2, 0.5)
+    C0 = rnd((M, N), 3)
+    dA, dB = to_dev(A, dev, bf16), to_dev(B, dev, bf16)
+    dC = to_dev(C0, dev)
+    wsb = int(lib.load().simx_gemm_tn_workspace_bytes(M, N, K))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+    lib.call("simx_gemm_tn", lib.stream_ptr(), int(bf16), M, N, K, lib.ptr(dA), M, lib.ptr(dB), N, lib.ptr(dC), N,
+             accumulate, lib.ptr(ws), wsb)
+    torch.cuda.synchronize()
+    ref = rounded(A, bf16).T @ rounded(B, bf16) + (C0 if accumulate else 0.0)
+    assert_close(back(dC), ref, rtol=2e-5, atol=2e-5 * math.sqrt(K), what="gemm_tn")
+
+
+def test_colsum_and_cast(dev):
+    lib = L()
+    x = rnd((1234, 200), 1)
+    for bf16 in (False, True):
+        dx = to_dev(x, dev, bf16)
+        out = torch.full((200,), 1.0, device=dev)
+        lib.call("simx_colsum", lib.stream_ptr(), int(bf16), 1234, 200, lib.ptr(dx), 200, lib.ptr(out), 1)
+        assert_close(back(out), rounded(x, bf16).sum(0) + 1.0, rtol=1e-5, atol=1e-3, what="colsum")
+    w = rnd((100, 36), 2)
+    dw = to_dev(w, dev)
+    o = torch.empty(100, 36, device=dev, dtype=torch.bfloat16)
+    ot = torch.empty(36, 100, device=dev, dtype=torch.bfloat16)
+    lib.call("simx_cast_weight", lib.stream_ptr(), lib.ptr(dw), 100, 36, lib.ptr(o), lib.ptr(ot))
+    assert torch.equal(o, dw.to(torch.bfloat16)) and torch.equal(ot, dw.to(torch.bfloat16).t().contiguous())
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm family
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("T,H", [(37, 64), (300, 768), (50, 1024)])
+def test_ln_fwd_bwd(dev, bf16, T, H):
+    lib = L()
+    z, dy = rnd((T, H), 1, 2.0) + 0.3, rnd((T, H), 2)
+    g, b = 1.0 + rnd((H,), 3, 0.1), rnd((H,), 4, 0.1)
+    dz_, dy_, dg_, db_ = to_dev(z, dev, bf16), to_dev(dy, dev, bf16), to_dev(g, dev), to_dev(b, dev)
+    y = torch.empty_like(dz_)
+    lib.call("simx_ln_fwd", lib.stream_ptr(), int(bf16), T, H, lib.ptr(dz_), lib.ptr(dg_), lib.ptr(db_), 1e-12, lib.ptr(y))
+    zr = rounded(z, bf16)
+    yr, cache = obert._ln_fwd(zr, g.astype(np.float64), b.astype(np.float64), 1e-12)
+    assert_close(back(y), yr, what="ln_fwd", **TOL[bf16])
+    dzo = torch.empty_like(dz_)
+    dgam, dbet, dbias = (torch.zeros(H, device=dev) for _ in range(3))
+    lib.call("simx_ln_bwd", lib.stream_ptr(), int(bf16), T, H, lib.ptr(dz_), lib.ptr(dg_), 1e-12, lib.ptr(dy_), lib.ptr(dzo),
+             lib.ptr(dgam), lib.ptr(dbet), lib.ptr(dbias))
+    dx, dg, db = obert._ln_bwd(rounded(dy, bf16), cache, g.astype(np.float64))
+    assert_close(back(dzo), dx, what="ln_bwd dz", **TOL[bf16])
+    assert_close(back(dgam), dg, rtol=1e-4, atol=1e-3, what="ln_bwd dgamma")
+    assert_close(back(dbet), db, rtol=1e-4, atol=1e-3, what="ln_bwd dbeta")
+    assert_close(back(dbias), dx.sum(0), rtol=1e-4, atol=2e-3, what="ln_bwd dbias")
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_embed_ln(dev, bf16):
+    lib = L()
+    T, H, V, P = 211, 64, 300, 40
+    rs = np.random.RandomState(0)
+    ids = rs.randint(0, V, size=T).astype(np.int32)
+    ids[:20] = 7                                    # collisions on one row (the [CLS] case)
+    pos = rs.randint(0, P, size=T).astype(np.int32)
+    word, posw, typew = rnd((V, H), 1), rnd((P, H), 2), rnd((2, H), 3)
+    g, b = 1.0 + rnd((H,), 4, 0.1), rnd((H,), 5, 0.1)
+    dy = rnd((T, H), 6)
+    d = lambda a, bf=False: to_dev(a, dev, bf)
+    dids, dpos, dword, dposw, dtype_, dg, db = d(ids), d(pos), d(word), d(posw), d(typew), d(g), d(b)
+    out = torch.empty(T, H, device=dev, dtype=torch.bfloat16 if bf16 else torch.float32)
+    lib.call("simx_embed_ln_fwd", lib.stream_ptr(), int(bf16), T, H, lib.ptr(dids), lib.ptr(dpos), lib.ptr(dword), lib.ptr(dposw),
+             lib.ptr(dtype_), lib.ptr(dg), lib.ptr(db), 1e-12, lib.ptr(out))
+    e = (word[ids] + posw[pos] + typew[0][None]).astype(np.float64)
+    yr, cache = obert._ln_fwd(e, g.astype(np.float64), b.astype(np.float64), 1e-12)
+    assert_close(back(out), yr, what="embed_ln_fwd", **TOL[bf16])
+    ddy = d(dy, bf16)
+    gw, gp, gt = torch.zeros(V, H, device=dev), torch.zeros(P, H, device=dev), torch.zeros(2, H, device=dev)
+    gg, gb = torch.zeros(H, device=dev), torch.zeros(H, device=dev)
+    lib.call("simx_embed_ln_bwd", lib.stream_ptr(), int(bf16), T, H, lib.ptr(dids), lib.ptr(dpos), lib.ptr(dword), lib.ptr(dposw),
+             lib.ptr(dtype_), lib.ptr(dg), 1e-12, lib.ptr(ddy), lib.ptr(gw), lib.ptr(gp), lib.ptr(gt), lib.ptr(gg), lib.ptr(gb))
+    de, dgr, dbr = obert._ln_bwd(rounded(dy, bf16), cache, g.astype(np.float64))
+    rw, rp = np.zeros((V, H)), np.zeros((P, H))
+    np.add.at(rw, ids, de)
+    np.add.at(rp, pos, de)
+    assert_close(back(gw), rw, rtol=1e-4, atol=1e-4, what="dword")
+    assert_close(back(gp), rp, rtol=1e-4, atol=1e-4, what="dpos")
+    assert_close(back(gt)[0], de.sum(0), rtol=1e-4, atol=1e-3, what="dtype0")
+    assert np.abs(back(gt)[1]).max() == 0.0
+    assert_close(back(gg), dgr, rtol=1e-4, atol=1e-3, what="dgamma")
+    assert_close(back(gb), dbr, rtol=1e-4, atol=1e-3, what="dbeta")
+
+
+# ------------------------------------------------------------------------------------------ attention
+def _mha_ref(qkv, lens, heads, d, dctx=None):
+    """float64 reference on the packed layout."""
+    T = qkv.shape[0]
+    H = heads * d
+    ctx = np.zeros((T, H))
+    lse = np.zeros((heads, T))
+    dqkv = np.zeros_like(qkv) if dctx is not None else None
+    t0 = 0
+    for n in lens:
+        for h in range(heads):
+            q = qkv[t0:t0 + n, h * d:(h + 1) * d]
+            k = qkv[t0:t0 + n, H + h * d:H + (h + 1) * d]
+            v = qkv[t0:t0 + n, 2 * H + h * d:2 * H + (h + 1) * d]
+            s = q @ k.T / math.sqrt(d)
+            m = s.max(1, keepdims=True)
+            e = np.exp(s - m)
+            p = e / e.sum(1, keepdims=True)
+            ctx[t0:t0 + n, h * d:(h + 1) * d] = p @ v
+            lse[h, t0:t0 + n] = (m + np.log(e.sum(1, keepdims=True)))[:, 0]
+            if dctx is not None:
+                do = dctx[t0:t0 + n, h * d:(h + 1) * d]
+                dp = do @ v.T
+                ds = p * (dp - (dp * p).sum(1, keepdims=True)) / math.sqrt(d)
+                dqkv[t0:t0 + n, h * d:(h + 1) * d] = ds @ k
+                dqkv[t0:t0 + n, H + h * d:H + (h + 1) * d] = ds.T @ q
+                dqkv[t0:t0 + n, 2 * H + h * d:2 * H + (h + 1) * d] = p.T @ do
+        t0 += n
+    return ctx, lse, dqkv
+
+
+@pytest.mark.parametrize("bf16,heads,d,lens", [
+    (False, 4, 16, [5, 32, 17, 1]),
+    (False, 2, 64, [40, 7]),
+    (True, 4, 16, [5, 32, 17]),                 # generic kernel in bf16
+    (True, 2, 64, [128, 1, 17, 33, 16, 100]),   # MFMA kernel, NKT=8
+    (True, 3, 64, [9, 32, 4, 31]),              # NKT=2
+    (True, 2, 64, [160, 129, 45]),              # NKT=10
+    (True, 1, 64, [250, 200]),                  # NKT=16
+    (True, 1, 64, [300, 512, 33]),              # fwd NKT=32, bwd generic
+])
+def test_mha_fwd_bwd(dev, bf16, heads, d, lens):
+    lib = L()
+    T, H = sum(lens), heads * d
+    qkv, dctx = rnd((T, 3 * H), 1, 1.0), rnd((T, H), 2)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    dq_, dd_, dcu = to_dev(qkv, dev, bf16), to_dev(dctx, dev, bf16), to_dev(cu, dev)
+    adt = torch.bfloat16 if bf16 else torch.float32
+    ctx = torch.zeros(T, H, device=dev, dtype=adt)
+    lse = torch.zeros(heads, T, device=dev)
+    lib.call("simx_mha_fwd", lib.stream_ptr(), int(bf16), len(lens), heads, d, lib.ptr(dcu), max(lens), T, lib.ptr(dq_), lib.ptr(ctx), lib.ptr(lse))
+    rc, rl, rdq = _mha_ref(rounded(qkv, bf16), lens, heads, d, rounded(dctx, bf16))
+    tol = dict(rtol=2e-5, atol=2e-5) if not bf16 else dict(rtol=2e-2, atol=2e-2)
+    assert_close(back(ctx), rc, what="mha ctx", **tol)
+    assert_close(back(lse), rl, rtol=1e-5, atol=2e-5 if not bf16 else 5e-3, what="mha lse")
+    dqkv = torch.zeros(T, 3 * H, device=dev, dtype=adt)
+    lib.call("simx_mha_bwd", lib.stream_ptr(), int(bf16), len(lens), heads, d, lib.ptr(dcu), max(lens), T, lib.ptr(dq_), lib.ptr(ctx),
+             lib.ptr(lse), lib.ptr(dd_), lib.ptr(dqkv))
+    tolb = dict(rtol=1e-4, atol=1e-4) if not bf16 else dict(rtol=3e-2, atol=6e-2)
+    assert_close(back(dqkv), rdq, what="mha dqkv", **tolb)
+
+
+def test_mha_bf16_spiked_scores(dev):
+    """large-magnitude logits: one key dominates each row (softmax saturation / max subtraction)."""
+    lib = L()
+    heads, d, lens = 1, 64, [64]
+    T, H = 64, 64
+    qkv = rnd((T, 3 * H), 3, 1.0)
+    qkv[:, :H] *= 6.0
+    qkv[:, H:2 * H] *= 6.0
+    cu = np.array([0, 64], dtype=np.int32)
+    dq_, dcu = to_dev(qkv, dev, True), to_dev(cu, dev)
+    ctx = torch.zeros(T, H, device=dev, dtype=torch.bfloat16)
+    lse = torch.zeros(1, T, device=dev)
+    lib.call("simx_mha_fwd", lib.stream_ptr(), 1, 1, heads, d, lib.ptr(dcu), 64, T, lib.ptr(dq_), lib.ptr(ctx), lib.ptr(lse))
+    rc, rl, _ = _mha_ref(rounded(qkv, True), lens, heads, d)
+    assert np.isfinite(back(ctx)).all()
+    assert_close(back(ctx), rc, rtol=2e-2, atol=3e-2, what="spiked ctx")
+    assert_close(back(lse), rl, rtol=1e-4, atol=2e-2, what="spiked lse")
+
+
+# ------------------------------------------------------------------------------------------ optimiser
+def test_adamw_clip(dev):
+    lib = L()
+    n = 10007
+    p, g = rnd((n,), 1), rnd((n,), 2, 3.0)
+    m, v = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    dp, dg, dm, dv = (to_dev(a.copy(), dev) for a in (p, g, m, v))
+    pad = lambda t: t          # kernels take any n (tail handled by block 0)
+    P, M, V = p.astype(np.float64), m.astype(np.float64), v.astype(np.float64)
+    for step in (1, 2, 3):
+        sq = torch.zeros(1, device=dev)
+        lib.call("simx_sqnorm_accum", lib.stream_ptr(), lib.ptr(dg), n, lib.ptr(sq))
+        tot, coef = ooptim.clip_coef([g], 2.0)
+        assert abs(math.sqrt(float(sq)) - tot) < 1e-3 * tot
+        lib.call("simx_adamw_step", lib.stream_ptr(), lib.ptr(dp), lib.ptr(dg), lib.ptr(dm), lib.ptr(dv), n, 1e-3, 0.9, 0.999, 1e-8, 0.01,
+                 step, lib.ptr(sq), 2.0, 1.0, 0)
+        ooptim.adamw_hf_step(P, g.astype(np.float64) * coef, M, V, step, 1e-3, wd=0.01)
+        assert_close(back(dp), P, rtol=1e-5, atol=1e-6, what="adamw p step %d" % step)
+    lib.call("simx_adamw_step", lib.stream_ptr(), lib.ptr(dp), lib.ptr(dg), lib.ptr(dm), lib.ptr(dv), n, 1e-3, 0.9, 0.999, 1e-8, 0.0, 4,
+             None, 0.0, 0.5, 1)
+    assert float(dg.abs().max()) == 0.0

@@ -1,0 +1,247 @@
+#!/usr/bin/env python
+"""bench.py -- SimANS / co_training retriever step on MI355X (BASELINE.json metric).
+
+One "step" = one full pass of the hot path over one synthetic batch, exactly the reference's
+retriever step (SimANS/co_training/co_training_marco_train.py:175-263) with the SimANS sampler on the GPU:
+    SimANS draw of N hard negatives per query (on device)  -> batch assembly by device gather
+    -> BiBertEncoder forward (query tower + passage tower) -> Reranker (cross-encoder teacher) forward, no grad
+    -> einsum similarity + softmax/KL-distill loss         -> backward through both towers
+    -> (N>1: RCCL all-reduce of the flat gradients)        -> clip_grad_norm_(2.0) + AdamW + schedule + zero_grad
+Workload = BASELINE.json configs[1]: BERT-base, B=128 queries/GPU, 15 hard negatives, q_len 32 / p_len 128 /
+cross-encoder len 160, bf16 operands with f32 accumulation and f32 master weights.  Default lengths are the
+worst case (every sequence at its maximum length); --varlen draws realistic lengths.
+--inbatch adds BASELINE configs[2]: RCCL all-gather of the [CLS] embeddings and the in-batch NLL term
+(MASTER fused loss, KL + 0.2*NLL) over the global score matrix.
+
+Launch:  python bench.py --gpus 1 --steps K --warmup W
+         python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic FLOPs: forward per sequence of S tokens = L*S*(8H^2 + 4HF + 4SH), train = 3x forward
+H_, F_, L_ = 768, 3072, 12
+
+
+def fwd_flops_seq(S, L=L_, H=H_, F=F_):
+    return L * S * (8 * H * H + 4 * H * F + 4 * S * H)
+
+
+def cpu_baseline(sample_queries=2, negs=15, threads=None):
+    """The CPU restatement (oracle/, f32 NumPy on the host BLAS) of the SAME step on a bounded sample."""
+    from oracle import bert as ob
+    from oracle import losses as ol
+    from oracle.weights import BertCfg, make_bert_params, make_batch
+    cfg = BertCfg()
+    B, P = sample_queries, sample_queries * (1 + negs)
+    Pq, Pc, Pt = (make_bert_params(cfg, s, perturb=False) for s in (1, 2, 3))
+    Pt2 = {"encoder." + k: v for k, v in Pt.items()}
+    Pt2["qa_classifier.weight"] = np.full((1, cfg.hidden), 0.01, np.float32)
+    Pt2["qa_classifier.bias"] = np.zeros((1,), np.float32)
+    q_ids, q_mask, _ = make_batch(1, B, 32, cfg.vocab, 9, 3, 4, full=True)
+    c_ids, c_mask, _ = make_batch(2, P, 128, cfg.vocab, 80, 25, 16, full=True)
+    t_ids, t_mask, _ = make_batch(3, P, 160, cfg.vocab, 90, 25, 20, full=True)
+    f32 = np.float32
+
+    def step():
+        _, q, cq = ob.bert_forward(Pq, q_ids, q_mask, cfg.heads, dtype=f32)
+        _, c, cc = ob.bert_forward(Pc, c_ids, c_mask, cfg.heads, dtype=f32)
+        z, _, _ = ob.reranker_forward(Pt2, t_ids.reshape(B, 1 + negs, -1), t_mask.reshape(B, 1 + negs, -1), cfg.heads,
+                                      dtype=f32, keep=False)
+        sim = ol.sim_block(q, c)
+        _, _, ds = ol.kl_distill(sim, z)
+        dq, dc = ol.sim_block_bwd(q, c, ds.astype(f32))
+        ob.bert_backward(Pq, q_ids, q_mask, cfg.heads, cq, dq, dtype=f32)
+        ob.bert_backward(Pc, c_ids, c_mask, cfg.heads, cc, dc, dtype=f32)
+
+    t0 = time.time()
+    step()
+    t = time.time() - t0
+    cores = threads or os.cpu_count()
+    return {"value": round(P / t, 3), "unit": "query+passage pairs/sec", "cores": cores, "kind": "port",
+            "sample": "1 step of the oracle (NumPy f32 restatement, host BLAS threads) on %d queries x %d passages, "
+                      "BERT-base q32/p128/ce160 incl. teacher forward, fwd+bwd, %.1f s" % (B, 1 + negs, t)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=128, help="queries per GPU")
+    ap.add_argument("--negs", type=int, default=15)
+    ap.add_argument("--cands", type=int, default=200, help="SimANS candidate pool per query")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--varlen", action="store_true", help="realistic sequence lengths instead of all-max")
+    ap.add_argument("--inbatch", action="store_true", help="config 3: all-gather embeddings + in-batch NLL term")
+    ap.add_argument("--no-teacher", action="store_true", help="feed fixed teacher logits (student-only flops)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from simxns_amd import _lib as L
+    from simxns_amd import ops
+    from simxns_amd.engine import BertConfigLite
+    from simxns_amd.model.models import HFBertEncoder, BiBertEncoder, Reranker
+    from simxns_amd.optim import FusedAdamW, LinearWarmupSchedule
+    from simxns_amd.utils import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+    L.load()
+
+    B, N, Cn = args.batch, args.negs, args.cands
+    P = B * (1 + N)
+    QL, PL, CL = 32, 128, 160
+    cfg = BertConfigLite()
+    torch.manual_seed(1234 + rank)
+
+    def tower():
+        return HFBertEncoder(cfg, compute_dtype=args.dtype)
+
+    bi = BiBertEncoder.__new__(BiBertEncoder)
+    torch.nn.Module.__init__(bi)
+    bi.question_model, bi.ctx_model = tower(), tower()
+    teacher = Reranker(tower(), cfg.hidden_size)
+    if world > 1:                                   # identical replicas on every rank
+        torch.manual_seed(1234)
+        for m in (bi.question_model, bi.ctx_model, teacher.encoder):
+            m.init_weights()
+    bi.to(dev)
+    teacher.to(dev)
+    opt = FusedAdamW(bi, lr=5e-6, eps=1e-8)
+    sch = LinearWarmupSchedule(opt, 5400, 54000)
+
+    # ---- synthetic, pre-tokenised candidate pool in HBM (per rank: B queries x (1 positive + Cn candidates))
+    def toks(seed, n, S, mean, std, lo):
+        ids, mask, lens = synth.make_batch(seed, n, S, cfg.vocab_size, mean, std, lo, full=not args.varlen)
+        return torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
+    q_ids, q_mask = toks(100 + rank, B, QL, 9, 3, 4)
+    pool_ids, pool_mask = toks(200 + rank, B * (1 + Cn), PL, 80, 25, 16)
+    ce_ids, ce_mask = toks(300 + rank, B * (1 + Cn), CL, 90, 25, 20)
+    pool_ids, pool_mask = pool_ids.view(B, 1 + Cn, PL), pool_mask.view(B, 1 + Cn, PL)
+    ce_ids, ce_mask = ce_ids.view(B, 1 + Cn, CL), ce_mask.view(B, 1 + Cn, CL)
+    rs = np.random.RandomState(7 + rank)
+    s_pos = 70.0 + 20.0 * rs.rand(B)
+    scores = np.sort(s_pos[:, None] - np.abs(rs.randn(B, Cn)) * 1.5, axis=1)[:, ::-1].copy()
+    d_scores, d_spos = torch.from_numpy(scores).to(dev), torch.from_numpy(s_pos).to(dev)
+    fixed_z = torch.randn(B, 1 + N, device=dev) * 2.0
+    zero_col = torch.zeros(B, 1, dtype=torch.long, device=dev)
+    nll = None
+    step_no = [0]
+
+    def one_step():
+        step_no[0] += 1
+        # S1+S2 on the GPU, then device-side batch assembly (gather of pre-tokenised passages)
+        neg = ops.simans_sample(d_scores, d_spos, N, form=ops.LAPLACE, tau=3.0, seed=42 + rank, offset=step_no[0])
+        sel = torch.cat([zero_col, neg.long() + 1], dim=1)                         # [B,1+N] rows of the pool
+        gi = sel.unsqueeze(-1)
+        c_ids = torch.gather(pool_ids, 1, gi.expand(-1, -1, PL)).reshape(P, PL)
+        c_mask = torch.gather(pool_mask, 1, gi.expand(-1, -1, PL)).reshape(P, PL)
+        q, c = bi(q_ids, q_mask, c_ids, c_mask)
+        if args.no_teacher:
+            z = fixed_z
+        else:
+            t_ids = torch.gather(ce_ids, 1, gi.expand(-1, -1, CL))
+            t_mask = torch.gather(ce_mask, 1, gi.expand(-1, -1, CL))
+            with torch.no_grad():
+                z = teacher(t_ids, t_mask)
+        loss, distill, sim = ops.kl_distill_loss(q, c, z, 1.0, False, 1)
+        if args.inbatch:
+            from simxns_amd import parallel
+            loss = loss + 0.2 * parallel.inbatch_nll_allgather(q, c, 1 + N)
+        loss.backward()
+        sch.step()
+        opt.step(max_grad_norm=2.0, world_size=world)
+        return loss
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    sync()
+    prof = None
+    if not args.no_prof:
+        L.call("simx_prof_begin", 4096 * max(1, args.steps))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step()
+    sync()
+    dt = time.perf_counter() - t0
+    if not args.no_prof:
+        nk = L.load().simx_prof_kernel_count()
+        cnt, ms, wk = (C.c_int32 * nk)(), (C.c_double * nk)(), (C.c_double * nk)()
+        L.call("simx_prof_end", cnt, ms, wk)
+        prof = {L.PROF_NAMES[k]: (cnt[k], ms[k], wk[k]) for k in range(nk) if cnt[k]}
+    final_loss = float(loss.item())
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_step = dt / args.steps * 1e3
+    pairs_per_s = world * P * args.steps / dt
+    stu = 3 * (B * fwd_flops_seq(QL) + P * fwd_flops_seq(PL))
+    tea = 0 if args.no_teacher else P * fwd_flops_seq(CL)
+    out = {"metric": "query+passage pairs/sec (bi-encoder step)", "value": round(pairs_per_s, 1),
+           "unit": "query+passage pairs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(ms_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": "SimANS MS-MARCO Passage retriever step (BASELINE configs[%d]): BERT-base x2 towers + "
+                                  "BERT-base cross-encoder teacher fwd, B=%d/GPU, %d hard negs from %d candidates (SimANS "
+                                  "sampler on GPU), q%d/p%d/ce%d, %s lengths, KL-distill%s loss, clip 2.0 + AdamW"
+                                  % (2 if args.inbatch else 1, B, N, Cn, QL, PL, CL, "realistic" if args.varlen else "all-max",
+                                     " + 0.2*in-batch NLL (all-gather)" if args.inbatch else ""),
+                      "global_batch": world * B, "pairs_per_step_per_gpu": P, "parallelism": "dp%d" % world,
+                      "teacher_in_step": not args.no_teacher},
+           "algorithmic_tflop_per_step_per_gpu": {"student_fwd_bwd": round(stu / 1e12, 2), "teacher_fwd": round(tea / 1e12, 2)},
+           "step_mfma_util": round((stu + tea) / (ms_step * 1e-3) / 2.5e15, 4) if args.dtype == "bf16" and not args.varlen else None,
+           "final_loss": round(final_loss, 5)}
+    if prof and "gemm_nt" in prof:
+        c_, ms_, wk_ = prof["gemm_nt"]
+        ach = wk_ / (ms_ * 1e-3) / 1e12
+        peak = 2500.0 if args.dtype == "bf16" else 157.3
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_bf16_kernel (forward + dgrad GEMMs)", "achieved": round(ach, 1),
+                           "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                           "launches": c_, "avg_launch_ms": round(ms_ / c_, 4)}
+        out["kernel_breakdown_ms_per_step"] = {k: round(v[1] / args.steps, 3) for k, v in prof.items()}
+        out["kernel_rates"] = {k: round(v[2] / (v[1] * 1e-3) / 1e12, 2) for k, v in prof.items() if v[1] > 0}
+    if not args.no_cpu_baseline and world == 1:
+        try:
+            out["cpu_baseline"] = cpu_baseline()
+        except Exception as e:            # the baseline must never take the GPU number down with it
+            out["cpu_baseline"] = {"value": None, "error": repr(e)}
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -205,6 +205,17 @@ int simx_adamw_step(simx_stream_t stream, float* p, float* g, float* m, float* v
                     float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                     const float* sqnorm, float max_norm, float grad_scale, int zero_grad);
 
+/* ------------------------------------------------------------------ measurement
+ * Optional per-launch timing with HIP events recorded on the launch stream (bench.py's live roofline
+ * figure).  simx_prof_begin(max_launches) starts recording; simx_prof_end() stops, waits for the
+ * events and fills host arrays of length simx_prof_kernel_count(): launches, total milliseconds and
+ * total "work" (flops for GEMM/attention classes, algorithmic bytes for the HBM-bound classes).
+ * Class ids: 0 gemm_nt, 1 gemm_tn, 2 mha_fwd, 3 mha_bwd, 4 ln_fwd, 5 ln_bwd, 6 embed_fwd, 7 embed_bwd,
+ * 8 colsum, 9 cast, 10 loss, 11 sampler, 12 adamw(+norm), 13 other. */
+int simx_prof_begin(int max_launches);
+int simx_prof_end(int32_t* counts_host, double* total_ms_host, double* total_work_host);
+int simx_prof_kernel_count(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -68,7 +68,12 @@ SIGNATURES = {
     "simx_simans_sample": (_i, [_p, _i, _i, _i, _p, _p, _i, _d, _d, _d, C.c_uint64, C.c_uint32, _p, _p, _p, _p]),
     "simx_sqnorm_accum": (_i, [_p, _p, _z, _p]),
     "simx_adamw_step": (_i, [_p, _p, _p, _p, _p, _z, _f, _f, _f, _f, _f, _i, _p, _f, _f, _i]),
+    "simx_prof_begin": (_i, [_i]),
+    "simx_prof_end": (_i, [_p, _p, _p]),
+    "simx_prof_kernel_count": (_i, []),
 }
+PROF_NAMES = ["gemm_nt", "gemm_tn", "mha_fwd", "mha_bwd", "ln_fwd", "ln_bwd", "embed_fwd", "embed_bwd", "colsum", "cast",
+              "loss", "sampler", "adamw", "other"]
 
 _lib = None
 

@@ -15,6 +15,7 @@
 // Keys are restricted to the sequence's own real tokens, which equals the reference's additive
 // (1-mask)*finfo.min bias (exp underflows to exactly 0).
 #include "common.h"
+#include "prof.h"
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -462,6 +463,7 @@ static int check_common(int dtype, int nseq, int heads, int d, int max_len, int 
 extern "C" int simx_mha_fwd(simx_stream_t stream, int dtype, int nseq, int heads, int d, const int32_t* cu, int max_len,
                             int T, const void* qkv, void* ctx, float* lse) {
   hipStream_t s = (hipStream_t)stream;
+  SIMX_PROF(SIMX_K_MHA_FWD, s, 4.0 * T * max_len * heads * d);
   int rc = check_common(dtype, nseq, heads, d, max_len, T, "mha_fwd");
   if (rc) return rc;
   const float scale = 1.0f / sqrtf((float)d);
@@ -503,6 +505,7 @@ extern "C" int simx_mha_fwd(simx_stream_t stream, int dtype, int nseq, int heads
 extern "C" int simx_mha_bwd(simx_stream_t stream, int dtype, int nseq, int heads, int d, const int32_t* cu, int max_len,
                             int T, const void* qkv, const void* ctx, const float* lse, const void* dctx, void* dqkv) {
   hipStream_t s = (hipStream_t)stream;
+  SIMX_PROF(SIMX_K_MHA_BWD, s, 8.0 * T * max_len * heads * d);
   int rc = check_common(dtype, nseq, heads, d, max_len, T, "mha_bwd");
   if (rc) return rc;
   const float scale = 1.0f / sqrtf((float)d);

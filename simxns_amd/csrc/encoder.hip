@@ -282,3 +282,57 @@ extern "C" int simx_bert_bwd(simx_stream_t stream, const simx_bert_cfg* c, const
                         goff(-1, SIMX_P_TYPE), goff(-1, SIMX_P_EMB_LN_G), goff(-1, SIMX_P_EMB_LN_B)));
   return SIMX_OK;
 }
+
+// ------------------------------------------------------------------------------------------ profiler
+#include <vector>
+#include "prof.h"
+namespace {
+struct ProfRec { int id; double work; hipEvent_t a, b; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+std::vector<hipEvent_t> g_pool;
+size_t g_pool_next = 0;
+}  // namespace
+
+void simx_prof_mark(int id, hipStream_t s, double work, int end) {
+  if (!g_prof_on) return;
+  if (!end) {
+    if (g_pool_next + 2 > g_pool.size()) return;
+    ProfRec r{id, work, g_pool[g_pool_next], g_pool[g_pool_next + 1]};
+    g_pool_next += 2;
+    (void)hipEventRecord(r.a, s);
+    g_prof.push_back(r);
+  } else if (!g_prof.empty() && g_prof.back().id == id) {
+    (void)hipEventRecord(g_prof.back().b, s);
+  }
+}
+
+extern "C" int simx_prof_begin(int max_launches) {
+  while ((int)g_pool.size() < 2 * max_launches) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) { simx_set_error("prof_begin: hipEventCreate failed"); return SIMX_ERR_HIP; }
+    g_pool.push_back(e);
+  }
+  g_prof.clear();
+  g_pool_next = 0;
+  g_prof_on = true;
+  return SIMX_OK;
+}
+
+// Stops recording, waits for the recorded events and aggregates per kernel class:
+// counts[k], total_ms[k], total_work[k] for k < SIMX_K_COUNT (host arrays).
+extern "C" int simx_prof_end(int32_t* counts_host, double* total_ms_host, double* total_work_host) {
+  g_prof_on = false;
+  for (int k = 0; k < SIMX_K_COUNT; ++k) { counts_host[k] = 0; total_ms_host[k] = 0; total_work_host[k] = 0; }
+  for (auto& r : g_prof) {
+    if (hipEventSynchronize(r.b) != hipSuccess) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+    counts_host[r.id] += 1;
+    total_ms_host[r.id] += ms;
+    total_work_host[r.id] += r.work;
+  }
+  g_prof.clear();
+  return SIMX_OK;
+}
+extern "C" int simx_prof_kernel_count(void) { return SIMX_K_COUNT; }

@@ -17,6 +17,7 @@
 //     range of tiles so that the N-tiles sharing an A panel hit the same L2.
 // f32 path ("parity mode") and odd shapes: a plain LDS-tiled FMA kernel, k-ordered f32 accumulate.
 #include "common.h"
+#include "prof.h"
 
 // ------------------------------------------------------------------------------------------
 // generic tiled kernel (f32 parity mode, and bf16 shapes the MFMA kernels do not take)
@@ -415,6 +416,7 @@ extern "C" int simx_gemm_nt(simx_stream_t stream, int dtype, int M, int N, int K
                             const void* B, int ldb, void* C, int ldc, const float* bias, const void* residual,
                             int ldr, int epilogue, const void* aux, int ldaux, void* C2, int ldc2) {
   hipStream_t s = (hipStream_t)stream;
+  SIMX_PROF(SIMX_K_GEMM_NT, s, 2.0 * M * N * K);
   SIMX_REQUIRE(M > 0 && N > 0 && K > 0, SIMX_ERR_BAD_SHAPE, "gemm_nt: bad shape %d %d %d", M, N, K);
   SIMX_REQUIRE(lda >= K && ldb >= K && ldc >= N, SIMX_ERR_BAD_SHAPE, "gemm_nt: leading dims too small");
   SIMX_REQUIRE(epilogue >= 0 && epilogue <= 2, SIMX_ERR_UNSUPPORTED, "gemm_nt: epilogue %d", epilogue);
@@ -475,6 +477,7 @@ extern "C" size_t simx_gemm_tn_workspace_bytes(int M, int N, int K) {
 extern "C" int simx_gemm_tn(simx_stream_t stream, int dtype, int M, int N, int K, const void* A, int lda,
                             const void* B, int ldb, float* C, int ldc, int accumulate, void* ws, size_t ws_bytes) {
   hipStream_t s = (hipStream_t)stream;
+  SIMX_PROF(SIMX_K_GEMM_TN, s, 2.0 * M * N * K);
   SIMX_REQUIRE(M > 0 && N > 0 && K > 0, SIMX_ERR_BAD_SHAPE, "gemm_tn: bad shape %d %d %d", M, N, K);
   SIMX_REQUIRE(lda >= M && ldb >= N && ldc >= N, SIMX_ERR_BAD_SHAPE, "gemm_tn: leading dims too small");
   if (dtype == SIMX_F32)
@@ -520,6 +523,7 @@ extern "C" int simx_gemm_tn(simx_stream_t stream, int dtype, int M, int N, int K
 extern "C" int simx_colsum(simx_stream_t stream, int dtype, int T, int N, const void* x, int ldx, float* out,
                            int accumulate) {
   hipStream_t s = (hipStream_t)stream;
+  SIMX_PROF(SIMX_K_COLSUM, s, (double)T * N * (dtype == SIMX_F32 ? 4 : 2));
   SIMX_REQUIRE(T > 0 && N > 0 && ldx >= N, SIMX_ERR_BAD_SHAPE, "colsum: bad shape");
   if (!accumulate) {
     if (hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s) != hipSuccess) { simx_set_error("colsum: memset failed"); return SIMX_ERR_HIP; }
@@ -539,6 +543,7 @@ extern "C" int simx_colsum(simx_stream_t stream, int dtype, int T, int N, const 
 
 extern "C" int simx_transpose_cast(simx_stream_t stream, int out_dtype, const float* w, int rows, int cols, void* out,
                                    void* outT) {
+  SIMX_PROF(SIMX_K_CAST, stream, (double)rows * cols * 8);
   SIMX_REQUIRE(rows > 0 && cols > 0 && w, SIMX_ERR_BAD_SHAPE, "transpose_cast: bad shape");
   dim3 grid(cdiv(cols, 32), cdiv(rows, 32));
   if (out_dtype == SIMX_BF16)

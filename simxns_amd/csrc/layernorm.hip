@@ -6,6 +6,7 @@
 // per-lane column partial sums (dgamma, dbeta, dbias / dtype0) across the rows a workgroup walks and
 // flush them once with f32 atomics.
 #include "common.h"
+#include "prof.h"
 
 #define LN_VPL 4   // 4-element vectors per lane -> H <= 64*4*4 = 1024
 
@@ -295,6 +296,7 @@ static int bwd_rows_per_block(int T) {
 
 extern "C" int simx_ln_fwd(simx_stream_t stream, int dtype, int T, int H, const void* z, const float* gamma,
                            const float* beta, float eps, void* y) {
+  SIMX_PROF(SIMX_K_LN_FWD, stream, 2.0 * T * H * (dtype == SIMX_F32 ? 4 : 2));
   int rc = ln_check(dtype, T, H, "ln_fwd");
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
@@ -308,6 +310,7 @@ extern "C" int simx_ln_fwd(simx_stream_t stream, int dtype, int T, int H, const 
 
 extern "C" int simx_ln_bwd(simx_stream_t stream, int dtype, int T, int H, const void* z, const float* gamma, float eps,
                            const void* dy, void* dz, float* dgamma, float* dbeta, float* dbias) {
+  SIMX_PROF(SIMX_K_LN_BWD, stream, 3.0 * T * H * (dtype == SIMX_F32 ? 4 : 2));
   int rc = ln_check(dtype, T, H, "ln_bwd");
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
@@ -326,6 +329,7 @@ extern "C" int simx_ln_bwd(simx_stream_t stream, int dtype, int T, int H, const 
 extern "C" int simx_embed_ln_fwd(simx_stream_t stream, int dtype, int T, int H, const int32_t* ids, const int32_t* pos_ids,
                                  const float* word, const float* posw, const float* typew, const float* gamma,
                                  const float* beta, float eps, void* out) {
+  SIMX_PROF(SIMX_K_EMBED_FWD, stream, (double)T * H * (4 + (dtype == SIMX_F32 ? 4 : 2)));
   int rc = ln_check(dtype, T, H, "embed_ln_fwd");
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
@@ -342,6 +346,7 @@ extern "C" int simx_embed_ln_fwd(simx_stream_t stream, int dtype, int T, int H, 
 extern "C" int simx_embed_ln_bwd(simx_stream_t stream, int dtype, int T, int H, const int32_t* ids, const int32_t* pos_ids,
                                  const float* word, const float* posw, const float* typew, const float* gamma, float eps,
                                  const void* dy, float* dword, float* dpos, float* dtype0, float* dgamma, float* dbeta) {
+  SIMX_PROF(SIMX_K_EMBED_BWD, stream, (double)T * H * (12 + (dtype == SIMX_F32 ? 4 : 2)));
   int rc = ln_check(dtype, T, H, "embed_ln_bwd");
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;

@@ -5,6 +5,7 @@
 //   nll rows        : M2 log_softmax / nll_loss / argmax over the all-pairs score matrix
 //                     (SimANS/model/models.py:468-505) and dS in place.
 #include "common.h"
+#include "prof.h"
 
 #define LOSS_EPS 1e-7f
 
@@ -164,6 +165,7 @@ extern "C" int simx_sim_loss_fwd_bwd(simx_stream_t stream, int B, int D, int H, 
                                      const float* teacher, const simx_loss_params* lp, float* sim, float* losses,
                                      float* dq, float* dctx) {
   hipStream_t s = (hipStream_t)stream;
+  SIMX_PROF(SIMX_K_LOSS, s, 16.0 * B * D * (H > 0 ? H : 1));
   SIMX_REQUIRE(lp != nullptr, SIMX_ERR_BAD_SHAPE, "sim_loss: params are NULL");
   SIMX_REQUIRE(B > 0 && D > 0 && D <= 64, SIMX_ERR_UNSUPPORTED, "sim_loss: need 0 < D=%d <= 64", D);
   SIMX_REQUIRE(lp->kind >= 0 && lp->kind <= 3, SIMX_ERR_UNSUPPORTED, "sim_loss: kind %d", lp->kind);

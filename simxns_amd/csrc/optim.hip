@@ -4,6 +4,7 @@
 // 28 (+4) B/param, 16-byte accesses, no host synchronisation (the clip coefficient is computed on
 // device from the norm accumulator).
 #include "common.h"
+#include "prof.h"
 
 __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, size_t n, float* __restrict__ out) {
   __shared__ float part[4];
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
 }
 
 extern "C" int simx_sqnorm_accum(simx_stream_t stream, const float* g, size_t n, float* sqnorm) {
+  SIMX_PROF(SIMX_K_ADAMW, stream, 4.0 * n);
   SIMX_REQUIRE(g && sqnorm && n > 0, SIMX_ERR_BAD_SHAPE, "sqnorm_accum: bad arguments");
   SIMX_REQUIRE((((uintptr_t)g) & 15) == 0, SIMX_ERR_BAD_SHAPE, "sqnorm_accum: g not 16-B aligned");
   size_t blocks = (n / 4 + 255) / 256;
@@ -72,6 +74,7 @@ extern "C" int simx_sqnorm_accum(simx_stream_t stream, const float* g, size_t n,
 extern "C" int simx_adamw_step(simx_stream_t stream, float* p, float* g, float* m, float* v, size_t n, float lr, float beta1,
                                float beta2, float eps, float weight_decay, int step, const float* sqnorm, float max_norm,
                                float grad_scale, int zero_grad) {
+  SIMX_PROF(SIMX_K_ADAMW, stream, 32.0 * n);
   SIMX_REQUIRE(p && g && m && v && n > 0 && step >= 1, SIMX_ERR_BAD_SHAPE, "adamw_step: bad arguments");
   SIMX_REQUIRE(((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0, SIMX_ERR_BAD_SHAPE,
                "adamw_step: buffers not 16-B aligned");

@@ -6,6 +6,7 @@
 // round with Philox4x32-10 uniforms (bisect_right == count of cum <= x, clamped) -> dedupe ->
 // zero the chosen weights -> repeat until >= N -> truncate in draw order.
 #include "common.h"
+#include "prof.h"
 
 #define SAMP_MAXK 16   // candidates per lane -> C <= 1024
 
@@ -113,6 +114,7 @@ __global__ __launch_bounds__(256) void simans_kernel(int nq, int C, int N, const
 extern "C" int simx_simans_sample(simx_stream_t stream, int nq, int C, int N, const double* scores, const double* pos_score,
                                   int form, double a, double b, double tau, uint64_t seed, uint32_t offset,
                                   int32_t* neg_idx, int32_t* union_idx, int32_t* union_cnt, double* weights_out) {
+  SIMX_PROF(SIMX_K_SAMPLER, stream, (double)nq * (8.0 * C + 8 + 4.0 * N));
   SIMX_REQUIRE(nq > 0 && N > 0 && C >= N, SIMX_ERR_BAD_SHAPE, "simans_sample: need nq>0 and C >= N > 0 (C=%d N=%d)", C, N);
   SIMX_REQUIRE(C <= 64 * SAMP_MAXK, SIMX_ERR_UNSUPPORTED, "simans_sample: C=%d > %d", C, 64 * SAMP_MAXK);
   SIMX_REQUIRE(form == 0 || form == 1, SIMX_ERR_UNSUPPORTED, "simans_sample: form %d", form);

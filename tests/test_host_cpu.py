@@ -1,0 +1,215 @@
+"""CPU: host-side logic and the C-ABI surface (no compute calls -- those need a GPU)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lib():
+    from simxns_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        subprocess.check_call(["bash", os.path.join(ROOT, "simxns_amd", "csrc", "build.sh")])
+    return _lib
+
+
+def test_library_exports_every_header_symbol():
+    L = _lib()
+    lib = L.load()
+    hdr = open(os.path.join(ROOT, "include", "simx.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(simx_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"simx_bert_cfg", "simx_loss_params", "simx_stream_t"}
+    assert len(declared) >= 30
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libsimx_hip.so does not export %s" % name
+        assert name in L.SIGNATURES, "ctypes stub has no signature for %s" % name
+    assert set(L.SIGNATURES) <= declared
+    assert lib.simx_version() >= 100
+
+
+def test_param_layout_matches_bert_base():
+    L = _lib()
+    lib = L.load()
+    cfg = L.BertCfg(L.SIMX_BF16, 12, 768, 12, 3072, 30522, 512, 2, 1e-12)
+    n = lib.simx_bert_param_count(C.byref(cfg))
+    assert n == 109482240                                # BertModel(bert-base-uncased) incl. pooler
+    offs = []
+    for layer, kinds in [(-1, range(0, 5))] + [(l, range(5, 17)) for l in range(12)] + [(12, range(17, 19))]:
+        for k in kinds:
+            o = lib.simx_bert_param_offset(C.byref(cfg), layer, k)
+            assert o != C.c_size_t(-1).value and o % 4 == 0
+            offs.append(o)
+    assert offs == sorted(offs) and len(set(offs)) == len(offs) and offs[-1] < n
+    assert lib.simx_bert_param_offset(C.byref(cfg), 3, 0) == C.c_size_t(-1).value      # embeddings id on a layer: rejected
+    bad = L.BertCfg(L.SIMX_BF16, 12, 770, 12, 3072, 30522, 512, 2, 1e-12)
+    assert lib.simx_bert_param_count(C.byref(bad)) == 0
+    assert lib.simx_bert_act_bytes(C.byref(cfg), 262144, 2048, 1) > 70 * 2 ** 30       # cfg2 activations ~77 GB, kept
+
+
+def test_module_api_and_state_dict_schema(golden_dir):
+    """Key schema of BiBertEncoder / Reranker == the imported reference's (names recorded in the golden file)."""
+    _lib()
+    from simxns_amd.engine import BertConfigLite
+    from simxns_amd.model.models import BiBertEncoder, HFBertEncoder, Reranker, BiEncoderNllLoss, dot_product_scores  # noqa
+    G = np.load(os.path.join(golden_dir, "step_base_cfg1.npz"))
+    ref_names = set(str(n) for n in G["grad_names"])
+    cfg = BertConfigLite(vocab_size=100, hidden_size=64, num_hidden_layers=12, num_attention_heads=4, intermediate_size=128,
+                         max_position_embeddings=64)
+    bi = BiBertEncoder.__new__(BiBertEncoder)
+    torch.nn.Module.__init__(bi)
+    bi.question_model, bi.ctx_model = HFBertEncoder(cfg), HFBertEncoder(cfg)
+    names = set(k for k, _ in bi.named_parameters())
+    assert names == ref_names
+    assert set(bi.state_dict().keys()) == ref_names
+    # optimiser grouping of the reference works on the names (co_training_marco_train.py:59)
+    nd = [n for n in names if any(x in n for x in ("bias", "LayerNorm.weight"))]
+    assert len(nd) == 2 * (2 + 12 * 10 + 1)
+    # parameters are views of ONE flat buffer; load_state_dict writes through
+    enc = bi.question_model
+    assert sum(p.numel() for p in enc.parameters()) == enc.engine.n_params
+    w = enc.state_dict()["encoder.layer.3.attention.self.key.weight"]
+    sd = {k: torch.full_like(v, 0.5) for k, v in enc.state_dict().items()}
+    enc.load_state_dict(sd)
+    assert float(enc.engine.flat.min()) == 0.5 and float(enc.engine.flat.max()) == 0.5
+    assert w.data_ptr() != 0
+    r = Reranker(HFBertEncoder(cfg), 64)
+    assert {"qa_classifier.weight", "qa_classifier.bias", "encoder.pooler.dense.weight"} <= set(r.state_dict().keys())
+    # share_weight aliasing (models.py:92-95)
+    import types
+    d = os.path.join(str(pytest.importorskip("tempfile").mkdtemp()), "m")
+    os.makedirs(d)
+    import json
+    json.dump(cfg.to_dict(), open(os.path.join(d, "config.json"), "w"))
+    bi2 = BiBertEncoder(types.SimpleNamespace(model_type=d, share_weight=True, gradient_checkpointing=False))
+    assert bi2.ctx_model is bi2.question_model
+
+
+def test_product_path_fails_loudly_without_gpu():
+    _lib()
+    from simxns_amd import _lib as L
+    from simxns_amd.engine import BertConfigLite
+    from simxns_amd.model.models import HFBertEncoder
+    from simxns_amd import ops
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    enc = HFBertEncoder(BertConfigLite(vocab_size=50, hidden_size=32, num_hidden_layers=1, num_attention_heads=2,
+                                       intermediate_size=64, max_position_embeddings=16))
+    ids = torch.randint(1, 50, (2, 8))
+    with pytest.raises(L.SimxError):
+        enc(input_ids=ids, attention_mask=torch.ones_like(ids))
+    with pytest.raises(L.SimxError):
+        ops.kl_distill_loss(torch.randn(2, 8), torch.randn(4, 8), torch.randn(2, 2))
+    with pytest.raises(L.SimxError):
+        ops.simans_sample(torch.randn(2, 8, dtype=torch.float64), torch.ones(2, dtype=torch.float64), 2)
+
+
+def test_missing_library_is_an_error(tmp_path, monkeypatch):
+    from simxns_amd import _lib as L
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(L.SimxError):
+        L.load()
+
+
+def test_packed_batch_layout():
+    _lib()
+    from simxns_amd.engine import PackedBatch
+    ids = torch.tensor([[101, 5, 6, 102, 0, 0], [101, 7, 102, 0, 0, 0], [101, 1, 2, 3, 4, 102]])
+    mask = (ids != 0).long()
+    pb = PackedBatch(ids, mask)
+    assert pb.T == 13 and pb.max_len == 6 and pb.nseq == 3
+    assert pb.cu.tolist() == [0, 4, 7, 13]
+    assert pb.ids.tolist() == [101, 5, 6, 102, 101, 7, 102, 101, 1, 2, 3, 4, 102]
+    assert pb.pos.tolist() == [0, 1, 2, 3, 0, 1, 2, 0, 1, 2, 3, 4, 5]
+    x = torch.arange(13.0).unsqueeze(1).repeat(1, 2)
+    padded = pb.unpack(x)
+    assert padded.shape == (3, 6, 2) and padded[1, 2, 0] == 6 and padded[1, 3, 0] == 0
+    full = PackedBatch(torch.ones(2, 4, dtype=torch.long), torch.ones(2, 4, dtype=torch.long))
+    assert full.index is None and full.pos.tolist() == [0, 1, 2, 3, 0, 1, 2, 3]
+    with pytest.raises(ValueError):
+        PackedBatch(ids, torch.tensor([[0, 1, 1, 1, 0, 0], [1, 1, 1, 0, 0, 0], [1, 1, 1, 1, 1, 1]]))
+
+
+def test_synth_generator_equals_oracle_generator():
+    from oracle import weights as ow
+    from simxns_amd.utils import synth
+    cfg = ow.BertCfg(**ow.TINY)
+    a = ow.make_bert_params(cfg, 77, std=0.08)
+    b = synth.fill_bert_state_dict(ow.bert_param_shapes(cfg), 77, std=0.08)
+    assert a.keys() == b.keys() and all(np.array_equal(a[k], b[k]) for k in a)
+    x, y = ow.make_batch(5, 7, 32, 1000, 9, 3, 4), synth.make_batch(5, 7, 32, 1000, 9, 3, 4)
+    assert all(np.array_equal(p, q) for p, q in zip(x, y))
+
+
+def test_schedule_and_checkpoint_state(tmp_path):
+    _lib()
+    from oracle import optim as oo
+    from simxns_amd.optim import LinearWarmupSchedule
+    from simxns_amd.utils.dpr_utils import CheckpointState, load_states_from_checkpoint, get_model_obj
+
+    class O(object):
+        base_lr = 5e-6
+        param_groups = [{"lr": 5e-6}]
+    s = LinearWarmupSchedule(O(), 5400, 54000)
+    assert s.get_last_lr()[0] == 0.0
+    for t in range(1, 40):
+        s.step()
+        assert abs(s.get_last_lr()[0] - 5e-6 * oo.linear_schedule(t, 5400, 54000)) < 1e-18
+    assert CheckpointState._fields == ('model_dict', 'optimizer_dict', 'scheduler_dict', 'offset', 'epoch', 'encoder_params')
+    p = str(tmp_path / "checkpoint-5")
+    torch.save(CheckpointState({"w": torch.ones(2)}, {}, {"t": 3}, 0, 0, None)._asdict(), p)
+    st = load_states_from_checkpoint(p)
+    assert st.scheduler_dict == {"t": 3} and torch.equal(st.model_dict["w"], torch.ones(2))
+    m = torch.nn.Linear(2, 2)
+
+    class W(object):
+        module = m
+    assert get_model_obj(W()) is m and get_model_obj(m) is m
+
+
+DIST_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["SIMX_ROOT"])
+from simxns_amd import parallel
+rank, W = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+torch.manual_seed(rank)
+B, D, H = 3, 4, 8
+q = (torch.arange(B * H, dtype=torch.float32).view(B, H) + 100 * rank).requires_grad_(True)
+c = (torch.arange(B * D * H, dtype=torch.float32).view(B * D, H) + 1000 * rank).requires_grad_(True)
+gq, gc = parallel.gather_with_local_grad(q), parallel.gather_with_local_grad(c)
+assert gq.shape == (W * B, H) and gc.shape == (W * B * D, H)
+for r in range(W):                                           # rank order, exact payload
+    assert torch.equal(gq[r * B:(r + 1) * B], torch.arange(B * H, dtype=torch.float32).view(B, H) + 100 * r)
+wq = torch.arange(W * B, dtype=torch.float32).view(-1, 1) + 1
+(gq * wq).sum().backward()                                    # gradient reaches ONLY the local slot
+assert torch.equal(q.grad, wq[rank * B:(rank + 1) * B].expand(B, H))
+assert parallel.global_positive_indices(W, B, D) == [r * B * D + j * D for r in range(W) for j in range(B)]
+objs = parallel.all_gather_list({"rank": rank, "t": torch.ones(2) * rank}, max_size=640000000)
+assert [o["rank"] for o in objs] == list(range(W)) and float(objs[1]["t"][0]) == 1.0
+g1, g2 = torch.full((10,), float(rank + 1)), torch.full((6,), 2.0 * (rank + 1))
+hs, scale = parallel.allreduce_flat_grads([g1, g2])
+assert scale == 1.0 / W and float(g1[0]) == sum(range(1, W + 1)) and float(g2[0]) == 2.0 * sum(range(1, W + 1))
+dist.barrier()
+dist.destroy_process_group()
+print("rank %d ok" % rank)
+'''
+
+
+def test_distributed_gather_semantics_gloo_world2(tmp_path):
+    """N>1 path on CPU: gloo, world_size 2 (127.0.0.1 rendezvous)."""
+    script = tmp_path / "w.py"
+    script.write_text(DIST_WORKER)
+    env = dict(os.environ, SIMX_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("rank %d ok" % r) in o, o

@@ -5,7 +5,8 @@ oracle/make_golden.py).  Weights are regenerated on the box from the seeded inte
 Tolerances
   f32 parity mode : |x - ref| <= 1e-3 on loss / log-probs and 1e-3 * max(1,|x|) on embeddings / logits
                     (BASELINE.json north_star: "loss/logits within 1e-3 of reference"); measured errors
-                    are ~1e-5.  Parameter gradients: 2e-3 relative to the largest entry of each tensor.
+                    are ~1e-5.  Parameter gradients: 2e-4 of each tensor's largest entry + 1e-5 of the model's
+                    largest gradient entry (absolute floor for analytically-zero gradients); measured 4e-5.
   bf16 perf mode  : documented looser bound (bf16 has 8 mantissa bits): embeddings 6e-2 abs on O(1)
                     values, loss 5e-2, gradients checked by cosine similarity >= 0.98.
 """
@@ -91,16 +92,16 @@ def test_tiny_step_fp32_vs_reference_golden(dev, golden_dir):
     _close(R["q"], G["q_emb"], 2e-5, "q_emb (tight)")
     _close(R["sim"], G["sim"], 5e-5, "sim (tight)")
     assert abs(R["loss"] - float(G["loss_kl"])) <= 5e-5
+    # Per tensor: |g - ref| <= 2e-4 * max|ref| + 1e-5 * (largest gradient entry of the model).  The absolute term
+    # covers the gradients that are analytically 0 (key biases: softmax shift invariance; last-layer LayerNorm bias
+    # of the passage tower: sum_d ds[b,d] = 0), where f32 leaves ~1e-7 of round-off.  Measured: <= 4e-5 relative.
+    gmax = max(np.abs(G["grad." + k]).max() for k in R["grads"])
     worst = 0.0
-    # key-bias gradients are analytically 0 (softmax shift invariance): tensors whose reference gradient is
-    # below 1e-4 of the largest gradient entry are held to that absolute floor instead of their own scale
-    floor = 1e-4 * max(np.abs(G["grad." + k]).max() for k in R["grads"])
     for k, g in R["grads"].items():
         ref = G["grad." + k]
-        scale = max(np.abs(ref).max(), floor)
-        e = np.abs(g - ref).max() / scale
-        worst = max(worst, e)
-        assert e <= 2e-3, "grad %s: rel-to-max err %.3e" % (k, e)
+        err = np.abs(g - ref).max()
+        assert err <= 2e-4 * np.abs(ref).max() + 1e-5 * gmax, "grad %s: err %.3e (scale %.3e)" % (k, err, np.abs(ref).max())
+        worst = max(worst, err / max(np.abs(ref).max(), 1e-3 * gmax))
     assert np.abs(R["grads"]["question_model.pooler.dense.weight"]).max() == 0.0      # pooler grads exactly 0
     print("worst grad rel-to-max err", worst)
 
@@ -130,18 +131,16 @@ def test_base_cfg1_step_fp32_vs_reference_golden(dev, golden_dir):
     assert abs(R["loss"] - float(G["loss_kl"])) <= 1e-3
     names = [str(n) for n in G["grad_names"]]
     norms = G["grad_norms"]
-    floor = 1e-4 * norms.max()          # key-bias grads are analytically 0 (softmax shift invariance)
-    for n, ref in zip(names, norms):
+    for n, ref in zip(names, norms):       # same rule on the per-tensor L2 norms (398 tensors)
         got = np.sqrt((R["grads"][n] ** 2).sum())
-        assert abs(got - ref) <= 2e-3 * max(ref, floor), "grad norm %s: %.6e vs %.6e" % (n, got, ref)
+        assert abs(got - ref) <= 2e-4 * ref + 1e-6 * norms.max(), "grad norm %s: %.6e vs %.6e" % (n, got, ref)
     for k in G.files:
         if k.startswith("gslice."):
             name = k[len("gslice."):]
             g = R["grads"][name]
             ref = G[k]
             got = g[:8, :64] if ref.ndim == 2 else g
-            scale = max(np.abs(ref).max(), 1e-7)
-            assert np.abs(got - ref).max() / scale <= 3e-3, "grad slice %s" % name
+            assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max() + 1e-6 * norms.max(), "grad slice %s" % name
 
 
 def test_base_cfg1_step_bf16(dev, golden_dir):

@@ -9,6 +9,7 @@ typedef unsigned short bf16_t;   // raw bf16 bits
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) short bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 #define WAVE 64
@@ -87,6 +88,29 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float gelu_erf(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_erf_grad(float u) {
   return 0.5f * (1.0f + erff(u * 0.70710678118654752f)) + u * __expf(-0.5f * u * u) * 0.39894228040143268f;
+}
+
+// fast erf-GELU for the bf16 epilogues: Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7, i.e. f32 round-off class),
+// one v_rcp + one v_exp + 7 FMAs instead of the ~50-instruction erff; the exponential is shared with the derivative.
+__device__ __forceinline__ void erf_and_gauss(float u, float& erf_x, float& gauss) {
+  const float x = fabsf(u) * 0.70710678118654752f;
+  const float t = __frcp_rn(fmaf(0.3275911f, x, 1.0f));
+  gauss = __expf(-x * x);                                 // = exp(-u^2/2)
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  erf_x = copysignf(1.0f - p * t * gauss, u);
+}
+__device__ __forceinline__ float gelu_fast(float u) {
+  float e, g;
+  erf_and_gauss(u, e, g);
+  return 0.5f * u * (1.0f + e);
+}
+__device__ __forceinline__ float gelu_grad_fast(float u) {
+  float e, g;
+  erf_and_gauss(u, e, g);
+  return 0.5f * (1.0f + e) + u * g * 0.39894228040143268f;
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -56,7 +56,9 @@ TOL = {False: dict(rtol=2e-5, atol=2e-5), True: dict(rtol=1.2e-2, atol=2e-2)}
 
 # ------------------------------------------------------------------------------------------ GEMM NT
 @pytest.mark.parametrize("bf16", [False, True])
-@pytest.mark.parametrize("M,N,K", [(200, 192, 64), (300, 768, 768), (129, 64, 128), (77, 100, 40), (1000, 3072, 768)])
+@pytest.mark.parametrize("M,N,K", [(200, 192, 64), (300, 768, 768), (129, 64, 128), (77, 100, 40), (1000, 3072, 768),
+                                   (8300, 768, 768), (4100, 1536, 128), (8300, 768, 192), (6200, 1024, 3072),
+                                   (8300, 1536, 128), (16500, 768, 64), (16500, 700, 192), (16400, 768, 768)])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_gemm_nt(dev, bf16, M, N, K, epi):
     lib = L()

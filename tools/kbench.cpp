@@ -1,0 +1,77 @@
+// Kernel micro-benchmark against libsimx_hip.so on the step's real shapes (not part of the product).
+// Build: hipcc -O2 tools/kbench.cpp -Iinclude -Lsimxns_amd -lsimx_hip -Wl,-rpath,$PWD/simxns_amd -o tools/kbench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <string>
+#include "simx.h"
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+#define SX(x) do { int r = (x); if (r) { printf("simx error %d: %s (line %d)\n", r, simx_last_error(), __LINE__); exit(1);} } while (0)
+
+static void* dalloc(size_t bytes, int fill) {
+  void* p; CK(hipMalloc(&p, bytes));
+  std::vector<unsigned short> h(1 << 20);
+  for (size_t i = 0; i < h.size(); ++i) { float f = ((int)((i * 2654435761u) >> 20 & 1023) - 512) / 1024.0f * (fill ? 1.f : 0.f); unsigned u; memcpy(&u, &f, 4); h[i] = (unsigned short)(u >> 16); }
+  for (size_t off = 0; off < bytes; off += h.size() * 2) CK(hipMemcpy((char*)p + off, h.data(), std::min(h.size() * 2, bytes - off), hipMemcpyHostToDevice));
+  return p;
+}
+template <typename F> static double timeit(F f, int iters) {
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  f(); f(); CK(hipDeviceSynchronize());
+  CK(hipEventRecord(a, 0)); for (int i = 0; i < iters; ++i) f(); CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
+  float ms; CK(hipEventElapsedTime(&ms, a, b)); return ms / iters;
+}
+int main(int argc, char** argv) {
+  const int T = argc > 1 ? atoi(argv[1]) : 262144;
+  const int H = 768, F = 3072, iters = 10;
+  void* A = dalloc((size_t)T * F * 2, 1);      // activations (bf16), up to [T,F]
+  void* A2 = dalloc((size_t)T * F * 2, 1);
+  void* C = dalloc((size_t)T * F * 2, 0);
+  void* C2 = dalloc((size_t)T * F * 2, 0);
+  void* W = dalloc((size_t)F * H * 2 * 2, 1);
+  float* bias = (float*)dalloc(F * 4 * 2, 0);
+  float* G = (float*)dalloc((size_t)F * H * 4, 0);
+  size_t wsb = 0; { size_t v; v = simx_gemm_tn_workspace_bytes(3*H, H, T); wsb = v; v = simx_gemm_tn_workspace_bytes(F, H, T); if (v > wsb) wsb = v; v = simx_gemm_tn_workspace_bytes(H, F, T); if (v > wsb) wsb = v; }
+  void* ws = dalloc(wsb + 256, 0);
+  struct S { const char* name; int N, K, epi, res; } nt[] = {
+    {"qkv   fwd  N=2304 K=768 bias", 3 * H, H, 0, 0}, {"oproj fwd  N=768  K=768 bias+res", H, H, 0, 1},
+    {"ffn1  fwd  N=3072 K=768 gelu", F, H, 1, 0},     {"ffn2  fwd  N=768  K=3072 bias+res", H, F, 0, 1},
+    {"ffn2 dgrad N=3072 K=768 dgelu", F, H, 2, 0},    {"ffn1 dgrad N=768  K=3072 +res", H, F, 0, 1},
+    {"qkv  dgrad N=768  K=2304 +res", H, 3 * H, 0, 1}};
+  double tot = 0, totf = 0;
+  const char* only = getenv("KB_ONLY"); int oi = only ? atoi(only) : -1; int idx = -1;
+  for (auto& s : nt) {
+    ++idx; if (oi >= 0 && idx != oi) continue;
+    double ms = timeit([&] { SX(simx_gemm_nt(0, SIMX_BF16, T, s.N, s.K, A, s.K, W, s.K, C, s.N, s.epi == 2 ? nullptr : bias, s.res ? A2 : nullptr, s.N, s.epi, s.epi == 2 ? A2 : nullptr, s.N, s.epi == 1 ? C2 : nullptr, s.N)); }, iters);
+    double fl = 2.0 * T * s.N * s.K; tot += ms; totf += fl;
+    printf("gemm_nt %-36s %8.3f ms  %7.1f TF/s\n", s.name, ms, fl / ms / 1e9);
+  }
+  printf("gemm_nt total %.2f ms  avg %.1f TF/s\n", tot, totf / tot / 1e9);
+  if (oi >= 0) return 0;
+  struct S2 { const char* name; int M, N; } tn[] = {{"wqkv [2304,768]", 3 * H, H}, {"wo [768,768]", H, H}, {"w1 [3072,768]", F, H}, {"w2 [768,3072]", H, F}};
+  tot = 0; totf = 0;
+  for (auto& s : tn) {
+    double ms = timeit([&] { SX(simx_gemm_tn(0, SIMX_BF16, s.M, s.N, T, A, s.M, A2, s.N, G, s.N, 1, ws, wsb)); }, iters);
+    double fl = 2.0 * T * s.M * s.N; tot += ms; totf += fl;
+    printf("gemm_tn %-36s %8.3f ms  %7.1f TF/s\n", s.name, ms, fl / ms / 1e9);
+  }
+  printf("gemm_tn total %.2f ms  avg %.1f TF/s\n", tot, totf / tot / 1e9);
+  // attention + LN + colsum at S=128
+  const int S = 128, nseq = T / S, heads = 12;
+  std::vector<int> cu(nseq + 1); for (int i = 0; i <= nseq; ++i) cu[i] = i * S;
+  int* dcu; CK(hipMalloc(&dcu, (nseq + 1) * 4)); CK(hipMemcpy(dcu, cu.data(), (nseq + 1) * 4, hipMemcpyHostToDevice));
+  float* lse = (float*)dalloc((size_t)heads * T * 4, 0);
+  double ms = timeit([&] { SX(simx_mha_fwd(0, SIMX_BF16, nseq, heads, 64, dcu, S, T, A, C, lse)); }, iters);
+  printf("mha_fwd S=128 %8.3f ms  %7.1f TF/s\n", ms, 4.0 * T * S * H / ms / 1e9);
+  ms = timeit([&] { SX(simx_mha_bwd(0, SIMX_BF16, nseq, heads, 64, dcu, S, T, A, C, lse, A2, C2)); }, iters);
+  printf("mha_bwd S=128 %8.3f ms  %7.1f TF/s (5-GEMM count)\n", ms, 10.0 * T * S * H / ms / 1e9);
+  ms = timeit([&] { SX(simx_ln_fwd(0, SIMX_BF16, T, H, A, bias, bias, 1e-12f, C)); }, iters);
+  printf("ln_fwd  %8.3f ms  %6.2f TB/s\n", ms, 2.0 * T * H * 2 / ms / 1e9);
+  ms = timeit([&] { SX(simx_ln_bwd(0, SIMX_BF16, T, H, A, bias, 1e-12f, A2, C, G, G + 1024, G + 2048)); }, iters);
+  printf("ln_bwd  %8.3f ms  %6.2f TB/s\n", ms, 3.0 * T * H * 2 / ms / 1e9);
+  ms = timeit([&] { SX(simx_colsum(0, SIMX_BF16, T, F, A, F, G, 1)); }, iters);
+  printf("colsum F %8.3f ms  %6.2f TB/s\n", ms, 1.0 * T * F * 2 / ms / 1e9);
+  return 0;
+}

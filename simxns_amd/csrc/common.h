@@ -34,14 +34,14 @@ void simx_set_error(const char* fmt, ...);
 
 // ---- bf16 <-> f32 (round to nearest even; NaN kept quiet) --------------------------------
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// f32 -> bf16 through the native type: hipcc lowers it to v_cvt_pk_bf16_f32 (round to nearest even, NaN kept),
+// one instruction per PAIR -- the hand-rolled integer rounding cost ~12 VALU ops and a divergent NaN branch per element.
+typedef __bf16 bf16v2_t __attribute__((ext_vector_type(2)));
+typedef float f32v2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, static_cast<__bf16>(f)); }
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  const f32v2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16v2_t));
 }
 
 // element load/store by activation type
@@ -94,7 +94,7 @@ __device__ __forceinline__ float gelu_erf_grad(float u) {
 // one v_rcp + one v_exp + 7 FMAs instead of the ~50-instruction erff; the exponential is shared with the derivative.
 __device__ __forceinline__ void erf_and_gauss(float u, float& erf_x, float& gauss) {
   const float x = fabsf(u) * 0.70710678118654752f;
-  const float t = __frcp_rn(fmaf(0.3275911f, x, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));      // v_rcp_f32 (1 ulp), not an IEEE divide
   gauss = __expf(-x * x);                                 // = exp(-u^2/2)
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);

@@ -552,6 +552,334 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_v3_kernel(
   }
 }
 
+// v6: the v3 pipeline with FOUR waves per workgroup (2x2 of 128x64 -> 256x128 block tile) and a 3-slab ring of
+// 24 KB (72 KB): TWO workgroups per CU, so that one workgroup's epilogue (VALU + global stores, measured at ~40 %
+// of a one-workgroup-per-CU kernel's time) overlaps the other's main loop.
+#define V6_SLAB 24576
+#define V6_LDS (3 * V6_SLAB)
+__device__ __forceinline__ void v6_stage(const bf16_t* __restrict__ A, int lda, int m0, int M,
+                                         const bf16_t* __restrict__ B, int ldb, int n0, int N, int k0,
+                                         char* slab, int wave, int lane) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {                 // A: 128 LDS rows (tile rows R and R+128) = 16 wave-instructions
+    const int i = wave * 4 + j;
+    const int R = i * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((R >> 1) & 7);
+    int ga = m0 + R + ((c & 4) ? 128 : 0);
+    ga = ga < M ? ga : M - 1;
+    glds16(A + (long)ga * lda + k0 + (c & 3) * 8, slab + i * 1024);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {                 // B: 64 LDS rows (tile rows R and R+64) = 8 wave-instructions
+    const int i = wave * 2 + j;
+    const int R = i * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((R >> 1) & 7);
+    int gb = n0 + R + ((c & 4) ? 64 : 0);
+    gb = gb < N ? gb : N - 1;
+    glds16(B + (long)gb * ldb + k0 + (c & 3) * 8, slab + 16384 + i * 1024);
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_v6_kernel(
+    int M, int N, int K, const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
+    bf16_t* __restrict__ C, int ldc, const float* __restrict__ bias, const bf16_t* __restrict__ res, int ldr,
+    const bf16_t* __restrict__ aux, int ldaux, bf16_t* __restrict__ C2, int ldc2, int tiles_n, int nwg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = xcd_remap(blockIdx.x, nwg);
+  const int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 128;
+  const int wr = wave >> 1, wc = wave & 1;       // wave tile: rows wr*128.., cols wc*64..
+  const int fr = lane & 15, fg = lane >> 4;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nt = K / 32;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  // per-lane fragment offsets inside a slab
+  const uint32_t offA = (uint32_t)(fr * 128 + (((wr * 4 + fg) ^ ((fr >> 1) & 7)) << 4));
+  const uint32_t offB = (uint32_t)(16384 + fr * 128 + (((wc * 4 + fg) ^ ((fr >> 1) & 7)) << 4));
+
+  // prologue: slabs 0..2 in flight, wait for slab 0
+  v6_stage(A, lda, m0, M, B, ldb, n0, N, 0, smem, wave, lane);
+  if (nt > 1) v6_stage(A, lda, m0, M, B, ldb, n0, N, 32, smem + V6_SLAB, wave, lane);
+  if (nt > 1) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  int ring = 0;                                  // slab index of k-step t in the 3-slab ring
+
+  bf16x8 al0, al1, al2, al3, ah0, ah1, ah2, ah3, bx0, bx1, bx2, bx3, by0, by1, by2, by3;
+  {
+    const uint32_t aa = lds0 + offA, ab = lds0 + offB;
+    V3_READ4(al0, al1, al2, al3, aa, 0, 2048, 4096, 6144);
+    V3_READ4(bx0, bx1, bx2, bx3, ab, 0, 2048, 4096, 6144);
+    V3_PIN8("s_waitcnt lgkmcnt(0)", al0, al1, al2, al3, bx0, bx1, bx2, bx3);
+  }
+
+#define V3_MFMA_ROW(I, AF, B0, B1, B2, B3)                                                     \
+  acc[I][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B0, AF, acc[I][0], 0, 0, 0);             \
+  acc[I][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B1, AF, acc[I][1], 0, 0, 0);             \
+  acc[I][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B2, AF, acc[I][2], 0, 0, 0);             \
+  acc[I][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B3, AF, acc[I][3], 0, 0, 0)
+
+#define V3_RD1(F, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=&v"(F) : "v"(ADDR) : "memory")
+#define V3_SB __builtin_amdgcn_sched_barrier(0)
+// reads are sprinkled between the MFMA rows (one ds_read per 4 MFMAs in phase 1, two in phase 2) instead of being
+// issued as bursts right after the barrier, where all 8 waves would queue on the LDS while the matrix pipes idle.
+#define V3_ITER(T, BC0, BC1, BC2, BC3, BN0, BN1, BN2, BN3)                                      \
+  do {                                                                                         \
+    const int t__ = (T);                                                                       \
+    const int r1__ = ring == 2 ? 0 : ring + 1, r2__ = r1__ == 2 ? 0 : r1__ + 1;                \
+    const uint32_t aa__ = lds0 + (uint32_t)(ring * V6_SLAB) + offA;                            \
+    const uint32_t na__ = lds0 + (uint32_t)(r1__ * V6_SLAB) + offA;                            \
+    const uint32_t nb__ = lds0 + (uint32_t)(r1__ * V6_SLAB) + offB;                            \
+    if (t__ + 2 < nt)                                                                          \
+      v6_stage(A, lda, m0, M, B, ldb, n0, N, (t__ + 2) * 32, smem + r2__ * V6_SLAB, wave, lane); \
+    V3_SB; V3_MFMA_ROW(0, al0, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah0, aa__, 8192);            \
+    V3_SB; V3_MFMA_ROW(1, al1, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah1, aa__, 10240);           \
+    V3_SB; V3_MFMA_ROW(2, al2, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah2, aa__, 12288);           \
+    V3_SB; V3_MFMA_ROW(3, al3, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah3, aa__, 14336);           \
+    V3_SB;                                                                                     \
+    /* no branch may sit between an asm read and the asm wait that pins its registers: hipcc would   \
+       place phi copies of the still-in-flight registers there */                                 \
+    V3_PIN4("s_waitcnt lgkmcnt(0)", ah0, ah1, ah2, ah3);                                       \
+    if (t__ + 2 < nt) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");            \
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                         \
+    /* next slab's A[0..3], B (past the end: stale slab, never consumed) */                      \
+    V3_SB; V3_MFMA_ROW(4, ah0, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al0, na__, 0); V3_RD1(BN0, nb__, 0);       \
+    V3_SB; V3_MFMA_ROW(5, ah1, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al1, na__, 2048); V3_RD1(BN1, nb__, 2048); \
+    V3_SB; V3_MFMA_ROW(6, ah2, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al2, na__, 4096); V3_RD1(BN2, nb__, 4096); \
+    V3_SB; V3_MFMA_ROW(7, ah3, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al3, na__, 6144); V3_RD1(BN3, nb__, 6144); \
+    V3_SB;                                                                                     \
+    V3_PIN8("s_waitcnt lgkmcnt(0)", al0, al1, al2, al3, BN0, BN1, BN2, BN3);                   \
+    ring = r1__;                                                                               \
+  } while (0)
+
+  for (int t = 0; t < nt; t += 2) {
+    V3_ITER(t, bx0, bx1, bx2, bx3, by0, by1, by2, by3);
+    if (t + 1 < nt) V3_ITER(t + 1, by0, by1, by2, by3, bx0, bx1, bx2, bx3);
+  }
+#undef V3_ITER
+#undef V3_MFMA_ROW
+
+  // epilogue: lane holds row m (fr) and 4 consecutive columns of each 16x16 tile
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + wr * 128 + i * 16 + fr;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wc * 64 + j * 16 + fg * 4;
+      if (n >= N) continue;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (bias) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias + n);
+        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+      }
+      if (EPI == SIMX_EPI_NONE) {
+        if (res) { float r4[4]; ld4(res + (long)m * ldr + n, r4); v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3]; }
+        st4(C + (long)m * ldc + n, v);
+      } else if (EPI == SIMX_EPI_GELU) {
+        st4(C + (long)m * ldc + n, v);
+        float g4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g4[e] = gelu_fast(bf2f(f2bf(v[e])));
+        st4(C2 + (long)m * ldc2 + n, g4);
+      } else {
+        if (res) { float r4[4]; ld4(res + (long)m * ldr + n, r4); v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3]; }
+        float u4[4]; ld4(aux + (long)m * ldaux + n, u4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_fast(u4[e]);
+        st4(C + (long)m * ldc + n, v);
+      }
+    }
+  }
+}
+
+
+__device__ int g_gemm_dbg = 0;   // measurement hook, set from env SIMX_GEMM_DBG (bit0: skip global stores, bit1: skip LDS staging loop)
+// v5: 256x256x64 stages (full 128-B lines per row: the LDS-DMA path is request-bound, measured ~20 B/clk/CU with full
+// lines on v2 and only ~13 with v3's half lines), TWO 64 KB stages, 128x64 wave tiles.  A stage is re-filled as soon as
+// its last fragment has been read (stage boundary = the only barrier, once per 64 k), so the DMA queue never drains.
+#define V5_STAGE 65536
+#define V5_LDS (2 * V5_STAGE)
+__device__ __forceinline__ void v5_stage(const bf16_t* __restrict__ A, int lda, int m0, int M,
+                                         const bf16_t* __restrict__ B, int ldb, int n0, int N, int k0,
+                                         char* stage, int wave, int lane) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {                 // 32 wave-instructions of 8 rows per operand
+    const int i = wave * 4 + j;
+    const int r = i * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    int ga = m0 + r, gb = n0 + r;
+    ga = ga < M ? ga : M - 1;
+    gb = gb < N ? gb : N - 1;
+    glds16(A + (long)ga * lda + k0 + c * 8, stage + i * 1024);
+    glds16(B + (long)gb * ldb + k0 + c * 8, stage + 32768 + i * 1024);
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_bf16_v5_kernel(
+    int M, int N, int K, const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
+    bf16_t* __restrict__ C, int ldc, const float* __restrict__ bias, const bf16_t* __restrict__ res, int ldr,
+    const bf16_t* __restrict__ aux, int ldaux, bf16_t* __restrict__ C2, int ldc2, int tiles_n, int nwg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = xcd_remap(blockIdx.x, nwg);
+  const int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
+  const int wr = wave >> 2, wc = wave & 3;       // wave tile: rows wr*128.., cols wc*64..
+  const int fr = lane & 15, fg = lane >> 4;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nst = K / 64;                         // 64-deep stages; two 32-deep k-steps ("slabs") per stage
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const int swz = (fr >> 1) & 7;
+  const uint32_t rowA = (uint32_t)((wr * 128 + fr) * 128), rowB = (uint32_t)(32768 + (wc * 64 + fr) * 128);
+  // fragment byte offsets inside a stage for k-step 0 / 1
+  const uint32_t oA0 = rowA + (uint32_t)(((0 + fg) ^ swz) << 4), oA1 = rowA + (uint32_t)(((4 + fg) ^ swz) << 4);
+  const uint32_t oB0 = rowB + (uint32_t)(((0 + fg) ^ swz) << 4), oB1 = rowB + (uint32_t)(((4 + fg) ^ swz) << 4);
+
+  v5_stage(A, lda, m0, M, B, ldb, n0, N, 0, smem, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  if (nst > 1) v5_stage(A, lda, m0, M, B, ldb, n0, N, 64, smem + V5_STAGE, wave, lane);
+
+  bf16x8 al0, al1, al2, al3, ah0, ah1, ah2, ah3, bx0, bx1, bx2, bx3, by0, by1, by2, by3;
+  {
+    const uint32_t aa = lds0 + oA0, ab = lds0 + oB0;
+    V3_READ4(al0, al1, al2, al3, aa, 0, 2048, 4096, 6144);
+    V3_READ4(bx0, bx1, bx2, bx3, ab, 0, 2048, 4096, 6144);
+    V3_PIN8("s_waitcnt lgkmcnt(0)", al0, al1, al2, al3, bx0, bx1, bx2, bx3);
+  }
+
+#define V3_MFMA_ROW(I, AF, B0, B1, B2, B3)                                                     \
+  acc[I][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B0, AF, acc[I][0], 0, 0, 0);             \
+  acc[I][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B1, AF, acc[I][1], 0, 0, 0);             \
+  acc[I][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B2, AF, acc[I][2], 0, 0, 0);             \
+  acc[I][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B3, AF, acc[I][3], 0, 0, 0)
+#define V3_RD1(F, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=&v"(F) : "v"(ADDR) : "memory")
+#define V3_SB __builtin_amdgcn_sched_barrier(0)
+  // one k-step: CUR = this k-step's A-high address, NA/NB = next k-step's A-low / B addresses; SYNC: stage boundary
+#define V5_STEP(CURA, NA, NB, BC0, BC1, BC2, BC3, BN0, BN1, BN2, BN3, SYNC, ST)                  \
+  do {                                                                                         \
+    const uint32_t aa__ = (CURA), na__ = (NA), nb__ = (NB);                                    \
+    V3_SB; V3_MFMA_ROW(0, al0, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah0, aa__, 8192);            \
+    V3_SB; V3_MFMA_ROW(1, al1, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah1, aa__, 10240);           \
+    V3_SB; V3_MFMA_ROW(2, al2, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah2, aa__, 12288);           \
+    V3_SB; V3_MFMA_ROW(3, al3, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah3, aa__, 14336);           \
+    V3_SB;                                                                                     \
+    V3_PIN4("s_waitcnt lgkmcnt(0)", ah0, ah1, ah2, ah3);                                       \
+    if (SYNC) {                                                                                \
+      /* every read of stage ST is done (pinned above); the next stage has landed for this wave  \
+         once vmcnt hits 0, for everyone after the barrier; stage ST is then free for ST+2 */    \
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                            \
+      if ((ST) + 2 < nst)                                                                      \
+        v5_stage(A, lda, m0, M, B, ldb, n0, N, ((ST) + 2) * 64, smem + ((ST) & 1) * V5_STAGE, wave, lane); \
+    }                                                                                          \
+    V3_SB; V3_MFMA_ROW(4, ah0, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al0, na__, 0); V3_RD1(BN0, nb__, 0);       \
+    V3_SB; V3_MFMA_ROW(5, ah1, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al1, na__, 2048); V3_RD1(BN1, nb__, 2048); \
+    V3_SB; V3_MFMA_ROW(6, ah2, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al2, na__, 4096); V3_RD1(BN2, nb__, 4096); \
+    V3_SB; V3_MFMA_ROW(7, ah3, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al3, na__, 6144); V3_RD1(BN3, nb__, 6144); \
+    V3_SB;                                                                                     \
+    V3_PIN8("s_waitcnt lgkmcnt(0)", al0, al1, al2, al3, BN0, BN1, BN2, BN3);                   \
+  } while (0)
+
+  for (int st = 0; st < nst; ++st) {
+    const uint32_t sc = lds0 + (uint32_t)((st & 1) * V5_STAGE), sn = lds0 + (uint32_t)(((st + 1) & 1) * V5_STAGE);
+    // k-step 0 of stage st (B in bx*), prefetching k-step 1 of the same stage into by*
+    V5_STEP(sc + oA0, sc + oA1, sc + oB1, bx0, bx1, bx2, bx3, by0, by1, by2, by3, false, st);
+    // k-step 1 (B in by*), stage boundary inside, prefetching k-step 0 of stage st+1 into bx* (stale past the end)
+    V5_STEP(sc + oA1, sn + oA0, sn + oB0, by0, by1, by2, by3, bx0, bx1, bx2, bx3, true, st);
+  }
+#undef V5_STEP
+#undef V3_RD1
+#undef V3_SB
+#undef V3_MFMA_ROW
+
+  if (C == nullptr) return;                      // measurement hook (SIMX_NOEPI): main loop only
+  // ---- epilogue through LDS.  The memory path is REQUEST-bound (~1 request / 6 clk / CU, measured): the natural
+  // MFMA-layout epilogue issues 32-B requests (16 rows x 32 B per store instruction, 4096 per output tile, as many
+  // as a K=768 main loop).  Each wave therefore stages its 128x64 tile in its own 16 KB of the (now free) LDS ring:
+  // residual / GELU-input rows arrive by full-line LDS-DMA, results leave as 16 B per lane = full 128-B lines.
+  asm volatile("s_barrier" ::: "memory");        // every wave is done with the operand stages
+  {
+    char* reg = smem + wave * 16384;             // [128 rows][128 B], 16-B chunk c of row r at c ^ ((r>>1)&7)
+    const uint32_t reg_a = lds0 + (uint32_t)(wave * 16384);
+    const int mw = m0 + wr * 128, nw = n0 + wc * 64;
+    const bf16_t* in = (EPI == SIMX_EPI_DGELU) ? aux : res;
+    const int ldin = (EPI == SIMX_EPI_DGELU) ? ldaux : ldr;
+    if (in) {
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int r = it * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        int gm = mw + r, gn = nw + c * 8;
+        gm = gm < M ? gm : M - 1;
+        gn = gn + 8 <= N ? gn : N - 8;
+        glds16(in + (long)gm * ldin + gn, reg + it * 1024);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // lane's 8-B slot for (i,j): row i*16+fr, cols j*16+fg*4..+3
+    const uint32_t slot0 = reg_a + (uint32_t)(fr * 128 + (fg & 1) * 8);
+    const int sw = (fr >> 1) & 7;
+#pragma unroll
+    for (int pass = 0; pass < (EPI == SIMX_EPI_GELU ? 2 : 1); ++pass) {
+#pragma unroll
+      for (int i = 0; i < ((g_gemm_dbg & 2) ? 0 : 8); ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t ad = slot0 + (uint32_t)(i * 2048 + (((j * 2 + (fg >> 1)) ^ sw) << 4));
+          float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+          if (bias) {
+            const int n = nw + j * 16 + fg * 4;
+            const float4 bv = *reinterpret_cast<const float4*>(bias + (n + 4 <= N ? n : 0));
+            v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+          }
+          if (EPI != SIMX_EPI_GELU && in) {
+            uint2 t;
+            asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(ad) : "memory");
+            const float x0 = __uint_as_float(t.x << 16), x1 = __uint_as_float(t.x & 0xFFFF0000u);
+            const float x2 = __uint_as_float(t.y << 16), x3 = __uint_as_float(t.y & 0xFFFF0000u);
+            if (EPI == SIMX_EPI_NONE) { v[0] += x0; v[1] += x1; v[2] += x2; v[3] += x3; }
+            else { v[0] *= gelu_grad_fast(x0); v[1] *= gelu_grad_fast(x1); v[2] *= gelu_grad_fast(x2); v[3] *= gelu_grad_fast(x3); }
+          }
+          if (EPI == SIMX_EPI_GELU && pass == 1) {
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) v[e2] = gelu_fast(bf2f(f2bf(v[e2])));
+          }
+          const uint2 o = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+          asm volatile("ds_write_b64 %0, %1" ::"v"(ad), "v"(o) : "memory");
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      bf16_t* out = pass == 0 ? C : C2;
+      const int ldo = pass == 0 ? ldc : ldc2;
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int r = it * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const uint4 val = *reinterpret_cast<const uint4*>(reg + r * 128 + (lane & 7) * 16);
+        const int gm = mw + r, gn = nw + c * 8;
+        if (gm < M && gn + 8 <= N && !(g_gemm_dbg & 1)) *reinterpret_cast<uint4*>(out + (long)gm * ldo + gn) = val;
+      }
+    }
+  }
+}
+
+
 // v4: the v3 pipeline on v_mfma_f32_32x32x16_bf16 (the 16x16x32 form tops out at ~83 % of the MFMA peak, the
 // 32x32x16 form at ~95 %): wave tile 128x64 = 4x2 tiles of 32x32, per slab two k-steps of 16.
 template <int EPI>
@@ -936,7 +1264,51 @@ extern "C" int simx_gemm_nt(simx_stream_t stream, int dtype, int M, int N, int K
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_v4_kernel<SIMX_EPI_DGELU>), hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
       attr4 = true;
     }
-    if ((variant == 0 || variant == 4) && nwg3 >= 192) {
+    static bool attr6 = false;
+    if (!attr6) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_v6_kernel<SIMX_EPI_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, V6_LDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_v6_kernel<SIMX_EPI_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, V6_LDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_v6_kernel<SIMX_EPI_DGELU>), hipFuncAttributeMaxDynamicSharedMemorySize, V6_LDS);
+      attr6 = true;
+    }
+    {
+      const int t6m = cdiv(M, 256), t6n = cdiv(N, 128), nwg6 = t6m * t6n;
+      if ((variant == 0 || variant == 6) && nwg6 >= 384) {
+#define L6(E) hipLaunchKernelGGL((gemm_nt_bf16_v6_kernel<E>), dim3(nwg6), dim3(256), V6_LDS, s, M, N, K, (const bf16_t*)A, lda, \
+                                 (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, (const bf16_t*)residual, ldr,                  \
+                                 (const bf16_t*)aux, ldaux, (bf16_t*)C2, ldc2, t6n, nwg6)
+        if (epilogue == SIMX_EPI_NONE) L6(SIMX_EPI_NONE);
+        else if (epilogue == SIMX_EPI_GELU) L6(SIMX_EPI_GELU);
+        else L6(SIMX_EPI_DGELU);
+#undef L6
+        SIMX_CHECK_LAUNCH("gemm_nt_bf16_v6");
+        return SIMX_OK;
+      }
+    }
+    static bool attr5 = false;
+    if (!attr5) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_v5_kernel<SIMX_EPI_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, V5_LDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_v5_kernel<SIMX_EPI_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, V5_LDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_v5_kernel<SIMX_EPI_DGELU>), hipFuncAttributeMaxDynamicSharedMemorySize, V5_LDS);
+      attr5 = true;
+    }
+    if ((variant == 0 || variant == 5) && nwg3 >= 192 && N % 8 == 0 && ldc % 8 == 0 && (!residual || ldr % 8 == 0) &&
+        (!aux || ldaux % 8 == 0) && (!C2 || ldc2 % 8 == 0)) {
+      static const bool noepi = getenv("SIMX_NOEPI") != nullptr;
+      static bool dbg_set = false;
+      if (!dbg_set) { const char* d = getenv("SIMX_GEMM_DBG"); int v = d ? atoi(d) : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_dbg), &v, sizeof(int)); dbg_set = true; }
+      if (noepi) C = nullptr;
+#define L5(E) hipLaunchKernelGGL((gemm_nt_bf16_v5_kernel<E>), dim3(nwg3), dim3(512), V5_LDS, s, M, N, K, (const bf16_t*)A, lda, \
+                                 (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, (const bf16_t*)residual, ldr,                  \
+                                 (const bf16_t*)aux, ldaux, (bf16_t*)C2, ldc2, t3n, nwg3)
+      if (epilogue == SIMX_EPI_NONE) L5(SIMX_EPI_NONE);
+      else if (epilogue == SIMX_EPI_GELU) L5(SIMX_EPI_GELU);
+      else L5(SIMX_EPI_DGELU);
+#undef L5
+      SIMX_CHECK_LAUNCH("gemm_nt_bf16_v5");
+      return SIMX_OK;
+    }
+    if ((variant == 4) && nwg3 >= 192) {
 #define L4(E) hipLaunchKernelGGL((gemm_nt_bf16_v4_kernel<E>), dim3(nwg3), dim3(512), V3_LDS, s, M, N, K, (const bf16_t*)A, lda, \
                                  (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, (const bf16_t*)residual, ldr,                  \
                                  (const bf16_t*)aux, ldaux, (bf16_t*)C2, ldc2, t3n, nwg3)

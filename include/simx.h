@@ -61,6 +61,12 @@ int simx_gemm_tn(simx_stream_t stream, int dtype, int M, int N, int K,
                  const void* A, int lda, const void* B, int ldb, float* C, int ldc,
                  int accumulate, void* ws, size_t ws_bytes);
 
+/* same, and dbias[M] (f32, may be NULL) += column sums of A over K (the dense layer's bias gradient, fused into
+ * the wgrad GEMM on the large-shape path; accumulates with atomics). */
+int simx_gemm_tn_bias(simx_stream_t stream, int dtype, int M, int N, int K,
+                      const void* A, int lda, const void* B, int ldb, float* C, int ldc,
+                      int accumulate, void* ws, size_t ws_bytes, float* dbias);
+
 /* out[N] (f32) (+)= column sums of x[T,N]  (bias gradients). */
 int simx_colsum(simx_stream_t stream, int dtype, int T, int N, const void* x, int ldx,
                 float* out, int accumulate);

@@ -43,6 +43,7 @@ SIGNATURES = {
     "simx_gemm_nt": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _i, _i, _p, _i, _p, _i]),
     "simx_gemm_tn_workspace_bytes": (_z, [_i, _i, _i]),
     "simx_gemm_tn": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p, _z]),
+    "simx_gemm_tn_bias": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p, _z, _p]),
     "simx_colsum": (_i, [_p, _i, _i, _i, _p, _i, _p, _i]),
     "simx_cast_weight": (_i, [_p, _p, _i, _i, _p, _p]),
     "simx_transpose_cast": (_i, [_p, _i, _p, _i, _i, _p, _p]),

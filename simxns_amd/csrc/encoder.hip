@@ -262,8 +262,7 @@ extern "C" int simx_bert_bwd(simx_stream_t stream, const simx_bert_cfg* c, const
     RUN(simx_gemm_tn(stream, dt, H, F, T, bufA, H, a.h, F, goff(l, SIMX_P_W2), F, 1, tnws, tnws_bytes));
     // dx1 = du . W1 + dz2
     RUN(simx_gemm_nt(stream, dt, T, H, F, du, F, w.w1T, F, bufB, H, nullptr, bufA, H, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
-    RUN(simx_gemm_tn(stream, dt, F, H, T, du, F, a.x1, H, goff(l, SIMX_P_W1), H, 1, tnws, tnws_bytes));
-    RUN(simx_colsum(stream, dt, T, F, du, F, goff(l, SIMX_P_B1), 1));
+    RUN(simx_gemm_tn_bias(stream, dt, F, H, T, du, F, a.x1, H, goff(l, SIMX_P_W1), H, 1, tnws, tnws_bytes, goff(l, SIMX_P_B1)));
     // attention-output LayerNorm : dz1, dgamma1, dbeta1, dbo
     RUN(simx_ln_bwd(stream, dt, T, H, a.z1, off(l, SIMX_P_LN1_G), c->eps, bufB, bufA, goff(l, SIMX_P_LN1_G),
                     goff(l, SIMX_P_LN1_B), goff(l, SIMX_P_BO)));
@@ -274,8 +273,8 @@ extern "C" int simx_bert_bwd(simx_stream_t stream, const simx_bert_cfg* c, const
     // dx = dqkv . Wqkv + dz1
     RUN(simx_gemm_nt(stream, dt, T, H, 3 * H, dqkv, 3 * H, w.wqkvT, 3 * H, bufB, H, nullptr, bufA, H, SIMX_EPI_NONE, nullptr, 0,
                      nullptr, 0));
-    RUN(simx_gemm_tn(stream, dt, 3 * H, H, T, dqkv, 3 * H, xin, H, goff(l, SIMX_P_WQKV), H, 1, tnws, tnws_bytes));
-    RUN(simx_colsum(stream, dt, T, 3 * H, dqkv, 3 * H, goff(l, SIMX_P_BQKV), 1));
+    RUN(simx_gemm_tn_bias(stream, dt, 3 * H, H, T, dqkv, 3 * H, xin, H, goff(l, SIMX_P_WQKV), H, 1, tnws, tnws_bytes,
+                          goff(l, SIMX_P_BQKV)));
   }
   RUN(simx_embed_ln_bwd(stream, dt, T, H, ids, pos_ids, off(-1, SIMX_P_WORD), off(-1, SIMX_P_POS), off(-1, SIMX_P_TYPE),
                         off(-1, SIMX_P_EMB_LN_G), c->eps, bufB, goff(-1, SIMX_P_WORD), goff(-1, SIMX_P_POS),

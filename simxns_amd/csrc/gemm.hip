@@ -1133,6 +1133,205 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// bf16 TN kernel v2 (large wgrad): 256x256 block tile, 8 waves (2x4) of 128x64, 64-token stages (two 64 KB
+// stages, full 512-B rows by LDS-DMA), fragments by ds_read_b64_tr_b16 interleaved with the MFMAs, one barrier
+// per stage.  With 128x128 tiles the wgrad GEMM sat exactly on the LDS-DMA request ceiling (~20 B/clk/CU x
+// 64 flop/B = 690 TFLOP/s measured 640-660); this tile needs half the bytes per flop.
+// Optional fused bias gradient: workgroups of the first N-tile (waves with wc == 0) also sum the A operand
+// (= dY) over tokens on the VALU, in the shadow of the MFMAs, and flush with one atomic per column.
+// LDS image of a 64(k) x 256(col) operand stage: row kr at kr*512 B, 32-B chunk q stored at q ^ (kr & 7).
+// ------------------------------------------------------------------------------------------
+#define TN2_STAGE 65536
+#define TN2_LDS (2 * TN2_STAGE)
+
+__device__ __forceinline__ void tn2_stage(const bf16_t* __restrict__ A, int lda, int m0, int M,
+                                          const bf16_t* __restrict__ B, int ldb, int n0, int N, int k0, int k_end,
+                                          char* stage, int wave, int lane) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {                 // 32 wave-instructions of 2 k-rows per operand
+    const int i = wave * 4 + j;
+    const int kr = i * 2 + (lane >> 5);
+    const int p16 = lane & 31;
+    const int q = (p16 >> 1) ^ (kr & 7);
+    int gk = k0 + kr;
+    gk = gk < k_end ? gk : k_end - 1;
+    int ca = m0 + q * 16 + (p16 & 1) * 8, cb = n0 + q * 16 + (p16 & 1) * 8;
+    ca = ca + 8 <= M ? ca : M - 8;
+    cb = cb + 8 <= N ? cb : N - 8;
+    glds16(A + (long)gk * lda + ca, stage + i * 1024);
+    glds16(B + (long)gk * ldb + cb, stage + 32768 + i * 1024);
+  }
+}
+
+// one fragment = two transpose reads (k rows base+4g.. and base+16+4g..)
+#define TN2_RD(F_LO, F_HI, ADDR_LO, ADDR_HI)                                                        \
+  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3" : "=&v"(F_LO), "=&v"(F_HI) : "v"(ADDR_LO), "v"(ADDR_HI) : "memory")
+
+__global__ __launch_bounds__(512, 2) void gemm_tn2_bf16_kernel(
+    int M, int N, int K, const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
+    float* __restrict__ out, long slab_stride, int ldo, int tiles_n, int tiles_mn, int k_per_split, int accumulate,
+    float* __restrict__ dbias) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int split = blockIdx.x / tiles_mn;
+  const int tile = blockIdx.x % tiles_mn;
+  const int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int kb = split * k_per_split;
+  const int ke = min(K, kb + k_per_split);
+  const int fs = lane & 15, fg = lane >> 4;
+  const bool do_bias = dbias != nullptr && (tile % tiles_n) == 0 && wc == 0;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  const int nst = (ke - kb + 63) / 64;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  // transpose-read addressing: lane (fg, fs) supplies row 4*fg + (fs>>2) (+16 for the high half) of a 32-row k-step,
+  // 8 B at element column ct*16 + (fs&3)*4 of 16-column tile ct -> 32-B chunk ct, byte (fs&3)*8 in it.
+  const int r_lo = 4 * fg + (fs >> 2);                      // row within the k-step (low half); high half = +16
+  const int x_lo = r_lo & 7, x_hi = (r_lo + 16) & 7;        // XOR terms (k-step bases are multiples of 32)
+  const uint32_t row_lo = (uint32_t)(r_lo * 512 + (fs & 3) * 8), row_hi = (uint32_t)((r_lo + 16) * 512 + (fs & 3) * 8);
+
+  tn2_stage(A, lda, m0, M, B, ldb, n0, N, kb, ke, smem, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  if (nst > 1) tn2_stage(A, lda, m0, M, B, ldb, n0, N, kb + 64, ke, smem + TN2_STAGE, wave, lane);
+
+  bf16x4 al_lo[4], al_hi[4], ah_lo[4], ah_hi[4], bx_lo[4], bx_hi[4], by_lo[4], by_hi[4];
+  // address of fragment (operand base, 16-col tile ct) for k-step base address `kbase` (stage + ks*32*512)
+#define TN2_ADDR_LO(KBASE, OP, CT) ((KBASE) + (OP) + row_lo + (uint32_t)((((CT)) ^ x_lo) << 5))
+#define TN2_ADDR_HI(KBASE, OP, CT) ((KBASE) + (OP) + row_hi + (uint32_t)((((CT)) ^ x_hi) << 5))
+#define TN2_FRAG(LO, HI) ((bf16x8){LO[0], LO[1], LO[2], LO[3], HI[0], HI[1], HI[2], HI[3]})
+#define TN2_MFMA_ROW(I, ALO, AHI, BLO, BHI)                                                                     \
+  do {                                                                                                          \
+    const bf16x8 af__ = TN2_FRAG(ALO, AHI);                                                                     \
+    acc[I][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(TN2_FRAG(BLO[0], BHI[0]), af__, acc[I][0], 0, 0, 0);    \
+    acc[I][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(TN2_FRAG(BLO[1], BHI[1]), af__, acc[I][1], 0, 0, 0);    \
+    acc[I][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(TN2_FRAG(BLO[2], BHI[2]), af__, acc[I][2], 0, 0, 0);    \
+    acc[I][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(TN2_FRAG(BLO[3], BHI[3]), af__, acc[I][3], 0, 0, 0);    \
+    if (do_bias) {                                                                                              \
+      _Pragma("unroll") for (int e__ = 0; e__ < 4; ++e__)                                                       \
+          bsum[I] += bf2f((bf16_t)ALO[e__]) + bf2f((bf16_t)AHI[e__]);                                           \
+    }                                                                                                           \
+  } while (0)
+#define TN2_SB __builtin_amdgcn_sched_barrier(0)
+#define TN2_PIN8(TXT, X, Y)                                                                                     \
+  asm volatile(TXT : "+v"(X[0]), "+v"(X[1]), "+v"(X[2]), "+v"(X[3]), "+v"(Y[0]), "+v"(Y[1]), "+v"(Y[2]), "+v"(Y[3])::"memory")
+
+  {
+    // A[0..3] and B of k-step 0: column tile index ct = (wave col offset)/16 + i
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      TN2_RD(al_lo[i], al_hi[i], TN2_ADDR_LO(lds0, 0u, wr * 8 + i), TN2_ADDR_HI(lds0, 0u, wr * 8 + i));
+      TN2_RD(bx_lo[i], bx_hi[i], TN2_ADDR_LO(lds0, 32768u, wc * 4 + i), TN2_ADDR_HI(lds0, 32768u, wc * 4 + i));
+    }
+    TN2_PIN8("s_waitcnt lgkmcnt(0)", al_lo, al_hi);
+    TN2_PIN8("s_waitcnt lgkmcnt(0)", bx_lo, bx_hi);
+  }
+
+  // one k-step (32 tokens): CUR = k-step base address, NXT = next k-step base address
+#define TN2_STEP(CUR, NXT, BCL, BCH, BNL, BNH, SYNC, ST)                                                        \
+  do {                                                                                                          \
+    const uint32_t cur__ = (CUR), nxt__ = (NXT);                                                                \
+    TN2_SB; TN2_MFMA_ROW(0, al_lo[0], al_hi[0], BCL, BCH); TN2_SB;                                              \
+    TN2_RD(ah_lo[0], ah_hi[0], TN2_ADDR_LO(cur__, 0u, wr * 8 + 4), TN2_ADDR_HI(cur__, 0u, wr * 8 + 4));         \
+    TN2_SB; TN2_MFMA_ROW(1, al_lo[1], al_hi[1], BCL, BCH); TN2_SB;                                              \
+    TN2_RD(ah_lo[1], ah_hi[1], TN2_ADDR_LO(cur__, 0u, wr * 8 + 5), TN2_ADDR_HI(cur__, 0u, wr * 8 + 5));         \
+    TN2_SB; TN2_MFMA_ROW(2, al_lo[2], al_hi[2], BCL, BCH); TN2_SB;                                              \
+    TN2_RD(ah_lo[2], ah_hi[2], TN2_ADDR_LO(cur__, 0u, wr * 8 + 6), TN2_ADDR_HI(cur__, 0u, wr * 8 + 6));         \
+    TN2_SB; TN2_MFMA_ROW(3, al_lo[3], al_hi[3], BCL, BCH); TN2_SB;                                              \
+    TN2_RD(ah_lo[3], ah_hi[3], TN2_ADDR_LO(cur__, 0u, wr * 8 + 7), TN2_ADDR_HI(cur__, 0u, wr * 8 + 7));         \
+    TN2_SB;                                                                                                     \
+    TN2_PIN8("s_waitcnt lgkmcnt(0)", ah_lo, ah_hi);                                                             \
+    if (SYNC) {                                                                                                 \
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                                             \
+      if ((ST) + 2 < nst)                                                                                       \
+        tn2_stage(A, lda, m0, M, B, ldb, n0, N, kb + ((ST) + 2) * 64, ke, smem + ((ST) & 1) * TN2_STAGE, wave, lane); \
+      if ((ST) + 1 == nst - 1 && (ke - kb) % 64 != 0) {                                                         \
+        /* ragged last stage: rows >= valid hold clamped copies -> zero them (both operands) */                \
+        const int valid__ = (ke - kb) - (nst - 1) * 64;                                                         \
+        char* sp__ = smem + (((ST) + 1) & 1) * TN2_STAGE;                                                       \
+        for (int idx = tid; idx < 64 * 64; idx += 512) {                                                        \
+          const int kr = idx >> 6, c16 = idx & 63;                                                              \
+          if (kr >= valid__) *reinterpret_cast<uint4*>(sp__ + kr * 512 + (c16 & 31) * 16 + (c16 >> 5) * 32768) = make_uint4(0, 0, 0, 0); \
+        }                                                                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                         \
+      }                                                                                                         \
+    }                                                                                                           \
+    TN2_SB; TN2_MFMA_ROW(4, ah_lo[0], ah_hi[0], BCL, BCH); TN2_SB;                                              \
+    TN2_RD(al_lo[0], al_hi[0], TN2_ADDR_LO(nxt__, 0u, wr * 8 + 0), TN2_ADDR_HI(nxt__, 0u, wr * 8 + 0));         \
+    TN2_RD(BNL[0], BNH[0], TN2_ADDR_LO(nxt__, 32768u, wc * 4 + 0), TN2_ADDR_HI(nxt__, 32768u, wc * 4 + 0));     \
+    TN2_SB; TN2_MFMA_ROW(5, ah_lo[1], ah_hi[1], BCL, BCH); TN2_SB;                                              \
+    TN2_RD(al_lo[1], al_hi[1], TN2_ADDR_LO(nxt__, 0u, wr * 8 + 1), TN2_ADDR_HI(nxt__, 0u, wr * 8 + 1));         \
+    TN2_RD(BNL[1], BNH[1], TN2_ADDR_LO(nxt__, 32768u, wc * 4 + 1), TN2_ADDR_HI(nxt__, 32768u, wc * 4 + 1));     \
+    TN2_SB; TN2_MFMA_ROW(6, ah_lo[2], ah_hi[2], BCL, BCH); TN2_SB;                                              \
+    TN2_RD(al_lo[2], al_hi[2], TN2_ADDR_LO(nxt__, 0u, wr * 8 + 2), TN2_ADDR_HI(nxt__, 0u, wr * 8 + 2));         \
+    TN2_RD(BNL[2], BNH[2], TN2_ADDR_LO(nxt__, 32768u, wc * 4 + 2), TN2_ADDR_HI(nxt__, 32768u, wc * 4 + 2));     \
+    TN2_SB; TN2_MFMA_ROW(7, ah_lo[3], ah_hi[3], BCL, BCH); TN2_SB;                                              \
+    TN2_RD(al_lo[3], al_hi[3], TN2_ADDR_LO(nxt__, 0u, wr * 8 + 3), TN2_ADDR_HI(nxt__, 0u, wr * 8 + 3));         \
+    TN2_RD(BNL[3], BNH[3], TN2_ADDR_LO(nxt__, 32768u, wc * 4 + 3), TN2_ADDR_HI(nxt__, 32768u, wc * 4 + 3));     \
+    TN2_SB;                                                                                                     \
+    TN2_PIN8("s_waitcnt lgkmcnt(0)", al_lo, al_hi);                                                             \
+    TN2_PIN8("s_waitcnt lgkmcnt(0)", BNL, BNH);                                                                 \
+  } while (0)
+
+  if (nst == 1 && (ke - kb) % 64 != 0) {
+    // single ragged stage: zero the tail rows before anything is consumed (fragments above are re-read)
+    const int valid = ke - kb;
+    for (int idx = tid; idx < 64 * 64; idx += 512) {
+      const int kr = idx >> 6, c16 = idx & 63;
+      if (kr >= valid) *reinterpret_cast<uint4*>(smem + kr * 512 + (c16 & 31) * 16 + (c16 >> 5) * 32768) = make_uint4(0, 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      TN2_RD(al_lo[i], al_hi[i], TN2_ADDR_LO(lds0, 0u, wr * 8 + i), TN2_ADDR_HI(lds0, 0u, wr * 8 + i));
+      TN2_RD(bx_lo[i], bx_hi[i], TN2_ADDR_LO(lds0, 32768u, wc * 4 + i), TN2_ADDR_HI(lds0, 32768u, wc * 4 + i));
+    }
+    TN2_PIN8("s_waitcnt lgkmcnt(0)", al_lo, al_hi);
+    TN2_PIN8("s_waitcnt lgkmcnt(0)", bx_lo, bx_hi);
+  }
+  for (int st = 0; st < nst; ++st) {
+    const uint32_t sc = lds0 + (uint32_t)((st & 1) * TN2_STAGE), sn = lds0 + (uint32_t)(((st + 1) & 1) * TN2_STAGE);
+    TN2_STEP(sc, sc + 32 * 512, bx_lo, bx_hi, by_lo, by_hi, false, st);
+    TN2_STEP(sc + 32 * 512, sn, by_lo, by_hi, bx_lo, bx_hi, true, st);
+  }
+#undef TN2_STEP
+
+  float* o = out + (long)split * slab_stride;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + wr * 128 + i * 16 + fs;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wc * 64 + j * 16 + fg * 4;
+      if (n >= N) continue;
+      float4* dst = reinterpret_cast<float4*>(o + (long)m * ldo + n);
+      float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      if (accumulate) { float4 c = *dst; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
+      *dst = v;
+    }
+  }
+  if (do_bias) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float t = bsum[i];
+      t += __shfl_xor(t, 16, 64);
+      t += __shfl_xor(t, 32, 64);
+      const int m = m0 + wr * 128 + i * 16 + fs;
+      if (fg == 0 && m < M) atomicAdd(dbias + m, t);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int splits,
                                                           int M, int N, float* __restrict__ C, int ldc, int accumulate) {
   const long total4 = (long)M * N / 4;
@@ -1354,9 +1553,16 @@ extern "C" int simx_gemm_nt(simx_stream_t stream, int dtype, int M, int N, int K
   return SIMX_OK;
 }
 
+extern "C" int simx_colsum(simx_stream_t stream, int dtype, int T, int N, const void* x, int ldx, float* out, int accumulate);
+static bool tn_use_v2(int M, int N, int K) {
+  static const char* pin = getenv("SIMX_GEMM_TN");
+  if (pin && pin[1] == '1') return false;
+  return M >= 256 && N >= 256 && K >= 2048;
+}
 static void tn_plan(int M, int N, int K, int* splits, int* k_per_split) {
-  const int tiles = cdiv(M, 128) * cdiv(N, 128);
-  int s = cdiv(1024, tiles);
+  const bool v2 = tn_use_v2(M, N, K);
+  const int tiles = v2 ? cdiv(M, 256) * cdiv(N, 256) : cdiv(M, 128) * cdiv(N, 128);
+  int s = cdiv(v2 ? 512 : 1024, tiles);
   const int max_s = cdiv(K, 512);          // at least 8 k-tiles per split
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
@@ -1372,19 +1578,31 @@ extern "C" size_t simx_gemm_tn_workspace_bytes(int M, int N, int K) {
   return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
 }
 
+extern "C" int simx_gemm_tn_bias(simx_stream_t stream, int dtype, int M, int N, int K, const void* A, int lda,
+                                 const void* B, int ldb, float* C, int ldc, int accumulate, void* ws, size_t ws_bytes,
+                                 float* dbias);
 extern "C" int simx_gemm_tn(simx_stream_t stream, int dtype, int M, int N, int K, const void* A, int lda,
                             const void* B, int ldb, float* C, int ldc, int accumulate, void* ws, size_t ws_bytes) {
+  return simx_gemm_tn_bias(stream, dtype, M, N, K, A, lda, B, ldb, C, ldc, accumulate, ws, ws_bytes, nullptr);
+}
+
+extern "C" int simx_gemm_tn_bias(simx_stream_t stream, int dtype, int M, int N, int K, const void* A, int lda,
+                                 const void* B, int ldb, float* C, int ldc, int accumulate, void* ws, size_t ws_bytes,
+                                 float* dbias) {
   hipStream_t s = (hipStream_t)stream;
   SIMX_PROF(SIMX_K_GEMM_TN, s, 2.0 * M * N * K);
   SIMX_REQUIRE(M > 0 && N > 0 && K > 0, SIMX_ERR_BAD_SHAPE, "gemm_tn: bad shape %d %d %d", M, N, K);
   SIMX_REQUIRE(lda >= M && ldb >= N && ldc >= N, SIMX_ERR_BAD_SHAPE, "gemm_tn: leading dims too small");
-  if (dtype == SIMX_F32)
+  if (dtype == SIMX_F32) {
+    if (dbias) { int rcb = simx_colsum(stream, dtype, K, M, A, lda, dbias, 1); if (rcb) return rcb; }
     return launch_simple<float, float>(s, SIMX_EPI_NONE, M, N, K, (const float*)A, 1, lda, (const float*)B, ldb, 1, C,
                                        ldc, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, accumulate);
+  }
   SIMX_REQUIRE(dtype == SIMX_BF16, SIMX_ERR_BAD_DTYPE, "gemm_tn: dtype %d", dtype);
   const bool fast = (M % 8 == 0) && (N % 8 == 0) && (lda % 8 == 0) && (ldb % 8 == 0) && (ldc % 4 == 0) && aligned16(A) &&
                     aligned16(B) && aligned16(C);
   if (!fast) {
+    if (dbias) { int rcb = simx_colsum(stream, dtype, K, M, A, lda, dbias, 1); if (rcb) return rcb; }
     // generic path: bf16 in, f32 out
     dim3 grid(cdiv(N, 64), cdiv(M, 64));
     hipLaunchKernelGGL((gemm_simple_kernel<bf16_t, float, SIMX_EPI_NONE>), grid, dim3(256), 0, s, M, N, K,
@@ -1395,6 +1613,36 @@ extern "C" int simx_gemm_tn(simx_stream_t stream, int dtype, int M, int N, int K
   }
   int splits, kps;
   tn_plan(M, N, K, &splits, &kps);
+  if (tn_use_v2(M, N, K)) {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn2_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TN2_LDS);
+      attr = true;
+    }
+    const int t_m = cdiv(M, 256), t_n = cdiv(N, 256), t_mn = t_m * t_n;
+    if (splits == 1) {
+      hipLaunchKernelGGL(gemm_tn2_bf16_kernel, dim3(t_mn), dim3(512), TN2_LDS, s, M, N, K, (const bf16_t*)A, lda,
+                         (const bf16_t*)B, ldb, C, 0L, ldc, t_n, t_mn, kps, accumulate, dbias);
+      SIMX_CHECK_LAUNCH("gemm_tn2_bf16");
+      return SIMX_OK;
+    }
+    const size_t need2 = (size_t)splits * M * N * sizeof(float);
+    SIMX_REQUIRE(ws && ws_bytes >= need2, SIMX_ERR_WORKSPACE, "gemm_tn: workspace %zu < %zu", ws_bytes, need2);
+    SIMX_REQUIRE(aligned16(ws), SIMX_ERR_WORKSPACE, "gemm_tn: workspace not 16-B aligned");
+    hipLaunchKernelGGL(gemm_tn2_bf16_kernel, dim3(t_mn * splits), dim3(512), TN2_LDS, s, M, N, K, (const bf16_t*)A, lda,
+                       (const bf16_t*)B, ldb, (float*)ws, (long)M * N, N, t_n, t_mn, kps, 0, dbias);
+    SIMX_CHECK_LAUNCH("gemm_tn2_bf16");
+    const long tot4 = (long)M * N / 4;
+    int rb = (int)((tot4 + 255) / 256);
+    if (rb > 2048) rb = 2048;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(rb), dim3(256), 0, s, (const float*)ws, (long)M * N, splits, M, N, C, ldc, accumulate);
+    SIMX_CHECK_LAUNCH("slab_reduce");
+    return SIMX_OK;
+  }
+  if (dbias) {                                   // small problems: separate column-sum pass
+    int rcb = simx_colsum(stream, dtype, K, M, A, lda, dbias, 1);
+    if (rcb) return rcb;
+  }
   const int tiles_m = cdiv(M, 128), tiles_n = cdiv(N, 128), tiles_mn = tiles_m * tiles_n;
   const size_t lds = 2 * NT_STAGE_BYTES;
   if (splits == 1) {

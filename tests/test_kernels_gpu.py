@@ -109,6 +109,24 @@ def test_gemm_tn(dev, bf16, M, N, K, accumulate):
     assert_close(back(dC), ref, rtol=2e-5, atol=2e-5 * math.sqrt(K), what="gemm_tn")
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("M,N,K", [(768, 768, 4100), (2304, 768, 2048), (512, 256, 2111), (192, 64, 333)])
+def test_gemm_tn_fused_bias_grad(dev, bf16, M, N, K):
+    """wgrad + bias gradient (column sums of dY) in one call; large shapes take the 256x256 transpose-read kernel."""
+    lib = L()
+    A, B = rnd((K, M), 1, 0.5), rnd((K, N), 2, 0.5)
+    dA, dB = to_dev(A, dev, bf16), to_dev(B, dev, bf16)
+    dC = torch.zeros(M, N, device=dev)
+    db = torch.full((M,), 0.25, device=dev)
+    wsb = int(lib.load().simx_gemm_tn_workspace_bytes(M, N, K))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+    lib.call("simx_gemm_tn_bias", lib.stream_ptr(), int(bf16), M, N, K, lib.ptr(dA), M, lib.ptr(dB), N, lib.ptr(dC), N,
+             1, lib.ptr(ws), wsb, lib.ptr(db))
+    torch.cuda.synchronize()
+    assert_close(back(dC), rounded(A, bf16).T @ rounded(B, bf16), rtol=2e-5, atol=2e-5 * math.sqrt(K), what="gemm_tn")
+    assert_close(back(db), rounded(A, bf16).sum(0) + 0.25, rtol=1e-5, atol=2e-3, what="fused bias grad")
+
+
 def test_colsum_and_cast(dev):
     lib = L()
     x = rnd((1234, 200), 1)

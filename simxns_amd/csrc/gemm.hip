@@ -215,212 +215,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// bf16 NT kernel, large-M version: 256x128x64 tile, 8 waves (4x2) of 64x64, THREE LDS stages
-// (144 KB, one workgroup per CU, two waves per SIMD).  Loads run two K-tiles ahead and stay in
-// flight across the barrier: the only vmcnt wait in the loop is a COUNTED one (6 = this wave's
-// loads of the newest tile), followed by a raw s_barrier.  Fragment reads are software-pipelined
-// against the MFMAs: every ds_read batch is issued in front of a 16-MFMA block that does not
-// depend on it.
-//   iteration t:  issue loads(t+2) | read frags(t,ks1) | MFMA(t,ks0) | wait tile t+1, barrier |
-//                 read frags(t+1,ks0) | MFMA(t,ks1)
-// ------------------------------------------------------------------------------------------
-#define V2_BM 256
-#define V2_BN 128
-#define V2_STAGE (48 * 1024)
-#define V2_LDS (3 * V2_STAGE)
-
-__device__ __forceinline__ void v2_stage(const bf16_t* __restrict__ A, int lda, int m0, int M,
-                                         const bf16_t* __restrict__ B, int ldb, int n0, int N, int k0,
-                                         char* stage, int wave, int lane) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {                 // A: 32 wave-instructions of 8 rows
-    const int i = wave * 4 + j;
-    const int r = i * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((r >> 1) & 7);
-    int gr = m0 + r;
-    gr = gr < M ? gr : M - 1;
-    glds16(A + (long)gr * lda + k0 + c * 8, stage + i * 1024);
-  }
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {                 // B: 16 wave-instructions
-    const int i = wave * 2 + j;
-    const int r = i * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((r >> 1) & 7);
-    int gr = n0 + r;
-    gr = gr < N ? gr : N - 1;
-    glds16(B + (long)gr * ldb + k0 + c * 8, stage + 32768 + i * 1024);
-  }
-}
-
-__device__ __forceinline__ void v2_read_frags(const char* stage, int ks, int wr, int wc, int fr, int fg,
-                                              bf16x8 (&af)[4], bf16x8 (&bfr)[4]) {
-  const int sw = (((ks * 4 + fg) ^ ((fr >> 1) & 7)) << 4);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    af[i] = *reinterpret_cast<const bf16x8*>(stage + (wr * 64 + i * 16 + fr) * 128 + sw);
-    bfr[i] = *reinterpret_cast<const bf16x8*>(stage + 32768 + (wc * 64 + i * 16 + fr) * 128 + sw);
-  }
-}
-
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_nt_bf16_v2_kernel(
-    int M, int N, int K, const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
-    bf16_t* __restrict__ C, int ldc, const float* __restrict__ bias, const bf16_t* __restrict__ res, int ldr,
-    const bf16_t* __restrict__ aux, int ldaux, bf16_t* __restrict__ C2, int ldc2, int tiles_n, int nwg) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tile = xcd_remap(blockIdx.x, nwg);
-  const int m0 = (tile / tiles_n) * V2_BM, n0 = (tile % tiles_n) * V2_BN;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int fr = lane & 15, fg = lane >> 4;
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nt = K / 64;                          // host guarantees nt >= 2
-  v2_stage(A, lda, m0, M, B, ldb, n0, N, 0, smem, wave, lane);
-  v2_stage(A, lda, m0, M, B, ldb, n0, N, 64, smem + V2_STAGE, wave, lane);
-  asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
-  bf16x8 a0[4], b0[4], a1[4], b1[4];
-  // fragment reads and their waits are hand-placed (inline asm): hipcc's scoreboard falls back to
-  // lgkmcnt(0) in this loop, which would expose one LDS round trip per K-tile.
-  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-  const uint32_t fa = (uint32_t)((wr * 64 + fr) * 128), fb = (uint32_t)(32768 + (wc * 64 + fr) * 128);
-  const uint32_t sw0 = (uint32_t)(((0 + fg) ^ ((fr >> 1) & 7)) << 4), sw1 = (uint32_t)(((4 + fg) ^ ((fr >> 1) & 7)) << 4);
-#define V2_READ(AF, BF, STAGE_ADDR, SW)                                                            \
-  do {                                                                                             \
-    const uint32_t ra__ = (STAGE_ADDR) + fa + (SW), rb__ = (STAGE_ADDR) + fb + (SW);               \
-    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:2048\n\t"                      \
-                 "ds_read_b128 %2, %8 offset:4096\n\tds_read_b128 %3, %8 offset:6144\n\t"          \
-                 "ds_read_b128 %4, %9\n\tds_read_b128 %5, %9 offset:2048\n\t"                      \
-                 "ds_read_b128 %6, %9 offset:4096\n\tds_read_b128 %7, %9 offset:6144"               \
-                 : "=&v"(AF[0]), "=&v"(AF[1]), "=&v"(AF[2]), "=&v"(AF[3]), "=&v"(BF[0]), "=&v"(BF[1]), \
-                   "=&v"(BF[2]), "=&v"(BF[3])                                                      \
-                 : "v"(ra__), "v"(rb__)                                                            \
-                 : "memory");                                                                      \
-  } while (0)
-#define V2_WAIT(ASM_TEXT, AF, BF)                                                                  \
-  asm volatile(ASM_TEXT                                                                            \
-               : "+v"(AF[0]), "+v"(AF[1]), "+v"(AF[2]), "+v"(AF[3]), "+v"(BF[0]), "+v"(BF[1]), "+v"(BF[2]), "+v"(BF[3]) \
-               :                                                                                   \
-               : "memory")
-#define V2_MFMA(AF, BF)                                                                   \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[j], AF[i], acc[i][j], 0, 0, 0)
-
-  uint32_t p0 = lds0, p1 = lds0 + V2_STAGE, p2 = lds0 + 2 * V2_STAGE;
-  char* g2 = smem + 2 * V2_STAGE;               // generic pointer of stage p2 for the DMA builtin
-  V2_READ(a0, b0, p0, sw0);
-  V2_WAIT("s_waitcnt lgkmcnt(0)", a0, b0);
-
-  for (int t = 0; t < nt - 2; ++t) {
-    v2_stage(A, lda, m0, M, B, ldb, n0, N, (t + 2) * 64, g2, wave, lane);
-    V2_READ(a1, b1, p0, sw1);
-    __builtin_amdgcn_sched_barrier(0);
-    V2_MFMA(a0, b0);
-    __builtin_amdgcn_sched_barrier(0);
-    V2_WAIT("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier", a1, b1);      // tile t+1 landed (this wave), then everyone
-    V2_READ(a0, b0, p1, sw0);
-    __builtin_amdgcn_sched_barrier(0);
-    V2_MFMA(a1, b1);
-    __builtin_amdgcn_sched_barrier(0);
-    V2_WAIT("s_waitcnt lgkmcnt(0)", a0, b0);                              // issued 16 MFMAs ago: free
-    const uint32_t tmp = p0; p0 = p1; p1 = p2; p2 = tmp;
-    g2 = smem + (p2 - lds0);
-  }
-  // tile nt-2 (no further loads)
-  V2_READ(a1, b1, p0, sw1);
-  __builtin_amdgcn_sched_barrier(0);
-  V2_MFMA(a0, b0);
-  __builtin_amdgcn_sched_barrier(0);
-  V2_WAIT("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier", a1, b1);
-  V2_READ(a0, b0, p1, sw0);
-  __builtin_amdgcn_sched_barrier(0);
-  V2_MFMA(a1, b1);
-  __builtin_amdgcn_sched_barrier(0);
-  V2_WAIT("s_waitcnt lgkmcnt(0)", a0, b0);
-  // tile nt-1
-  V2_READ(a1, b1, p1, sw1);
-  __builtin_amdgcn_sched_barrier(0);
-  V2_MFMA(a0, b0);
-  V2_WAIT("s_waitcnt lgkmcnt(0)", a1, b1);
-  V2_MFMA(a1, b1);
-#undef V2_READ
-#undef V2_WAIT
-#undef V2_MFMA
-
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wr * 64 + i * 16 + fr;
-    if (m >= M) continue;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wc * 64 + j * 16 + fg * 4;
-      if (n >= N) continue;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (bias) {
-        const float4 bv = *reinterpret_cast<const float4*>(bias + n);
-        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-      }
-      if (EPI == SIMX_EPI_NONE) {
-        if (res) { float r4[4]; ld4(res + (long)m * ldr + n, r4); v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3]; }
-        st4(C + (long)m * ldc + n, v);
-      } else if (EPI == SIMX_EPI_GELU) {
-        st4(C + (long)m * ldc + n, v);
-        float g4[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) g4[e] = gelu_fast(bf2f(f2bf(v[e])));
-        st4(C2 + (long)m * ldc2 + n, g4);
-      } else {
-        if (res) { float r4[4]; ld4(res + (long)m * ldr + n, r4); v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3]; }
-        float u4[4]; ld4(aux + (long)m * ldaux + n, u4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_fast(u4[e]);
-        st4(C + (long)m * ldc + n, v);
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// bf16 NT kernel v3: 256x256 block tile, 8 waves (2x4) of 128x64, K walked in 32-deep SLABS through
-// a FOUR-slab LDS ring (4 x 32 KB).  Rationale (measured on v2): with 64x64 wave tiles the LDS read
-// traffic (16 KB per 32 MFMAs per wave) plus the DMA writes keep the LDS ~90 % busy at MFMA peak and
-// the 256x128 block tile pulls ~10 TB/s out of L2/MALL; 128x64 wave tiles need 12 KB per 32 MFMAs and
-// the 256x256 tile 0.75x the L2 bytes per flop.  Loads run three slabs ahead (counted vmcnt(8)),
-// one raw barrier per slab, fragment reads hand-placed in front of MFMA blocks that do not need them.
-// LDS slab image: 128 rows x 128 B per operand; LDS row R holds tile row R (chunks 0-3) and tile row
-// R+128 (chunks 4-7) of the 32-deep slab, chunk c stored at c ^ ((R>>1)&7)  (same conflict-free
-// pattern as the 64-deep tiles).
-//   slab t:  issue loads(t+3) | read A[4..7](t) | MFMA rows 0-3 | wait slab t+1, barrier |
-//            read A[0..3](t+1), B(t+1) | MFMA rows 4-7
-// ------------------------------------------------------------------------------------------
-#define V3_SLAB 32768
-#define V3_LDS (4 * V3_SLAB)
-
-__device__ __forceinline__ void v3_stage(const bf16_t* __restrict__ A, int lda, int m0, int M,
-                                         const bf16_t* __restrict__ B, int ldb, int n0, int N, int k0,
-                                         char* slab, int wave, int lane) {
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int i = wave * 2 + j;                 // 16 wave-instructions of 8 LDS rows per operand
-    const int R = i * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((R >> 1) & 7);
-    const int row = R + ((c & 4) ? 128 : 0);
-    int ga = m0 + row, gb = n0 + row;
-    ga = ga < M ? ga : M - 1;
-    gb = gb < N ? gb : N - 1;
-    glds16(A + (long)ga * lda + k0 + (c & 3) * 8, slab + i * 1024);
-    glds16(B + (long)gb * ldb + k0 + (c & 3) * 8, slab + 16384 + i * 1024);
-  }
-}
-
 #define V3_READ4(F0, F1, F2, F3, ADDR, O0, O1, O2, O3)                                              \
   asm volatile("ds_read_b128 %0, %4 offset:" #O0 "\n\tds_read_b128 %1, %4 offset:" #O1 "\n\t"       \
                "ds_read_b128 %2, %4 offset:" #O2 "\n\tds_read_b128 %3, %4 offset:" #O3               \
@@ -430,277 +224,6 @@ __device__ __forceinline__ void v3_stage(const bf16_t* __restrict__ A, int lda, 
 #define V3_PIN4(TXT, F0, F1, F2, F3) asm volatile(TXT : "+v"(F0), "+v"(F1), "+v"(F2), "+v"(F3)::"memory")
 #define V3_PIN8(TXT, F0, F1, F2, F3, F4, F5, F6, F7) \
   asm volatile(TXT : "+v"(F0), "+v"(F1), "+v"(F2), "+v"(F3), "+v"(F4), "+v"(F5), "+v"(F6), "+v"(F7)::"memory")
-
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_nt_bf16_v3_kernel(
-    int M, int N, int K, const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
-    bf16_t* __restrict__ C, int ldc, const float* __restrict__ bias, const bf16_t* __restrict__ res, int ldr,
-    const bf16_t* __restrict__ aux, int ldaux, bf16_t* __restrict__ C2, int ldc2, int tiles_n, int nwg) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tile = xcd_remap(blockIdx.x, nwg);
-  const int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
-  const int wr = wave >> 2, wc = wave & 3;       // wave tile: rows wr*128.., cols wc*64..
-  const int fr = lane & 15, fg = lane >> 4;
-
-  f32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nt = K / 32;
-  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-  // per-lane fragment offsets inside a slab
-  const uint32_t offA = (uint32_t)(fr * 128 + (((wr * 4 + fg) ^ ((fr >> 1) & 7)) << 4));
-  const uint32_t offB = (uint32_t)(16384 + ((wc & 1) * 64 + fr) * 128 + ((((wc >> 1) * 4 + fg) ^ ((fr >> 1) & 7)) << 4));
-
-  // prologue: slabs 0..2 in flight, wait for slab 0
-  v3_stage(A, lda, m0, M, B, ldb, n0, N, 0, smem, wave, lane);
-  if (nt > 1) v3_stage(A, lda, m0, M, B, ldb, n0, N, 32, smem + V3_SLAB, wave, lane);
-  if (nt > 2) v3_stage(A, lda, m0, M, B, ldb, n0, N, 64, smem + 2 * V3_SLAB, wave, lane);
-  if (nt > 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-  else if (nt > 1) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-
-  bf16x8 al0, al1, al2, al3, ah0, ah1, ah2, ah3, bx0, bx1, bx2, bx3, by0, by1, by2, by3;
-  {
-    const uint32_t aa = lds0 + offA, ab = lds0 + offB;
-    V3_READ4(al0, al1, al2, al3, aa, 0, 2048, 4096, 6144);
-    V3_READ4(bx0, bx1, bx2, bx3, ab, 0, 2048, 4096, 6144);
-    V3_PIN8("s_waitcnt lgkmcnt(0)", al0, al1, al2, al3, bx0, bx1, bx2, bx3);
-  }
-
-#define V3_MFMA_ROW(I, AF, B0, B1, B2, B3)                                                     \
-  acc[I][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B0, AF, acc[I][0], 0, 0, 0);             \
-  acc[I][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B1, AF, acc[I][1], 0, 0, 0);             \
-  acc[I][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B2, AF, acc[I][2], 0, 0, 0);             \
-  acc[I][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B3, AF, acc[I][3], 0, 0, 0)
-
-#define V3_RD1(F, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=&v"(F) : "v"(ADDR) : "memory")
-#define V3_SB __builtin_amdgcn_sched_barrier(0)
-// reads are sprinkled between the MFMA rows (one ds_read per 4 MFMAs in phase 1, two in phase 2) instead of being
-// issued as bursts right after the barrier, where all 8 waves would queue on the LDS while the matrix pipes idle.
-#define V3_ITER(T, BC0, BC1, BC2, BC3, BN0, BN1, BN2, BN3)                                      \
-  do {                                                                                         \
-    const int t__ = (T);                                                                       \
-    const uint32_t aa__ = lds0 + (uint32_t)((t__ & 3) * V3_SLAB) + offA;                       \
-    const uint32_t na__ = lds0 + (uint32_t)(((t__ + 1) & 3) * V3_SLAB) + offA;                 \
-    const uint32_t nb__ = lds0 + (uint32_t)(((t__ + 1) & 3) * V3_SLAB) + offB;                 \
-    if (t__ + 3 < nt)                                                                          \
-      v3_stage(A, lda, m0, M, B, ldb, n0, N, (t__ + 3) * 32, smem + ((t__ + 3) & 3) * V3_SLAB, wave, lane); \
-    V3_SB; V3_MFMA_ROW(0, al0, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah0, aa__, 8192);            \
-    V3_SB; V3_MFMA_ROW(1, al1, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah1, aa__, 10240);           \
-    V3_SB; V3_MFMA_ROW(2, al2, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah2, aa__, 12288);           \
-    V3_SB; V3_MFMA_ROW(3, al3, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah3, aa__, 14336);           \
-    V3_SB;                                                                                     \
-    /* no branch may sit between an asm read and the asm wait that pins its registers: hipcc would   \
-       place phi copies of the still-in-flight registers there */                                 \
-    V3_PIN4("s_waitcnt lgkmcnt(0)", ah0, ah1, ah2, ah3);                                       \
-    if (t__ + 3 < nt) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");            \
-    else if (t__ + 2 < nt) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");       \
-    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                         \
-    /* next slab's A[0..3], B (past the end: stale slab, never consumed) */                      \
-    V3_SB; V3_MFMA_ROW(4, ah0, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al0, na__, 0); V3_RD1(BN0, nb__, 0);       \
-    V3_SB; V3_MFMA_ROW(5, ah1, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al1, na__, 2048); V3_RD1(BN1, nb__, 2048); \
-    V3_SB; V3_MFMA_ROW(6, ah2, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al2, na__, 4096); V3_RD1(BN2, nb__, 4096); \
-    V3_SB; V3_MFMA_ROW(7, ah3, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al3, na__, 6144); V3_RD1(BN3, nb__, 6144); \
-    V3_SB;                                                                                     \
-    V3_PIN8("s_waitcnt lgkmcnt(0)", al0, al1, al2, al3, BN0, BN1, BN2, BN3);                   \
-  } while (0)
-
-  for (int t = 0; t < nt; t += 2) {
-    V3_ITER(t, bx0, bx1, bx2, bx3, by0, by1, by2, by3);
-    if (t + 1 < nt) V3_ITER(t + 1, by0, by1, by2, by3, bx0, bx1, bx2, bx3);
-  }
-#undef V3_ITER
-#undef V3_MFMA_ROW
-
-  // epilogue: lane holds row m (fr) and 4 consecutive columns of each 16x16 tile
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int m = m0 + wr * 128 + i * 16 + fr;
-    if (m >= M) continue;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wc * 64 + j * 16 + fg * 4;
-      if (n >= N) continue;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (bias) {
-        const float4 bv = *reinterpret_cast<const float4*>(bias + n);
-        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-      }
-      if (EPI == SIMX_EPI_NONE) {
-        if (res) { float r4[4]; ld4(res + (long)m * ldr + n, r4); v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3]; }
-        st4(C + (long)m * ldc + n, v);
-      } else if (EPI == SIMX_EPI_GELU) {
-        st4(C + (long)m * ldc + n, v);
-        float g4[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) g4[e] = gelu_fast(bf2f(f2bf(v[e])));
-        st4(C2 + (long)m * ldc2 + n, g4);
-      } else {
-        if (res) { float r4[4]; ld4(res + (long)m * ldr + n, r4); v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3]; }
-        float u4[4]; ld4(aux + (long)m * ldaux + n, u4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_fast(u4[e]);
-        st4(C + (long)m * ldc + n, v);
-      }
-    }
-  }
-}
-
-// v6: the v3 pipeline with FOUR waves per workgroup (2x2 of 128x64 -> 256x128 block tile) and a 3-slab ring of
-// 24 KB (72 KB): TWO workgroups per CU, so that one workgroup's epilogue (VALU + global stores, measured at ~40 %
-// of a one-workgroup-per-CU kernel's time) overlaps the other's main loop.
-#define V6_SLAB 24576
-#define V6_LDS (3 * V6_SLAB)
-__device__ __forceinline__ void v6_stage(const bf16_t* __restrict__ A, int lda, int m0, int M,
-                                         const bf16_t* __restrict__ B, int ldb, int n0, int N, int k0,
-                                         char* slab, int wave, int lane) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {                 // A: 128 LDS rows (tile rows R and R+128) = 16 wave-instructions
-    const int i = wave * 4 + j;
-    const int R = i * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((R >> 1) & 7);
-    int ga = m0 + R + ((c & 4) ? 128 : 0);
-    ga = ga < M ? ga : M - 1;
-    glds16(A + (long)ga * lda + k0 + (c & 3) * 8, slab + i * 1024);
-  }
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {                 // B: 64 LDS rows (tile rows R and R+64) = 8 wave-instructions
-    const int i = wave * 2 + j;
-    const int R = i * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((R >> 1) & 7);
-    int gb = n0 + R + ((c & 4) ? 64 : 0);
-    gb = gb < N ? gb : N - 1;
-    glds16(B + (long)gb * ldb + k0 + (c & 3) * 8, slab + 16384 + i * 1024);
-  }
-}
-
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_v6_kernel(
-    int M, int N, int K, const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
-    bf16_t* __restrict__ C, int ldc, const float* __restrict__ bias, const bf16_t* __restrict__ res, int ldr,
-    const bf16_t* __restrict__ aux, int ldaux, bf16_t* __restrict__ C2, int ldc2, int tiles_n, int nwg) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tile = xcd_remap(blockIdx.x, nwg);
-  const int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 128;
-  const int wr = wave >> 1, wc = wave & 1;       // wave tile: rows wr*128.., cols wc*64..
-  const int fr = lane & 15, fg = lane >> 4;
-
-  f32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nt = K / 32;
-  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-  // per-lane fragment offsets inside a slab
-  const uint32_t offA = (uint32_t)(fr * 128 + (((wr * 4 + fg) ^ ((fr >> 1) & 7)) << 4));
-  const uint32_t offB = (uint32_t)(16384 + fr * 128 + (((wc * 4 + fg) ^ ((fr >> 1) & 7)) << 4));
-
-  // prologue: slabs 0..2 in flight, wait for slab 0
-  v6_stage(A, lda, m0, M, B, ldb, n0, N, 0, smem, wave, lane);
-  if (nt > 1) v6_stage(A, lda, m0, M, B, ldb, n0, N, 32, smem + V6_SLAB, wave, lane);
-  if (nt > 1) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-  int ring = 0;                                  // slab index of k-step t in the 3-slab ring
-
-  bf16x8 al0, al1, al2, al3, ah0, ah1, ah2, ah3, bx0, bx1, bx2, bx3, by0, by1, by2, by3;
-  {
-    const uint32_t aa = lds0 + offA, ab = lds0 + offB;
-    V3_READ4(al0, al1, al2, al3, aa, 0, 2048, 4096, 6144);
-    V3_READ4(bx0, bx1, bx2, bx3, ab, 0, 2048, 4096, 6144);
-    V3_PIN8("s_waitcnt lgkmcnt(0)", al0, al1, al2, al3, bx0, bx1, bx2, bx3);
-  }
-
-#define V3_MFMA_ROW(I, AF, B0, B1, B2, B3)                                                     \
-  acc[I][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B0, AF, acc[I][0], 0, 0, 0);             \
-  acc[I][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B1, AF, acc[I][1], 0, 0, 0);             \
-  acc[I][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B2, AF, acc[I][2], 0, 0, 0);             \
-  acc[I][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B3, AF, acc[I][3], 0, 0, 0)
-
-#define V3_RD1(F, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=&v"(F) : "v"(ADDR) : "memory")
-#define V3_SB __builtin_amdgcn_sched_barrier(0)
-// reads are sprinkled between the MFMA rows (one ds_read per 4 MFMAs in phase 1, two in phase 2) instead of being
-// issued as bursts right after the barrier, where all 8 waves would queue on the LDS while the matrix pipes idle.
-#define V3_ITER(T, BC0, BC1, BC2, BC3, BN0, BN1, BN2, BN3)                                      \
-  do {                                                                                         \
-    const int t__ = (T);                                                                       \
-    const int r1__ = ring == 2 ? 0 : ring + 1, r2__ = r1__ == 2 ? 0 : r1__ + 1;                \
-    const uint32_t aa__ = lds0 + (uint32_t)(ring * V6_SLAB) + offA;                            \
-    const uint32_t na__ = lds0 + (uint32_t)(r1__ * V6_SLAB) + offA;                            \
-    const uint32_t nb__ = lds0 + (uint32_t)(r1__ * V6_SLAB) + offB;                            \
-    if (t__ + 2 < nt)                                                                          \
-      v6_stage(A, lda, m0, M, B, ldb, n0, N, (t__ + 2) * 32, smem + r2__ * V6_SLAB, wave, lane); \
-    V3_SB; V3_MFMA_ROW(0, al0, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah0, aa__, 8192);            \
-    V3_SB; V3_MFMA_ROW(1, al1, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah1, aa__, 10240);           \
-    V3_SB; V3_MFMA_ROW(2, al2, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah2, aa__, 12288);           \
-    V3_SB; V3_MFMA_ROW(3, al3, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah3, aa__, 14336);           \
-    V3_SB;                                                                                     \
-    /* no branch may sit between an asm read and the asm wait that pins its registers: hipcc would   \
-       place phi copies of the still-in-flight registers there */                                 \
-    V3_PIN4("s_waitcnt lgkmcnt(0)", ah0, ah1, ah2, ah3);                                       \
-    if (t__ + 2 < nt) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");            \
-    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                         \
-    /* next slab's A[0..3], B (past the end: stale slab, never consumed) */                      \
-    V3_SB; V3_MFMA_ROW(4, ah0, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al0, na__, 0); V3_RD1(BN0, nb__, 0);       \
-    V3_SB; V3_MFMA_ROW(5, ah1, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al1, na__, 2048); V3_RD1(BN1, nb__, 2048); \
-    V3_SB; V3_MFMA_ROW(6, ah2, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al2, na__, 4096); V3_RD1(BN2, nb__, 4096); \
-    V3_SB; V3_MFMA_ROW(7, ah3, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al3, na__, 6144); V3_RD1(BN3, nb__, 6144); \
-    V3_SB;                                                                                     \
-    V3_PIN8("s_waitcnt lgkmcnt(0)", al0, al1, al2, al3, BN0, BN1, BN2, BN3);                   \
-    ring = r1__;                                                                               \
-  } while (0)
-
-  for (int t = 0; t < nt; t += 2) {
-    V3_ITER(t, bx0, bx1, bx2, bx3, by0, by1, by2, by3);
-    if (t + 1 < nt) V3_ITER(t + 1, by0, by1, by2, by3, bx0, bx1, bx2, bx3);
-  }
-#undef V3_ITER
-#undef V3_MFMA_ROW
-
-  // epilogue: lane holds row m (fr) and 4 consecutive columns of each 16x16 tile
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int m = m0 + wr * 128 + i * 16 + fr;
-    if (m >= M) continue;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wc * 64 + j * 16 + fg * 4;
-      if (n >= N) continue;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (bias) {
-        const float4 bv = *reinterpret_cast<const float4*>(bias + n);
-        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-      }
-      if (EPI == SIMX_EPI_NONE) {
-        if (res) { float r4[4]; ld4(res + (long)m * ldr + n, r4); v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3]; }
-        st4(C + (long)m * ldc + n, v);
-      } else if (EPI == SIMX_EPI_GELU) {
-        st4(C + (long)m * ldc + n, v);
-        float g4[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) g4[e] = gelu_fast(bf2f(f2bf(v[e])));
-        st4(C2 + (long)m * ldc2 + n, g4);
-      } else {
-        if (res) { float r4[4]; ld4(res + (long)m * ldr + n, r4); v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3]; }
-        float u4[4]; ld4(aux + (long)m * ldaux + n, u4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_fast(u4[e]);
-        st4(C + (long)m * ldc + n, v);
-      }
-    }
-  }
-}
-
 
 __device__ int g_gemm_dbg = 0;   // measurement hook, set from env SIMX_GEMM_DBG (bit0: skip global stores, bit1: skip LDS staging loop)
 // v5: 256x256x64 stages (full 128-B lines per row: the LDS-DMA path is request-bound, measured ~20 B/clk/CU with full
@@ -874,137 +397,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_v5_kernel(
         const uint4 val = *reinterpret_cast<const uint4*>(reg + r * 128 + (lane & 7) * 16);
         const int gm = mw + r, gn = nw + c * 8;
         if (gm < M && gn + 8 <= N && !(g_gemm_dbg & 1)) *reinterpret_cast<uint4*>(out + (long)gm * ldo + gn) = val;
-      }
-    }
-  }
-}
-
-
-// v4: the v3 pipeline on v_mfma_f32_32x32x16_bf16 (the 16x16x32 form tops out at ~83 % of the MFMA peak, the
-// 32x32x16 form at ~95 %): wave tile 128x64 = 4x2 tiles of 32x32, per slab two k-steps of 16.
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_nt_bf16_v4_kernel(
-    int M, int N, int K, const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
-    bf16_t* __restrict__ C, int ldc, const float* __restrict__ bias, const bf16_t* __restrict__ res, int ldr,
-    const bf16_t* __restrict__ aux, int ldaux, bf16_t* __restrict__ C2, int ldc2, int tiles_n, int nwg) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tile = xcd_remap(blockIdx.x, nwg);
-  const int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
-  const int wr = wave >> 2, wc = wave & 3;       // wave tile: rows wr*128.., cols wc*64..
-  const int l31 = lane & 31, lh = lane >> 5;
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int nt = K / 32;
-  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-  // per-lane fragment offsets inside a slab, for k-step 0 / 1 (16 k each)
-  const int swz = (lane >> 1) & 7;               // ((R>>1)&7) with R = 32*i + (lane&31)
-  const uint32_t rowA = (uint32_t)(l31 * 128), rowB = (uint32_t)(16384 + ((wc & 1) * 64 + l31) * 128);
-  const uint32_t offA0 = rowA + (uint32_t)(((wr * 4 + 0 + lh) ^ swz) << 4), offA1 = rowA + (uint32_t)(((wr * 4 + 2 + lh) ^ swz) << 4);
-  const uint32_t offB0 = rowB + (uint32_t)((((wc >> 1) * 4 + 0 + lh) ^ swz) << 4), offB1 = rowB + (uint32_t)((((wc >> 1) * 4 + 2 + lh) ^ swz) << 4);
-
-  v3_stage(A, lda, m0, M, B, ldb, n0, N, 0, smem, wave, lane);
-  if (nt > 1) v3_stage(A, lda, m0, M, B, ldb, n0, N, 32, smem + V3_SLAB, wave, lane);
-  if (nt > 2) v3_stage(A, lda, m0, M, B, ldb, n0, N, 64, smem + 2 * V3_SLAB, wave, lane);
-  if (nt > 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-  else if (nt > 1) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-
-  bf16x8 p0, p1, p2, p3, q0, q1;     // k-step 0 fragments: A x4, B x2
-  bf16x8 r0, r1, r2, r3, s0, s1;     // k-step 1 fragments
-#define V4_READ6(A0, A1, A2, A3, B0, B1, AA, AB)                                                   \
-  asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:4096\n\t"                      \
-               "ds_read_b128 %2, %6 offset:8192\n\tds_read_b128 %3, %6 offset:12288\n\t"          \
-               "ds_read_b128 %4, %7\n\tds_read_b128 %5, %7 offset:4096"                            \
-               : "=&v"(A0), "=&v"(A1), "=&v"(A2), "=&v"(A3), "=&v"(B0), "=&v"(B1)                  \
-               : "v"(AA), "v"(AB)                                                                  \
-               : "memory")
-#define V4_PIN6(TXT, A0, A1, A2, A3, B0, B1) \
-  asm volatile(TXT : "+v"(A0), "+v"(A1), "+v"(A2), "+v"(A3), "+v"(B0), "+v"(B1)::"memory")
-#define V4_MFMA8(A0, A1, A2, A3, B0, B1)                                                          \
-  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B0, A0, acc[0][0], 0, 0, 0);                \
-  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B1, A0, acc[0][1], 0, 0, 0);                \
-  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B0, A1, acc[1][0], 0, 0, 0);                \
-  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B1, A1, acc[1][1], 0, 0, 0);                \
-  acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B0, A2, acc[2][0], 0, 0, 0);                \
-  acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B1, A2, acc[2][1], 0, 0, 0);                \
-  acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B0, A3, acc[3][0], 0, 0, 0);                \
-  acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B1, A3, acc[3][1], 0, 0, 0)
-
-  {
-    const uint32_t aa = lds0 + offA0, ab = lds0 + offB0;
-    V4_READ6(p0, p1, p2, p3, q0, q1, aa, ab);
-    V4_PIN6("s_waitcnt lgkmcnt(0)", p0, p1, p2, p3, q0, q1);
-  }
-  for (int t = 0; t < nt; ++t) {
-    const uint32_t sc = lds0 + (uint32_t)((t & 3) * V3_SLAB);
-    const uint32_t sn = lds0 + (uint32_t)(((t + 1) & 3) * V3_SLAB);
-    if (t + 3 < nt) v3_stage(A, lda, m0, M, B, ldb, n0, N, (t + 3) * 32, smem + ((t + 3) & 3) * V3_SLAB, wave, lane);
-    {
-      const uint32_t aa = sc + offA1, ab = sc + offB1;
-      V4_READ6(r0, r1, r2, r3, s0, s1, aa, ab);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    V4_MFMA8(p0, p1, p2, p3, q0, q1);
-    __builtin_amdgcn_sched_barrier(0);
-    V4_PIN6("s_waitcnt lgkmcnt(0)", r0, r1, r2, r3, s0, s1);
-    if (t + 3 < nt) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-    else if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    {
-      const uint32_t aa = sn + offA0, ab = sn + offB0;      // past the end: stale slab, never consumed
-      V4_READ6(p0, p1, p2, p3, q0, q1, aa, ab);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    V4_MFMA8(r0, r1, r2, r3, s0, s1);
-    __builtin_amdgcn_sched_barrier(0);
-    V4_PIN6("s_waitcnt lgkmcnt(0)", p0, p1, p2, p3, q0, q1);
-  }
-#undef V4_READ6
-#undef V4_PIN6
-#undef V4_MFMA8
-
-  // epilogue: lane holds row m (lane&31) and, per 32x32 tile, four groups of 4 consecutive columns
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wr * 128 + i * 32 + l31;
-    if (m >= M) continue;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wc * 64 + j * 32 + q * 8 + lh * 4;
-        if (n >= N) continue;
-        float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-        if (bias) {
-          const float4 bv = *reinterpret_cast<const float4*>(bias + n);
-          v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-        }
-        if (EPI == SIMX_EPI_NONE) {
-          if (res) { float r4[4]; ld4(res + (long)m * ldr + n, r4); v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3]; }
-          st4(C + (long)m * ldc + n, v);
-        } else if (EPI == SIMX_EPI_GELU) {
-          st4(C + (long)m * ldc + n, v);
-          float g4[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) g4[e] = gelu_fast(bf2f(f2bf(v[e])));
-          st4(C2 + (long)m * ldc2 + n, g4);
-        } else {
-          if (res) { float r4[4]; ld4(res + (long)m * ldr + n, r4); v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3]; }
-          float u4[4]; ld4(aux + (long)m * ldaux + n, u4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_fast(u4[e]);
-          st4(C + (long)m * ldc + n, v);
-        }
       }
     }
   }
@@ -1438,52 +830,12 @@ extern "C" int simx_gemm_nt(simx_stream_t stream, int dtype, int M, int N, int K
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<SIMX_EPI_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<SIMX_EPI_DGELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_v2_kernel<SIMX_EPI_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_v2_kernel<SIMX_EPI_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_v2_kernel<SIMX_EPI_DGELU>), hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS);
     attr_done = true;
   }
   {
-    // large problems: 256x256 tiles / 4-slab ring (v3) or 256x128 tiles / 3-stage ring (v2), one workgroup per CU.
-    // env SIMX_GEMM=v1|v2|v3 pins a variant (A/B measurements).
+    // large problems: 256x256x64 two-stage pipeline (one workgroup per CU); env SIMX_GEMM=v1 pins the small-tile kernel
     static const char* pin = getenv("SIMX_GEMM");
-    const int variant = pin ? (pin[1] - '0') : 0;
-    static bool attr3 = false;
-    if (!attr3) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_v3_kernel<SIMX_EPI_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_v3_kernel<SIMX_EPI_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_v3_kernel<SIMX_EPI_DGELU>), hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
-      attr3 = true;
-    }
-    const int t3m = cdiv(M, 256), t3n = cdiv(N, 256), nwg3 = t3m * t3n;
-    static bool attr4 = false;
-    if (!attr4) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_v4_kernel<SIMX_EPI_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_v4_kernel<SIMX_EPI_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_v4_kernel<SIMX_EPI_DGELU>), hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
-      attr4 = true;
-    }
-    static bool attr6 = false;
-    if (!attr6) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_v6_kernel<SIMX_EPI_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, V6_LDS);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_v6_kernel<SIMX_EPI_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, V6_LDS);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_v6_kernel<SIMX_EPI_DGELU>), hipFuncAttributeMaxDynamicSharedMemorySize, V6_LDS);
-      attr6 = true;
-    }
-    {
-      const int t6m = cdiv(M, 256), t6n = cdiv(N, 128), nwg6 = t6m * t6n;
-      if ((variant == 0 || variant == 6) && nwg6 >= 384) {
-#define L6(E) hipLaunchKernelGGL((gemm_nt_bf16_v6_kernel<E>), dim3(nwg6), dim3(256), V6_LDS, s, M, N, K, (const bf16_t*)A, lda, \
-                                 (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, (const bf16_t*)residual, ldr,                  \
-                                 (const bf16_t*)aux, ldaux, (bf16_t*)C2, ldc2, t6n, nwg6)
-        if (epilogue == SIMX_EPI_NONE) L6(SIMX_EPI_NONE);
-        else if (epilogue == SIMX_EPI_GELU) L6(SIMX_EPI_GELU);
-        else L6(SIMX_EPI_DGELU);
-#undef L6
-        SIMX_CHECK_LAUNCH("gemm_nt_bf16_v6");
-        return SIMX_OK;
-      }
-    }
+    const bool force_v1 = pin && pin[1] == '1';
     static bool attr5 = false;
     if (!attr5) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_v5_kernel<SIMX_EPI_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, V5_LDS);
@@ -1491,7 +843,8 @@ extern "C" int simx_gemm_nt(simx_stream_t stream, int dtype, int M, int N, int K
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_v5_kernel<SIMX_EPI_DGELU>), hipFuncAttributeMaxDynamicSharedMemorySize, V5_LDS);
       attr5 = true;
     }
-    if ((variant == 0 || variant == 5) && nwg3 >= 192 && N % 8 == 0 && ldc % 8 == 0 && (!residual || ldr % 8 == 0) &&
+    const int t3m = cdiv(M, 256), t3n = cdiv(N, 256), nwg3 = t3m * t3n;
+    if (!force_v1 && nwg3 >= 192 && N % 8 == 0 && ldc % 8 == 0 && (!residual || ldr % 8 == 0) &&
         (!aux || ldaux % 8 == 0) && (!C2 || ldc2 % 8 == 0)) {
       static const bool noepi = getenv("SIMX_NOEPI") != nullptr;
       static bool dbg_set = false;
@@ -1505,40 +858,6 @@ extern "C" int simx_gemm_nt(simx_stream_t stream, int dtype, int M, int N, int K
       else L5(SIMX_EPI_DGELU);
 #undef L5
       SIMX_CHECK_LAUNCH("gemm_nt_bf16_v5");
-      return SIMX_OK;
-    }
-    if ((variant == 4) && nwg3 >= 192) {
-#define L4(E) hipLaunchKernelGGL((gemm_nt_bf16_v4_kernel<E>), dim3(nwg3), dim3(512), V3_LDS, s, M, N, K, (const bf16_t*)A, lda, \
-                                 (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, (const bf16_t*)residual, ldr,                  \
-                                 (const bf16_t*)aux, ldaux, (bf16_t*)C2, ldc2, t3n, nwg3)
-      if (epilogue == SIMX_EPI_NONE) L4(SIMX_EPI_NONE);
-      else if (epilogue == SIMX_EPI_GELU) L4(SIMX_EPI_GELU);
-      else L4(SIMX_EPI_DGELU);
-#undef L4
-      SIMX_CHECK_LAUNCH("gemm_nt_bf16_v4");
-      return SIMX_OK;
-    }
-    if ((variant == 3) && nwg3 >= 192) {
-#define L3(E) hipLaunchKernelGGL((gemm_nt_bf16_v3_kernel<E>), dim3(nwg3), dim3(512), V3_LDS, s, M, N, K, (const bf16_t*)A, lda, \
-                                 (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, (const bf16_t*)residual, ldr,                  \
-                                 (const bf16_t*)aux, ldaux, (bf16_t*)C2, ldc2, t3n, nwg3)
-      if (epilogue == SIMX_EPI_NONE) L3(SIMX_EPI_NONE);
-      else if (epilogue == SIMX_EPI_GELU) L3(SIMX_EPI_GELU);
-      else L3(SIMX_EPI_DGELU);
-#undef L3
-      SIMX_CHECK_LAUNCH("gemm_nt_bf16_v3");
-      return SIMX_OK;
-    }
-    const int t2m = cdiv(M, V2_BM), t2n = cdiv(N, V2_BN), nwg2 = t2m * t2n;
-    if ((variant == 0 || variant == 2) && nwg2 >= 192 && K >= 128) {
-#define L2(E) hipLaunchKernelGGL((gemm_nt_bf16_v2_kernel<E>), dim3(nwg2), dim3(512), V2_LDS, s, M, N, K, (const bf16_t*)A, lda, \
-                                 (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, (const bf16_t*)residual, ldr,                  \
-                                 (const bf16_t*)aux, ldaux, (bf16_t*)C2, ldc2, t2n, nwg2)
-      if (epilogue == SIMX_EPI_NONE) L2(SIMX_EPI_NONE);
-      else if (epilogue == SIMX_EPI_GELU) L2(SIMX_EPI_GELU);
-      else L2(SIMX_EPI_DGELU);
-#undef L2
-      SIMX_CHECK_LAUNCH("gemm_nt_bf16_v2");
       return SIMX_OK;
     }
   }

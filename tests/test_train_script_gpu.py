@@ -1,0 +1,64 @@
+"""The drop-in train job (co_training_marco_train.py) end to end on a synthetic MS-MARCO-shaped corpus: tiny BERT
+config, hash tokenizer, 6 optimiser steps through the retriever phase, checkpoint files in CheckpointState layout,
+then a resume from that checkpoint (the shell loop's second iteration)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_corpus(root, n_pass=400, n_q=24, n_cand=30):
+    rs = np.random.RandomState(0)
+    words = ["w%d" % i for i in range(300)]
+    os.makedirs(root, exist_ok=True)
+    with open(os.path.join(root, "para.txt"), "w") as f, open(os.path.join(root, "para.title.txt"), "w") as g:
+        for pid in range(n_pass):
+            f.write("%d\t%s\n" % (pid, " ".join(rs.choice(words, size=rs.randint(10, 60)))))
+            g.write("%d\t%s\n" % (pid, " ".join(rs.choice(words, size=3))))
+    with open(os.path.join(root, "train_ce_0.tsv"), "w") as f:
+        for q in range(n_q):
+            pids = rs.choice(n_pass, size=n_cand + 1, replace=False)
+            sp = 70 + 20 * rs.rand()
+            sc = np.sort(sp - np.abs(rs.randn(n_cand)) * 1.5)[::-1]
+            f.write("%d\t%s\t%d %.4f\t%s\n" % (q, " ".join(rs.choice(words, size=6)), pids[0], sp,
+                                               ",".join("%d %.4f" % (p, s) for p, s in zip(pids[1:], sc))))
+    for name in ("student", "teacher"):
+        d = os.path.join(root, name)
+        os.makedirs(d, exist_ok=True)
+        json.dump(dict(vocab_size=30522, hidden_size=64, num_hidden_layers=2, num_attention_heads=1, intermediate_size=128,
+                       max_position_embeddings=192, type_vocab_size=2, layer_norm_eps=1e-12), open(os.path.join(d, "config.json"), "w"))
+
+
+def test_train_job_runs_and_resumes(dev, tmp_path):
+    from simxns_amd.co_training import co_training_marco_train as T
+    from simxns_amd.utils.dpr_utils import load_states_from_checkpoint
+    root = str(tmp_path / "data")
+    _write_corpus(root)
+    out = str(tmp_path / "ckpt")
+    common = ["--model_type", os.path.join(root, "student"), "--teacher_model_type", os.path.join(root, "teacher"),
+              "--tokenizer_name", "hash", "--per_gpu_train_batch_size", "4", "--gradient_accumulation_steps", "1",
+              "--number_neg", "7", "--learning_rate", "1e-3", "--teacher_learning_rate", "1e-4", "--output_dir", out,
+              "--log_dir", str(tmp_path / "tb"), "--origin_data_dir", os.path.join(root, "train_ce_0.tsv"),
+              "--passage_path", root, "--logging_steps", "2", "--save_steps", "1000", "--max_steps", "12",
+              "--iteration_step", "6", "--iteration_reranker_step", "2", "--temperature_distill", "1",
+              "--ann_dir", root, "--num_workers", "0", "--fp16"]
+    gs = T.main(common + ["--global_step", "0"])
+    assert gs == 6                                                   # breaks at the iteration boundary (:283-297)
+    st = load_states_from_checkpoint(os.path.join(out, "checkpoint-6"))
+    assert set(st._fields) == {"model_dict", "optimizer_dict", "scheduler_dict", "offset", "epoch", "encoder_params"}
+    assert "question_model.encoder.layer.1.output.dense.weight" in st.model_dict
+    tst = load_states_from_checkpoint(os.path.join(out, "checkpoint-reranker6"))
+    assert "qa_classifier.weight" in tst.model_dict and "encoder.embeddings.word_embeddings.weight" in tst.model_dict
+    assert all(torch.isfinite(v).all() for v in st.model_dict.values())
+    # second shell-loop iteration: resume from checkpoint-6 with the mined file train_ce_6.tsv; goes through a teacher phase
+    os.replace(os.path.join(root, "train_ce_0.tsv"), os.path.join(root, "train_ce_6.tsv"))
+    gs2 = T.main(common + ["--global_step", "6"])
+    assert gs2 == 12 and os.path.exists(os.path.join(out, "checkpoint-reranker12"))
+    st2 = load_states_from_checkpoint(os.path.join(out, "checkpoint-12"))
+    assert st2.scheduler_dict["t"] > st.scheduler_dict["t"]
+    w0, w1 = st.model_dict["ctx_model.encoder.layer.0.output.dense.weight"], st2.model_dict["ctx_model.encoder.layer.0.output.dense.weight"]
+    assert not torch.equal(w0, w1)

@@ -213,3 +213,28 @@ def test_distributed_gather_semantics_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and ("rank %d ok" % r) in o, o
+
+
+def test_host_samplers_replay_reference_picks(golden_dir):
+    """simxns_amd's host-side SimANS draws (the DataLoader path of the drop-in datasets) on CPython's ``random``
+    reproduce what the imported reference datasets picked (recorded seeds, tests/golden/sampler_ref.json)."""
+    import json
+    import random
+    from simxns_amd.utils.MARCO_until_new import simans_draw
+    from simxns_amd.utils.util_wiki import simans_draw_gauss
+    meta = json.load(open(os.path.join(golden_dir, "sampler_ref.json")))
+    N = meta["N"]
+    random.seed(meta["marco_seed"])
+    for m in meta["queries"]:
+        random.choice([0])
+        got = simans_draw(list(zip(m["cand"], m["scores"])), m["s_pos"], N, tau=3.0)
+        assert got == m["picked"]
+    random.seed(meta["wiki_seed"])
+    for i, want in enumerate(meta["wiki_picked"]):
+        m = meta["queries"][i]
+        sp = m["s_pos"] if m["s_pos"] else 75.0
+        order = list(range(len(m["cand"])))
+        random.shuffle(order)
+        cand, sc = [m["cand"][j] for j in order], [m["scores"][j] for j in order]
+        chosen = simans_draw_gauss(cand, sc, sp, N, a=0.5, b=1.0)
+        assert [c for c in cand if c in chosen][0:N] == want

@@ -62,3 +62,28 @@ def test_train_job_runs_and_resumes(dev, tmp_path):
     assert st2.scheduler_dict["t"] > st.scheduler_dict["t"]
     w0, w1 = st.model_dict["ctx_model.encoder.layer.0.output.dense.weight"], st2.model_dict["ctx_model.encoder.layer.0.output.dense.weight"]
     assert not torch.equal(w0, w1)
+
+
+def test_wiki_train_job(dev, tmp_path):
+    """NQ/TQ variant: JSON data, Gaussian SimANS sampler (--a/--b), dynamic padding, reranker phase first."""
+    from simxns_amd.wiki import co_training_wiki_train as W
+    root = str(tmp_path / "data")
+    _write_corpus(root)
+    rs = np.random.RandomState(1)
+    words = ["w%d" % i for i in range(300)]
+    data = []
+    for q in range(20):
+        sp = 70 + 20 * rs.rand()
+        sc = np.sort(sp - np.abs(rs.randn(25)) * 1.5)[::-1]
+        mk = lambda pid, s_: dict(text=" ".join(rs.choice(words, size=rs.randint(8, 40))), title="t %d" % pid, score=float(s_), passage_id=int(pid))
+        data.append(dict(question="what is %s?" % " ".join(rs.choice(words, size=5)), answers=["w1"],
+                         positive_ctxs=[mk(1000 + q, sp)], hard_negative_ctxs=[mk(2000 + q * 30 + j, sc[j]) for j in range(25)]))
+    json.dump(data, open(os.path.join(root, "train_ce_0.json"), "w"))
+    out = str(tmp_path / "ckpt")
+    gs = W.main(["--model_type", os.path.join(root, "student"), "--reranker_model_type", os.path.join(root, "teacher"),
+                 "--tokenizer_name", "hash", "--per_gpu_train_batch_size", "4", "--number_neg", "7", "--learning_rate", "1e-3",
+                 "--reranker_learning_rate", "1e-4", "--output_dir", out, "--log_dir", str(tmp_path / "tb"),
+                 "--origin_data_dir", os.path.join(root, "train_ce_0.json"), "--logging_steps", "2", "--max_steps", "12",
+                 "--iteration_step", "6", "--iteration_reranker_step", "2", "--temperature_normal", "1", "--adv_lambda", "0",
+                 "--b", "1.0", "--ann_dir", root, "--num_workers", "0", "--fp16", "--max_seq_length", "128"])
+    assert gs == 6 and os.path.exists(os.path.join(out, "checkpoint-6")) and os.path.exists(os.path.join(out, "checkpoint-reranker6"))

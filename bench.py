@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--varlen", action="store_true", help="realistic sequence lengths instead of all-max")
     ap.add_argument("--inbatch", action="store_true", help="config 3: all-gather embeddings + in-batch NLL term")
     ap.add_argument("--no-teacher", action="store_true", help="feed fixed teacher logits (student-only flops)")
+    ap.add_argument("--no-dropout", action="store_true", help="eval-mode step (the reference trains with dropout 0.1, models.py:70-72)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
     args = ap.parse_args()
@@ -113,7 +114,8 @@ def main():
     B, N, Cn = args.batch, args.negs, args.cands
     P = B * (1 + N)
     QL, PL, CL = 32, 128, 160
-    cfg = BertConfigLite()
+    pdrop = 0.0 if args.no_dropout else 0.1
+    cfg = BertConfigLite(hidden_dropout_prob=pdrop, attention_probs_dropout_prob=pdrop)
     torch.manual_seed(1234 + rank)
 
     def tower():
@@ -127,8 +129,8 @@ def main():
         torch.manual_seed(1234)
         for m in (bi.question_model, bi.ctx_model, teacher.encoder):
             m.init_weights()
-    bi.to(dev)
-    teacher.to(dev)
+    bi.to(dev).train()              # retriever step: model.train(), teacher_model.eval() (co_training_marco_train.py:196-197)
+    teacher.to(dev).eval()
     opt = FusedAdamW(bi, lr=5e-6, eps=1e-8)
     sch = LinearWarmupSchedule(opt, 5400, 54000)
 
@@ -220,7 +222,7 @@ def main():
                                   % (2 if args.inbatch else 1, B, N, Cn, QL, PL, CL, "realistic" if args.varlen else "all-max",
                                      " + 0.2*in-batch NLL (all-gather)" if args.inbatch else ""),
                       "global_batch": world * B, "pairs_per_step_per_gpu": P, "parallelism": "dp%d" % world,
-                      "teacher_in_step": not args.no_teacher},
+                      "teacher_in_step": not args.no_teacher, "dropout": pdrop},
            "algorithmic_tflop_per_step_per_gpu": {"student_fwd_bwd": round(stu / 1e12, 2), "teacher_fwd": round(tea / 1e12, 2)},
            "step_mfma_util": round((stu + tea) / (ms_step * 1e-3) / 2.5e15, 4) if args.dtype == "bf16" and not args.varlen else None,
            "final_loss": round(final_loss, 5)}

@@ -47,12 +47,30 @@ enum { SIMX_EPI_NONE = 0,   /* C = acc (+bias) (+residual)                      
        SIMX_EPI_GELU = 1,   /* C = acc + bias (pre-activation), C2 = gelu_erf(C)        */
        SIMX_EPI_DGELU = 2   /* C = (acc (+residual)) * gelu_erf'(aux)                   */ };
 
+/* Dropout descriptor (nn.Dropout of BertEmbeddings / BertSelfAttention / BertSelfOutput / BertOutput,
+ * LEAD/modeling_bert.py:239, 358, 386, 464; p = 0.1 forced in training, SimANS/model/models.py:70-72).
+ * The keep-mask is a stateless hash of (seed, stream, row, column): element (row, col) is kept iff the 16-bit lane
+ * (col & 1) of mix32(seed, stream, row, col >> 1) is >= round(p * 65536); kept values are scaled by 1/(1-p).  Nothing is
+ * stored: backward kernels recompute the mask from the same descriptor.  p == 0 (or a NULL descriptor) = no dropout. */
+typedef struct simx_dropout {
+  float p;
+  uint32_t seed;
+  uint32_t stream;      /* layer * 8 + site: 0 embeddings, 1 attention output, 2 FFN output, 3 attention probabilities */
+} simx_dropout;
+
 /* C[M,N] = A[M,K] . B[N,K]^T  (both operands K-contiguous; nn.Linear: B = weight [out,in]).
  * bias: f32 [N] or NULL; residual/aux/C/C2: same dtype as A, row strides in elements. */
 int simx_gemm_nt(simx_stream_t stream, int dtype, int M, int N, int K,
                  const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                  const float* bias, const void* residual, int ldr, int epilogue,
                  const void* aux, int ldaux, void* C2, int ldc2);
+
+/* same; with SIMX_EPI_NONE the dense result (acc + bias) goes through dropout `drop` (rows = M index, cols = N index)
+ * BEFORE the residual is added -- BertSelfOutput / BertOutput order. */
+int simx_gemm_nt_ex(simx_stream_t stream, int dtype, int M, int N, int K,
+                    const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                    const float* bias, const void* residual, int ldr, int epilogue,
+                    const void* aux, int ldaux, void* C2, int ldc2, const simx_dropout* drop);
 
 /* C[M,N] (f32) (+)= A[K,M]^T . B[K,N]   (weight gradient: A = dY [T,out], B = X [T,in]).
  * Split over K into f32 slabs in `ws`, reduced deterministically. */
@@ -93,6 +111,17 @@ int simx_embed_ln_bwd(simx_stream_t stream, int dtype, int T, int H,
                       const float* gamma, float eps, const void* dy,
                       float* dword, float* dpos, float* dtype0, float* dgamma, float* dbeta);
 
+/* dropout variants: the forward masks the LayerNorm OUTPUT, the backward masks the incoming dy first. */
+int simx_embed_ln_fwd_ex(simx_stream_t stream, int dtype, int T, int H,
+                         const int32_t* ids, const int32_t* pos_ids,
+                         const float* word, const float* posw, const float* typew,
+                         const float* gamma, const float* beta, float eps, void* out, const simx_dropout* drop);
+int simx_embed_ln_bwd_ex(simx_stream_t stream, int dtype, int T, int H,
+                         const int32_t* ids, const int32_t* pos_ids,
+                         const float* word, const float* posw, const float* typew,
+                         const float* gamma, float eps, const void* dy,
+                         float* dword, float* dpos, float* dtype0, float* dgamma, float* dbeta, const simx_dropout* drop);
+
 /* y = LN(z) ; z already holds dense(x)+bias+residual (BertSelfOutput / BertOutput,
  * LEAD/modeling_bert.py:384-388, 462-466). */
 int simx_ln_fwd(simx_stream_t stream, int dtype, int T, int H, const void* z,
@@ -101,6 +130,12 @@ int simx_ln_fwd(simx_stream_t stream, int dtype, int T, int H, const void* z,
 int simx_ln_bwd(simx_stream_t stream, int dtype, int T, int H, const void* z,
                 const float* gamma, float eps, const void* dy, void* dz,
                 float* dgamma, float* dbeta, float* dbias);
+
+/* with dropout on the dense branch that produced z (z = drop(dense) + residual): dz (gradient of the residual branch)
+ * and dz_masked = dz * mask / (1-p) (gradient of the dense output; feeds dgrad / wgrad); dbias = colsum(dz_masked). */
+int simx_ln_bwd_ex(simx_stream_t stream, int dtype, int T, int H, const void* z,
+                   const float* gamma, float eps, const void* dy, void* dz, void* dz_masked,
+                   float* dgamma, float* dbeta, float* dbias, const simx_dropout* drop);
 
 /* ------------------------------------------------------------ self-attention
  * BertSelfAttention core (LEAD/modeling_bert.py:318-374): softmax(QK^T/sqrt(d)) V per head,
@@ -112,6 +147,15 @@ int simx_mha_fwd(simx_stream_t stream, int dtype, int nseq, int heads, int head_
 int simx_mha_bwd(simx_stream_t stream, int dtype, int nseq, int heads, int head_dim,
                  const int32_t* cu_seqlens, int max_len, int T,
                  const void* qkv, const void* ctx, const float* lse, const void* dctx, void* dqkv);
+
+/* dropout on the attention probabilities (rows = head*T + query token, cols = key index inside the sequence). */
+int simx_mha_fwd_ex(simx_stream_t stream, int dtype, int nseq, int heads, int head_dim,
+                    const int32_t* cu_seqlens, int max_len, int T,
+                    const void* qkv, void* ctx, float* lse, const simx_dropout* drop);
+int simx_mha_bwd_ex(simx_stream_t stream, int dtype, int nseq, int heads, int head_dim,
+                    const int32_t* cu_seqlens, int max_len, int T,
+                    const void* qkv, const void* ctx, const float* lse, const void* dctx, void* dqkv,
+                    const simx_dropout* drop);
 
 /* [CLS] slice sequence_output[:,0,:] (SimANS/model/models.py:81) -> f32 [nseq,H], and its adjoint
  * (writes dcls into the first row of each sequence of dx, zero elsewhere). */
@@ -128,6 +172,8 @@ int simx_cls_scatter(simx_stream_t stream, int dtype, int nseq, int H, int T, co
 typedef struct simx_bert_cfg {
   int32_t dtype, layers, hidden, heads, inter, vocab, max_pos, type_vocab;
   float eps;
+  float hidden_dropout, attn_dropout;   /* 0 = off (eval / parity mode) */
+  uint32_t dropout_seed;                /* per forward call; the matching backward call must pass the same value */
 } simx_bert_cfg;
 
 enum { SIMX_P_WORD = 0, SIMX_P_POS, SIMX_P_TYPE, SIMX_P_EMB_LN_G, SIMX_P_EMB_LN_B,   /* layer = -1 */

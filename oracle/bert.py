@@ -50,8 +50,61 @@ def gelu_grad(u):
     return 0.5 * (1.0 + erf(u * SQRT1_2)) + u * np.exp(-0.5 * u * u) * INV_SQRT_2PI
 
 
-def bert_forward(P, ids, mask, heads, eps=1e-12, dtype=np.float64, keep=True, prefix=""):
-    """Returns (seq [n,S,H], cls [n,H], caches).  ``P``: HF-keyed dict."""
+def _mix32(seed, stream, row, colpair):
+    """uint32 hash of the product's dropout mask (simxns_amd/csrc/common.h drop_mix), vectorised."""
+    M = np.uint64(0xFFFFFFFF)
+    row = np.asarray(row, dtype=np.uint64)
+    cp = np.asarray(colpair, dtype=np.uint64)
+    h = ((row * np.uint64(0x9E3779B1)) & M) ^ ((((cp + np.uint64((stream * 0x632BE5AB) & 0xFFFFFFFF)) & M) * np.uint64(0x85EBCA77)) & M) ^ np.uint64(seed & 0xFFFFFFFF)
+    h ^= h >> np.uint64(16)
+    h = (h * np.uint64(0x7FEB352D)) & M
+    h ^= h >> np.uint64(15)
+    h = (h * np.uint64(0x846CA68B)) & M
+    h ^= h >> np.uint64(16)
+    return h
+
+
+def drop_multipliers(p, seed, stream, rows, cols):
+    """[len(rows), len(cols)] multipliers (0 or 1/(1-p)) of the stateless dropout mask (include/simx.h simx_dropout)."""
+    rows = np.asarray(rows, dtype=np.uint64)[:, None]
+    cols = np.asarray(cols, dtype=np.uint64)[None, :]
+    if p <= 0:
+        return np.ones((rows.shape[0], cols.shape[1]))
+    thr = int(np.float32(p) * np.float32(65536.0) + np.float32(0.5))
+    h = _mix32(seed, stream, rows, cols >> np.uint64(1))
+    lane = np.where((cols & np.uint64(1)) == 1, h >> np.uint64(16), h & np.uint64(0xFFFF))
+    return np.where(lane >= thr, 1.0 / (1.0 - float(np.float32(p))), 0.0)
+
+
+def _drop_masks(drop, ids, mask, heads, layers):
+    """Multipliers in the PADDED layout for every dropout site, from the packed-row hash definition.
+    -> dict: ('h', layer, site) -> [n,S,H] ; ('a', layer) -> [n,heads,S,S]"""
+    n, S = ids.shape
+    lens = mask.sum(1).astype(np.int64)
+    cu = np.concatenate([[0], np.cumsum(lens)])
+    T = int(cu[-1])
+    out = {}
+    H = drop["H"]
+    trow = np.zeros((n, S), dtype=np.int64)          # packed token index (pad positions: 0, never used)
+    for s_ in range(n):
+        trow[s_, :lens[s_]] = cu[s_] + np.arange(lens[s_])
+    for layer in range(-1, layers):
+        for site in ((0,) if layer == -1 else (1, 2)):
+            m = drop_multipliers(drop["p_hidden"], drop["seed"], (layer + 1) * 8 + site, trow.reshape(-1), np.arange(H))
+            out[("h", layer, site)] = m.reshape(n, S, H)
+        if layer >= 0:
+            a = np.ones((n, heads, S, S))
+            if drop["p_attn"] > 0:
+                for hh in range(heads):
+                    m = drop_multipliers(drop["p_attn"], drop["seed"], (layer + 1) * 8 + 3, (hh * T + trow).reshape(-1), np.arange(S))
+                    a[:, hh] = m.reshape(n, S, S)
+            out[("a", layer)] = a
+    return out
+
+
+def bert_forward(P, ids, mask, heads, eps=1e-12, dtype=np.float64, keep=True, prefix="", drop=None):
+    """Returns (seq [n,S,H], cls [n,H], caches).  ``P``: HF-keyed dict.
+    ``drop`` = dict(p_hidden, p_attn, seed) enables training-mode dropout with the product's stateless masks."""
     g = lambda k: np.asarray(P[prefix + k], dtype=dtype)
     n, S = ids.shape
     H = g("embeddings.word_embeddings.weight").shape[1]
@@ -66,6 +119,12 @@ def bert_forward(P, ids, mask, heads, eps=1e-12, dtype=np.float64, keep=True, pr
     L = 0
     while (prefix + "encoder.layer.%d.attention.self.query.weight" % L) in P:
         L += 1
+    DM = None
+    if drop is not None:
+        DM = _drop_masks(dict(drop, H=H), ids, mask, heads, L)
+        x = x * DM[("h", -1, 0)]
+        if keep:
+            caches["DM"] = DM
     for i in range(L):
         p = "encoder.layer.%d." % i
         def lin(t, name):
@@ -77,16 +136,21 @@ def bert_forward(P, ids, mask, heads, eps=1e-12, dtype=np.float64, keep=True, pr
         s = s - s.max(-1, keepdims=True)
         e = np.exp(s)
         pr = e / e.sum(-1, keepdims=True)
-        ctx = (pr @ v).transpose(0, 2, 1, 3).reshape(n, S, H)
+        prd = pr * DM[("a", i)] if DM is not None else pr
+        ctx = (prd @ v).transpose(0, 2, 1, 3).reshape(n, S, H)
         a = lin(ctx, "attention.output.dense")
+        if DM is not None:
+            a = a * DM[("h", i, 1)]
         x1, ln1 = _ln_fwd(a + x, g(p + "attention.output.LayerNorm.weight"),
                           g(p + "attention.output.LayerNorm.bias"), eps)
         u = lin(x1, "intermediate.dense")
         h = gelu(u)
         y = lin(h, "output.dense")
+        if DM is not None:
+            y = y * DM[("h", i, 2)]
         x2, ln2 = _ln_fwd(y + x1, g(p + "output.LayerNorm.weight"), g(p + "output.LayerNorm.bias"), eps)
         if keep:
-            caches["layers"].append(dict(x=x, q=q, k=k, v=v, pr=pr, ctx=ctx, ln1=ln1, x1=x1, u=u, h=h, ln2=ln2))
+            caches["layers"].append(dict(x=x, q=q, k=k, v=v, pr=pr, prd=prd, ctx=ctx, ln1=ln1, x1=x1, u=u, h=h, ln2=ln2))
         x = x2
     return x, x[:, 0, :].copy(), caches
 
@@ -106,6 +170,7 @@ def bert_backward(P, ids, mask, heads, caches, d_cls, d_seq=None, dtype=np.float
     if d_seq is not None:
         dx += d_seq
     L = len(caches["layers"])
+    DM = caches.get("DM")
     flat = lambda t: t.reshape(-1, t.shape[-1])
 
     def lin_bwd(dy, x_in, name, p):
@@ -118,16 +183,20 @@ def bert_backward(P, ids, mask, heads, caches, d_cls, d_seq=None, dtype=np.float
         c = caches["layers"][i]
         dz, dg_, db_ = _ln_bwd(dx, c["ln2"], g(p + "output.LayerNorm.weight"))
         G[prefix + p + "output.LayerNorm.weight"], G[prefix + p + "output.LayerNorm.bias"] = dg_, db_
-        dh = lin_bwd(dz, c["h"], "output.dense", p)
+        dzd = dz * DM[("h", i, 2)] if DM is not None else dz
+        dh = lin_bwd(dzd, c["h"], "output.dense", p)
         du = dh * gelu_grad(c["u"])
         dx1 = dz + lin_bwd(du, c["x1"], "intermediate.dense", p)
         dz1, dg_, db_ = _ln_bwd(dx1, c["ln1"], g(p + "attention.output.LayerNorm.weight"))
         G[prefix + p + "attention.output.LayerNorm.weight"] = dg_
         G[prefix + p + "attention.output.LayerNorm.bias"] = db_
-        dctx = lin_bwd(dz1, c["ctx"], "attention.output.dense", p)
+        dz1d = dz1 * DM[("h", i, 1)] if DM is not None else dz1
+        dctx = lin_bwd(dz1d, c["ctx"], "attention.output.dense", p)
         dctx = dctx.reshape(n, S, heads, d).transpose(0, 2, 1, 3)
         dpr = dctx @ c["v"].transpose(0, 1, 3, 2)
-        dv = c["pr"].transpose(0, 1, 3, 2) @ dctx
+        if DM is not None:
+            dpr = dpr * DM[("a", i)]
+        dv = c["prd"].transpose(0, 1, 3, 2) @ dctx
         ds = c["pr"] * (dpr - (dpr * c["pr"]).sum(-1, keepdims=True))
         ds = ds / np.sqrt(d)
         dq = ds @ c["k"]
@@ -137,6 +206,8 @@ def bert_backward(P, ids, mask, heads, caches, d_cls, d_seq=None, dtype=np.float
                + lin_bwd(back(dk), c["x"], "attention.self.key", p)
                + lin_bwd(back(dv), c["x"], "attention.self.value", p))
         dx = dz1 + dxa
+    if DM is not None:
+        dx = dx * DM[("h", -1, 0)]
     demb, dg_, db_ = _ln_bwd(dx, caches["ln0"], g("embeddings.LayerNorm.weight"))
     G[prefix + "embeddings.LayerNorm.weight"], G[prefix + "embeddings.LayerNorm.bias"] = dg_, db_
     # only real tokens contribute in the product (packed layout); in the padded

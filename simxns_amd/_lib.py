@@ -25,7 +25,11 @@ class SimxError(RuntimeError):
 class BertCfg(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("layers", C.c_int32), ("hidden", C.c_int32), ("heads", C.c_int32),
                 ("inter", C.c_int32), ("vocab", C.c_int32), ("max_pos", C.c_int32), ("type_vocab", C.c_int32),
-                ("eps", C.c_float)]
+                ("eps", C.c_float), ("hidden_dropout", C.c_float), ("attn_dropout", C.c_float), ("dropout_seed", C.c_uint32)]
+
+
+class Dropout(C.Structure):
+    _fields_ = [("p", C.c_float), ("seed", C.c_uint32), ("stream", C.c_uint32)]
 
 
 class LossParams(C.Structure):
@@ -34,13 +38,19 @@ class LossParams(C.Structure):
 
 
 _p, _i, _f, _d, _z, _l = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t, C.c_long
-_cfgp, _lpp = C.POINTER(BertCfg), C.POINTER(LossParams)
+_cfgp, _lpp, _dp = C.POINTER(BertCfg), C.POINTER(LossParams), C.POINTER(Dropout)
 
 # name -> (restype, argtypes); every symbol of include/simx.h
 SIGNATURES = {
     "simx_version": (_i, []),
     "simx_last_error": (C.c_char_p, []),
     "simx_gemm_nt": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _i, _i, _p, _i, _p, _i]),
+    "simx_gemm_nt_ex": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _i, _i, _p, _i, _p, _i, _dp]),
+    "simx_embed_ln_fwd_ex": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _p, _dp]),
+    "simx_embed_ln_bwd_ex": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _dp]),
+    "simx_ln_bwd_ex": (_i, [_p, _i, _i, _i, _p, _p, _f, _p, _p, _p, _p, _p, _p, _dp]),
+    "simx_mha_fwd_ex": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _dp]),
+    "simx_mha_bwd_ex": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _dp]),
     "simx_gemm_tn_workspace_bytes": (_z, [_i, _i, _i]),
     "simx_gemm_tn": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p, _z]),
     "simx_gemm_tn_bias": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p, _z, _p]),

@@ -67,7 +67,7 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
 template <int NKT>
 __global__ __launch_bounds__(256) void mha_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
                                                            float* __restrict__ lse, const int* __restrict__ cu,
-                                                           int heads, int T, float scale) {
+                                                           int heads, int T, float scale, DropCtx drop) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -129,6 +129,16 @@ __global__ __launch_bounds__(256) void mha_fwd_bf16_kernel(const bf16_t* __restr
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
+    if (drop.thr) {                              // dropout on the probabilities (the normaliser stays unmasked)
+      const uint32_t drow = (uint32_t)(h * T + t0 + q);
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+        if (kt < nkt) {
+          float m4[4];
+          drop_mult4(drop, drow, (uint32_t)(kt * 16 + 4 * fg), m4);
+          s[kt][0] *= m4[0]; s[kt][1] *= m4[1]; s[kt][2] *= m4[2]; s[kt][3] *= m4[3];
+        }
+    }
 
     f32x4 o[4];
 #pragma unroll
@@ -162,7 +172,7 @@ template <int NKT>
 __global__ __launch_bounds__(256) void mha_bwd_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ O,
                                                            const float* __restrict__ lse, const bf16_t* __restrict__ dO,
                                                            bf16_t* __restrict__ dqkv, const int* __restrict__ cu,
-                                                           int heads, int T, float scale) {
+                                                           int heads, int T, float scale, DropCtx drop) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -231,11 +241,13 @@ __global__ __launch_bounds__(256) void mha_bwd_bf16_kernel(const bf16_t* __restr
         s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(sK, kt * 16 + fr, 4 + fg), qf1, s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(sV, kt * 16 + fr, fg), df0, dp, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(sV, kt * 16 + fr, 4 + fg), df1, dp, 0, 0, 0);
+        float m4[4] = {1.f, 1.f, 1.f, 1.f};
+        if (drop.thr) drop_mult4(drop, (uint32_t)(h * T + t0 + q), (uint32_t)(kt * 16 + 4 * fg), m4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = kt * 16 + 4 * fg + r;
           const float p = (key < len && q < len) ? exp2f(s[r] * c2 - lq) : 0.f;
-          ds[hf][r] = p * (dp[r] - dq_) * scale;
+          ds[hf][r] = p * (dp[r] * m4[r] - dq_) * scale;
         }
       }
       const bf16x8 dsf = pack8(ds[0], ds[1]);
@@ -278,8 +290,9 @@ __global__ __launch_bounds__(256) void mha_bwd_bf16_kernel(const bf16_t* __restr
         for (int r = 0; r < 4; ++r) {
           const int q = qt * 16 + 4 * fg + r;
           const float p = (q < len && key < len) ? exp2f(s[r] * c2 - sLse[q]) : 0.f;
-          pp[hf][r] = p;
-          ds[hf][r] = p * (dp[r] - sDel[q]) * scale;
+          const float mm = drop.thr ? drop_mult(drop, (uint32_t)(h * T + t0 + q), (uint32_t)key) : 1.f;
+          pp[hf][r] = p * mm;
+          ds[hf][r] = p * (dp[r] * mm - sDel[q]) * scale;
         }
       }
       const bf16x8 pf = pack8(pp[0], pp[1]);
@@ -313,7 +326,7 @@ __global__ __launch_bounds__(256) void mha_bwd_bf16_kernel(const bf16_t* __restr
 template <typename TT>
 __global__ __launch_bounds__(256) void mha_fwd_simple_kernel(const TT* __restrict__ qkv, TT* __restrict__ ctx,
                                                              float* __restrict__ lse, const int* __restrict__ cu,
-                                                             int heads, int d, int T, float scale, int max_len) {
+                                                             int heads, int d, int T, float scale, int max_len, DropCtx drop) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sq = reinterpret_cast<float*>(smem);              // [4][128]
   float* sc = sq + 4 * 128;                                // [4][max_len]
@@ -342,7 +355,7 @@ __global__ __launch_bounds__(256) void mha_fwd_simple_kernel(const TT* __restric
   float sum = 0.f;
   for (int j = lane; j < len; j += 64) {
     const float p = expf(sc[w * max_len + j] - mx);
-    sc[w * max_len + j] = p;
+    sc[w * max_len + j] = drop.thr ? p * drop_mult(drop, (uint32_t)(h * T + t0 + qc), (uint32_t)j) : p;
     sum += p;
   }
   sum = wave_sum(sum);
@@ -362,7 +375,7 @@ template <typename TT, int MODE>
 __global__ __launch_bounds__(256) void mha_bwd_simple_kernel(const TT* __restrict__ qkv, const TT* __restrict__ O,
                                                              const float* __restrict__ lse, const TT* __restrict__ dO,
                                                              TT* __restrict__ dqkv, const int* __restrict__ cu, int heads,
-                                                             int d, int T, float scale, int max_len) {
+                                                             int d, int T, float scale, int max_len, DropCtx drop) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sa = reinterpret_cast<float*>(smem);              // [4][128] own row of Q (mode 0) / K (mode 1)
   float* sb = sa + 4 * 128;                                // [4][128] own row of dO (mode 0) / V (mode 1)
@@ -398,7 +411,8 @@ __global__ __launch_bounds__(256) void mha_bwd_simple_kernel(const TT* __restric
         dp = fmaf(sb[w * 128 + dd], Elem<TT>::ld(Vb + (long)j * H3 + dd), dp);
       }
       const float p = expf(dot * scale - li);
-      s1[w * max_len + j] = p * (dp - del) * scale;
+      const float mm = drop.thr ? drop_mult(drop, (uint32_t)(h * T + t0 + rc), (uint32_t)j) : 1.f;
+      s1[w * max_len + j] = p * (dp * mm - del) * scale;
     }
     __syncthreads();
     if (row < len)
@@ -422,8 +436,9 @@ __global__ __launch_bounds__(256) void mha_bwd_simple_kernel(const TT* __restric
         del = fmaf(g, Elem<TT>::ld(Ob + (long)i * H + dd), del);
       }
       const float p = expf(dot * scale - lse[(long)h * T + t0 + i]);
-      s2[w * max_len + i] = p;
-      s1[w * max_len + i] = p * (dp - del) * scale;
+      const float mm = drop.thr ? drop_mult(drop, (uint32_t)(h * T + t0 + i), (uint32_t)rc) : 1.f;
+      s2[w * max_len + i] = p * mm;
+      s1[w * max_len + i] = p * (dp * mm - del) * scale;
     }
     __syncthreads();
     if (row < len)
@@ -460,9 +475,24 @@ static int check_common(int dtype, int nseq, int heads, int d, int max_len, int 
   return SIMX_OK;
 }
 
+extern "C" int simx_mha_fwd_ex(simx_stream_t stream, int dtype, int nseq, int heads, int d, const int32_t* cu, int max_len,
+                               int T, const void* qkv, void* ctx, float* lse, const simx_dropout* dropd);
+extern "C" int simx_mha_bwd_ex(simx_stream_t stream, int dtype, int nseq, int heads, int d, const int32_t* cu, int max_len,
+                               int T, const void* qkv, const void* ctx, const float* lse, const void* dctx, void* dqkv,
+                               const simx_dropout* dropd);
 extern "C" int simx_mha_fwd(simx_stream_t stream, int dtype, int nseq, int heads, int d, const int32_t* cu, int max_len,
                             int T, const void* qkv, void* ctx, float* lse) {
+  return simx_mha_fwd_ex(stream, dtype, nseq, heads, d, cu, max_len, T, qkv, ctx, lse, nullptr);
+}
+extern "C" int simx_mha_bwd(simx_stream_t stream, int dtype, int nseq, int heads, int d, const int32_t* cu, int max_len,
+                            int T, const void* qkv, const void* ctx, const float* lse, const void* dctx, void* dqkv) {
+  return simx_mha_bwd_ex(stream, dtype, nseq, heads, d, cu, max_len, T, qkv, ctx, lse, dctx, dqkv, nullptr);
+}
+
+extern "C" int simx_mha_fwd_ex(simx_stream_t stream, int dtype, int nseq, int heads, int d, const int32_t* cu, int max_len,
+                               int T, const void* qkv, void* ctx, float* lse, const simx_dropout* dropd) {
   hipStream_t s = (hipStream_t)stream;
+  const DropCtx drop = make_drop(dropd);
   SIMX_PROF(SIMX_K_MHA_FWD, s, 4.0 * T * max_len * heads * d);
   int rc = check_common(dtype, nseq, heads, d, max_len, T, "mha_fwd");
   if (rc) return rc;
@@ -474,7 +504,7 @@ extern "C" int simx_mha_fwd(simx_stream_t stream, int dtype, int nseq, int heads
     rc = set_lds(mha_fwd_bf16_kernel<NKT>, lds, "mha_fwd");                                                          \
     if (rc) return rc;                                                                                               \
     hipLaunchKernelGGL((mha_fwd_bf16_kernel<NKT>), dim3(nseq * heads), dim3(256), lds, s, (const bf16_t*)qkv,        \
-                       (bf16_t*)ctx, lse, cu, heads, T, scale);                                                      \
+                       (bf16_t*)ctx, lse, cu, heads, T, scale, drop);                                                \
   } while (0)
     if (max_len <= 32) LF(2);
     else if (max_len <= 128) LF(8);
@@ -491,20 +521,22 @@ extern "C" int simx_mha_fwd(simx_stream_t stream, int dtype, int nseq, int heads
     rc = set_lds(mha_fwd_simple_kernel<float>, lds, "mha_fwd");
     if (rc) return rc;
     hipLaunchKernelGGL((mha_fwd_simple_kernel<float>), grid, dim3(256), lds, s, (const float*)qkv, (float*)ctx, lse, cu,
-                       heads, d, T, scale, max_len);
+                       heads, d, T, scale, max_len, drop);
   } else {
     rc = set_lds(mha_fwd_simple_kernel<bf16_t>, lds, "mha_fwd");
     if (rc) return rc;
     hipLaunchKernelGGL((mha_fwd_simple_kernel<bf16_t>), grid, dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)ctx, lse,
-                       cu, heads, d, T, scale, max_len);
+                       cu, heads, d, T, scale, max_len, drop);
   }
   SIMX_CHECK_LAUNCH("mha_fwd_simple");
   return SIMX_OK;
 }
 
-extern "C" int simx_mha_bwd(simx_stream_t stream, int dtype, int nseq, int heads, int d, const int32_t* cu, int max_len,
-                            int T, const void* qkv, const void* ctx, const float* lse, const void* dctx, void* dqkv) {
+extern "C" int simx_mha_bwd_ex(simx_stream_t stream, int dtype, int nseq, int heads, int d, const int32_t* cu, int max_len,
+                               int T, const void* qkv, const void* ctx, const float* lse, const void* dctx, void* dqkv,
+                               const simx_dropout* dropd) {
   hipStream_t s = (hipStream_t)stream;
+  const DropCtx drop = make_drop(dropd);
   SIMX_PROF(SIMX_K_MHA_BWD, s, 8.0 * T * max_len * heads * d);
   int rc = check_common(dtype, nseq, heads, d, max_len, T, "mha_bwd");
   if (rc) return rc;
@@ -516,7 +548,7 @@ extern "C" int simx_mha_bwd(simx_stream_t stream, int dtype, int nseq, int heads
     rc = set_lds(mha_bwd_bf16_kernel<NKT>, lds, "mha_bwd");                                                          \
     if (rc) return rc;                                                                                               \
     hipLaunchKernelGGL((mha_bwd_bf16_kernel<NKT>), dim3(nseq * heads), dim3(256), lds, s, (const bf16_t*)qkv,        \
-                       (const bf16_t*)ctx, lse, (const bf16_t*)dctx, (bf16_t*)dqkv, cu, heads, T, scale);            \
+                       (const bf16_t*)ctx, lse, (const bf16_t*)dctx, (bf16_t*)dqkv, cu, heads, T, scale, drop);      \
   } while (0)
     if (max_len <= 32) LB(2);
     else if (max_len <= 128) LB(8);
@@ -533,7 +565,7 @@ extern "C" int simx_mha_bwd(simx_stream_t stream, int dtype, int nseq, int heads
     rc = set_lds(mha_bwd_simple_kernel<TT, MODE>, lds, "mha_bwd");                                                   \
     if (rc) return rc;                                                                                               \
     hipLaunchKernelGGL((mha_bwd_simple_kernel<TT, MODE>), grid, dim3(256), lds, s, (const TT*)qkv, (const TT*)ctx, lse, \
-                       (const TT*)dctx, (TT*)dqkv, cu, heads, d, T, scale, max_len);                                 \
+                       (const TT*)dctx, (TT*)dqkv, cu, heads, d, T, scale, max_len, drop);                           \
   } while (0)
   if (dtype == SIMX_F32) { LS(float, 0); LS(float, 1); } else { LS(bf16_t, 0); LS(bf16_t, 1); }
 #undef LS

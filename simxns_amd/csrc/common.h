@@ -72,6 +72,37 @@ __device__ __forceinline__ void st4(bf16_t* p, const float (&v)[4]) {
   *reinterpret_cast<uint2*>(p) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
 }
 
+// ---- stateless dropout mask (see simx_dropout in include/simx.h) ---------------------------------------------
+struct DropCtx { uint32_t thr; float scale; uint32_t seed; uint32_t stream; };   // thr == 0: disabled
+static inline DropCtx make_drop(const simx_dropout* d) {
+  DropCtx c = {0u, 1.0f, 0u, 0u};
+  if (d && d->p > 0.f) {
+    c.thr = (uint32_t)(d->p * 65536.0f + 0.5f);
+    c.scale = 1.0f / (1.0f - d->p);
+    c.seed = d->seed;
+    c.stream = d->stream;
+  }
+  return c;
+}
+__device__ __forceinline__ uint32_t drop_mix(uint32_t seed, uint32_t stream, uint32_t row, uint32_t colpair) {
+  uint32_t h = (row * 0x9E3779B1u) ^ ((colpair + stream * 0x632BE5ABu) * 0x85EBCA77u) ^ seed;
+  h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+  return h;
+}
+// multiplier (0 or 1/(1-p)) for element (row, col)
+__device__ __forceinline__ float drop_mult(const DropCtx& d, uint32_t row, uint32_t col) {
+  const uint32_t h = drop_mix(d.seed, d.stream, row, col >> 1);
+  return (((col & 1u) ? (h >> 16) : (h & 0xFFFFu)) >= d.thr) ? d.scale : 0.f;
+}
+// 4 consecutive columns starting at an EVEN col (two hashes)
+__device__ __forceinline__ void drop_mult4(const DropCtx& d, uint32_t row, uint32_t col, float (&m)[4]) {
+  const uint32_t h0 = drop_mix(d.seed, d.stream, row, col >> 1), h1 = drop_mix(d.seed, d.stream, row, (col >> 1) + 1);
+  m[0] = ((h0 & 0xFFFFu) >= d.thr) ? d.scale : 0.f;
+  m[1] = ((h0 >> 16) >= d.thr) ? d.scale : 0.f;
+  m[2] = ((h1 & 0xFFFFu) >= d.thr) ? d.scale : 0.f;
+  m[3] = ((h1 >> 16) >= d.thr) ? d.scale : 0.f;
+}
+
 // ---- wave64 reductions -------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

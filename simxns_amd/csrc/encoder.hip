@@ -153,7 +153,7 @@ extern "C" size_t simx_bert_bwd_scratch_bytes(const simx_bert_cfg* c, int T, int
   if (!cfg_ok(c) || T <= 0) return 0;
   (void)nseq;
   const size_t H = c->hidden, F = c->inter, e = esz(c->dtype);
-  return 2 * al((size_t)T * H * e) + al((size_t)T * F * e) + al((size_t)T * 3 * H * e) + tn_ws_max(c, T);
+  return 3 * al((size_t)T * H * e) + al((size_t)T * F * e) + al((size_t)T * 3 * H * e) + tn_ws_max(c, T);
 }
 
 // ------------------------------------------------------------------------------------------ driver
@@ -182,8 +182,19 @@ extern "C" int simx_bert_cast_weights(simx_stream_t stream, const simx_bert_cfg*
   return SIMX_OK;
 }
 
+// dropout descriptor of (layer, site); layer -1 = embeddings
+static simx_dropout drop_of(const simx_bert_cfg* c, int layer, int site) {
+  simx_dropout d;
+  d.p = site == 3 ? c->attn_dropout : c->hidden_dropout;
+  d.seed = c->dropout_seed;
+  d.stream = (uint32_t)((layer + 1) * 8 + site);
+  return d;
+}
+
 static int check_io(const simx_bert_cfg* c, int nseq, int T, int max_len, const char* who) {
   SIMX_REQUIRE(cfg_ok(c), SIMX_ERR_BAD_SHAPE, "%s: bad config", who);
+  SIMX_REQUIRE(c->hidden_dropout >= 0.f && c->hidden_dropout < 1.f && c->attn_dropout >= 0.f && c->attn_dropout < 1.f,
+               SIMX_ERR_BAD_SHAPE, "%s: dropout probabilities must be in [0,1)", who);
   SIMX_REQUIRE(nseq > 0 && T >= nseq && max_len > 0 && max_len <= c->max_pos, SIMX_ERR_BAD_SHAPE,
                "%s: bad batch (nseq=%d T=%d max_len=%d max_pos=%d)", who, nseq, T, max_len, c->max_pos);
   return SIMX_OK;
@@ -200,21 +211,25 @@ extern "C" int simx_bert_fwd(simx_stream_t stream, const simx_bert_cfg* c, const
   const float* P = params;
   auto off = [&](int l, int w) { return P + simx_bert_param_offset(c, l, w); };
   char* x = act_x0(act);
-  RUN(simx_embed_ln_fwd(stream, dt, T, H, ids, pos_ids, off(-1, SIMX_P_WORD), off(-1, SIMX_P_POS), off(-1, SIMX_P_TYPE),
-                        off(-1, SIMX_P_EMB_LN_G), off(-1, SIMX_P_EMB_LN_B), c->eps, x));
+  {
+    const simx_dropout d0 = drop_of(c, -1, 0);
+    RUN(simx_embed_ln_fwd_ex(stream, dt, T, H, ids, pos_ids, off(-1, SIMX_P_WORD), off(-1, SIMX_P_POS), off(-1, SIMX_P_TYPE),
+                             off(-1, SIMX_P_EMB_LN_G), off(-1, SIMX_P_EMB_LN_B), c->eps, x, &d0));
+  }
   for (int l = 0; l < c->layers; ++l) {
     const WLayer w = wlayer(c, params, wcache, l);
     const ALayer a = alayer(c, act, T, l, save);
     RUN(simx_gemm_nt(stream, dt, T, 3 * H, H, x, H, w.wqkv, H, a.qkv, 3 * H, off(l, SIMX_P_BQKV), nullptr, 0, SIMX_EPI_NONE,
                      nullptr, 0, nullptr, 0));
-    RUN(simx_mha_fwd(stream, dt, nseq, c->heads, d, cu, max_len, T, a.qkv, a.ctx, a.lse));
-    RUN(simx_gemm_nt(stream, dt, T, H, H, a.ctx, H, w.wo, H, a.z1, H, off(l, SIMX_P_BO), x, H, SIMX_EPI_NONE, nullptr, 0,
-                     nullptr, 0));
+    const simx_dropout d1 = drop_of(c, l, 1), d2 = drop_of(c, l, 2), d3 = drop_of(c, l, 3);
+    RUN(simx_mha_fwd_ex(stream, dt, nseq, c->heads, d, cu, max_len, T, a.qkv, a.ctx, a.lse, &d3));
+    RUN(simx_gemm_nt_ex(stream, dt, T, H, H, a.ctx, H, w.wo, H, a.z1, H, off(l, SIMX_P_BO), x, H, SIMX_EPI_NONE, nullptr, 0,
+                        nullptr, 0, &d1));
     RUN(simx_ln_fwd(stream, dt, T, H, a.z1, off(l, SIMX_P_LN1_G), off(l, SIMX_P_LN1_B), c->eps, a.x1));
     RUN(simx_gemm_nt(stream, dt, T, F, H, a.x1, H, w.w1, H, a.u, F, off(l, SIMX_P_B1), nullptr, 0, SIMX_EPI_GELU, nullptr, 0,
                      a.h, F));
-    RUN(simx_gemm_nt(stream, dt, T, H, F, a.h, F, w.w2, F, a.z2, H, off(l, SIMX_P_B2), a.x1, H, SIMX_EPI_NONE, nullptr, 0,
-                     nullptr, 0));
+    RUN(simx_gemm_nt_ex(stream, dt, T, H, F, a.h, F, w.w2, F, a.z2, H, off(l, SIMX_P_B2), a.x1, H, SIMX_EPI_NONE, nullptr, 0,
+                        nullptr, 0, &d2));
     RUN(simx_ln_fwd(stream, dt, T, H, a.z2, off(l, SIMX_P_LN2_G), off(l, SIMX_P_LN2_B), c->eps, a.xout));
     x = a.xout;
   }
@@ -244,7 +259,9 @@ extern "C" int simx_bert_bwd(simx_stream_t stream, const simx_bert_cfg* c, const
   auto goff = [&](int l, int w) { return grads + simx_bert_param_offset(c, l, w); };
   char* bufA = (char*)scratch;
   char* bufB = bufA + al((size_t)T * H * e);
-  char* du = bufB + al((size_t)T * H * e);
+  char* bufC = bufB + al((size_t)T * H * e);                    // dropout-masked copy of dz (only with hidden dropout)
+  char* du = bufC + al((size_t)T * H * e);
+  const bool hd = c->hidden_dropout > 0.f;
   char* dqkv = du + al((size_t)T * F * e);
   char* tnws = dqkv + al((size_t)T * 3 * H * e);
   const size_t tnws_bytes = tn_ws_max(c, T);
@@ -254,31 +271,34 @@ extern "C" int simx_bert_bwd(simx_stream_t stream, const simx_bert_cfg* c, const
     const WLayer w = wlayer(c, params, wcache, l);
     const ALayer a = alayer(c, const_cast<void*>(act), T, l, 1);
     const char* xin = l == 0 ? act_x0(const_cast<void*>(act)) : alayer(c, const_cast<void*>(act), T, l - 1, 1).xout;
+    const simx_dropout d1 = drop_of(c, l, 1), d2 = drop_of(c, l, 2), d3 = drop_of(c, l, 3);
+    char* dzm = hd ? bufC : bufA;        // gradient of the (dropped) dense output; bufA = gradient of the residual branch
     // output LayerNorm : dz2, dgamma2, dbeta2, db2
-    RUN(simx_ln_bwd(stream, dt, T, H, a.z2, off(l, SIMX_P_LN2_G), c->eps, bufB, bufA, goff(l, SIMX_P_LN2_G),
-                    goff(l, SIMX_P_LN2_B), goff(l, SIMX_P_B2)));
-    // du = (dz2 . W2) * gelu'(u)
-    RUN(simx_gemm_nt(stream, dt, T, F, H, bufA, H, w.w2T, H, du, F, nullptr, nullptr, 0, SIMX_EPI_DGELU, a.u, F, nullptr, 0));
-    RUN(simx_gemm_tn(stream, dt, H, F, T, bufA, H, a.h, F, goff(l, SIMX_P_W2), F, 1, tnws, tnws_bytes));
+    RUN(simx_ln_bwd_ex(stream, dt, T, H, a.z2, off(l, SIMX_P_LN2_G), c->eps, bufB, bufA, hd ? bufC : nullptr, goff(l, SIMX_P_LN2_G),
+                       goff(l, SIMX_P_LN2_B), goff(l, SIMX_P_B2), &d2));
+    // du = (dz2m . W2) * gelu'(u)
+    RUN(simx_gemm_nt(stream, dt, T, F, H, dzm, H, w.w2T, H, du, F, nullptr, nullptr, 0, SIMX_EPI_DGELU, a.u, F, nullptr, 0));
+    RUN(simx_gemm_tn(stream, dt, H, F, T, dzm, H, a.h, F, goff(l, SIMX_P_W2), F, 1, tnws, tnws_bytes));
     // dx1 = du . W1 + dz2
     RUN(simx_gemm_nt(stream, dt, T, H, F, du, F, w.w1T, F, bufB, H, nullptr, bufA, H, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
     RUN(simx_gemm_tn_bias(stream, dt, F, H, T, du, F, a.x1, H, goff(l, SIMX_P_W1), H, 1, tnws, tnws_bytes, goff(l, SIMX_P_B1)));
     // attention-output LayerNorm : dz1, dgamma1, dbeta1, dbo
-    RUN(simx_ln_bwd(stream, dt, T, H, a.z1, off(l, SIMX_P_LN1_G), c->eps, bufB, bufA, goff(l, SIMX_P_LN1_G),
-                    goff(l, SIMX_P_LN1_B), goff(l, SIMX_P_BO)));
-    // dctx = dz1 . Wo
-    RUN(simx_gemm_nt(stream, dt, T, H, H, bufA, H, w.woT, H, bufB, H, nullptr, nullptr, 0, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
-    RUN(simx_gemm_tn(stream, dt, H, H, T, bufA, H, a.ctx, H, goff(l, SIMX_P_WO), H, 1, tnws, tnws_bytes));
-    RUN(simx_mha_bwd(stream, dt, nseq, c->heads, d, cu, max_len, T, a.qkv, a.ctx, a.lse, bufB, dqkv));
+    RUN(simx_ln_bwd_ex(stream, dt, T, H, a.z1, off(l, SIMX_P_LN1_G), c->eps, bufB, bufA, hd ? bufC : nullptr, goff(l, SIMX_P_LN1_G),
+                       goff(l, SIMX_P_LN1_B), goff(l, SIMX_P_BO), &d1));
+    // dctx = dz1m . Wo
+    RUN(simx_gemm_nt(stream, dt, T, H, H, dzm, H, w.woT, H, bufB, H, nullptr, nullptr, 0, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
+    RUN(simx_gemm_tn(stream, dt, H, H, T, dzm, H, a.ctx, H, goff(l, SIMX_P_WO), H, 1, tnws, tnws_bytes));
+    RUN(simx_mha_bwd_ex(stream, dt, nseq, c->heads, d, cu, max_len, T, a.qkv, a.ctx, a.lse, bufB, dqkv, &d3));
     // dx = dqkv . Wqkv + dz1
     RUN(simx_gemm_nt(stream, dt, T, H, 3 * H, dqkv, 3 * H, w.wqkvT, 3 * H, bufB, H, nullptr, bufA, H, SIMX_EPI_NONE, nullptr, 0,
                      nullptr, 0));
     RUN(simx_gemm_tn_bias(stream, dt, 3 * H, H, T, dqkv, 3 * H, xin, H, goff(l, SIMX_P_WQKV), H, 1, tnws, tnws_bytes,
                           goff(l, SIMX_P_BQKV)));
   }
-  RUN(simx_embed_ln_bwd(stream, dt, T, H, ids, pos_ids, off(-1, SIMX_P_WORD), off(-1, SIMX_P_POS), off(-1, SIMX_P_TYPE),
-                        off(-1, SIMX_P_EMB_LN_G), c->eps, bufB, goff(-1, SIMX_P_WORD), goff(-1, SIMX_P_POS),
-                        goff(-1, SIMX_P_TYPE), goff(-1, SIMX_P_EMB_LN_G), goff(-1, SIMX_P_EMB_LN_B)));
+  const simx_dropout d0 = drop_of(c, -1, 0);
+  RUN(simx_embed_ln_bwd_ex(stream, dt, T, H, ids, pos_ids, off(-1, SIMX_P_WORD), off(-1, SIMX_P_POS), off(-1, SIMX_P_TYPE),
+                           off(-1, SIMX_P_EMB_LN_G), c->eps, bufB, goff(-1, SIMX_P_WORD), goff(-1, SIMX_P_POS),
+                           goff(-1, SIMX_P_TYPE), goff(-1, SIMX_P_EMB_LN_G), goff(-1, SIMX_P_EMB_LN_B), &d0));
   return SIMX_OK;
 }
 

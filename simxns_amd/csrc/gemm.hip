@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void gemm_simple_kernel(
     int M, int N, int K, const TI* __restrict__ A, long a_rs, long a_cs,
     const TI* __restrict__ B, long b_ks, long b_ns, TO* __restrict__ C, int ldc,
     const float* __restrict__ bias, const TI* __restrict__ res, int ldr,
-    const TI* __restrict__ aux, int ldaux, TO* __restrict__ C2, int ldc2, int accumulate) {
+    const TI* __restrict__ aux, int ldaux, TO* __restrict__ C2, int ldc2, int accumulate, DropCtx drop) {
   __shared__ float As[16][68];
   __shared__ float Bs[16][68];
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256) void gemm_simple_kernel(
       float v = acc[i][j];
       if (bias) v += bias[n];
       if (EPI == SIMX_EPI_NONE) {
+        if (drop.thr) v *= drop_mult(drop, (uint32_t)m, (uint32_t)n);
         if (res) v += Elem<TI>::ld(res + (long)m * ldr + n);
         if (accumulate) v += Elem<TO>::ld(C + (long)m * ldc + n);
         Elem<TO>::st(C + (long)m * ldc + n, v);
@@ -128,7 +129,7 @@ template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(
     int M, int N, int K, const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
     bf16_t* __restrict__ C, int ldc, const float* __restrict__ bias, const bf16_t* __restrict__ res, int ldr,
-    const bf16_t* __restrict__ aux, int ldaux, bf16_t* __restrict__ C2, int ldc2, int tiles_n, int nwg) {
+    const bf16_t* __restrict__ aux, int ldaux, bf16_t* __restrict__ C2, int ldc2, int tiles_n, int nwg, DropCtx drop) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -195,6 +196,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(
         v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
       }
       if (EPI == SIMX_EPI_NONE) {
+        if (drop.thr) { float m4[4]; drop_mult4(drop, (uint32_t)m, (uint32_t)n, m4); v[0] *= m4[0]; v[1] *= m4[1]; v[2] *= m4[2]; v[3] *= m4[3]; }
         if (res) { float r4[4]; ld4(res + (long)m * ldr + n, r4); v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3]; }
         st4(C + (long)m * ldc + n, v);
       } else if (EPI == SIMX_EPI_GELU) {
@@ -251,7 +253,7 @@ template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_v5_kernel(
     int M, int N, int K, const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
     bf16_t* __restrict__ C, int ldc, const float* __restrict__ bias, const bf16_t* __restrict__ res, int ldr,
-    const bf16_t* __restrict__ aux, int ldaux, bf16_t* __restrict__ C2, int ldc2, int tiles_n, int nwg) {
+    const bf16_t* __restrict__ aux, int ldaux, bf16_t* __restrict__ C2, int ldc2, int tiles_n, int nwg, DropCtx drop) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -370,6 +372,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_v5_kernel(
             const int n = nw + j * 16 + fg * 4;
             const float4 bv = *reinterpret_cast<const float4*>(bias + (n + 4 <= N ? n : 0));
             v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+          }
+          if (EPI == SIMX_EPI_NONE && drop.thr) {
+            float m4[4];
+            drop_mult4(drop, (uint32_t)(mw + i * 16 + fr), (uint32_t)(nw + j * 16 + fg * 4), m4);
+            v[0] *= m4[0]; v[1] *= m4[1]; v[2] *= m4[2]; v[3] *= m4[3];
           }
           if (EPI != SIMX_EPI_GELU && in) {
             uint2 t;
@@ -785,10 +792,10 @@ __global__ __launch_bounds__(256) void cast_weight_kernel(const float* __restric
 template <typename TI, typename TO>
 static int launch_simple(hipStream_t s, int epi, int M, int N, int K, const TI* A, long a_rs, long a_cs,
                          const TI* B, long b_ks, long b_ns, TO* C, int ldc, const float* bias, const TI* res, int ldr,
-                         const TI* aux, int ldaux, TO* C2, int ldc2, int accumulate) {
+                         const TI* aux, int ldaux, TO* C2, int ldc2, int accumulate, DropCtx drop = DropCtx{0u, 1.f, 0u, 0u}) {
   dim3 grid(cdiv(N, 64), cdiv(M, 64));
 #define L(E) hipLaunchKernelGGL((gemm_simple_kernel<TI, TO, E>), grid, dim3(256), 0, s, M, N, K, A, a_rs, a_cs, B, b_ks, \
-                                b_ns, C, ldc, bias, res, ldr, aux, ldaux, C2, ldc2, accumulate)
+                                b_ns, C, ldc, bias, res, ldr, aux, ldaux, C2, ldc2, accumulate, drop)
   if (epi == SIMX_EPI_NONE) L(SIMX_EPI_NONE);
   else if (epi == SIMX_EPI_GELU) L(SIMX_EPI_GELU);
   else L(SIMX_EPI_DGELU);
@@ -799,10 +806,24 @@ static int launch_simple(hipStream_t s, int epi, int M, int N, int K, const TI* 
 
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+extern "C" int simx_gemm_nt_ex(simx_stream_t stream, int dtype, int M, int N, int K, const void* A, int lda,
+                               const void* B, int ldb, void* C, int ldc, const float* bias, const void* residual,
+                               int ldr, int epilogue, const void* aux, int ldaux, void* C2, int ldc2,
+                               const simx_dropout* dropd);
 extern "C" int simx_gemm_nt(simx_stream_t stream, int dtype, int M, int N, int K, const void* A, int lda,
                             const void* B, int ldb, void* C, int ldc, const float* bias, const void* residual,
                             int ldr, int epilogue, const void* aux, int ldaux, void* C2, int ldc2) {
+  return simx_gemm_nt_ex(stream, dtype, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, epilogue, aux, ldaux, C2, ldc2,
+                         nullptr);
+}
+
+extern "C" int simx_gemm_nt_ex(simx_stream_t stream, int dtype, int M, int N, int K, const void* A, int lda,
+                               const void* B, int ldb, void* C, int ldc, const float* bias, const void* residual,
+                               int ldr, int epilogue, const void* aux, int ldaux, void* C2, int ldc2,
+                               const simx_dropout* dropd) {
   hipStream_t s = (hipStream_t)stream;
+  const DropCtx drop = make_drop(epilogue == SIMX_EPI_NONE ? dropd : nullptr);
+  SIMX_REQUIRE(!dropd || (dropd->p >= 0.f && dropd->p < 1.f), SIMX_ERR_BAD_SHAPE, "gemm_nt: dropout p must be in [0,1)");
   SIMX_PROF(SIMX_K_GEMM_NT, s, 2.0 * M * N * K);
   SIMX_REQUIRE(M > 0 && N > 0 && K > 0, SIMX_ERR_BAD_SHAPE, "gemm_nt: bad shape %d %d %d", M, N, K);
   SIMX_REQUIRE(lda >= K && ldb >= K && ldc >= N, SIMX_ERR_BAD_SHAPE, "gemm_nt: leading dims too small");
@@ -812,7 +833,7 @@ extern "C" int simx_gemm_nt(simx_stream_t stream, int dtype, int M, int N, int K
   if (dtype == SIMX_F32)
     return launch_simple<float, float>(s, epilogue, M, N, K, (const float*)A, lda, 1, (const float*)B, 1, ldb,
                                        (float*)C, ldc, bias, (const float*)residual, ldr, (const float*)aux, ldaux,
-                                       (float*)C2, ldc2, 0);
+                                       (float*)C2, ldc2, 0, drop);
   SIMX_REQUIRE(dtype == SIMX_BF16, SIMX_ERR_BAD_DTYPE, "gemm_nt: dtype %d", dtype);
   const bool fast = (K % 64 == 0) && (N % 4 == 0) && (lda % 8 == 0) && (ldb % 8 == 0) && (ldc % 4 == 0) &&
                     aligned16(A) && aligned16(B) && aligned16(C) && (!bias || aligned16(bias)) &&
@@ -821,7 +842,7 @@ extern "C" int simx_gemm_nt(simx_stream_t stream, int dtype, int M, int N, int K
   if (!fast)
     return launch_simple<bf16_t, bf16_t>(s, epilogue, M, N, K, (const bf16_t*)A, lda, 1, (const bf16_t*)B, 1, ldb,
                                          (bf16_t*)C, ldc, bias, (const bf16_t*)residual, ldr, (const bf16_t*)aux,
-                                         ldaux, (bf16_t*)C2, ldc2, 0);
+                                         ldaux, (bf16_t*)C2, ldc2, 0, drop);
   const int tiles_m = cdiv(M, NT_BM), tiles_n = cdiv(N, NT_BN), nwg = tiles_m * tiles_n;
   const size_t lds = 2 * NT_STAGE_BYTES;
   static bool attr_done = false;
@@ -852,7 +873,7 @@ extern "C" int simx_gemm_nt(simx_stream_t stream, int dtype, int M, int N, int K
       if (noepi) C = nullptr;
 #define L5(E) hipLaunchKernelGGL((gemm_nt_bf16_v5_kernel<E>), dim3(nwg3), dim3(512), V5_LDS, s, M, N, K, (const bf16_t*)A, lda, \
                                  (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, (const bf16_t*)residual, ldr,                  \
-                                 (const bf16_t*)aux, ldaux, (bf16_t*)C2, ldc2, t3n, nwg3)
+                                 (const bf16_t*)aux, ldaux, (bf16_t*)C2, ldc2, t3n, nwg3, drop)
       if (epilogue == SIMX_EPI_NONE) L5(SIMX_EPI_NONE);
       else if (epilogue == SIMX_EPI_GELU) L5(SIMX_EPI_GELU);
       else L5(SIMX_EPI_DGELU);
@@ -863,7 +884,7 @@ extern "C" int simx_gemm_nt(simx_stream_t stream, int dtype, int M, int N, int K
   }
 #define L(E) hipLaunchKernelGGL((gemm_nt_bf16_kernel<E>), dim3(nwg), dim3(256), lds, s, M, N, K, (const bf16_t*)A, lda, \
                                 (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, (const bf16_t*)residual, ldr,               \
-                                (const bf16_t*)aux, ldaux, (bf16_t*)C2, ldc2, tiles_n, nwg)
+                                (const bf16_t*)aux, ldaux, (bf16_t*)C2, ldc2, tiles_n, nwg, drop)
   if (epilogue == SIMX_EPI_NONE) L(SIMX_EPI_NONE);
   else if (epilogue == SIMX_EPI_GELU) L(SIMX_EPI_GELU);
   else L(SIMX_EPI_DGELU);
@@ -926,7 +947,7 @@ extern "C" int simx_gemm_tn_bias(simx_stream_t stream, int dtype, int M, int N, 
     dim3 grid(cdiv(N, 64), cdiv(M, 64));
     hipLaunchKernelGGL((gemm_simple_kernel<bf16_t, float, SIMX_EPI_NONE>), grid, dim3(256), 0, s, M, N, K,
                        (const bf16_t*)A, 1L, (long)lda, (const bf16_t*)B, (long)ldb, 1L, C, ldc, nullptr, nullptr, 0,
-                       nullptr, 0, nullptr, 0, accumulate);
+                       nullptr, 0, nullptr, 0, accumulate, DropCtx{0u, 1.f, 0u, 0u});
     SIMX_CHECK_LAUNCH("gemm_simple(tn)");
     return SIMX_OK;
   }

@@ -8,6 +8,9 @@
 #include "common.h"
 #include "prof.h"
 
+extern "C" int simx_ln_bwd_ex(simx_stream_t, int, int, int, const void*, const float*, float, const void*, void*, void*, float*, float*, float*, const simx_dropout*);
+extern "C" int simx_embed_ln_fwd_ex(simx_stream_t, int, int, int, const int32_t*, const int32_t*, const float*, const float*, const float*, const float*, const float*, float, void*, const simx_dropout*);
+extern "C" int simx_embed_ln_bwd_ex(simx_stream_t, int, int, int, const int32_t*, const int32_t*, const float*, const float*, const float*, const float*, float, const void*, float*, float*, float*, float*, float*, const simx_dropout*);
 #define LN_VPL 4   // 4-element vectors per lane -> H <= 64*4*4 = 1024
 
 template <typename T>
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(int rows, int H, cons
                                                            const int* __restrict__ pos, const float* __restrict__ word,
                                                            const float* __restrict__ posw, const float* __restrict__ typew,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           float eps, T* __restrict__ y) {
+                                                           float eps, T* __restrict__ y, DropCtx drop) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + w;
   if (row >= rows) return;
@@ -95,6 +98,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(int rows, int H, cons
       ld4(beta + c, b);
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = x[v][e] * rstd * g[e] + b[e];
+      if (drop.thr) { float m4[4]; drop_mult4(drop, (uint32_t)row, (uint32_t)c, m4); o[0] *= m4[0]; o[1] *= m4[1]; o[2] *= m4[2]; o[3] *= m4[3]; }
       st4(yr + c, o);
     }
   }
@@ -166,7 +170,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int H, int rows_per_block, const T* __restrict__ z,
                                                      const float* __restrict__ gamma, float eps, const T* __restrict__ dyp,
                                                      T* __restrict__ dzp, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, float* __restrict__ dbias) {
+                                                     float* __restrict__ dbeta, float* __restrict__ dbias,
+                                                     T* __restrict__ dzm, DropCtx drop) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sred = reinterpret_cast<float*>(smem);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -195,6 +200,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int H, int rows_p
       const int c = (v * 64 + lane) * 4;
       if (c < H) {
         st4(o + c, dz[v]);
+        if (drop.thr) {                      // gradient of the dropped dense output (feeds dgrad / wgrad / bias grad)
+          float m4[4];
+          drop_mult4(drop, (uint32_t)row, (uint32_t)c, m4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dz[v][e] *= m4[e];
+          st4(dzm + (long)row * H + c, dz[v]);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) pz[v][e] += dz[v][e];
       }
@@ -212,7 +224,7 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(int rows, int H, int 
                                                            const float* __restrict__ gamma, float eps,
                                                            const T* __restrict__ dyp, float* __restrict__ dword,
                                                            float* __restrict__ dpos, float* __restrict__ dtype0,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, DropCtx drop) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sred = reinterpret_cast<float*>(smem);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -235,6 +247,7 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(int rows, int H, int 
         ld4(pr + c, b);
         ld4(typew + c, t);
         ld4(dr + c, dy[v]);
+        if (drop.thr) { float m4[4]; drop_mult4(drop, (uint32_t)row, (uint32_t)c, m4); dy[v][0] *= m4[0]; dy[v][1] *= m4[1]; dy[v][2] *= m4[2]; dy[v][3] *= m4[3]; }
 #pragma unroll
         for (int e = 0; e < 4; ++e) { x[v][e] = a[e] + b[e] + t[e]; sum += x[v][e]; }
       }
@@ -310,18 +323,26 @@ extern "C" int simx_ln_fwd(simx_stream_t stream, int dtype, int T, int H, const 
 
 extern "C" int simx_ln_bwd(simx_stream_t stream, int dtype, int T, int H, const void* z, const float* gamma, float eps,
                            const void* dy, void* dz, float* dgamma, float* dbeta, float* dbias) {
+  return simx_ln_bwd_ex(stream, dtype, T, H, z, gamma, eps, dy, dz, nullptr, dgamma, dbeta, dbias, nullptr);
+}
+
+extern "C" int simx_ln_bwd_ex(simx_stream_t stream, int dtype, int T, int H, const void* z, const float* gamma, float eps,
+                              const void* dy, void* dz, void* dz_masked, float* dgamma, float* dbeta, float* dbias,
+                              const simx_dropout* dropd) {
   SIMX_PROF(SIMX_K_LN_BWD, stream, 3.0 * T * H * (dtype == SIMX_F32 ? 4 : 2));
   int rc = ln_check(dtype, T, H, "ln_bwd");
   if (rc) return rc;
+  const DropCtx drop = make_drop(dropd);
+  SIMX_REQUIRE(!drop.thr || dz_masked, SIMX_ERR_BAD_SHAPE, "ln_bwd: dropout needs the dz_masked output");
   hipStream_t s = (hipStream_t)stream;
   const int rpb = bwd_rows_per_block(T);
   const size_t lds = (size_t)4 * H * sizeof(float);
   if (dtype == SIMX_F32)
     hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, (const float*)z, gamma, eps,
-                       (const float*)dy, (float*)dz, dgamma, dbeta, dbias);
+                       (const float*)dy, (float*)dz, dgamma, dbeta, dbias, (float*)dz_masked, drop);
   else
     hipLaunchKernelGGL((ln_bwd_kernel<bf16_t>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, (const bf16_t*)z, gamma, eps,
-                       (const bf16_t*)dy, (bf16_t*)dz, dgamma, dbeta, dbias);
+                       (const bf16_t*)dy, (bf16_t*)dz, dgamma, dbeta, dbias, (bf16_t*)dz_masked, drop);
   SIMX_CHECK_LAUNCH("ln_bwd");
   return SIMX_OK;
 }
@@ -329,16 +350,23 @@ extern "C" int simx_ln_bwd(simx_stream_t stream, int dtype, int T, int H, const 
 extern "C" int simx_embed_ln_fwd(simx_stream_t stream, int dtype, int T, int H, const int32_t* ids, const int32_t* pos_ids,
                                  const float* word, const float* posw, const float* typew, const float* gamma,
                                  const float* beta, float eps, void* out) {
+  return simx_embed_ln_fwd_ex(stream, dtype, T, H, ids, pos_ids, word, posw, typew, gamma, beta, eps, out, nullptr);
+}
+
+extern "C" int simx_embed_ln_fwd_ex(simx_stream_t stream, int dtype, int T, int H, const int32_t* ids, const int32_t* pos_ids,
+                                    const float* word, const float* posw, const float* typew, const float* gamma,
+                                    const float* beta, float eps, void* out, const simx_dropout* dropd) {
+  const DropCtx drop = make_drop(dropd);
   SIMX_PROF(SIMX_K_EMBED_FWD, stream, (double)T * H * (4 + (dtype == SIMX_F32 ? 4 : 2)));
   int rc = ln_check(dtype, T, H, "embed_ln_fwd");
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == SIMX_F32)
     hipLaunchKernelGGL((embed_ln_fwd_kernel<float>), dim3(cdiv(T, 4)), dim3(256), 0, s, T, H, ids, pos_ids, word, posw, typew,
-                       gamma, beta, eps, (float*)out);
+                       gamma, beta, eps, (float*)out, drop);
   else
     hipLaunchKernelGGL((embed_ln_fwd_kernel<bf16_t>), dim3(cdiv(T, 4)), dim3(256), 0, s, T, H, ids, pos_ids, word, posw, typew,
-                       gamma, beta, eps, (bf16_t*)out);
+                       gamma, beta, eps, (bf16_t*)out, drop);
   SIMX_CHECK_LAUNCH("embed_ln_fwd");
   return SIMX_OK;
 }
@@ -346,6 +374,15 @@ extern "C" int simx_embed_ln_fwd(simx_stream_t stream, int dtype, int T, int H, 
 extern "C" int simx_embed_ln_bwd(simx_stream_t stream, int dtype, int T, int H, const int32_t* ids, const int32_t* pos_ids,
                                  const float* word, const float* posw, const float* typew, const float* gamma, float eps,
                                  const void* dy, float* dword, float* dpos, float* dtype0, float* dgamma, float* dbeta) {
+  return simx_embed_ln_bwd_ex(stream, dtype, T, H, ids, pos_ids, word, posw, typew, gamma, eps, dy, dword, dpos, dtype0, dgamma,
+                              dbeta, nullptr);
+}
+
+extern "C" int simx_embed_ln_bwd_ex(simx_stream_t stream, int dtype, int T, int H, const int32_t* ids, const int32_t* pos_ids,
+                                    const float* word, const float* posw, const float* typew, const float* gamma, float eps,
+                                    const void* dy, float* dword, float* dpos, float* dtype0, float* dgamma, float* dbeta,
+                                    const simx_dropout* dropd) {
+  const DropCtx drop = make_drop(dropd);
   SIMX_PROF(SIMX_K_EMBED_BWD, stream, (double)T * H * (12 + (dtype == SIMX_F32 ? 4 : 2)));
   int rc = ln_check(dtype, T, H, "embed_ln_bwd");
   if (rc) return rc;
@@ -354,10 +391,10 @@ extern "C" int simx_embed_ln_bwd(simx_stream_t stream, int dtype, int T, int H, 
   const size_t lds = (size_t)4 * H * sizeof(float);
   if (dtype == SIMX_F32)
     hipLaunchKernelGGL((embed_ln_bwd_kernel<float>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, ids, pos_ids, word, posw,
-                       typew, gamma, eps, (const float*)dy, dword, dpos, dtype0, dgamma, dbeta);
+                       typew, gamma, eps, (const float*)dy, dword, dpos, dtype0, dgamma, dbeta, drop);
   else
     hipLaunchKernelGGL((embed_ln_bwd_kernel<bf16_t>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, ids, pos_ids, word, posw,
-                       typew, gamma, eps, (const bf16_t*)dy, dword, dpos, dtype0, dgamma, dbeta);
+                       typew, gamma, eps, (const bf16_t*)dy, dword, dpos, dtype0, dgamma, dbeta, drop);
   SIMX_CHECK_LAUNCH("embed_ln_bwd");
   return SIMX_OK;
 }

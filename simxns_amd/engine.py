@@ -126,9 +126,9 @@ class PackedBatch(object):
 
 class _EncoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchor, engine, pb, want_hidden):
-        cls, hidden, act = engine._run_forward(pb, True, want_hidden)
-        ctx.engine, ctx.pb, ctx.act = engine, pb, act
+    def forward(ctx, anchor, engine, pb, want_hidden, ccfg):
+        cls, hidden, act = engine._run_forward(pb, True, want_hidden, ccfg)
+        ctx.engine, ctx.pb, ctx.act, ctx.ccfg = engine, pb, act, ccfg
         if want_hidden:
             ctx.mark_non_differentiable(hidden)
             return cls, hidden
@@ -136,9 +136,9 @@ class _EncoderFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dcls, *unused):
-        ctx.engine._run_backward(ctx.pb, ctx.act, dcls)
+        ctx.engine._run_backward(ctx.pb, ctx.act, dcls, ctx.ccfg)      # same config copy: same dropout seed
         ctx.act = None
-        return None, None, None, None
+        return None, None, None, None, None
 
 
 class BertEngine(object):
@@ -156,6 +156,7 @@ class BertEngine(object):
         self._wcache_version = None
         self._dirty = True
         self.anchor = torch.zeros((), requires_grad=True)
+        self.dropout_seed = 0                # base seed of the stateless dropout masks (set_seed / manual)
         self.grad_ready_hook = None          # called after every backward (DP all-reduce launch)
         self.after_backward = None           # module callback: expose flat_grad as param.grad views
 
@@ -165,7 +166,7 @@ class BertEngine(object):
         self.dtype_code = _dtype_code(name)
         self.ccfg = L.BertCfg(self.dtype_code, c.num_hidden_layers, c.hidden_size, c.num_attention_heads,
                               c.intermediate_size, c.vocab_size, c.max_position_embeddings, c.type_vocab_size,
-                              float(c.layer_norm_eps))
+                              float(c.layer_norm_eps), 0.0, 0.0, 0)
         self.wcache = None
         self._dirty = True
 
@@ -215,27 +216,39 @@ class BertEngine(object):
         self._dirty = False
         self._wcache_version = self.flat._version
 
-    def _run_forward(self, pb, save, want_hidden):
+    def call_cfg(self, training):
+        """Per-call copy of the C config: dropout on only in training mode (nn.Dropout semantics), fresh seed per call."""
+        c = L.BertCfg.from_buffer_copy(self.ccfg)
+        if training and (self.cfg.hidden_dropout_prob > 0 or self.cfg.attention_probs_dropout_prob > 0):
+            self._drop_calls = getattr(self, "_drop_calls", 0) + 1
+            c.hidden_dropout = float(self.cfg.hidden_dropout_prob)
+            c.attn_dropout = float(self.cfg.attention_probs_dropout_prob)
+            c.dropout_seed = (self.dropout_seed * 0x9E3779B1 + self._drop_calls * 0x85EBCA6B) & 0xFFFFFFFF
+        return c
+
+    def _run_forward(self, pb, save, want_hidden, ccfg=None):
         self._require_gpu()
         self._refresh_wcache()
+        ccfg = ccfg if ccfg is not None else self.ccfg
         dev = self.flat.device
         H = self.cfg.hidden_size
         nbytes = int(self.lib.simx_bert_act_bytes(C.byref(self.ccfg), pb.T, pb.nseq, 1 if save else 0))
         act = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         cls = torch.empty(pb.nseq, H, dtype=torch.float32, device=dev)
         hidden = torch.empty(pb.T, H, dtype=self.act_torch_dtype, device=dev) if want_hidden else None
-        L.call("simx_bert_fwd", L.stream_ptr(), C.byref(self.ccfg), L.ptr(self.flat), L.ptr(self.wcache),
+        L.call("simx_bert_fwd", L.stream_ptr(), C.byref(ccfg), L.ptr(self.flat), L.ptr(self.wcache),
                L.ptr(pb.ids), L.ptr(pb.pos), L.ptr(pb.cu), pb.nseq, pb.T, pb.max_len, L.ptr(act), nbytes,
                1 if save else 0, L.ptr(cls), L.ptr(hidden))
         return cls, hidden, (act if save else None)
 
-    def _run_backward(self, pb, act, dcls):
+    def _run_backward(self, pb, act, dcls, ccfg=None):
+        ccfg = ccfg if ccfg is not None else self.ccfg
         g = self.ensure_grad()
         dev = self.flat.device
         dcls = dcls.contiguous().to(torch.float32)
         nbytes = int(self.lib.simx_bert_bwd_scratch_bytes(C.byref(self.ccfg), pb.T, pb.nseq))
         scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        L.call("simx_bert_bwd", L.stream_ptr(), C.byref(self.ccfg), L.ptr(self.flat), L.ptr(self.wcache),
+        L.call("simx_bert_bwd", L.stream_ptr(), C.byref(ccfg), L.ptr(self.flat), L.ptr(self.wcache),
                L.ptr(pb.ids), L.ptr(pb.pos), L.ptr(pb.cu), pb.nseq, pb.T, pb.max_len, L.ptr(act), act.numel(),
                L.ptr(dcls), L.ptr(g), L.ptr(scratch), nbytes)
         if self.after_backward is not None:
@@ -243,15 +256,16 @@ class BertEngine(object):
         if self.grad_ready_hook is not None:
             self.grad_ready_hook(self)
 
-    def encode(self, input_ids, attention_mask, want_hidden=False, requires_grad=None):
+    def encode(self, input_ids, attention_mask, want_hidden=False, requires_grad=None, training=False):
         """-> cls [n,H] f32 (and the packed last hidden state + PackedBatch when want_hidden)."""
         pb = PackedBatch(input_ids, attention_mask)
+        ccfg = self.call_cfg(training)
         if requires_grad is None:
             requires_grad = torch.is_grad_enabled()
         if requires_grad and torch.is_grad_enabled():
             if self.anchor.device != self.flat.device:
                 self.anchor = torch.zeros((), requires_grad=True, device=self.flat.device)
-            out = _EncoderFn.apply(self.anchor, self, pb, want_hidden)
+            out = _EncoderFn.apply(self.anchor, self, pb, want_hidden, ccfg)
             return (out[0], out[1], pb) if want_hidden else out
-        cls, hidden, _ = self._run_forward(pb, False, want_hidden)
+        cls, hidden, _ = self._run_forward(pb, False, want_hidden, ccfg)
         return (cls, hidden, pb) if want_hidden else cls

@@ -142,7 +142,7 @@ class HFBertEncoder(nn.Module):
             raise NotImplementedError("token_type_ids other than 0 are not used on this path (models.py:654)")
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
-        cls_vec, hidden, pb = self.engine.encode(input_ids, attention_mask, want_hidden=True)
+        cls_vec, hidden, pb = self.engine.encode(input_ids, attention_mask, want_hidden=True, training=self.training)
         if self.engine.flat_grad is not None:
             self.attach_grads()
         seq = pb.unpack(hidden.to(torch.float32))
@@ -152,8 +152,7 @@ class HFBertEncoder(nn.Module):
 
     def embed(self, input_ids, attention_mask):
         """Fast path used by BiBertEncoder / Reranker: [CLS] embeddings [n,H] f32 only."""
-        out = self.engine.encode(input_ids, attention_mask)
-        return out
+        return self.engine.encode(input_ids, attention_mask, training=self.training)
 
 
 class BiBertEncoder(nn.Module):

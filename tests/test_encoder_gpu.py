@@ -25,7 +25,8 @@ def _cfg_from(G):
     c = json.loads(str(G["cfg"]))
     return BertConfigLite(vocab_size=c["vocab"], hidden_size=c["hidden"], num_hidden_layers=c["layers"],
                           num_attention_heads=c["heads"], intermediate_size=c["inter"],
-                          max_position_embeddings=c["max_pos"], type_vocab_size=c["type_vocab"], layer_norm_eps=c["eps"])
+                          max_position_embeddings=c["max_pos"], type_vocab_size=c["type_vocab"], layer_norm_eps=c["eps"],
+                          hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)   # goldens are dropout-free
 
 
 def _named_shapes(enc):

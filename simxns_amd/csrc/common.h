@@ -104,15 +104,33 @@ __device__ __forceinline__ void drop_mult4(const DropCtx& d, uint32_t row, uint3
 }
 
 // ---- wave64 reductions -------------------------------------------------------------------
+// DPP butterflies (no LDS traffic, ~1 VALU op per step): quad swaps, half-row / row mirrors give every lane its
+// 16-lane row total; row_bcast15 / row_bcast31 chain the four rows into lane 63; v_readlane broadcasts it as a scalar.
+// (__shfl_xor lowers to ds_bpermute_b32: an LDS round trip per step.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_mov<0xB1, 0xF>(v);          // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E, 0xF>(v);          // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141, 0xF>(v);         // row_half_mirror
+  v += dpp_mov<0x140, 0xF>(v);         // row_mirror      -> every lane: total of its row of 16
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));   // row_bcast15 -> rows 1,3
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));   // row_bcast31 -> rows 2,3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_mov<0xB1, 0xF>(v));
+  v = fmaxf(v, dpp_mov<0x4E, 0xF>(v));
+  v = fmaxf(v, dpp_mov<0x141, 0xF>(v));
+  v = fmaxf(v, dpp_mov<0x140, 0xF>(v));
+  // rows -> wave: lanes 15/31/47/63 hold the row maxima
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 15));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 47));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
 // ---- erf-GELU (HF "gelu", LEAD/modeling_bert.py:440-452) -----------------------------------

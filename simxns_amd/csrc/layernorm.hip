@@ -13,42 +13,81 @@ extern "C" int simx_embed_ln_fwd_ex(simx_stream_t, int, int, int, const int32_t*
 extern "C" int simx_embed_ln_bwd_ex(simx_stream_t, int, int, int, const int32_t*, const int32_t*, const float*, const float*, const float*, const float*, float, const void*, float*, float*, float*, float*, float*, const simx_dropout*);
 #define LN_VPL 4   // 4-element vectors per lane -> H <= 64*4*4 = 1024
 
-template <typename T>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int H, const T* __restrict__ z,
+// raw (still packed) 4-element vectors: lets the next row's loads stay in flight while this row is processed
+template <typename T> struct Raw4;
+template <> struct Raw4<float> {
+  float4 r;
+  __device__ __forceinline__ void load(const float* p) { r = *reinterpret_cast<const float4*>(p); }
+  __device__ __forceinline__ void unpack(float (&v)[4]) const { v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w; }
+};
+template <> struct Raw4<bf16_t> {
+  uint2 r;
+  __device__ __forceinline__ void load(const bf16_t* p) { r = *reinterpret_cast<const uint2*>(p); }
+  __device__ __forceinline__ void unpack(float (&v)[4]) const {
+    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xFFFF0000u);
+    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xFFFF0000u);
+  }
+};
+
+// One wave per row, rows strided by 4 inside a block; the next row's loads are issued before this row's
+// reductions, and gamma/beta are read from LDS so the row body never queues behind those loads on vmcnt.
+template <typename T, int VPL>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int H, int rows_per_block, const T* __restrict__ z,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float eps, T* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sgam = reinterpret_cast<float*>(smem);
+  float* sbet = sgam + H;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int row = blockIdx.x * 4 + w;
-  if (row >= rows) return;
-  const T* zr = z + (long)row * H;
-  float x[LN_VPL][4];
-  float sum = 0.f;
+  for (int c = threadIdx.x; c < H; c += 256) { sgam[c] = gamma[c]; sbet[c] = beta[c]; }
+  __syncthreads();
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(rows, r0 + rows_per_block);
+  Raw4<T> nx[VPL];
+  if (r0 + w < r1) {
 #pragma unroll
-  for (int v = 0; v < LN_VPL; ++v) {
-    const int c = (v * 64 + lane) * 4;
-    if (c < H) { ld4(zr + c, x[v]); sum += x[v][0] + x[v][1] + x[v][2] + x[v][3]; }
+    for (int v = 0; v < VPL; ++v) {
+      const int c = (v * 64 + lane) * 4;
+      if (c < H) nx[v].load(z + (long)(r0 + w) * H + c);
+    }
   }
-  const float mu = wave_sum(sum) / (float)H;
-  float sq = 0.f;
+  for (int row = r0 + w; row < r1; row += 4) {
+    float x[VPL][4];
+    float sum = 0.f;
 #pragma unroll
-  for (int v = 0; v < LN_VPL; ++v) {
-    const int c = (v * 64 + lane) * 4;
-    if (c < H)
+    for (int v = 0; v < VPL; ++v) {
+      const int c = (v * 64 + lane) * 4;
+      if (c < H) { nx[v].unpack(x[v]); sum += x[v][0] + x[v][1] + x[v][2] + x[v][3]; }
+    }
+    if (row + 4 < r1) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { x[v][e] -= mu; sq += x[v][e] * x[v][e]; }
-  }
-  const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)H + eps);
-  T* yr = y + (long)row * H;
+      for (int v = 0; v < VPL; ++v) {
+        const int c = (v * 64 + lane) * 4;
+        if (c < H) nx[v].load(z + (long)(row + 4) * H + c);
+      }
+    }
+    const float mu = wave_sum(sum) / (float)H;
+    float sq = 0.f;
 #pragma unroll
-  for (int v = 0; v < LN_VPL; ++v) {
-    const int c = (v * 64 + lane) * 4;
-    if (c < H) {
-      float g[4], b[4], o[4];
-      ld4(gamma + c, g);
-      ld4(beta + c, b);
+    for (int v = 0; v < VPL; ++v) {
+      const int c = (v * 64 + lane) * 4;
+      if (c < H)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = x[v][e] * rstd * g[e] + b[e];
-      st4(yr + c, o);
+        for (int e = 0; e < 4; ++e) { x[v][e] -= mu; sq += x[v][e] * x[v][e]; }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)H + eps);
+    T* yr = y + (long)row * H;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int c = (v * 64 + lane) * 4;
+      if (c < H) {
+        float g[4], b[4], o[4];
+        ld4(sgam + c, g);
+        ld4(sbet + c, b);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = x[v][e] * rstd * g[e] + b[e];
+        st4(yr + c, o);
+      }
     }
   }
 }
@@ -105,19 +144,20 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(int rows, int H, cons
 }
 
 // shared row-backward: given centred x (in/out: becomes xhat), dy -> dz ; accumulates column partials
-__device__ __forceinline__ void ln_row_bwd(int H, int lane, float (&x)[LN_VPL][4], float (&dy)[LN_VPL][4],
-                                           const float* __restrict__ gamma, float eps, float (&dz)[LN_VPL][4],
-                                           float (&pg)[LN_VPL][4], float (&pb)[LN_VPL][4]) {
+template <int VPL>
+__device__ __forceinline__ void ln_row_bwd(int H, int lane, float (&x)[VPL][4], float (&dy)[VPL][4],
+                                           const float* __restrict__ gamma, float eps, float (&dz)[VPL][4],
+                                           float (&pg)[VPL][4], float (&pb)[VPL][4]) {
   float sq = 0.f;
 #pragma unroll
-  for (int v = 0; v < LN_VPL; ++v)
+  for (int v = 0; v < VPL; ++v)
     if ((v * 64 + lane) * 4 < H)
 #pragma unroll
       for (int e = 0; e < 4; ++e) sq += x[v][e] * x[v][e];
   const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)H + eps);
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-  for (int v = 0; v < LN_VPL; ++v) {
+  for (int v = 0; v < VPL; ++v) {
     const int c = (v * 64 + lane) * 4;
     if (c < H) {
       float g[4];
@@ -136,17 +176,18 @@ __device__ __forceinline__ void ln_row_bwd(int H, int lane, float (&x)[LN_VPL][4
   s1 = wave_sum(s1) / (float)H;
   s2 = wave_sum(s2) / (float)H;
 #pragma unroll
-  for (int v = 0; v < LN_VPL; ++v)
+  for (int v = 0; v < VPL; ++v)
     if ((v * 64 + lane) * 4 < H)
 #pragma unroll
       for (int e = 0; e < 4; ++e) dz[v][e] = rstd * (dy[v][e] - s1 - x[v][e] * s2);
 }
 
-__device__ __forceinline__ void flush_cols(int H, int lane, int w, float (&p)[LN_VPL][4], float* __restrict__ out,
+template <int VPL>
+__device__ __forceinline__ void flush_cols(int H, int lane, int w, float (&p)[VPL][4], float* __restrict__ out,
                                            float* sred /* [4][H] */) {
   // sum the 4 waves' partials through LDS, wave 0 issues the atomics
 #pragma unroll
-  for (int v = 0; v < LN_VPL; ++v) {
+  for (int v = 0; v < VPL; ++v) {
     const int c = (v * 64 + lane) * 4;
     if (c < H)
 #pragma unroll
@@ -155,7 +196,7 @@ __device__ __forceinline__ void flush_cols(int H, int lane, int w, float (&p)[LN
   __syncthreads();
   if (w == 0) {
 #pragma unroll
-    for (int v = 0; v < LN_VPL; ++v) {
+    for (int v = 0; v < VPL; ++v) {
       const int c = (v * 64 + lane) * 4;
       if (c < H)
 #pragma unroll
@@ -166,37 +207,56 @@ __device__ __forceinline__ void flush_cols(int H, int lane, int w, float (&p)[LN
   __syncthreads();
 }
 
-template <typename T>
+// One wave per row, rows strided by 4 inside a block.  The loads of row+4 are issued before row is processed
+// (gamma comes from LDS so nothing in the row body queues behind them on vmcnt), which doubles the bytes each
+// wave keeps in flight; the three column partials stay in registers and are flushed once per block.
+template <typename T, int VPL>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int H, int rows_per_block, const T* __restrict__ z,
                                                      const float* __restrict__ gamma, float eps, const T* __restrict__ dyp,
                                                      T* __restrict__ dzp, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, float* __restrict__ dbias,
                                                      T* __restrict__ dzm, DropCtx drop) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* sred = reinterpret_cast<float*>(smem);
+  float* sred = reinterpret_cast<float*>(smem);          // [4][H] flush scratch
+  float* sgam = sred + 4 * H;                            // [H]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  float pg[LN_VPL][4] = {}, pb[LN_VPL][4] = {}, pz[LN_VPL][4] = {};
+  for (int c = threadIdx.x; c < H; c += 256) sgam[c] = gamma[c];
+  __syncthreads();
+  float pg[VPL][4] = {}, pb[VPL][4] = {}, pz[VPL][4] = {};
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(rows, r0 + rows_per_block);
+  Raw4<T> nx[VPL], nd[VPL];
+  if (r0 + w < r1) {
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int c = (v * 64 + lane) * 4;
+      if (c < H) { nx[v].load(z + (long)(r0 + w) * H + c); nd[v].load(dyp + (long)(r0 + w) * H + c); }
+    }
+  }
   for (int row = r0 + w; row < r1; row += 4) {
-    const T* zr = z + (long)row * H;
-    const T* dr = dyp + (long)row * H;
-    float x[LN_VPL][4], dy[LN_VPL][4], dz[LN_VPL][4];
+    float x[VPL][4], dy[VPL][4], dz[VPL][4];
     float sum = 0.f;
 #pragma unroll
-    for (int v = 0; v < LN_VPL; ++v) {
+    for (int v = 0; v < VPL; ++v) {
       const int c = (v * 64 + lane) * 4;
-      if (c < H) { ld4(zr + c, x[v]); ld4(dr + c, dy[v]); sum += x[v][0] + x[v][1] + x[v][2] + x[v][3]; }
+      if (c < H) { nx[v].unpack(x[v]); nd[v].unpack(dy[v]); sum += x[v][0] + x[v][1] + x[v][2] + x[v][3]; }
+    }
+    if (row + 4 < r1) {
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        const int c = (v * 64 + lane) * 4;
+        if (c < H) { nx[v].load(z + (long)(row + 4) * H + c); nd[v].load(dyp + (long)(row + 4) * H + c); }
+      }
     }
     const float mu = wave_sum(sum) / (float)H;
 #pragma unroll
-    for (int v = 0; v < LN_VPL; ++v)
+    for (int v = 0; v < VPL; ++v)
 #pragma unroll
       for (int e = 0; e < 4; ++e) x[v][e] -= mu;
-    ln_row_bwd(H, lane, x, dy, gamma, eps, dz, pg, pb);
+    ln_row_bwd(H, lane, x, dy, sgam, eps, dz, pg, pb);
     T* o = dzp + (long)row * H;
 #pragma unroll
-    for (int v = 0; v < LN_VPL; ++v) {
+    for (int v = 0; v < VPL; ++v) {
       const int c = (v * 64 + lane) * 4;
       if (c < H) {
         st4(o + c, dz[v]);
@@ -217,7 +277,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int H, int rows_p
   if (dbias) flush_cols(H, lane, w, pz, dbias, sred);
 }
 
-template <typename T>
+template <typename T, int VPL>
 __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(int rows, int H, int rows_per_block, const int* __restrict__ ids,
                                                            const int* __restrict__ pos, const float* __restrict__ word,
                                                            const float* __restrict__ posw, const float* __restrict__ typew,
@@ -228,7 +288,7 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(int rows, int H, int 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sred = reinterpret_cast<float*>(smem);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  float pg[LN_VPL][4] = {}, pb[LN_VPL][4] = {}, pz[LN_VPL][4] = {};
+  float pg[VPL][4] = {}, pb[VPL][4] = {}, pz[VPL][4] = {};
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(rows, r0 + rows_per_block);
   for (int row = r0 + w; row < r1; row += 4) {
@@ -236,10 +296,10 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(int rows, int H, int 
     const float* wr = word + wid * H;
     const float* pr = posw + pid * H;
     const T* dr = dyp + (long)row * H;
-    float x[LN_VPL][4], dy[LN_VPL][4], dz[LN_VPL][4];
+    float x[VPL][4], dy[VPL][4], dz[VPL][4];
     float sum = 0.f;
 #pragma unroll
-    for (int v = 0; v < LN_VPL; ++v) {
+    for (int v = 0; v < VPL; ++v) {
       const int c = (v * 64 + lane) * 4;
       if (c < H) {
         float a[4], b[4], t[4];
@@ -254,12 +314,12 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(int rows, int H, int 
     }
     const float mu = wave_sum(sum) / (float)H;
 #pragma unroll
-    for (int v = 0; v < LN_VPL; ++v)
+    for (int v = 0; v < VPL; ++v)
 #pragma unroll
       for (int e = 0; e < 4; ++e) x[v][e] -= mu;
     ln_row_bwd(H, lane, x, dy, gamma, eps, dz, pg, pb);
 #pragma unroll
-    for (int v = 0; v < LN_VPL; ++v) {
+    for (int v = 0; v < VPL; ++v) {
       const int c = (v * 64 + lane) * 4;
       if (c < H)
 #pragma unroll
@@ -301,11 +361,14 @@ static int ln_check(int dtype, int T, int H, const char* who) {
   return SIMX_OK;
 }
 
-static int bwd_rows_per_block(int T) {
-  int rpb = cdiv(T, 1024);
+// rows per block for the row-looping LN kernels: ~2 blocks per CU measured best on MI355X (sweep in DESIGN.md)
+static int ln_rows_per_block(int T, const char* env, int dflt) {
+  const char* e = getenv(env);
+  int rpb = cdiv(T, e ? atoi(e) : dflt);
   if (rpb < 16) rpb = 16;
   return cdiv(rpb, 4) * 4;
 }
+static int bwd_rows_per_block(int T) { return ln_rows_per_block(T, "SIMX_LN_BWD_BLOCKS", 512); }
 
 extern "C" int simx_ln_fwd(simx_stream_t stream, int dtype, int T, int H, const void* z, const float* gamma,
                            const float* beta, float eps, void* y) {
@@ -313,10 +376,15 @@ extern "C" int simx_ln_fwd(simx_stream_t stream, int dtype, int T, int H, const 
   int rc = ln_check(dtype, T, H, "ln_fwd");
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
+  const int rpb = ln_rows_per_block(T, "SIMX_LN_FWD_BLOCKS", 1 << 30);   // 16 rows (4 per wave) per block measured best
+  const size_t lds = (size_t)2 * H * sizeof(float);
+#define LF(TT, V) hipLaunchKernelGGL((ln_fwd_kernel<TT, V>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, (const TT*)z, gamma, beta, \
+                                    eps, (TT*)y)
   if (dtype == SIMX_F32)
-    hipLaunchKernelGGL((ln_fwd_kernel<float>), dim3(cdiv(T, 4)), dim3(256), 0, s, T, H, (const float*)z, gamma, beta, eps, (float*)y);
+    { if (H <= 256) LF(float, 1); else if (H <= 768) LF(float, 3); else LF(float, 4); }
   else
-    hipLaunchKernelGGL((ln_fwd_kernel<bf16_t>), dim3(cdiv(T, 4)), dim3(256), 0, s, T, H, (const bf16_t*)z, gamma, beta, eps, (bf16_t*)y);
+    { if (H <= 256) LF(bf16_t, 1); else if (H <= 768) LF(bf16_t, 3); else LF(bf16_t, 4); }
+#undef LF
   SIMX_CHECK_LAUNCH("ln_fwd");
   return SIMX_OK;
 }
@@ -336,13 +404,12 @@ extern "C" int simx_ln_bwd_ex(simx_stream_t stream, int dtype, int T, int H, con
   SIMX_REQUIRE(!drop.thr || dz_masked, SIMX_ERR_BAD_SHAPE, "ln_bwd: dropout needs the dz_masked output");
   hipStream_t s = (hipStream_t)stream;
   const int rpb = bwd_rows_per_block(T);
-  const size_t lds = (size_t)4 * H * sizeof(float);
-  if (dtype == SIMX_F32)
-    hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, (const float*)z, gamma, eps,
-                       (const float*)dy, (float*)dz, dgamma, dbeta, dbias, (float*)dz_masked, drop);
-  else
-    hipLaunchKernelGGL((ln_bwd_kernel<bf16_t>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, (const bf16_t*)z, gamma, eps,
-                       (const bf16_t*)dy, (bf16_t*)dz, dgamma, dbeta, dbias, (bf16_t*)dz_masked, drop);
+  const size_t lds = (size_t)5 * H * sizeof(float);
+#define LB(TT, V) hipLaunchKernelGGL((ln_bwd_kernel<TT, V>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, (const TT*)z, gamma, eps, \
+                                    (const TT*)dy, (TT*)dz, dgamma, dbeta, dbias, (TT*)dz_masked, drop)
+  if (dtype == SIMX_F32) { if (H <= 256) LB(float, 1); else if (H <= 768) LB(float, 3); else LB(float, 4); }
+  else { if (H <= 256) LB(bf16_t, 1); else if (H <= 768) LB(bf16_t, 3); else LB(bf16_t, 4); }
+#undef LB
   SIMX_CHECK_LAUNCH("ln_bwd");
   return SIMX_OK;
 }
@@ -389,12 +456,11 @@ extern "C" int simx_embed_ln_bwd_ex(simx_stream_t stream, int dtype, int T, int 
   hipStream_t s = (hipStream_t)stream;
   const int rpb = bwd_rows_per_block(T);
   const size_t lds = (size_t)4 * H * sizeof(float);
-  if (dtype == SIMX_F32)
-    hipLaunchKernelGGL((embed_ln_bwd_kernel<float>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, ids, pos_ids, word, posw,
-                       typew, gamma, eps, (const float*)dy, dword, dpos, dtype0, dgamma, dbeta, drop);
-  else
-    hipLaunchKernelGGL((embed_ln_bwd_kernel<bf16_t>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, ids, pos_ids, word, posw,
-                       typew, gamma, eps, (const bf16_t*)dy, dword, dpos, dtype0, dgamma, dbeta, drop);
+#define EB(TT, V) hipLaunchKernelGGL((embed_ln_bwd_kernel<TT, V>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, ids, pos_ids, word, posw, \
+                                    typew, gamma, eps, (const TT*)dy, dword, dpos, dtype0, dgamma, dbeta, drop)
+  if (dtype == SIMX_F32) { if (H <= 256) EB(float, 1); else if (H <= 768) EB(float, 3); else EB(float, 4); }
+  else { if (H <= 256) EB(bf16_t, 1); else if (H <= 768) EB(bf16_t, 3); else EB(bf16_t, 4); }
+#undef EB
   SIMX_CHECK_LAUNCH("embed_ln_bwd");
   return SIMX_OK;
 }

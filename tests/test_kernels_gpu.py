@@ -90,6 +90,50 @@ def test_gemm_nt(dev, bf16, M, N, K, epi):
         assert_close(back(dC), acc * obert.gelu_grad(rounded(aux, bf16)), what="gemm_nt dgelu", **t)
 
 
+@pytest.mark.parametrize("M,N,K", [(32768, 768, 128), (16384, 1536, 192), (24576, 768, 768), (16384, 768, 3072), (49152, 256, 64 * 5)])
+@pytest.mark.parametrize("variant", ["bias", "bias+res", "res", "plain", "gelu", "dgelu", "bias+res+drop"])
+def test_gemm_nt_persistent(dev, M, N, K, variant):
+    """Full-tile bf16 problems with >= 192 256x256 tiles run the persistent kernel (several tiles per workgroup when
+    there are more tiles than CUs, odd and even stage counts, every epilogue variant)."""
+    lib = L()
+    A, B = rnd((M, K), 1, 0.5), rnd((N, K), 2, 0.5)
+    epi = 1 if variant == "gelu" else 2 if variant == "dgelu" else 0
+    bias = rnd((N,), 3, 0.5) if "bias" in variant or epi == 1 else None
+    res = rnd((M, N), 4) if "res" in variant else None
+    aux = rnd((M, N), 5) if epi == 2 else None
+    dA, dB = to_dev(A, dev, True), to_dev(B, dev, True)
+    dbias = to_dev(bias, dev) if bias is not None else None
+    dres = to_dev(res, dev, True) if res is not None else None
+    daux = to_dev(aux, dev, True) if aux is not None else None
+    dC = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+    dC2 = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16) if epi == 1 else None
+    acc = rounded(A, True) @ rounded(B, True).T
+    if bias is not None:
+        acc = acc + bias.astype(np.float64)
+    t = dict(TOL[True])
+    t["atol"] *= max(1.0, math.sqrt(K) * 0.25)
+    if "drop" in variant:
+        from simxns_amd._lib import Dropout
+        d = Dropout(0.1, 77, 9)
+        lib.call("simx_gemm_nt_ex", lib.stream_ptr(), 1, M, N, K, lib.ptr(dA), K, lib.ptr(dB), K, lib.ptr(dC), N,
+                 lib.ptr(dbias), lib.ptr(dres), N, epi, lib.ptr(daux), N, lib.ptr(dC2), N, C.byref(d))
+        torch.cuda.synchronize()
+        mult = obert.drop_multipliers(0.1, 77, 9, np.arange(M), np.arange(N))
+        assert_close(back(dC), acc * mult + rounded(res, True), what="gemm_nt persistent dropout", **t)
+        return
+    lib.call("simx_gemm_nt", lib.stream_ptr(), 1, M, N, K, lib.ptr(dA), K, lib.ptr(dB), K, lib.ptr(dC), N,
+             lib.ptr(dbias), lib.ptr(dres), N, epi, lib.ptr(daux), N, lib.ptr(dC2), N)
+    torch.cuda.synchronize()
+    if epi == 0:
+        assert_close(back(dC), acc + (rounded(res, True) if res is not None else 0.0), what="gemm_nt persistent " + variant, **t)
+    elif epi == 1:
+        u = back(dC)
+        assert_close(u, acc, what="gemm_nt persistent gelu pre-activation", **t)
+        assert_close(back(dC2), obert.gelu(u), what="gemm_nt persistent gelu", **TOL[True])
+    else:
+        assert_close(back(dC), acc * obert.gelu_grad(rounded(aux, True)), what="gemm_nt persistent dgelu", **t)
+
+
 # ------------------------------------------------------------------------------------------ GEMM TN (wgrad)
 @pytest.mark.parametrize("bf16", [False, True])
 @pytest.mark.parametrize("M,N,K", [(64, 64, 200), (192, 64, 333), (768, 768, 5000), (3072, 768, 2100), (128, 256, 64), (72, 40, 130)])

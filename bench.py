@@ -230,9 +230,10 @@ def main():
         c_, ms_, wk_ = prof["gemm_nt"]
         ach = wk_ / (ms_ * 1e-3) / 1e12
         peak = 2500.0 if args.dtype == "bf16" else 157.3
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_bf16_kernel (forward + dgrad GEMMs)", "achieved": round(ach, 1),
-                           "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
-                           "launches": c_, "avg_launch_ms": round(ms_ / c_, 4)}
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_bf16_pers_kernel (simx_gemm_nt: forward + dgrad GEMMs)",
+                           "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                           "traffic": pmc_traffic("gemm_nt_bf16_pers_kernel"), "launches": c_,
+                           "avg_launch_ms": round(ms_ / c_, 4), "algorithmic_flop_per_launch": round(wk_ / c_)}
         out["kernel_breakdown_ms_per_step"] = {k: round(v[1] / args.steps, 3) for k, v in prof.items()}
         out["kernel_rates"] = {k: round(v[2] / (v[1] * 1e-3) / 1e12, 2) for k, v in prof.items() if v[1] > 0}
     if not args.no_cpu_baseline and world == 1:
@@ -243,6 +244,28 @@ def main():
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (tools/profile_round.sh -> profiles/*_traffic.json;
+    FETCH_SIZE / WRITE_SIZE collected in their own rocprofv3 runs of this same command and corrected as
+    MI355X_MICROARCH.md prescribes).  Counters cannot be read from inside the timed run, so this is the latest
+    committed measurement, or None."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_traffic.json"))):
+        try:
+            ks = json.load(open(f)).get("kernels", {})
+        except Exception:
+            continue
+        tot, n = 0.0, 0
+        for k, v in ks.items():
+            if kernel in k:
+                tot += v["hbm_bytes_per_launch"] * v["launches"]
+                n += v["launches"]
+        if n:
+            best = round(tot / n)
+    return best
 
 
 if __name__ == "__main__":

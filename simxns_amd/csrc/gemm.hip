@@ -470,10 +470,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_pers_kernel(
   const int lr = lane >> 3;
   const int ec0 = ((lane & 7) ^ (lane >> 4)) << 3, ec1 = ((lane & 7) ^ (4 + (lane >> 4))) << 3;   // element column of the lane's 16-B chunk, rows lr / 8+lr
   const uint32_t bmask = bias ? 0xFFFFFFFFu : 0u;
-  // VMEM ops one epilogue issues after the next tile's stage 1: 7x2 residual DMA + 8x2 stores, or 8x4 stores (GELU)
-  constexpr int NEPI = HAS_IN ? 30 : (EPI == SIMX_EPI_GELU ? 32 : 16);
-  const int dbg = __builtin_amdgcn_readfirstlane(g_gemm_dbg);   // measurement hooks (SIMX_GEMM_DBG), read once
-  const bool counted = !(dbg & 4);
   const uint32_t offA0 = (uint32_t)(lr * lda + ec0) * 2, offA1 = (uint32_t)(lr * lda + ec1) * 2;
   const uint32_t offB0 = (uint32_t)(lr * ldb + ec0) * 2, offB1 = (uint32_t)(lr * ldb + ec1) * 2;
   // Epilogue-only per-lane constants are recomputed per tile from a laundered copy of the lane id (P_LANE): left to
@@ -483,20 +479,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_pers_kernel(
   int v = blockIdx.x;
   int tile = xcd_remap(v, ntiles);
   int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
-  // Phase stagger.  All tiles cost the same, so CUs that start together reach their epilogues together and the
-  // whole chip's output lands on HBM in one burst (measured: 32-64 MB per round at ~5-6 TB/s = the entire epilogue
-  // time) while the HBM idles during the main loops.  Starting the CUs of every XCD in P phase groups, a fraction
-  // of a tile apart, spreads the stores under the other groups' main loops; the phases persist because tiles are
-  // equal.  Cost: the last group finishes (P-1)/P of a tile later, once per launch.
-  {
-    const int P = (dbg & 8) ? ((dbg >> 4) & 15) : 4;
-    const int phase = P > 1 ? (int)((blockIdx.x >> 3) % P) : 0;
-    if (phase && (int)gridDim.x < ntiles) {
-      const long long wait = (long long)phase * nst * (3400 / P);
-      const long long t0 = clock64();
-      while (clock64() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-    }
-  }
   p_stage(A, lda, m0, B, ldb, n0, 0, lds0, wave, offA0, offA1, offB0, offB1);
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
   p_stage(A, lda, m0, B, ldb, n0, 64, lds0 + V5_STAGE, wave, offA0, offA1, offB0, offB1);
@@ -541,10 +523,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_pers_kernel(
   // NEXT tile's stage 0 when st == nst-2
 #define P_BND_MID()                                                                            \
   do {                                                                                         \
-    /* st == 0: the only VMEM ops younger than this tile's stage 1 are the previous epilogue's (NEPI of them, \
-       stores last): a counted wait lets the store acks drain under this tile instead of stalling it */ \
-    if (st == 0 && counted) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NEPI) : "memory");         \
-    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                         \
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                              \
     const bool cur__ = st + 2 < nst;                                                           \
     p_stage(A, lda, cur__ ? m0 : m0n, B, ldb, cur__ ? n0 : n0n, cur__ ? (st + 2) * 64 : 0,     \
             lds0 + (uint32_t)(((st + par) & 1) * V5_STAGE), wave, offA0, offA1, offB0, offB1); \
@@ -606,9 +585,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_pers_kernel(
     }
 
     // ---- epilogue, 8 chunks of 16 rows (= accumulator row-block i), per wave, no barrier
-    if (C == nullptr) {                          // measurement hook (SIMX_NOEPI): main loop only
-      asm volatile("s_waitcnt vmcnt(8)" : "+v"(bq0), "+v"(bq1), "+v"(bq2), "+v"(bq3)::"memory");
-    } else {
+    // (the bias registers are pinned here, BEFORE any branch: a branch between an asm load and its pin makes hipcc
+    // copy the in-flight registers and the copies read garbage)
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(bq0), "+v"(bq1), "+v"(bq2), "+v"(bq3) : "n"(HAS_IN ? 10 : 8) : "memory");
+    if (C != nullptr) {                          // (nullptr: measurement hook SIMX_NOEPI, main loop only)
       P_LANE(le);
       const int fr = le & 15, fg = le >> 4, lr = le >> 3;          // shadow the kernel-scope copies on purpose
       const int ec0 = ((le & 7) ^ (le >> 4)) << 3, ec1 = ((le & 7) ^ (4 + (le >> 4))) << 3;
@@ -627,11 +607,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_pers_kernel(
             P_DMA16(io0, ib, nx);
             P_DMA16(io1, ib, nx + 1024u);
           }
-          if (i == 0) asm volatile("s_waitcnt vmcnt(10)" : "+v"(bq0), "+v"(bq1), "+v"(bq2), "+v"(bq3)::"memory");
+          if (i == 0) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
           else if (i < 7) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        } else if (i == 0) {
-          asm volatile("s_waitcnt vmcnt(8)" : "+v"(bq0), "+v"(bq1), "+v"(bq2), "+v"(bq3)::"memory");
         }
         uint2 t0, t1, t2, t3;
         const uint32_t ad0 = sub + slot + (uint32_t)(((0 + (fg >> 1)) ^ sw) << 4), ad1 = sub + slot + (uint32_t)(((2 + (fg >> 1)) ^ sw) << 4);
@@ -670,19 +648,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_pers_kernel(
         u32x4 w0, w1;
         asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
                      : "=&v"(w0), "=&v"(w1) : "v"(rd) : "memory");
-        if (!(dbg & 1)) {
         P_GST4(eo0, obase + (long)i * 16 * ldc, w0);
         P_GST4(eo1, obase + (long)i * 16 * ldc, w1);
-        }
         if (EPI == SIMX_EPI_GELU) {
           u32x4 w2, w3;
           asm volatile("ds_read_b128 %0, %2 offset:2048\n\tds_read_b128 %1, %2 offset:3072\n\ts_waitcnt lgkmcnt(0)"
                        : "=&v"(w2), "=&v"(w3) : "v"(rd) : "memory");
           bf16_t* const gbase = C2 + (long)(mw + i * 16) * ldc2 + nw;   // uniform
-          if (!(dbg & 1)) {
           P_GST4((uint32_t)(lr * ldc2 + ec0) * 2, gbase, w2);
           P_GST4((uint32_t)((lr + 8) * ldc2 + ec1) * 2, gbase, w3);
-          }
         }
       }
     }
@@ -1176,8 +1150,6 @@ extern "C" int simx_gemm_nt_ex(simx_stream_t stream, int dtype, int M, int N, in
       }
       const int grid = nwg3 < ncu ? nwg3 : ncu;
       static const bool noepi_p = getenv("SIMX_NOEPI") != nullptr;
-      static bool dbg_set_p = false;
-      if (!dbg_set_p) { const char* d = getenv("SIMX_GEMM_DBG"); int v = d ? atoi(d) : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_dbg), &v, sizeof(int)); dbg_set_p = true; }
       if (noepi_p) C = nullptr;
 #define LP(E, HI, INP, LDI) hipLaunchKernelGGL((gemm_nt_bf16_pers_kernel<E, HI>), dim3(grid), dim3(512), P_LDS, s, M, N, K, (const bf16_t*)A, lda, \
                                  (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, (const bf16_t*)(INP), LDI, (bf16_t*)C2, ldc2, t3n, nwg3, drop)

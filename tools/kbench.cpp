@@ -26,7 +26,8 @@ template <typename F> static double timeit(F f, int iters) {
 int main(int argc, char** argv) {
   const int T = argc > 1 ? atoi(argv[1]) : 262144;
   const int H = 768, F = 3072, iters = 10;
-  void* A = dalloc((size_t)T * F * 2, 1);      // activations (bf16), up to [T,F]
+  const int pad = getenv("KB_LDA_PAD") ? atoi(getenv("KB_LDA_PAD")) : 0;   // experiment: leading-dimension padding of A
+  void* A = dalloc((size_t)T * (F + pad) * 2, 1);      // activations (bf16), up to [T,F]
   void* A2 = dalloc((size_t)T * F * 2, 1);
   void* C = dalloc((size_t)T * F * 2, 0);
   void* C2 = dalloc((size_t)T * F * 2, 0);
@@ -44,7 +45,7 @@ int main(int argc, char** argv) {
   const char* only = getenv("KB_ONLY"); int oi = only ? atoi(only) : -1; int idx = -1;
   for (auto& s : nt) {
     ++idx; if (oi >= 0 && idx != oi) continue;
-    double ms = timeit([&] { SX(simx_gemm_nt(0, SIMX_BF16, T, s.N, s.K, A, s.K, W, s.K, C, s.N, s.epi == 2 ? nullptr : bias, s.res ? A2 : nullptr, s.N, s.epi, s.epi == 2 ? A2 : nullptr, s.N, s.epi == 1 ? C2 : nullptr, s.N)); }, iters);
+    double ms = timeit([&] { SX(simx_gemm_nt(0, SIMX_BF16, T, s.N, s.K, A, s.K + pad, W, s.K, C, s.N, s.epi == 2 ? nullptr : bias, s.res ? A2 : nullptr, s.N, s.epi, s.epi == 2 ? A2 : nullptr, s.N, s.epi == 1 ? C2 : nullptr, s.N)); }, iters);
     double fl = 2.0 * T * s.N * s.K; tot += ms; totf += fl;
     printf("gemm_nt %-36s %8.3f ms  %7.1f TF/s\n", s.name, ms, fl / ms / 1e9);
   }

@@ -1,0 +1,18 @@
+#!/bin/bash
+# usage (on the GPU box, from the repo root): tools/profile_round.sh <round-tag, e.g. r01>
+# Produces under gpurun_out/<tag>/ : bench line (un-profiled), rocprofv3 --kernel-trace --stats of the same command,
+# and two separate PMC passes (FETCH_SIZE / WRITE_SIZE) for the HBM traffic of the dominant kernel.
+# tools/traffic.py then turns them into profiles/<tag>_*.  PMC passes never combine with trace domains other than
+# --kernel-trace (pool rule).
+tag=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$PWD}
+O=$R/gpurun_out/$tag
+mkdir -p $O
+cd /tmp; export TMPDIR=/tmp
+CMD="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+python $R/bench.py --steps 5 --warmup 2 > $O/bench.json 2> $O/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- $CMD > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- $CMD > $O/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- $CMD > $O/pmc_write.log 2>&1
+cd $R && python tools/traffic.py $tag
+ls -la $O

@@ -233,6 +233,17 @@ int simx_scores_nll_fwd_bwd(simx_stream_t stream, int Q, int C, int H,
                             float loss_scale, int q_lo, int q_n, int c_lo, int c_n,
                             float* scores, float* row_stats, float* losses, float* dq_local, float* dctx_local);
 
+/* L4: BiEncoderKDLoss.calc, KD_softmax (PROD/ProD_KD/model/models.py:970-1038, kd_loss :772-781) on all-pairs scores
+ * of the student (q [Q,H], ctx [C,H]) and of the teacher embeddings (tq [Q,HT], tctx [C,HT], constants):
+ *   loss = ce_w * NLL(log_softmax(S), pos) + kd_w * T^2 * mean_q sum_c u (log u - log_softmax(S/T)),  u = softmax(Z/T).
+ * Same local-slot gradient semantics as simx_scores_nll_fwd_bwd.  scores / tscores: [Q,C] f32 scratch.
+ * losses[4] = {loss, hard, soft, correct_count}. */
+int simx_scores_kd_fwd_bwd(simx_stream_t stream, int Q, int C, int H, int HT,
+                           const float* q, const float* ctx, const float* tq, const float* tctx,
+                           const int32_t* pos_idx, float temperature, float ce_w, float kd_w, float loss_scale,
+                           int q_lo, int q_n, int c_lo, int c_n,
+                           float* scores, float* tscores, float* losses, float* dq_local, float* dctx_local);
+
 /* -------------------------------------------------------------- SimANS sampler
  * S1+S2 (SimANS/utils/MARCO_until_new.py:174-202, util_wiki.py:609-639, MARCO_until_Doc.py:110-148).
  * scores [nq,C] f64 candidate scores (rank order), pos_score [nq] f64.  form 0: exp(-|s-s+|*tau);

@@ -236,3 +236,17 @@ def reranker_forward(P, ids3, mask3, heads, dtype=np.float64, keep=True):
     b = np.asarray(P["qa_classifier.bias"], dtype=dtype)
     logits = (cls @ w.T + b).reshape(N, M)
     return logits, cls, caches
+
+
+def reranker_backward(P, ids3, mask3, heads, caches, cls, dlogits, dtype=np.float64):
+    """Backward of Reranker.forward: d logits [N,M] -> gradients of `encoder.*` and `qa_classifier.*`
+    (teacher train step, co_training_marco_train.py:225-245)."""
+    N, M, Lq = ids3.shape
+    w = np.asarray(P["qa_classifier.weight"], dtype=dtype)
+    dl = np.asarray(dlogits, dtype=dtype).reshape(N * M, 1)
+    d_cls = dl @ w
+    G = bert_backward(P, ids3.reshape(N * M, Lq), mask3.reshape(N * M, Lq), heads, caches, d_cls, dtype=dtype,
+                      prefix="encoder.")
+    G["qa_classifier.weight"] = dl.T @ cls
+    G["qa_classifier.bias"] = dl.sum(0)
+    return G

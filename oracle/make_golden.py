@@ -191,6 +191,34 @@ def gen_encoder_step(tmp, cfg_kw, tag, B, N, q_len, p_len, ce_len, seeds, full_g
         o2, _, _, _ = oloss.wiki_normal_adv(osim, oz, 1.0, lam)
         _cmp("loss_wiki lam=%g" % lam, o2, l2.item(), tol)
 
+    # --- teacher (reranker) train step, co_training_marco_train.py:225-245 (L6 + E3 backward) ---------
+    teacher.zero_grad()
+    rl = teacher(input_ids=tt(t_ids3), attention_mask=tt(t_mask3))
+    contr_loss = torch.nn.CrossEntropyLoss()(rl, torch.zeros(rl.size(0), dtype=torch.long))
+    contr_loss.backward()
+    TG = _grads(teacher)
+    out["teacher_ce_loss"] = np.float64(contr_loss.item())
+    ozk, ocls, ocache = obert.reranker_forward(Pt2, t_ids3, t_mask3, cfg.heads, keep=True)
+    otl, otd = oloss.teacher_ce(ozk)
+    _cmp("teacher_ce_loss", otl, contr_loss.item(), tol)
+    OTG = obert.reranker_backward(Pt2, t_ids3, t_mask3, cfg.heads, ocache, ocls, otd)
+    worst = 0.0
+    for k, g in OTG.items():
+        r = TG[k]
+        worst = max(worst, np.abs(g.reshape(r.shape) - r).max() / max(np.abs(r).max(), 1e-6))
+    print("   %-42s worst rel-to-max grad diff %.3e" % ("all %d teacher grads" % len(OTG), worst))
+    assert worst < 1e3 * tol, worst
+    if full_grads:
+        for k, g in TG.items():
+            out["tgrad." + k] = g
+    else:
+        tn = sorted(TG.keys())
+        out["tgrad_names"] = np.asarray(tn)
+        out["tgrad_norms"] = np.asarray([np.sqrt((TG[k] ** 2).sum()) for k in tn])
+        out["tgslice.encoder.encoder.layer.7.attention.output.dense.weight"] = TG["encoder.encoder.layer.7.attention.output.dense.weight"][:8, :64]
+        out["tgslice.encoder.encoder.layer.0.intermediate.dense.bias"] = TG["encoder.encoder.layer.0.intermediate.dense.bias"]
+        out["tgslice.qa_classifier.weight"] = TG["qa_classifier.weight"]
+
     # --- gradients kept in the fixture ---------------------------------------------------
     if full_grads:
         for k, g in G.items():

@@ -76,6 +76,7 @@ SIGNATURES = {
     "simx_bert_bwd": (_i, [_p, _cfgp, _p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p, _p, _p, _z]),
     "simx_sim_loss_fwd_bwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _lpp, _p, _p, _p, _p]),
     "simx_scores_nll_fwd_bwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _f, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "simx_scores_kd_fwd_bwd": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _f, _f, _f, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "simx_simans_sample": (_i, [_p, _i, _i, _i, _p, _p, _i, _d, _d, _d, C.c_uint64, C.c_uint32, _p, _p, _p, _p]),
     "simx_sqnorm_accum": (_i, [_p, _p, _z, _p]),
     "simx_adamw_step": (_i, [_p, _p, _p, _p, _p, _z, _f, _f, _f, _f, _f, _i, _p, _f, _f, _i]),

@@ -157,6 +157,63 @@ __global__ __launch_bounds__(256) void nll_rows_kernel(int Q, int C, float* __re
   }
 }
 
+// L4 rows (BiEncoderKDLoss, KD_softmax): student scores S [Q,C] and teacher scores Z [Q,C] ->
+//   hard = NLL(log_softmax(S), pos), soft = T^2 * sum_c u (log u - log_softmax(S/T)), u = softmax(Z/T)
+// per row; then S <- dS = gscale * (ce_w (softmax(S) - onehot) + kd_w T (softmax(S/T) - u)).
+__global__ __launch_bounds__(256) void kd_rows_kernel(int Q, int C, float* __restrict__ scores, const float* __restrict__ tscores,
+                                                      const int* __restrict__ pos_idx, float T, float ce_w, float kd_w,
+                                                      float gscale, float lscale, float* __restrict__ losses) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + w;
+  if (i >= Q) return;
+  float* r = scores + (long)i * C;
+  const float* z = tscores + (long)i * C;
+  const float iT = 1.0f / T;
+  float m = -INFINITY, mz = -INFINITY;
+  int am = 0x7FFFFFFF;
+  for (int c = lane; c < C; c += 64) {
+    const float v = r[c];
+    if (v > m) { m = v; am = c; }
+    mz = fmaxf(mz, z[c]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float om = __shfl_xor(m, o, 64);
+    const int oa = __shfl_xor(am, o, 64);
+    if (om > m || (om == m && oa < am)) { m = om; am = oa; }
+  }
+  mz = wave_max(mz);
+  float s1 = 0.f, sT = 0.f, sz = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float v = r[c];
+    s1 += expf(v - m);
+    sT += expf((v - m) * iT);
+    sz += expf((z[c] - mz) * iT);
+  }
+  s1 = wave_sum(s1); sT = wave_sum(sT); sz = wave_sum(sz);
+  const float lse = m + logf(s1), lseT = m * iT + logf(sT), lseZ = mz * iT + logf(sz);
+  const int pos = pos_idx[i];
+  const float sp = r[pos];
+  float soft = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float v = r[c];
+    const float lu = z[c] * iT - lseZ;                 // log u
+    const float u = expf(lu);
+    const float lpT = v * iT - lseT;                   // log_softmax(S/T)
+    if (u > 0.f) soft += u * (lu - lpT);
+    const float p1 = expf(v - lse), pT = expf(lpT);
+    r[c] = gscale * (ce_w * (p1 - (c == pos ? 1.f : 0.f)) + kd_w * T * (pT - u));
+  }
+  soft = wave_sum(soft) * T * T;
+  if (lane == 0) {
+    const float hard = lse - sp;
+    atomicAdd(losses + 0, (ce_w * hard + kd_w * soft) * lscale / (float)Q);
+    atomicAdd(losses + 1, hard / (float)Q);
+    atomicAdd(losses + 2, soft / (float)Q);
+    atomicAdd(losses + 3, am == pos ? 1.f : 0.f);
+  }
+}
+
 // strided f32 GEMM from gemm.hip
 extern "C" int simx_gemm_f32_strided(simx_stream_t stream, int M, int N, int K, const float* A, long a_rs, long a_cs,
                                      const float* B, long b_ks, long b_ns, float* C, int ldc, int accumulate);
@@ -197,6 +254,36 @@ extern "C" int simx_scores_nll_fwd_bwd(simx_stream_t stream, int Q, int C, int H
     if (rc) return rc;
   }
   if (c_n > 0 && dctx_local) {                                                              // dC_loc = dS[:,cols]^T q
+    rc = simx_gemm_f32_strided(stream, c_n, H, Q, scores + c_lo, 1, C, q, H, 1, dctx_local, H, 0);
+    if (rc) return rc;
+  }
+  return SIMX_OK;
+}
+
+extern "C" int simx_scores_kd_fwd_bwd(simx_stream_t stream, int Q, int C, int H, int HT, const float* q, const float* ctx,
+                                      const float* tq, const float* tctx, const int32_t* pos_idx, float temperature,
+                                      float ce_w, float kd_w, float loss_scale, int q_lo, int q_n, int c_lo, int c_n,
+                                      float* scores, float* tscores, float* losses, float* dq_local, float* dctx_local) {
+  hipStream_t s = (hipStream_t)stream;
+  SIMX_REQUIRE(Q > 0 && C > 0 && H > 0 && HT > 0, SIMX_ERR_BAD_SHAPE, "scores_kd: bad shape");
+  SIMX_REQUIRE(temperature > 0.f, SIMX_ERR_BAD_SHAPE, "scores_kd: temperature must be > 0");
+  SIMX_REQUIRE(q_lo >= 0 && q_n >= 0 && q_lo + q_n <= Q && c_lo >= 0 && c_n >= 0 && c_lo + c_n <= C, SIMX_ERR_BAD_SHAPE,
+               "scores_kd: local slot out of range");
+  SIMX_REQUIRE(q && ctx && tq && tctx && pos_idx && scores && tscores && losses, SIMX_ERR_BAD_SHAPE, "scores_kd: NULL argument");
+  if (hipMemsetAsync(losses, 0, 4 * sizeof(float), s) != hipSuccess) { simx_set_error("scores_kd: memset failed"); return SIMX_ERR_HIP; }
+  int rc = simx_gemm_f32_strided(stream, Q, C, H, q, H, 1, ctx, 1, H, scores, C, 0);          // S = q ctx^T
+  if (rc) return rc;
+  rc = simx_gemm_f32_strided(stream, Q, C, HT, tq, HT, 1, tctx, 1, HT, tscores, C, 0);        // Z = tq tctx^T
+  if (rc) return rc;
+  const float ls = loss_scale == 0.f ? 1.f : loss_scale;
+  hipLaunchKernelGGL(kd_rows_kernel, dim3(cdiv(Q, 4)), dim3(256), 0, s, Q, C, scores, tscores, pos_idx, temperature, ce_w, kd_w,
+                     ls / (float)Q, ls, losses);
+  SIMX_CHECK_LAUNCH("kd_rows");
+  if (q_n > 0 && dq_local) {
+    rc = simx_gemm_f32_strided(stream, q_n, H, C, scores + (long)q_lo * C, C, 1, ctx, H, 1, dq_local, H, 0);
+    if (rc) return rc;
+  }
+  if (c_n > 0 && dctx_local) {
     rc = simx_gemm_f32_strided(stream, c_n, H, Q, scores + c_lo, 1, C, q, H, 1, dctx_local, H, 0);
     if (rc) return rc;
   }

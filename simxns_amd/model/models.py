@@ -240,6 +240,48 @@ class BiEncoderNllLoss(object):
         return dot_product_scores
 
 
+class CrossBERTKDLoss(object):
+    """PROD/ProD_KD/model/models.py:668-760 (L3): CE_WEIGHT * NLL(log_softmax(sim), 0) + KD_WEIGHT * kd_loss(sim, teacher)
+    on the per-query block similarity; KD_type "KD_softmax" (the shipped configuration)."""
+
+    def calc(self, args, q_vectors, ctx_vectors, relevance_logits, hard_negative_idx_per_question: list = None,
+             loss_scale: float = None, LwF=False, ori_q_vector=None, ori_ctx_vectors=None):
+        if getattr(args, "KD_type", "KD_softmax") != "KD_softmax":
+            raise NotImplementedError("KD_type %r: only KD_softmax runs on the HIP path" % args.KD_type)
+        if LwF:
+            raise NotImplementedError("LwF term: not on the HIP path yet (oracle/losses.py::cross_kd restates it)")
+        loss, correct, _, _ = ops.cross_kd_loss(q_vectors, ctx_vectors, relevance_logits, args.TEMPERATURE,
+                                                args.CE_WEIGHT, args.KD_WEIGHT)
+        if loss_scale:
+            loss = loss * loss_scale
+        return loss, correct.to(torch.long)
+
+
+class BiEncoderKDLoss(object):
+    """PROD/ProD_KD/model/models.py:970-1038 (L4): the same loss on all-pairs scores of the student embeddings against
+    all-pairs scores of the teacher (dual-encoder) embeddings."""
+
+    def calc(self, args, q_vectors, ctx_vectors, teacher_q_vector, teacher_ctxs_vector, positive_idx_per_question: list,
+             hard_negative_idx_per_question: list = None, loss_scale: float = None, local_q=None, local_ctx=None):
+        if teacher_q_vector is None or teacher_ctxs_vector is None:
+            loss, correct = ops.inbatch_nll_loss(q_vectors, ctx_vectors, positive_idx_per_question, loss_scale, local_q, local_ctx)
+            return loss, correct.to(torch.long)
+        if getattr(args, "KD_type", "KD_softmax") != "KD_softmax":
+            raise NotImplementedError("KD_type %r: only KD_softmax runs on the HIP path" % args.KD_type)
+        loss, _, _, correct = ops.bi_kd_loss(q_vectors, ctx_vectors, teacher_q_vector, teacher_ctxs_vector,
+                                             positive_idx_per_question, args.TEMPERATURE, args.CE_WEIGHT, args.KD_WEIGHT,
+                                             loss_scale, local_q, local_ctx)
+        return loss, correct.to(torch.long)
+
+    @staticmethod
+    def get_scores(q_vector, ctx_vectors):
+        return dot_product_scores(q_vector, ctx_vectors)
+
+    @staticmethod
+    def get_similarity_function():
+        return dot_product_scores
+
+
 def dot_product_scores(q_vectors, ctx_vectors):
     """SimANS/model/models.py:564-572: q->ctx scores for every row in ctx_vector."""
     return ops.dot_product_scores(q_vectors, ctx_vectors)

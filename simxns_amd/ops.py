@@ -138,6 +138,52 @@ def inbatch_nll_loss(q_vectors, ctx_vectors, positive_idx_per_question, loss_sca
     return loss, allv[3]
 
 
+class _KdFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, c, tq, tc, pos_idx, T, ce_w, kd_w, loss_scale, q_lo, q_n, c_lo, c_n):
+        q, c, tq, tc = _f32c(q), _f32c(c), _f32c(tq.detach()), _f32c(tc.detach())
+        Q, H = q.shape
+        Cn, HT = c.shape[0], tq.shape[1]
+        pos = torch.as_tensor(pos_idx, dtype=torch.int32, device=q.device).contiguous()
+        scores = torch.empty(Q, Cn, dtype=torch.float32, device=q.device)
+        tscores = torch.empty(Q, Cn, dtype=torch.float32, device=q.device)
+        losses = torch.empty(4, dtype=torch.float32, device=q.device)
+        dq, dc = torch.zeros_like(q), torch.zeros_like(c)
+        L.call("simx_scores_kd_fwd_bwd", L.stream_ptr(), Q, Cn, H, HT, L.ptr(q), L.ptr(c), L.ptr(tq), L.ptr(tc), L.ptr(pos),
+               float(T), float(ce_w), float(kd_w), float(loss_scale or 1.0), q_lo, q_n, c_lo, c_n, L.ptr(scores),
+               L.ptr(tscores), L.ptr(losses), C.c_void_p(dq.data_ptr() + q_lo * H * 4), C.c_void_p(dc.data_ptr() + c_lo * H * 4))
+        ctx.save_for_backward(dq, dc)
+        return losses[0], losses.detach()
+
+    @staticmethod
+    def backward(ctx, g, g_all):
+        dq, dc = ctx.saved_tensors
+        return (dq * g, dc * g) + (None,) * 11
+
+
+def bi_kd_loss(q_vectors, ctx_vectors, teacher_q_vector, teacher_ctxs_vector, positive_idx_per_question, temperature=4.0,
+               ce_weight=0.1, kd_weight=0.9, loss_scale=None, local_q=None, local_ctx=None):
+    """BiEncoderKDLoss.calc with KD_type == "KD_softmax" (PROD/ProD_KD/model/models.py:970-1038): all-pairs scores of
+    the student and of the (constant) teacher embeddings; -> (loss, hard, soft, correct_count)."""
+    q_lo, q_n = local_q if local_q is not None else (0, q_vectors.shape[0])
+    c_lo, c_n = local_ctx if local_ctx is not None else (0, ctx_vectors.shape[0])
+    loss, allv = _KdFn.apply(q_vectors, ctx_vectors, teacher_q_vector, teacher_ctxs_vector, positive_idx_per_question,
+                             temperature, ce_weight, kd_weight, loss_scale, q_lo, q_n, c_lo, c_n)
+    return loss, allv[1], allv[2], allv[3]
+
+
+def fused_normal_inbatch_loss(q, ctx_vectors, reranker_logits, positive_idx_per_question, global_q=None, global_ctx=None,
+                              local_q=None, local_ctx=None, temperature_normal=1.0, inbatch_weight=0.2, grad_accum=1,
+                              scale_simmila=False):
+    """L5, MASTER/finetune/MS/co_training_model.py:249-270: AR2 normal loss (L2 with lambda = 0) on the local block
+    + inbatch_weight * BiEncoderNllLoss on the (gathered) all-pairs scores.  -> (loss, normal_loss, nll_loss, correct)."""
+    loss_n, normal, _, _ = wiki_normal_adv_loss(q, ctx_vectors, reranker_logits, temperature_normal, 0.0, scale_simmila, grad_accum)
+    gq = q if global_q is None else global_q
+    gc = ctx_vectors if global_ctx is None else global_ctx
+    nll, correct = inbatch_nll_loss(gq, gc, positive_idx_per_question, None, local_q, local_ctx)
+    return loss_n + inbatch_weight * nll / grad_accum, normal, nll, correct
+
+
 def dot_product_scores(q_vectors, ctx_vectors):
     """q @ ctx^T on the strided f32 GEMM kernel (no grad; the training path uses inbatch_nll_loss)."""
     q, c = _f32c(q_vectors.detach()), _f32c(ctx_vectors.detach())

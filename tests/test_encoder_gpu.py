@@ -202,3 +202,61 @@ def test_training_step_fused_optimizer(dev, golden_dir):
     assert losses[2] < losses[0]
     assert torch.equal(pool0, bi.question_model.pooler.dense.weight)
     assert np.isfinite(losses).all()
+
+
+# ------------------------------------------------------------------------------------------ teacher (reranker) train step
+def run_teacher_step(G, dev, dtype):
+    """co_training_marco_train.py:225-245: Reranker forward -> CrossEntropy(target 0) -> backward."""
+    from simxns_amd import ops
+    _, teacher = build_models(G, dev, dtype)
+    teacher.train()                                     # dropout probabilities of the golden config are 0
+    t = lambda k: torch.from_numpy(G[k]).to(dev)
+    teacher.zero_grad()
+    logits = teacher(t("t_ids"), t("t_mask"))
+    loss, contr = ops.teacher_ce_loss(logits, 1)
+    loss.backward()
+    torch.cuda.synchronize()
+    grads = {k: p.grad.detach().cpu().numpy().astype(np.float64) for k, p in teacher.named_parameters() if p.grad is not None}
+    return loss.item(), grads
+
+
+def test_tiny_teacher_step_fp32_vs_reference_golden(dev, golden_dir):
+    G = np.load(os.path.join(golden_dir, "step_tiny.npz"))
+    loss, grads = run_teacher_step(G, dev, "fp32")
+    assert abs(loss - float(G["teacher_ce_loss"])) <= 5e-5
+    names = [k[len("tgrad."):] for k in G.files if k.startswith("tgrad.")]
+    assert len(names) == 41
+    gmax = max(np.abs(G["tgrad." + k]).max() for k in names)
+    for k in names:
+        ref = G["tgrad." + k]
+        got = grads[k].reshape(ref.shape)
+        err = np.abs(got - ref).max()
+        assert err <= 2e-4 * np.abs(ref).max() + 1e-5 * gmax, "teacher grad %s: err %.3e (scale %.3e)" % (k, err, np.abs(ref).max())
+
+
+def test_base_cfg1_teacher_step_fp32_vs_reference_golden(dev, golden_dir):
+    G = np.load(os.path.join(golden_dir, "step_base_cfg1.npz"))
+    loss, grads = run_teacher_step(G, dev, "fp32")
+    assert abs(loss - float(G["teacher_ce_loss"])) <= 1e-3
+    names = [str(n) for n in G["tgrad_names"]]
+    norms = G["tgrad_norms"]
+    for n, ref in zip(names, norms):
+        got = np.sqrt((grads[n] ** 2).sum())
+        assert abs(got - ref) <= 2e-4 * ref + 1e-6 * norms.max(), "teacher grad norm %s: %.6e vs %.6e" % (n, got, ref)
+    for k in G.files:
+        if k.startswith("tgslice."):
+            name = k[len("tgslice."):]
+            ref = G[k]
+            g = grads[name]
+            got = g[:8, :64] if (ref.ndim == 2 and ref.shape != g.shape) else g.reshape(ref.shape)
+            assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max() + 1e-6 * norms.max(), "teacher grad slice %s" % name
+
+
+def test_tiny_teacher_step_bf16(dev, golden_dir):
+    G = np.load(os.path.join(golden_dir, "step_tiny.npz"))
+    loss, grads = run_teacher_step(G, dev, "bf16")
+    assert abs(loss - float(G["teacher_ce_loss"])) <= 5e-2
+    for k in ("encoder.encoder.layer.1.output.dense.weight", "encoder.encoder.layer.0.attention.self.query.weight", "qa_classifier.weight"):
+        g, ref = grads[k].ravel(), G["tgrad." + k].ravel()
+        cos = float(g @ ref / (np.linalg.norm(g) * np.linalg.norm(ref) + 1e-30))
+        assert cos >= 0.98, "teacher grad %s cosine %.4f" % (k, cos)

@@ -202,3 +202,57 @@ def test_sampler_big_batch_properties(dev):
     for qi in (0, 77):
         want, _, _ = osamp.scheme_draw(list(scores[qi]), float(spos[qi]), N, osamp.LAPLACE, 0.5, 0.0, 3.0, 11, 1, qi)
         assert list(a1[qi]) == want
+
+
+# ------------------------------------------------------------------------------------------ L4 / L5
+def test_bi_kd_golden(dev, G):
+    """BiEncoderKDLoss.calc (KD_softmax) against the imported reference's autograd (tests/golden/losses.npz, L4_*)."""
+    import types
+    from simxns_amd.model.models import BiEncoderKDLoss
+    tq, tc = _t(G["q2"], dev, True), _t(G["c2"], dev, True)
+    args = types.SimpleNamespace(KD_type="KD_softmax", TEMPERATURE=4.0, CE_WEIGHT=0.1, KD_WEIGHT=0.9)
+    loss, correct = BiEncoderKDLoss().calc(args, tq, tc, _t(G["qT"], dev), _t(G["cT"], dev), [int(v) for v in G["pos"]])
+    loss.backward()
+    _close(loss.item(), G["L4_loss"], what="L4 loss")
+    assert int(correct.item()) == int(G["L4_correct"])
+    _close(tq.grad.cpu().numpy(), G["L4_dq"], what="L4 dq")
+    _close(tc.grad.cpu().numpy(), G["L4_dc"], what="L4 dc")
+
+
+def test_bi_kd_big_local_slot(dev):
+    """cfg-3-like shapes, gradient only on the local slot, against the oracle."""
+    from simxns_amd import ops
+    rs = np.random.RandomState(9)
+    Q, Cn, H, HT = 64, 1024, 768, 256
+    q, c = rs.randn(Q, H) * 0.3, rs.randn(Cn, H) * 0.3
+    qT, cT = rs.randn(Q, HT) * 0.5, rs.randn(Cn, HT) * 0.5
+    pos = [i * 16 for i in range(Q)]
+    tq, tc = _t(q, dev, True), _t(c, dev, True)
+    loss, hard, soft, corr = ops.bi_kd_loss(tq, tc, _t(qT, dev), _t(cT, dev), pos, 4.0, 0.1, 0.9, None, (16, 32), (256, 512))
+    loss.backward()
+    f = lambda a: a.astype(np.float32).astype(np.float64)
+    l, h_, s_, cc, dq, dc = ol.bi_kd(f(q), f(c), f(qT), f(cT), pos, 4.0, 0.1, 0.9)
+    _close(loss.item(), l, tol=1e-4, what="loss"); _close(hard.item(), h_, tol=1e-4, what="hard"); _close(soft.item(), s_, tol=1e-4, what="soft")
+    assert int(corr.item()) == cc
+    gq, gc = tq.grad.cpu().numpy(), tc.grad.cpu().numpy()
+    _close(gq[16:48], dq[16:48], tol=1e-4, what="dq local"); _close(gc[256:768], dc[256:768], tol=1e-4, what="dc local")
+    assert np.abs(gq[:16]).max() == 0.0 and np.abs(gq[48:]).max() == 0.0 and np.abs(gc[:256]).max() == 0.0 and np.abs(gc[768:]).max() == 0.0
+
+
+def test_fused_normal_inbatch_loss_oracle(dev, G):
+    """L5 (MASTER/finetune/MS/co_training_model.py:249-270): normal loss + 0.2 * in-batch NLL, gradients add up."""
+    from simxns_amd import ops
+    q, c, z = G["q"], G["c"], G["z"]
+    B, D = z.shape
+    pos = [i * D for i in range(B)]
+    tq, tc = _t(q, dev, True), _t(c, dev, True)
+    loss, normal, nll, correct = ops.fused_normal_inbatch_loss(tq, tc, _t(z, dev), pos, grad_accum=2)
+    loss.backward()
+    f = lambda a: a.astype(np.float32).astype(np.float64)
+    sim = ol.sim_block(f(q), f(c))
+    l2, n_, _, ds = ol.wiki_normal_adv(sim, f(z), 1.0, 0.0, 1.0, 2)
+    dq1, dc1 = ol.sim_block_bwd(f(q), f(c), ds)
+    l3, cc, dq2, dc2, _ = ol.nll_inbatch(f(q), f(c), pos)
+    _close(loss.item(), l2 + 0.2 * l3 / 2, what="L5 loss")
+    assert int(correct.item()) == cc
+    _close(tq.grad.cpu().numpy(), dq1 + 0.2 * dq2 / 2, what="L5 dq"); _close(tc.grad.cpu().numpy(), dc1 + 0.2 * dc2 / 2, what="L5 dc")

@@ -56,6 +56,24 @@ def test_tiny_step_forward_backward_matches_reference(golden_dir):
     assert np.abs(G["grad.question_model.pooler.dense.weight"]).max() == 0.0
 
 
+def test_tiny_teacher_step_matches_reference(golden_dir):
+    """teacher (reranker) train step: CE(target 0) through Linear(H,1) and the cross-encoder (co_training_marco_train.py:225-245)."""
+    G = np.load(os.path.join(golden_dir, "step_tiny.npz"))
+    cfg, (_, _, Pt) = _params(G)
+    Pt2 = {"encoder." + k: v for k, v in Pt.items()}
+    Pt2["qa_classifier.weight"], Pt2["qa_classifier.bias"] = G["qa_w"], G["qa_b"]
+    z, cls, caches = ob.reranker_forward(Pt2, G["t_ids"], G["t_mask"], cfg.heads, keep=True)
+    loss, dz = ol.teacher_ce(z)
+    assert abs(loss - float(G["teacher_ce_loss"])) < 1e-12
+    TG = ob.reranker_backward(Pt2, G["t_ids"], G["t_mask"], cfg.heads, caches, cls, dz)
+    n = 0
+    for k, g in TG.items():
+        ref = G["tgrad." + k]
+        assert np.abs(g.reshape(ref.shape) - ref).max() <= 1e-9 * max(np.abs(ref).max(), 1e-3), k
+        n += 1
+    assert n == 41
+
+
 def test_loss_restatements_match_reference_autograd(golden_dir):
     G = np.load(os.path.join(golden_dir, "losses.npz"))
     s, z = G["s"], G["z"]

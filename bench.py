@@ -134,15 +134,17 @@ def main():
     opt = FusedAdamW(bi, lr=5e-6, eps=1e-8)
     sch = LinearWarmupSchedule(opt, 5400, 54000)
 
-    # ---- synthetic, pre-tokenised candidate pool in HBM (per rank: B queries x (1 positive + Cn candidates))
+    # ---- synthetic, PRE-TOKENISED candidate pool in HBM (per rank: B queries x (1 positive + Cn candidates)); the
+    # per-step batch (passage rows, masks, cross-encoder rows q + ctx[1:-1]) is assembled on the device by
+    # simx_assemble_batch from the sampler's picks -- the reference does this in 15 DataLoader workers per rank.
     def toks(seed, n, S, mean, std, lo):
         ids, mask, lens = synth.make_batch(seed, n, S, cfg.vocab_size, mean, std, lo, full=not args.varlen)
-        return torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
-    q_ids, q_mask = toks(100 + rank, B, QL, 9, 3, 4)
-    pool_ids, pool_mask = toks(200 + rank, B * (1 + Cn), PL, 80, 25, 16)
-    ce_ids, ce_mask = toks(300 + rank, B * (1 + Cn), CL, 90, 25, 20)
-    pool_ids, pool_mask = pool_ids.view(B, 1 + Cn, PL), pool_mask.view(B, 1 + Cn, PL)
-    ce_ids, ce_mask = ce_ids.view(B, 1 + Cn, CL), ce_mask.view(B, 1 + Cn, CL)
+        return torch.from_numpy(ids.astype(np.int32)).to(dev), lens
+    q_tok, q_lens = toks(100 + rank, B, QL, 9, 3, 4)
+    p_tok, p_lens = toks(200 + rank, B * (1 + Cn), PL, 80, 25, 16)
+    q_rows = torch.arange(B, dtype=torch.int32, device=dev)
+    row_base = (torch.arange(B, device=dev) * (1 + Cn)).unsqueeze(1)
+    ce_tokens = int(min(CL, int(np.max(q_lens)) + int(np.max(p_lens)) - 2))     # longest cross-encoder row
     rs = np.random.RandomState(7 + rank)
     s_pos = 70.0 + 20.0 * rs.rand(B)
     scores = np.sort(s_pos[:, None] - np.abs(rs.randn(B, Cn)) * 1.5, axis=1)[:, ::-1].copy()
@@ -156,18 +158,15 @@ def main():
         step_no[0] += 1
         # S1+S2 on the GPU, then device-side batch assembly (gather of pre-tokenised passages)
         neg = ops.simans_sample(d_scores, d_spos, N, form=ops.LAPLACE, tau=3.0, seed=42 + rank, offset=step_no[0])
-        sel = torch.cat([zero_col, neg.long() + 1], dim=1)                         # [B,1+N] rows of the pool
-        gi = sel.unsqueeze(-1)
-        c_ids = torch.gather(pool_ids, 1, gi.expand(-1, -1, PL)).reshape(P, PL)
-        c_mask = torch.gather(pool_mask, 1, gi.expand(-1, -1, PL)).reshape(P, PL)
+        sel = torch.cat([zero_col, neg.long() + 1], dim=1)                         # [B,1+N] rows of the query's pool
+        batch = ops.assemble_batch(q_tok, p_tok, q_rows, (row_base + sel).to(torch.int32), 1 + N, pad_id=0, sep_id=102, ce_len=CL)
+        q_ids, q_mask, c_ids, c_mask, _ = batch["student"]
         q, c = bi(q_ids, q_mask, c_ids, c_mask)
         if args.no_teacher:
             z = fixed_z
         else:
-            t_ids = torch.gather(ce_ids, 1, gi.expand(-1, -1, CL))
-            t_mask = torch.gather(ce_mask, 1, gi.expand(-1, -1, CL))
             with torch.no_grad():
-                z = teacher(t_ids, t_mask)
+                z = teacher(batch["teacher"][0], batch["teacher"][1])
         loss, distill, sim = ops.kl_distill_loss(q, c, z, 1.0, False, 1)
         if args.inbatch:
             from simxns_amd import parallel
@@ -211,15 +210,16 @@ def main():
     ms_step = dt / args.steps * 1e3
     pairs_per_s = world * P * args.steps / dt
     stu = 3 * (B * fwd_flops_seq(QL) + P * fwd_flops_seq(PL))
-    tea = 0 if args.no_teacher else P * fwd_flops_seq(CL)
+    tea = 0 if args.no_teacher else P * fwd_flops_seq(ce_tokens)
     out = {"metric": "query+passage pairs/sec (bi-encoder step)", "value": round(pairs_per_s, 1),
            "unit": "query+passage pairs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(ms_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": "SimANS MS-MARCO Passage retriever step (BASELINE configs[%d]): BERT-base x2 towers + "
                                   "BERT-base cross-encoder teacher fwd, B=%d/GPU, %d hard negs from %d candidates (SimANS "
-                                  "sampler on GPU), q%d/p%d/ce%d, %s lengths, KL-distill%s loss, clip 2.0 + AdamW"
-                                  % (2 if args.inbatch else 1, B, N, Cn, QL, PL, CL, "realistic" if args.varlen else "all-max",
+                                  "sampler + batch assembly on GPU), q%d/p%d/ce%d (= q + ctx[1:-1], padded to %d), %s lengths, KL-distill%s "
+                                  "loss, clip 2.0 + AdamW"
+                                  % (2 if args.inbatch else 1, B, N, Cn, QL, PL, ce_tokens, CL, "realistic" if args.varlen else "all-max",
                                      " + 0.2*in-batch NLL (all-gather)" if args.inbatch else ""),
                       "global_batch": world * B, "pairs_per_step_per_gpu": P, "parallelism": "dp%d" % world,
                       "teacher_in_step": not args.no_teacher, "dropout": pdrop},

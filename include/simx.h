@@ -244,6 +244,20 @@ int simx_scores_kd_fwd_bwd(simx_stream_t stream, int Q, int C, int H, int HT,
                            int q_lo, int q_n, int c_lo, int c_n,
                            float* scores, float* tscores, float* losses, float* dq_local, float* dctx_local);
 
+/* -------------------------------------------------------------- D1: device-side batch assembly
+ * The collate of SimANS/utils/MARCO_until_new.py:204-258 (Rocketqa_v2Dataset.__getitem__ tail +
+ * create_biencoder_input2) on PRE-TOKENISED rows resident in HBM: q_tok [NQ,QL], p_tok [NP,PL] int32, each row =
+ * tokens (special tokens included) + pad_id.  For query b (row q_rows[b]) and its D passages (rows p_rows[b*D+d],
+ * d = 0 the positive): q_ids/q_mask [B,QL], ctx_ids/ctx_mask [B*D,PL], and the cross-encoder rows
+ * ce_ids/ce_mask [B*D,CL] = question tokens + passage tokens without the first one and without a trailing sep_id
+ * (remove_special_token, :220-224), truncated to CL, padded with pad_id; masks are ids != pad_id.  int64 like the
+ * reference's LongTensors.  Optional (may be NULL) token counts q_len [B], ctx_len [B*D], ce_len [B*D]. */
+int simx_assemble_batch(simx_stream_t stream, int B, int D, int QL, int PL, int CL,
+                        const int32_t* q_tok, const int32_t* p_tok, const int32_t* q_rows, const int32_t* p_rows,
+                        int pad_id, int sep_id,
+                        int64_t* q_ids, int64_t* q_mask, int64_t* ctx_ids, int64_t* ctx_mask,
+                        int64_t* ce_ids, int64_t* ce_mask, int32_t* q_len, int32_t* ctx_len, int32_t* ce_len);
+
 /* -------------------------------------------------------------- SimANS sampler
  * S1+S2 (SimANS/utils/MARCO_until_new.py:174-202, util_wiki.py:609-639, MARCO_until_Doc.py:110-148).
  * scores [nq,C] f64 candidate scores (rank order), pos_score [nq] f64.  form 0: exp(-|s-s+|*tau);

@@ -439,6 +439,73 @@ def gen_sampler(tmp):
                        wiki_seed=77, marco_seed=1234), f)
 
 
+class _VarTok(object):
+    """Variable-length stand-in for the HF tokenizer (third-party, no vocab in this image): deterministic token ids from
+    the text, [CLS] a [SEP] b [SEP], truncated to max_length keeping the final [SEP] -- except that every 5th passage
+    is returned WITHOUT the trailing [SEP] so the reference's other remove_special_token branch is exercised."""
+    sep_token_id, pad_token_id, cls_token_id = 102, 0, 101
+
+    @staticmethod
+    def _toks(text, n):
+        h = 1469598103934665603
+        out = []
+        for i in range(n):
+            for ch in (str(text) + "/%d" % i):
+                h = ((h ^ ord(ch)) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+            out.append(1000 + h % 29000)
+        return out
+
+    def encode(self, text, text_pair=None, add_special_tokens=True, max_length=None, truncation=True, pad_to_max_length=False):
+        key = sum(ord(c) for c in (str(text) + "|" + str(text_pair)))
+        a = self._toks(text, 2 + key % 7 if text_pair is not None else 3 + key % 40)
+        ids = [101] + a + [102]
+        if text_pair is not None:
+            ids += self._toks(text_pair, 5 + (key * 7) % 170) + [102]
+        if max_length is not None and len(ids) > max_length:
+            ids = ids[:max_length - 1] + [102]
+        if text_pair is not None and key % 5 == 0:
+            ids = ids[:-1]
+        return ids
+
+
+def gen_collate(tmp):
+    """Batch assembly of the imported Rocketqa_v2Dataset + its collate (MARCO_until_new.py:204-258) -> collate_ref.npz."""
+    from . import collate as ocoll
+    MU = _load("ref_marco_until_new2", os.path.join(REF, "SimANS/utils/MARCO_until_new.py"))
+    rs = np.random.RandomState(21)
+    n_q, C, N = 6, 30, 15
+    para = os.path.join(tmp, "corpus2")
+    os.makedirs(para, exist_ok=True)
+    with open(os.path.join(para, "para.txt"), "w") as f, open(os.path.join(para, "para.title.txt"), "w") as g:
+        for pid in range(3000):
+            f.write("%d\tpassage text number %d\n" % (pid, pid * 7919)); g.write("%d\ttitle %d\n" % (pid, pid % 97))
+    rows = []
+    for qi in range(n_q):
+        s_pos = float(np.round(70 + 20 * rs.rand(), 4))
+        pids = rs.choice(np.arange(1, 3000), size=C + 1, replace=False)
+        scores = np.sort(np.round(s_pos - np.abs(rs.randn(C)) * 1.5, 4))[::-1]
+        rows.append("%d\tquery words %d %s\t%d %s\t%s" % (qi, qi, "x " * (qi * 9), pids[0], repr(s_pos),
+                                                        ",".join("%d %s" % (p, repr(float(s))) for p, s in zip(pids[1:], scores))))
+    tsv = os.path.join(tmp, "train2.tsv")
+    with open(tsv, "w") as f:
+        f.write("\n".join(rows) + "\n")
+    ds = MU.Rocketqa_v2Dataset(tsv, _VarTok(), num_hard_negatives=N, corpus_path=para)
+    random.seed(99)
+    batch = MU.Rocketqa_v2Dataset.get_collate_fn(None)([ds[i] for i in range(n_q)])
+    q, qm, doc, dm, pos = batch["student"]
+    ce, cem, tgt = batch["teacher"]
+    q, doc, ce = q.numpy(), doc.numpy(), ce.numpy()
+    assert (doc[:, -1] == 102).any() and (np.array([doc[r, ocoll.row_len(doc[r], 0) - 1] for r in range(len(doc))]) != 102).any()
+    # the oracle, fed the reference's own padded rows as the pre-tokenised pool, reproduces the teacher tensors exactly
+    o = ocoll.assemble(q, doc, list(range(n_q)), list(range(len(doc))), 1 + N)
+    assert (o["ce_ids"] == ce).all() and (o["ce_mask"] == cem.numpy()).all() and (o["q_mask"] == qm.numpy()).all()
+    assert (o["ctx_mask"] == dm.numpy()).all() and o["positive_ctx_indices"] == pos and (o["tgt"] == tgt.numpy()).all()
+    print(" [collate] oracle == imported Rocketqa_v2Dataset + create_biencoder_input2 (%d queries x %d passages, max ce len %d)"
+          % (n_q, 1 + N, int(o["ce_len"].max())))
+    np.savez_compressed(os.path.join(OUT, "collate_ref.npz"), q_ids=q, q_mask=qm.numpy(), ctx_ids=doc, ctx_mask=dm.numpy(),
+                        ce_ids=ce, ce_mask=cem.numpy(), tgt=tgt.numpy(), pos=np.asarray(pos))
+
+
 def main():
     global RM
     os.makedirs(OUT, exist_ok=True)
@@ -448,6 +515,9 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         gen_losses()
         gen_sampler(tmp)
+        gen_collate(tmp)
+        if "--only-small" in sys.argv:
+            return
         gen_encoder_step(tmp, TINY, "tiny", B=4, N=3, q_len=32, p_len=128, ce_len=160,
                          seeds=(1234, 1235, 1236), full_grads=True, tol=1e-11, std=0.08)
         if "--no-base" not in sys.argv:

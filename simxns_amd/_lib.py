@@ -77,6 +77,7 @@ SIGNATURES = {
     "simx_sim_loss_fwd_bwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _lpp, _p, _p, _p, _p]),
     "simx_scores_nll_fwd_bwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _f, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "simx_scores_kd_fwd_bwd": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _f, _f, _f, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "simx_assemble_batch": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "simx_simans_sample": (_i, [_p, _i, _i, _i, _p, _p, _i, _d, _d, _d, C.c_uint64, C.c_uint32, _p, _p, _p, _p]),
     "simx_sqnorm_accum": (_i, [_p, _p, _z, _p]),
     "simx_adamw_step": (_i, [_p, _p, _p, _p, _p, _z, _f, _f, _f, _f, _f, _i, _p, _f, _f, _i]),
@@ -85,7 +86,7 @@ SIGNATURES = {
     "simx_prof_kernel_count": (_i, []),
 }
 PROF_NAMES = ["gemm_nt", "gemm_tn", "mha_fwd", "mha_bwd", "ln_fwd", "ln_bwd", "embed_fwd", "embed_bwd", "colsum", "cast",
-              "loss", "sampler", "adamw", "other"]
+              "loss", "sampler", "adamw", "other", "collate", "topk"]
 
 _lib = None
 

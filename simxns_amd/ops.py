@@ -257,3 +257,31 @@ def simans_sample(scores, pos_score, num_neg, form=LAPLACE, a=0.5, b=0.0, tau=3.
     if return_weights:
         out += (wts,)
     return out if len(out) > 1 else neg
+
+
+# ------------------------------------------------------------------------------------------ D1
+def assemble_batch(q_tok, p_tok, q_rows, p_rows, docs_per_question, pad_id=0, sep_id=102, ce_len=160):
+    """Device-side collate (MARCO_until_new.py:204-258) on pre-tokenised int32 tables in HBM.
+    -> dict(student=[q_ids, q_mask, ctx_ids, ctx_mask, positive_ctx_indices], teacher=[ce_ids, ce_mask, tgt], lens=...)
+    with the reference's shapes/dtypes ([B,QL], [B*D,PL], [B,D,CL] int64)."""
+    assert q_tok.dtype == torch.int32 and p_tok.dtype == torch.int32 and q_tok.is_contiguous() and p_tok.is_contiguous()
+    dev = q_tok.device
+    q_rows = torch.as_tensor(q_rows, dtype=torch.int32, device=dev).contiguous()
+    p_rows = torch.as_tensor(p_rows, dtype=torch.int32, device=dev).contiguous().view(-1)
+    B, D = q_rows.numel(), int(docs_per_question)
+    assert p_rows.numel() == B * D
+    QL, PL = q_tok.shape[1], p_tok.shape[1]
+    e = lambda *sh: torch.empty(*sh, dtype=torch.int64, device=dev)
+    q_ids, q_mask, c_ids, c_mask = e(B, QL), e(B, QL), e(B * D, PL), e(B * D, PL)
+    ce_ids, ce_mask = e(B, D, ce_len), e(B, D, ce_len)
+    ql = torch.empty(B, dtype=torch.int32, device=dev)
+    cl = torch.empty(B * D, dtype=torch.int32, device=dev)
+    cel = torch.empty(B * D, dtype=torch.int32, device=dev)
+    L.call("simx_assemble_batch", L.stream_ptr(), B, D, QL, PL, ce_len, L.ptr(q_tok), L.ptr(p_tok), L.ptr(q_rows), L.ptr(p_rows),
+           int(pad_id), int(sep_id), L.ptr(q_ids), L.ptr(q_mask), L.ptr(c_ids), L.ptr(c_mask), L.ptr(ce_ids), L.ptr(ce_mask),
+           L.ptr(ql), L.ptr(cl), L.ptr(cel))
+    pos = [i * D for i in range(B)]
+    tgt = torch.zeros(B, D, dtype=torch.int64, device=dev)
+    tgt[:, 0] = 1
+    return {"student": [q_ids, q_mask, c_ids, c_mask, pos], "teacher": [ce_ids, ce_mask, tgt],
+            "lens": {"q": ql, "ctx": cl, "ce": cel}}

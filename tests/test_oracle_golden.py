@@ -177,3 +177,17 @@ def test_adamw_restatement_vs_torch():
     assert oo.linear_schedule(10, 10, 100) == 1.0 and abs(oo.linear_schedule(55, 10, 100) - 0.5) < 1e-12
     tot, coef = oo.clip_coef([np.ones(4) * 3.0], 2.0)
     assert abs(tot - 6.0) < 1e-12 and abs(coef - 2.0 / (6.0 + 1e-6)) < 1e-12
+
+
+def test_collate_oracle_matches_reference(golden_dir):
+    """oracle/collate.py reproduces the imported Rocketqa_v2Dataset + create_biencoder_input2 tensors bit for bit."""
+    from oracle import collate as oc
+    G = np.load(os.path.join(golden_dir, "collate_ref.npz"))
+    B, D = G["ce_ids"].shape[:2]
+    o = oc.assemble(G["q_ids"], G["ctx_ids"], list(range(B)), list(range(B * D)), D)
+    for k in ("q_ids", "q_mask", "ctx_ids", "ctx_mask", "ce_ids", "ce_mask", "tgt"):
+        assert (o[k] == G[k]).all(), k
+    assert o["positive_ctx_indices"] == [int(v) for v in G["pos"]]
+    # both remove_special_token branches are present in the fixture
+    last = np.array([G["ctx_ids"][r, oc.row_len(G["ctx_ids"][r], 0) - 1] for r in range(B * D)])
+    assert (last == 102).any() and (last != 102).any()

@@ -102,16 +102,18 @@ def _drop_masks(drop, ids, mask, heads, layers):
     return out
 
 
-def bert_forward(P, ids, mask, heads, eps=1e-12, dtype=np.float64, keep=True, prefix="", drop=None):
+def bert_forward(P, ids, mask, heads, eps=1e-12, dtype=np.float64, keep=True, prefix="", drop=None, pos_offset=0):
     """Returns (seq [n,S,H], cls [n,H], caches).  ``P``: HF-keyed dict.
-    ``drop`` = dict(p_hidden, p_attn, seed) enables training-mode dropout with the product's stateless masks."""
+    ``drop`` = dict(p_hidden, p_attn, seed) enables training-mode dropout with the product's stateless masks.
+    ``pos_offset``: position id of the first token (RoBERTa: padding_idx + 1 = 2, HF create_position_ids_from_input_ids
+    on right-padded rows; BERT: 0)."""
     g = lambda k: np.asarray(P[prefix + k], dtype=dtype)
     n, S = ids.shape
     H = g("embeddings.word_embeddings.weight").shape[1]
     d = H // heads
     fmin = float(np.finfo(np.float32).min)
     emb = (g("embeddings.word_embeddings.weight")[ids]
-           + g("embeddings.position_embeddings.weight")[None, :S]
+           + g("embeddings.position_embeddings.weight")[None, pos_offset:pos_offset + S]
            + g("embeddings.token_type_embeddings.weight")[0][None, None])
     x, ln0 = _ln_fwd(emb, g("embeddings.LayerNorm.weight"), g("embeddings.LayerNorm.bias"), eps)
     bias = ((1.0 - mask.astype(dtype)) * fmin)[:, None, None, :]          # [n,1,1,S]
@@ -155,7 +157,7 @@ def bert_forward(P, ids, mask, heads, eps=1e-12, dtype=np.float64, keep=True, pr
     return x, x[:, 0, :].copy(), caches
 
 
-def bert_backward(P, ids, mask, heads, caches, d_cls, d_seq=None, dtype=np.float64, prefix=""):
+def bert_backward(P, ids, mask, heads, caches, d_cls, d_seq=None, dtype=np.float64, prefix="", pos_offset=0):
     """Gradients of sum(cls*d_cls) (+ sum(seq*d_seq)) w.r.t. every parameter.
     Pad positions receive zero upstream gradient (they never reach the loss in
     the reference either: only [CLS] is used, and real tokens do not attend to
@@ -217,13 +219,14 @@ def bert_backward(P, ids, mask, heads, caches, d_cls, d_seq=None, dtype=np.float
     np.add.at(gw, ids.reshape(-1), flat(demb))
     G[prefix + "embeddings.word_embeddings.weight"] = gw
     gp = np.zeros_like(g("embeddings.position_embeddings.weight"))
-    gp[:S] = demb.sum(0)
+    gp[pos_offset:pos_offset + S] = demb.sum(0)
     G[prefix + "embeddings.position_embeddings.weight"] = gp
     gt = np.zeros_like(g("embeddings.token_type_embeddings.weight"))
     gt[0] = flat(demb).sum(0)
     G[prefix + "embeddings.token_type_embeddings.weight"] = gt
-    G[prefix + "pooler.dense.weight"] = np.zeros_like(g("pooler.dense.weight"))
-    G[prefix + "pooler.dense.bias"] = np.zeros_like(g("pooler.dense.bias"))
+    if (prefix + "pooler.dense.weight") in P:
+        G[prefix + "pooler.dense.weight"] = np.zeros_like(g("pooler.dense.weight"))
+        G[prefix + "pooler.dense.bias"] = np.zeros_like(g("pooler.dense.bias"))
     return G
 
 
@@ -249,4 +252,25 @@ def reranker_backward(P, ids3, mask3, heads, caches, cls, dlogits, dtype=np.floa
                       prefix="encoder.")
     G["qa_classifier.weight"] = dl.T @ cls
     G["qa_classifier.bias"] = dl.sum(0)
+    return G
+
+
+# ---- E4: RobertaDot (SimANS/model/models.py:277-359) -----------------------------------------
+def roberta_dot_forward(P, ids, mask, heads, eps=1e-5, head_eps=1e-5, pad_id=1, dtype=np.float64, keep=True):
+    """emb = LayerNorm(embeddingHead(roberta(ids, mask)[0][:, 0]))  (use_mean == False, the from_pretrained default).
+    ``P`` keys: roberta.* (no pooler), embeddingHead.{weight,bias}, norm.{weight,bias}."""
+    seq, cls, caches = bert_forward(P, ids, mask, heads, eps=eps, dtype=dtype, keep=keep, prefix="roberta.",
+                                    pos_offset=pad_id + 1)
+    w, b = np.asarray(P["embeddingHead.weight"], dtype), np.asarray(P["embeddingHead.bias"], dtype)
+    z = cls @ w.T + b
+    y, ln = _ln_fwd(z, np.asarray(P["norm.weight"], dtype), np.asarray(P["norm.bias"], dtype), head_eps)
+    return y, dict(enc=caches, cls=cls, ln=ln)
+
+
+def roberta_dot_backward(P, ids, mask, heads, cache, d_emb, pad_id=1, dtype=np.float64):
+    dz, dg, db = _ln_bwd(np.asarray(d_emb, dtype), cache["ln"], np.asarray(P["norm.weight"], dtype))
+    w = np.asarray(P["embeddingHead.weight"], dtype)
+    G = bert_backward(P, ids, mask, heads, cache["enc"], dz @ w, dtype=dtype, prefix="roberta.", pos_offset=pad_id + 1)
+    G["norm.weight"], G["norm.bias"] = dg, db
+    G["embeddingHead.weight"], G["embeddingHead.bias"] = dz.T @ cache["cls"], dz.sum(0)
     return G

@@ -506,6 +506,78 @@ def gen_collate(tmp):
                         ce_ids=ce, ce_mask=cem.numpy(), tgt=tgt.numpy(), pos=np.asarray(pos))
 
 
+def gen_roberta_dot(tmp):
+    """E4: the imported RobertaDot (SimANS/model/models.py:334-359) on a tiny RoBERTa config, shared encoder for queries
+    and documents, with the MS-Doc step's KL-distill loss (co_training_doc_train.py:209-224) -> roberta_dot_tiny.npz."""
+    import transformers
+    cfgd = dict(vocab=1000, hidden=64, layers=2, heads=4, inter=128, max_pos=140, type_vocab=1, eps=1e-5, pooler=False)
+    cfg = BertCfg(**cfgd)
+    hf = transformers.RobertaConfig(vocab_size=cfg.vocab, hidden_size=cfg.hidden, num_hidden_layers=cfg.layers,
+                                    num_attention_heads=cfg.heads, intermediate_size=cfg.inter,
+                                    max_position_embeddings=cfg.max_pos, type_vocab_size=1, layer_norm_eps=1e-5,
+                                    hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, pad_token_id=1)
+    hf.return_dict = False                      # the reference only sets this for transformers 4 (models.py:338-339, SURVEY 8c)
+    model = RM.RobertaDot(hf)
+    P = {"roberta." + k: v for k, v in make_bert_params(cfg, 4321, std=0.08).items()}
+    P["embeddingHead.weight"] = normal(4321, "embeddingHead.weight", (cfg.hidden, cfg.hidden), 0.08).astype(np.float32)
+    P["embeddingHead.bias"] = normal(4321, "embeddingHead.bias", (cfg.hidden,), 0.02).astype(np.float32)
+    P["norm.weight"] = (1.0 + normal(4321, "norm.weight", (cfg.hidden,), 0.05)).astype(np.float32)
+    P["norm.bias"] = normal(4321, "norm.bias", (cfg.hidden,), 0.02).astype(np.float32)
+    missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()}, strict=False)
+    assert not unexpected and all("position_ids" in m or "token_type_ids" in m for m in missing), (missing, unexpected)
+    model.eval()
+    B, N = 4, 3
+    def batch(seed, n, S, mean, std, lo):
+        ids, mask, lens = make_batch(seed, n, S, cfg.vocab, mean, std, lo)
+        ids = np.where(mask == 1, ids, 1)               # RoBERTa: pad id 1, mask = ids != 1 (MARCO_until_Doc.py:200-203)
+        ids[:, 0] = 0                                   # <s>
+        ids[np.arange(n), lens - 1] = 2                 # </s>
+        return ids, (ids != 1).astype(np.int64)
+    q_ids, q_mask = batch(501, B, 32, 9, 3, 4)
+    d_ids, d_mask = batch(502, B * (1 + N), 128, 80, 25, 16)
+    z = normal(503, "teacher", (B, 1 + N), 2.0)
+    tt = lambda a: torch.from_numpy(a)
+    with torch.no_grad():
+        q32 = model(tt(q_ids), tt(q_mask), True).numpy()
+        d32 = model(tt(d_ids), tt(d_mask), False).numpy()
+    model.double()
+    model.zero_grad()
+    q = model(tt(q_ids), tt(q_mask), True)
+    d = model(tt(d_ids), tt(d_mask), False)
+    sim = torch.einsum("bh,bdh->bd", q, d.reshape(B, 1 + N, -1))
+    loss = torch.nn.KLDivLoss(reduction="batchmean")((torch.softmax(sim, 1) + 1e-7).log(), torch.softmax(tt(z), 1))
+    loss.backward()
+    G = _grads(model)
+    print(" [roberta_dot] oracle vs imported reference")
+    oq, cq = obert.roberta_dot_forward(P, q_ids, q_mask, cfg.heads)
+    od, cd = obert.roberta_dot_forward(P, d_ids, d_mask, cfg.heads)
+    _cmp("q_emb (vs fp32 reference)", oq, q32, 2e-5)
+    _cmp("doc_emb (vs fp32 reference)", od, d32, 2e-5)
+    _cmp("q_emb", oq, q.detach().numpy(), 1e-11)
+    _cmp("doc_emb", od, d.detach().numpy(), 1e-11)
+    osim = oloss.sim_block(oq, od)
+    ol, _, ods = oloss.kl_distill(osim, z)
+    _cmp("loss", ol, loss.item(), 1e-11)
+    dq, dd = oloss.sim_block_bwd(oq, od, ods)
+    Gq = obert.roberta_dot_backward(P, q_ids, q_mask, cfg.heads, cq, dq)
+    Gd = obert.roberta_dot_backward(P, d_ids, d_mask, cfg.heads, cd, dd)
+    worst = 0.0
+    for k in Gq:
+        g = Gq[k] + Gd[k]                              # shared encoder: both passes accumulate
+        r = G[k]
+        worst = max(worst, np.abs(g.reshape(r.shape) - r).max() / max(np.abs(r).max(), 1e-6))
+    print("   %-42s worst rel-to-max grad diff %.3e" % ("all %d parameter grads" % len(Gq), worst))
+    assert worst < 1e-8, worst
+    out = dict(q_ids=q_ids, q_mask=q_mask, d_ids=d_ids, d_mask=d_mask, teacher=z, cfg=json.dumps(cfgd), seed=np.int64(4321),
+               q_emb=q.detach().numpy(), d_emb=d.detach().numpy(), q_emb_fp32=q32, d_emb_fp32=d32, sim=sim.detach().numpy(),
+               loss=np.float64(loss.item()))
+    for k in ("embeddingHead.weight", "embeddingHead.bias", "norm.weight", "norm.bias"):
+        out["param." + k] = P[k]
+    for k, g in G.items():
+        out["grad." + k] = g
+    np.savez_compressed(os.path.join(OUT, "roberta_dot_tiny.npz"), **out)
+
+
 def main():
     global RM
     os.makedirs(OUT, exist_ok=True)
@@ -516,6 +588,7 @@ def main():
         gen_losses()
         gen_sampler(tmp)
         gen_collate(tmp)
+        gen_roberta_dot(tmp)
         if "--only-small" in sys.argv:
             return
         gen_encoder_step(tmp, TINY, "tiny", B=4, N=3, q_len=32, p_len=128, ce_len=160,

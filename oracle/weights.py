@@ -59,9 +59,10 @@ def randint(seed, name, lo, hi, shape):
 
 class BertCfg:
     def __init__(self, vocab=30522, hidden=768, layers=12, heads=12, inter=3072,
-                 max_pos=512, type_vocab=2, eps=1e-12):
+                 max_pos=512, type_vocab=2, eps=1e-12, pooler=True):
         self.vocab, self.hidden, self.layers, self.heads = vocab, hidden, layers, heads
         self.inter, self.max_pos, self.type_vocab, self.eps = inter, max_pos, type_vocab, eps
+        self.pooler = pooler
 
     def as_dict(self):
         return dict(vocab=self.vocab, hidden=self.hidden, layers=self.layers, heads=self.heads,
@@ -90,7 +91,8 @@ def bert_param_shapes(cfg):
                 (p + "intermediate.dense.weight", (F, H)), (p + "intermediate.dense.bias", (F,)),
                 (p + "output.dense.weight", (H, F)), (p + "output.dense.bias", (H,)),
                 (p + "output.LayerNorm.weight", (H,)), (p + "output.LayerNorm.bias", (H,))]
-    out += [("pooler.dense.weight", (H, H)), ("pooler.dense.bias", (H,))]
+    if getattr(cfg, "pooler", True):
+        out += [("pooler.dense.weight", (H, H)), ("pooler.dense.bias", (H,))]
     return out
 
 

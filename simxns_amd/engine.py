@@ -28,6 +28,12 @@ class BertConfigLite(object):
         self.type_vocab_size, self.layer_norm_eps = type_vocab_size, layer_norm_eps
         self.hidden_dropout_prob, self.attention_probs_dropout_prob = hidden_dropout_prob, attention_probs_dropout_prob
         self.gradient_checkpointing = kw.get("gradient_checkpointing", False)
+        # RoBERTa (E4): position ids start at pad_token_id + 1 (HF create_position_ids_from_input_ids on right-padded
+        # rows) and the model is built without a pooler (RobertaModel(config, add_pooling_layer=False), models.py:340)
+        roberta = kw.get("model_type") == "roberta"
+        self.pad_token_id = kw.get("pad_token_id", 1 if roberta else 0)
+        self.position_offset = kw.get("position_offset", self.pad_token_id + 1 if roberta else 0)
+        self.add_pooling_layer = kw.get("add_pooling_layer", True)
         self.extra = kw
 
     @classmethod
@@ -85,14 +91,15 @@ def hf_param_layout(cfg, ccfg):
                 (p + "output.LayerNorm.weight", off(i, L.P_LN2_G), (H,)),
                 (p + "output.LayerNorm.bias", off(i, L.P_LN2_B), (H,))]
     n = cfg.num_hidden_layers
-    out += [("pooler.dense.weight", off(n, L.P_POOL_W), (H, H)), ("pooler.dense.bias", off(n, L.P_POOL_B), (H,))]
+    if getattr(cfg, "add_pooling_layer", True):      # (the slots stay in the flat buffer either way; never computed)
+        out += [("pooler.dense.weight", off(n, L.P_POOL_W), (H, H)), ("pooler.dense.bias", off(n, L.P_POOL_B), (H,))]
     return out
 
 
 class PackedBatch(object):
     """Right-padded (input_ids, attention_mask) -> packed real tokens + cu_seqlens (device, int32)."""
 
-    def __init__(self, input_ids, attention_mask):
+    def __init__(self, input_ids, attention_mask, pos_offset=0):
         assert input_ids.dim() == 2 and input_ids.shape == attention_mask.shape
         n, S = input_ids.shape
         m = attention_mask != 0
@@ -108,11 +115,11 @@ class PackedBatch(object):
         if self.T == n * S:
             self.index = None
             self.ids = input_ids.reshape(-1).to(torch.int32)
-            self.pos = torch.arange(S, device=input_ids.device, dtype=torch.int32).repeat(n)
+            self.pos = (torch.arange(S, device=input_ids.device, dtype=torch.int32) + pos_offset).repeat(n)
         else:
             self.index = m.reshape(-1).nonzero(as_tuple=False).squeeze(1)
             self.ids = input_ids.reshape(-1)[self.index].to(torch.int32)
-            self.pos = (self.index % S).to(torch.int32)
+            self.pos = (self.index % S + pos_offset).to(torch.int32)
 
     def unpack(self, packed, fill=0.0):
         """packed [T,H] -> padded [n,S,H] (pad rows = fill)."""
@@ -258,7 +265,7 @@ class BertEngine(object):
 
     def encode(self, input_ids, attention_mask, want_hidden=False, requires_grad=None, training=False):
         """-> cls [n,H] f32 (and the packed last hidden state + PackedBatch when want_hidden)."""
-        pb = PackedBatch(input_ids, attention_mask)
+        pb = PackedBatch(input_ids, attention_mask, getattr(self.cfg, "position_offset", 0))
         ccfg = self.call_cfg(training)
         if requires_grad is None:
             requires_grad = torch.is_grad_enabled()

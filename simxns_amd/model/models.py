@@ -155,6 +155,51 @@ class HFBertEncoder(nn.Module):
         return self.engine.encode(input_ids, attention_mask, training=self.training)
 
 
+class RobertaDot(nn.Module):
+    """SimANS/model/models.py:277-359 (E4, the MS-Doc student of co_training_doc_train.py:203-208): ONE shared RoBERTa
+    encoder without pooler for queries and documents, emb = LayerNorm(Linear(H -> output_embedding_size)(seq[:, 0])).
+    ``model_argobj.use_mean`` (masked mean pooling) is False on the from_pretrained path the reference uses
+    (models.py:283-286) and is not implemented here.  state_dict keys: roberta.*, embeddingHead.*, norm.*"""
+
+    def __init__(self, config, model_argobj=None, compute_dtype=None):
+        super(RobertaDot, self).__init__()
+        self.use_mean = False if model_argobj is None else bool(model_argobj.use_mean)
+        if self.use_mean:
+            raise NotImplementedError("use_mean=True (masked mean pooling) is not on the MI355X path")
+        if not isinstance(config, BertConfigLite):
+            d = config.to_dict() if hasattr(config, "to_dict") else dict(config)
+            d.setdefault("model_type", "roberta")
+            config = BertConfigLite(**d)
+        config.add_pooling_layer = False
+        if config.position_offset == 0:                 # a RoBERTa config without model_type
+            config.pad_token_id, config.position_offset = 1, 2
+        self.config = config
+        self.roberta = HFBertEncoder(config, compute_dtype=compute_dtype)
+        self.output_embedding_size = getattr(config, "output_embedding_size", None) or config.extra.get("output_embedding_size", config.hidden_size)
+        self.embeddingHead = nn.Linear(config.hidden_size, self.output_embedding_size)
+        self.norm = nn.LayerNorm(self.output_embedding_size)
+        with torch.no_grad():                            # EmbeddingMixin._init_weights: N(0, 0.02) on Linear weights
+            self.embeddingHead.weight.normal_(mean=0.0, std=0.02)
+
+    def query_emb(self, input_ids, attention_mask):
+        full_emb = self.roberta.embed(input_ids, attention_mask)
+        z = ops.linear_f32(full_emb, self.embeddingHead.weight, self.embeddingHead.bias)
+        return ops.layer_norm_f32(z, self.norm.weight, self.norm.bias, self.norm.eps)
+
+    def body_emb(self, input_ids, attention_mask):
+        return self.query_emb(input_ids, attention_mask)
+
+    def forward(self, input_ids, attention_mask, is_query, *args):
+        assert len(args) == 0
+        return self.query_emb(input_ids, attention_mask) if is_query else self.body_emb(input_ids, attention_mask)
+
+    def zero_grad(self, set_to_none=False):
+        self.roberta.zero_grad()
+        for p in list(self.embeddingHead.parameters()) + list(self.norm.parameters()):
+            if p.grad is not None:
+                p.grad.zero_()
+
+
 class BiBertEncoder(nn.Module):
     """ Bi-Encoder model component. Encapsulates query/question and context/passage encoders.
     (SimANS/model/models.py:85-118) """

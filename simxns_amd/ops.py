@@ -285,3 +285,32 @@ def assemble_batch(q_tok, p_tok, q_rows, p_rows, docs_per_question, pad_id=0, se
     tgt[:, 0] = 1
     return {"student": [q_ids, q_mask, c_ids, c_mask, pos], "teacher": [ce_ids, ce_mask, tgt],
             "lens": {"q": ql, "ctx": cl, "ce": cel}}
+
+
+# ------------------------------------------------------------------------------------------ small f32 LayerNorm (E4 head)
+class _LnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        x, w, b = _f32c(x), _f32c(weight), _f32c(bias)
+        T, H = x.shape
+        y = torch.empty_like(x)
+        L.call("simx_ln_fwd", L.stream_ptr(), L.SIMX_F32, T, H, L.ptr(x), L.ptr(w), L.ptr(b), float(eps), L.ptr(y))
+        ctx.save_for_backward(x, w)
+        ctx.eps = float(eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _f32c(dy)
+        T, H = x.shape
+        dx = torch.empty_like(x)
+        dg = torch.zeros(H, dtype=torch.float32, device=x.device)
+        db = torch.zeros(H, dtype=torch.float32, device=x.device)
+        L.call("simx_ln_bwd", L.stream_ptr(), L.SIMX_F32, T, H, L.ptr(x), L.ptr(w), ctx.eps, L.ptr(dy), L.ptr(dx), L.ptr(dg), L.ptr(db), None)
+        return dx, dg, db, None
+
+
+def layer_norm_f32(x, weight, bias, eps=1e-5):
+    """nn.LayerNorm on [n,H] f32 rows through simx_ln_fwd / simx_ln_bwd (H % 4 == 0, H <= 1024)."""
+    return _LnFn.apply(x, weight, bias, eps)

@@ -191,3 +191,28 @@ def test_collate_oracle_matches_reference(golden_dir):
     # both remove_special_token branches are present in the fixture
     last = np.array([G["ctx_ids"][r, oc.row_len(G["ctx_ids"][r], 0) - 1] for r in range(B * D)])
     assert (last == 102).any() and (last != 102).any()
+
+
+def test_roberta_dot_oracle_matches_reference(golden_dir):
+    """E4: oracle RobertaDot restatement vs the imported reference (fp64 golden), forward + all 41 gradients."""
+    import json
+    from oracle.weights import BertCfg
+    G = np.load(os.path.join(golden_dir, "roberta_dot_tiny.npz"))
+    cfg = BertCfg(**json.loads(str(G["cfg"])))
+    P = {"roberta." + k: v for k, v in make_bert_params(cfg, int(G["seed"]), std=0.08).items()}
+    for k in ("embeddingHead.weight", "embeddingHead.bias", "norm.weight", "norm.bias"):
+        P[k] = G["param." + k]
+    q, cq = ob.roberta_dot_forward(P, G["q_ids"], G["q_mask"], cfg.heads)
+    d, cd = ob.roberta_dot_forward(P, G["d_ids"], G["d_mask"], cfg.heads)
+    np.testing.assert_allclose(q, G["q_emb"], atol=1e-11)
+    np.testing.assert_allclose(d, G["d_emb"], atol=1e-11)
+    np.testing.assert_allclose(q, G["q_emb_fp32"], atol=2e-5)
+    sim = ol.sim_block(q, d)
+    loss, _, ds = ol.kl_distill(sim, G["teacher"])
+    assert abs(loss - float(G["loss"])) < 1e-12
+    dq, dd = ol.sim_block_bwd(q, d, ds)
+    Gq = ob.roberta_dot_backward(P, G["q_ids"], G["q_mask"], cfg.heads, cq, dq)
+    Gd = ob.roberta_dot_backward(P, G["d_ids"], G["d_mask"], cfg.heads, cd, dd)
+    for k in Gq:
+        ref = G["grad." + k]
+        assert np.abs((Gq[k] + Gd[k]).reshape(ref.shape) - ref).max() <= 1e-9 * max(np.abs(ref).max(), 1e-3), k

@@ -258,6 +258,26 @@ int simx_assemble_batch(simx_stream_t stream, int B, int D, int QL, int PL, int 
                         int64_t* q_ids, int64_t* q_mask, int64_t* ctx_ids, int64_t* ctx_mask,
                         int64_t* ce_ids, int64_t* ce_mask, int32_t* q_len, int32_t* ctx_len, int32_t* ce_len);
 
+/* -------------------------------------------------------------- generate job: exhaustive inner-product search
+ * Replaces faiss.IndexFlatIP + index_cpu_to_all_gpus(shard=True) + index.search(q, 200 | 1000)
+ * (SimANS/co_training/co_training_generate.py:359-384, 415-421) on a corpus shard resident in HBM.
+ * Scores are float32, one fused-multiply-add chain per (query, passage) in ascending h (bit-reproducible; the
+ * restatement is oracle/topk_ref.c); results per query are sorted by descending score, ties by ascending id.
+ *
+ * simx_ip_scores       scores[nq, ld] (first nc columns) = q[nq,H] . c[nc,H]^T
+ * simx_topk_update     folds m new candidates per query -- scores[nq, ld] with ids[nq, ld_ids] (int64, < 2^32, negative =
+ *                      skip) or, when ids == NULL, implicit ids id_base + column -- into the running result
+ *                      run_scores / run_ids [nq,k] (initialise to -inf / -1; k <= 1024).  Also the cross-shard merge.
+ * simx_flat_ip_search  = index.search: walks the shard in `chunk`-passage pieces (scores chunk -> top-k update);
+ *                      workspace >= simx_flat_ip_workspace_bytes(nq, chunk); ids returned are id_base + row. */
+int simx_ip_scores(simx_stream_t stream, int nq, int nc, int H, const float* q, const float* c, float* scores, long ld);
+int simx_topk_update(simx_stream_t stream, int nq, int m, const float* scores, long ld, const int64_t* ids, long ld_ids,
+                     int64_t id_base, int k, float* run_scores, int64_t* run_ids);
+size_t simx_flat_ip_workspace_bytes(int nq, int chunk);
+int simx_flat_ip_search(simx_stream_t stream, int nq, long nc, int H, const float* q, const float* corpus,
+                        int64_t id_base, int k, int chunk, void* workspace, size_t workspace_bytes,
+                        float* out_scores, int64_t* out_ids);
+
 /* -------------------------------------------------------------- SimANS sampler
  * S1+S2 (SimANS/utils/MARCO_until_new.py:174-202, util_wiki.py:609-639, MARCO_until_Doc.py:110-148).
  * scores [nq,C] f64 candidate scores (rank order), pos_score [nq] f64.  form 0: exp(-|s-s+|*tau);

@@ -78,6 +78,10 @@ SIGNATURES = {
     "simx_scores_nll_fwd_bwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _f, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "simx_scores_kd_fwd_bwd": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _f, _f, _f, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "simx_assemble_batch": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "simx_ip_scores": (_i, [_p, _i, _i, _i, _p, _p, _p, C.c_long]),
+    "simx_topk_update": (_i, [_p, _i, _i, _p, C.c_long, _p, C.c_long, C.c_int64, _i, _p, _p]),
+    "simx_flat_ip_workspace_bytes": (_z, [_i, _i]),
+    "simx_flat_ip_search": (_i, [_p, _i, C.c_long, _i, _p, _p, C.c_int64, _i, _i, _p, _z, _p, _p]),
     "simx_simans_sample": (_i, [_p, _i, _i, _i, _p, _p, _i, _d, _d, _d, C.c_uint64, C.c_uint32, _p, _p, _p, _p]),
     "simx_sqnorm_accum": (_i, [_p, _p, _z, _p]),
     "simx_adamw_step": (_i, [_p, _p, _p, _p, _p, _z, _f, _f, _f, _f, _f, _i, _p, _f, _f, _i]),

@@ -238,3 +238,27 @@ def test_host_samplers_replay_reference_picks(golden_dir):
         cand, sc = [m["cand"][j] for j in order], [m["scores"][j] for j in order]
         chosen = simans_draw_gauss(cand, sc, sp, N, a=0.5, b=1.0)
         assert [c for c in cand if c in chosen][0:N] == want
+
+
+def test_generate_job_metrics_and_tsv_writer(tmp_path):
+    """compute_metrics / write_to_file of the generate job (co_training_generate.py:153-266) on a hand-checked case."""
+    from simxns_amd.co_training.co_training_generate import compute_metrics, load_reference_from_stream, write_to_file
+    gold = tmp_path / "qrels.tsv"
+    gold.write_text("1 0 10 1\n1 0 11 1\n2 0 20 1\n3 0 30 1\n")
+    rel = load_reference_from_stream(str(gold))
+    assert rel == {1: [10, 11], 2: [20], 3: [30]}
+    cand = {1: [5, 10, 6] + list(range(100, 160)), 2: list(range(200, 260)) + [20], 3: [7, 8, 9]}
+    m = compute_metrics(rel, cand)
+    assert abs(m["MRR @10"] - (0.5 / 3)) < 1e-12                 # q1 hit at rank 2, q2 at rank 61 (> 10), q3 none
+    assert m["recall@1"] == 0 and abs(m["recall@50"] - 1 / 3) < 1e-12 and abs(m["recall@all"] - 2 / 3) < 1e-12
+    scores = {q: [100.0 - i for i in range(len(c))] for q, c in cand.items()}
+    path = write_to_file(cand, scores, [[1, "q one"], [2, "q two"], [3, "q three"]], rel, {}, "train", str(tmp_path), 7)
+    lines = open(path).read().splitlines()
+    assert os.path.basename(path) == "train_ce_7.tsv" and len(lines) == 3
+    f = lines[0].split("\t")
+    assert f[0] == "1" and f[1] == "q one" and f[2] == "10 99.0,11 0"          # 11 was not retrieved: score 0
+    assert f[3].split(",")[:2] == ["5 100.0", "6 98.0"] and len(f[3].split(",")) == 62
+    # the train job's parser reads it back (MARCO_until_new.py:170-172 format)
+    from simxns_amd.utils.MARCO_until_new import read_sharded_tsv
+    rows = read_sharded_tsv(path)
+    assert len(rows) == 3

@@ -87,3 +87,49 @@ def test_wiki_train_job(dev, tmp_path):
                  "--iteration_step", "6", "--iteration_reranker_step", "2", "--temperature_normal", "1", "--adv_lambda", "0",
                  "--b", "1.0", "--ann_dir", root, "--num_workers", "0", "--fp16", "--max_seq_length", "128"])
     assert gs == 6 and os.path.exists(os.path.join(out, "checkpoint-6")) and os.path.exists(os.path.join(out, "checkpoint-reranker6"))
+
+
+def test_generate_job_mines_hard_negatives_file(dev, tmp_path):
+    """The generate half of the iteration: embed corpus + queries, search, metrics, train_ce_<step>.tsv that the train
+    job's dataset parses; candidate ids equal the oracle's exhaustive search over the same embeddings."""
+    import types
+    from oracle import retrieval as orr
+    from simxns_amd.co_training import co_training_generate as Gn
+    from simxns_amd.model.models import BiBertEncoder
+    from simxns_amd.utils.MARCO_until_new import HashTokenizer, Rocketqa_v2Dataset
+    root = str(tmp_path / "data")
+    _write_corpus(root, n_pass=700, n_q=24)
+    rs = np.random.RandomState(1)
+    with open(os.path.join(root, "train.query.txt"), "w") as f, open(os.path.join(root, "qrels.train.tsv"), "w") as g:
+        for q in range(24):
+            f.write("%d\t%s\n" % (q, " ".join("w%d" % w for w in rs.randint(0, 300, size=6))))
+            g.write("%d 0 %d 1\n" % (q, rs.randint(0, 700)))
+    args = types.SimpleNamespace(model_type=os.path.join(root, "student"), gradient_checkpointing=False, share_weight=False, fp16=True)
+    model = BiBertEncoder(args).to(dev).eval()
+    tok = HashTokenizer(model.question_model.config.vocab_size)
+    out = str(tmp_path / "gen")
+    os.makedirs(out)
+    tools = Gn.RenewTools(os.path.join(root, "para.txt"), tok, out, os.path.join(root, "para.title.txt"))
+    index = tools.build_index(model, dev)
+    assert index.ntotal == 700
+    pos = Gn.load_pos_examples(os.path.join(root, "qrels.train.tsv"))
+    result, path = tools.get_question_topk(model, dev, index, os.path.join(root, "train.query.txt"),
+                                           os.path.join(root, "qrels.train.tsv"), pos, None, "train", 6)
+    assert os.path.basename(path) == "train_ce_6.tsv" and 0.0 <= result["MRR @10"] <= 1.0 and result["QueriesRanked"] == 24
+    # ids in the file == oracle exhaustive search over the very same embeddings
+    qids, qtab = Gn.tokenize_table([[q, l.split("\t")[1].strip()] for q, l in enumerate(open(os.path.join(root, "train.query.txt")))], tok, 32)
+    qemb = Gn.embed_table(model.query_emb, qtab, dev).cpu().numpy()
+    pemb = Gn.embed_table(model.body_emb, tools.passage_table, dev).cpu().numpy()
+    _, ref_ids = orr.search(qemb, pemb, 200)
+    lines = open(path).read().splitlines()
+    assert len(lines) == 24
+    for r, line in enumerate(lines):
+        f = line.split("\t")
+        posid = pos[r][0]
+        want = [int(i) for i in ref_ids[r] if int(i) != posid]
+        got = [int(p.split(" ")[0]) for p in f[3].split(",")]
+        assert got == want and int(f[2].split(" ")[0]) == posid
+    # and the train job's dataset consumes it
+    ds = Rocketqa_v2Dataset(path, tok, num_hard_negatives=7, corpus_path=root)
+    q, ctx, ce = ds[0]
+    assert tuple(ctx.shape) == (8, 128) and tuple(ce.shape) == (8, 160)

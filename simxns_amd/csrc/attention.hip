@@ -42,20 +42,6 @@ __device__ __forceinline__ bf16x8 lds_row_frag(const char* tile, int row, int c1
   return *reinterpret_cast<const bf16x8*>(tile + att_off(row, c16));
 }
 
-// transpose-read fragment: lane (fg,fs) receives column dt*16+fs of rows {base0+4fg..+3, base1+4fg..+3}
-__device__ __forceinline__ bf16x8 lds_tr_frag(uint32_t tile_addr, int base0, int base1, int dt, int fg, int fs) {
-  const int r0 = base0 + 4 * fg + (fs >> 2), r1 = base1 + 4 * fg + (fs >> 2);
-  const int c16 = dt * 2 + ((fs & 3) >> 1);
-  const uint32_t a0 = tile_addr + att_off(r0, c16) + (fs & 1) * 8;
-  const uint32_t a1 = tile_addr + att_off(r1, c16) + (fs & 1) * 8;
-  bf16x4 lo, hi;
-  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-               : "=&v"(lo), "=&v"(hi)
-               : "v"(a0), "v"(a1)
-               : "memory");
-  return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-}
-
 __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
   bf16x8 r;
   r[0] = (short)f2bf(a[0]); r[1] = (short)f2bf(a[1]); r[2] = (short)f2bf(a[2]); r[3] = (short)f2bf(a[3]);
@@ -89,6 +75,14 @@ __global__ __launch_bounds__(256) void mha_fwd_bf16_kernel(const bf16_t* __restr
   const uint32_t sV_addr = (uint32_t)(uintptr_t)sV;
   const int fr = lane & 15, fg = lane >> 4;
   const float c2 = scale * LOG2E;
+#define F2_RDTR(DST, ADDR, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #OFF : "=&v"(DST) : "v"(ADDR) : "memory")
+#define F2_CAT(LO, HI) ((bf16x8){LO[0], LO[1], LO[2], LO[3], HI[0], HI[1], HI[2], HI[3]})
+  uint32_t vtr[4];                                 // transpose-fragment lane constants (see mha_bwd2_bf16_kernel)
+  {
+    const int rr = 4 * fg + (fr >> 2), tsw = att_f(rr), tx = (fr & 3) >> 1;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) vtr[dt] = (uint32_t)(rr * 128 + (((dt * 2 + tx) ^ tsw) << 4) + (fr & 1) * 8);
+  }
 
   for (int qt = wave; qt < nkt; qt += 4) {
     const int q = qt * 16 + fr;
@@ -122,7 +116,7 @@ __global__ __launch_bounds__(256) void mha_fwd_bf16_kernel(const bf16_t* __restr
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = exp2f((s[kt][r] - m) * c2);
+        const float p = __builtin_amdgcn_exp2f((s[kt][r] - m) * c2);     // raw v_exp_f32: argument <= 0, exp2(-inf) = 0
         s[kt][r] = p;
         sum += p;
       }
@@ -143,15 +137,34 @@ __global__ __launch_bounds__(256) void mha_fwd_bf16_kernel(const bf16_t* __restr
     f32x4 o[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // V^T fragments two key-tile pairs at a time: 16 transpose reads in flight, ONE wait (the per-fragment wait of the
+    // first version left the wave parked ~40 % of its cycles); addresses = tile + pair*4096 + lane constant (+2048)
 #pragma unroll
-    for (int kp = 0; kp < NKT / 2; ++kp) {
-      if (2 * kp < nkt) {
-        const bf16x8 pf = pack8(s[2 * kp], s[2 * kp + 1]);
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const bf16x8 vf = lds_tr_frag(sV_addr, 2 * kp * 16, 2 * kp * 16 + 16, dt, fg, fr);
-          __builtin_amdgcn_sched_barrier(0);
-          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+    for (int kb = 0; kb < NKT / 2; kb += 2) {
+      if (2 * kb < nkt) {
+        const uint32_t b0 = sV_addr + (uint32_t)(kb * 4096);
+        bf16x4 a0l, a0h, a1l, a1h, a2l, a2h, a3l, a3h, c0l, c0h, c1l, c1h, c2l, c2h, c3l, c3h;
+        F2_RDTR(a0l, b0 + vtr[0], 0); F2_RDTR(a0h, b0 + vtr[0], 2048); F2_RDTR(a1l, b0 + vtr[1], 0); F2_RDTR(a1h, b0 + vtr[1], 2048);
+        F2_RDTR(a2l, b0 + vtr[2], 0); F2_RDTR(a2h, b0 + vtr[2], 2048); F2_RDTR(a3l, b0 + vtr[3], 0); F2_RDTR(a3h, b0 + vtr[3], 2048);
+        if (kb + 1 < NKT / 2) {                       // compile-time: the second pair's slots exist in the LDS tile
+          F2_RDTR(c0l, b0 + vtr[0], 4096); F2_RDTR(c0h, b0 + vtr[0], 6144); F2_RDTR(c1l, b0 + vtr[1], 4096); F2_RDTR(c1h, b0 + vtr[1], 6144);
+          F2_RDTR(c2l, b0 + vtr[2], 4096); F2_RDTR(c2h, b0 + vtr[2], 6144); F2_RDTR(c3l, b0 + vtr[3], 4096); F2_RDTR(c3h, b0 + vtr[3], 6144);
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c0l), "+v"(c0h), "+v"(c1l), "+v"(c1h), "+v"(c2l), "+v"(c2h), "+v"(c3l), "+v"(c3h)::"memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0l), "+v"(a0h), "+v"(a1l), "+v"(a1h), "+v"(a2l), "+v"(a2h), "+v"(a3l), "+v"(a3h)::"memory");
+        const bf16x8 pf = pack8(s[2 * kb], s[2 * kb + 1]);
+        o[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_CAT(a0l, a0h), pf, o[0], 0, 0, 0);
+        o[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_CAT(a1l, a1h), pf, o[1], 0, 0, 0);
+        o[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_CAT(a2l, a2h), pf, o[2], 0, 0, 0);
+        o[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_CAT(a3l, a3h), pf, o[3], 0, 0, 0);
+        if (kb + 1 < NKT / 2) {
+          if (2 * (kb + 1) < nkt) {                   // rows past the padded length are uninitialised LDS: skip, never multiply
+            const bf16x8 pg = pack8(s[2 * kb + 2], s[2 * kb + 3]);
+            o[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_CAT(c0l, c0h), pg, o[0], 0, 0, 0);
+            o[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_CAT(c1l, c1h), pg, o[1], 0, 0, 0);
+            o[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_CAT(c2l, c2h), pg, o[2], 0, 0, 0);
+            o[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_CAT(c3l, c3h), pg, o[3], 0, 0, 0);
+          }
         }
       }
     }
@@ -168,11 +181,46 @@ __global__ __launch_bounds__(256) void mha_fwd_bf16_kernel(const bf16_t* __restr
 }
 
 // ------------------------------------------------------------------------------------------ backward
+// Q, K, V, dO of the (sequence, head) staged once in LDS; phase A: dQ (waves own query tiles), phase B: dK, dV (waves
+// own key tiles).  How the instruction stream is built matters more than the MFMA count here (PMC on the first version: 38 % of wave cycles issuing ~5000 non-MFMA instructions per wave, 43 % parked in s_waitcnt):
+//   * every fragment address is (tile + pair*4096 + LANE CONSTANT [+2048]): the swizzle term f((row>>1)&7) does not
+//     depend on the 16-row tile index, so the six lane constants are computed once instead of ~12 VALU per read;
+//   * all LDS reads of one pair iteration (row fragments, transpose fragments, lse / delta vectors) are issued
+//     back to back by inline asm and waited for ONCE (v1 waited after every transpose fragment);
+//   * delta = dO.O uses 16-B loads, two threads per row;
+//   * dQ / dK / dV leave through a 2 KB per-wave LDS patch as 16 B per lane = full 128-B (token, head) lines
+//     instead of 8-B stores (32-B segments).
+#define A2_RD128(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=&v"(DST) : "v"(ADDR) : "memory")
+#define A2_RDTR(DST, ADDR, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #OFF : "=&v"(DST) : "v"(ADDR) : "memory")
+#define A2_CAT(LO, HI) ((bf16x8){LO[0], LO[1], LO[2], LO[3], HI[0], HI[1], HI[2], HI[3]})
+
+// stage a wave's 16x64 tile (MFMA layout: lane = row fr, 4 columns dt*16 + 4*fg) through its 2 KB LDS patch and store it
+// as full 128-B lines: rows t_row0 + r (r < nrows valid), column block h*64 of a [.., ld] bf16 matrix
+__device__ __forceinline__ void a2_store_tile(const f32x4 (&acc)[4], char* patch, uint32_t patch_addr, bf16_t* __restrict__ dst,
+                                              long ld, int nrows, int lane) {
+  const int fr = lane & 15, fg = lane >> 4;
+  const int sw = (fr >> 1) & 7;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    const uint2 o = make_uint2(pack2bf(acc[dt][0], acc[dt][1]), pack2bf(acc[dt][2], acc[dt][3]));
+    const uint32_t ad = patch_addr + (uint32_t)(fr * 128 + (((dt * 2 + (fg >> 1)) ^ sw) << 4) + (fg & 1) * 8);
+    asm volatile("ds_write_b64 %0, %1" ::"v"(ad), "v"(o) : "memory");
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int r = it * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    const uint4 v = *reinterpret_cast<const uint4*>(patch + r * 128 + (lane & 7) * 16);
+    if (r < nrows) *reinterpret_cast<uint4*>(dst + (long)r * ld + c * 8) = v;
+  }
+}
+
 template <int NKT>
-__global__ __launch_bounds__(256) void mha_bwd_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ O,
-                                                           const float* __restrict__ lse, const bf16_t* __restrict__ dO,
-                                                           bf16_t* __restrict__ dqkv, const int* __restrict__ cu,
-                                                           int heads, int T, float scale, DropCtx drop) {
+__global__ __launch_bounds__(256) void mha_bwd2_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ O,
+                                                            const float* __restrict__ lse, const bf16_t* __restrict__ dO,
+                                                            bf16_t* __restrict__ dqkv, const int* __restrict__ cu,
+                                                            int heads, int T, float scale, DropCtx drop) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -187,136 +235,186 @@ __global__ __launch_bounds__(256) void mha_bwd_bf16_kernel(const bf16_t* __restr
   const bf16_t* dOg = dO + (long)t0 * H + h * 64;
   const int nkt = (len + 15) >> 4;
   const int nkt2 = (nkt + 1) & ~1;
-  const int TILE = NKT * 16 * 128;
+  constexpr int TILE = NKT * 16 * 128;
   char* sQ = smem;
   char* sK = smem + TILE;
   char* sV = smem + 2 * TILE;
   char* sD = smem + 3 * TILE;
   float* sLse = reinterpret_cast<float*>(smem + 4 * TILE);
   float* sDel = sLse + NKT * 16;
+  char* patch = smem + 4 * TILE + 2 * NKT * 16 * 4 + wave * 2048;
   att_stage(Qg, H3, len, nkt2 * 16, sQ, wave, lane);
   att_stage(Kg, H3, len, nkt2 * 16, sK, wave, lane);
   att_stage(Vg, H3, len, nkt2 * 16, sV, wave, lane);
   att_stage(dOg, H, len, nkt2 * 16, sD, wave, lane);
-  // delta_i = dO_i . O_i ; lse_i (in log2 units)
-  for (int r = tid; r < nkt2 * 16; r += 256) {
-    float del = 0.f, l2 = 0.f;
+  // delta_i = dO_i . O_i (two threads per row, 16-B loads) ; lse_i in log2 units
+  for (int idx = tid; idx < nkt2 * 32; idx += 256) {
+    const int r = idx >> 1, half = idx & 1;
+    float del = 0.f;
     if (r < len) {
-      const bf16_t* po = Og + (long)r * H;
-      const bf16_t* pd = dOg + (long)r * H;
+      const bf16_t* po = Og + (long)r * H + half * 32;
+      const bf16_t* pd = dOg + (long)r * H + half * 32;
 #pragma unroll
-      for (int c = 0; c < 64; c += 4) {
-        float a[4], b[4];
-        ld4(po + c, a);
-        ld4(pd + c, b);
-        del += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+      for (int c = 0; c < 32; c += 8) {
+        const uint4 a = *reinterpret_cast<const uint4*>(po + c), b = *reinterpret_cast<const uint4*>(pd + c);
+        const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          del += __uint_as_float(aw[e] << 16) * __uint_as_float(bw[e] << 16) +
+                 __uint_as_float(aw[e] & 0xFFFF0000u) * __uint_as_float(bw[e] & 0xFFFF0000u);
       }
-      l2 = lse[(long)h * T + t0 + r] * LOG2E;
     }
-    sDel[r] = del;
-    sLse[r] = l2;
+    del += __shfl_xor(del, 1, 64);
+    if (half == 0) {
+      sDel[r] = del;
+      sLse[r] = r < len ? lse[(long)h * T + t0 + r] * LOG2E : 0.f;
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  const uint32_t sQ_addr = (uint32_t)(uintptr_t)sQ, sK_addr = (uint32_t)(uintptr_t)sK, sD_addr = (uint32_t)(uintptr_t)sD;
   const int fr = lane & 15, fg = lane >> 4;
   const float c2 = scale * LOG2E;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const uint32_t patch_addr = lds0 + (uint32_t)(4 * TILE + 2 * NKT * 16 * 4 + wave * 2048);
+  // lane constants: row-fragment offsets (chunks fg and 4+fg of row fr) and transpose-fragment offsets per 16-column tile
+  const int fsw = att_f(fr);
+  const uint32_t rf_lo = (uint32_t)(fr * 128 + ((fg ^ fsw) << 4)), rf_hi = (uint32_t)(fr * 128 + (((4 + fg) ^ fsw) << 4));
+  const int rr = 4 * fg + (fr >> 2), tsw = att_f(rr), tx = (fr & 3) >> 1;
+  uint32_t tr[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) tr[dt] = (uint32_t)(rr * 128 + (((dt * 2 + tx) ^ tsw) << 4) + (fr & 1) * 8);
+  const bool full = (len == nkt2 * 16);             // no ragged tail: skip the per-element masks
 
   // ---------------- phase A: dQ, waves own query tiles, loop over key-tile pairs
   for (int qt = wave; qt < nkt; qt += 4) {
     const int q = qt * 16 + fr;
-    const bf16x8 qf0 = lds_row_frag(sQ, q, fg), qf1 = lds_row_frag(sQ, q, 4 + fg);
-    const bf16x8 df0 = lds_row_frag(sD, q, fg), df1 = lds_row_frag(sD, q, 4 + fg);
+    bf16x8 qf0, qf1, df0, df1;
+    {
+      const uint32_t aq = lds0 + (uint32_t)(qt * 2048), ad = aq + 3 * TILE;
+      A2_RD128(qf0, aq + rf_lo, 0); A2_RD128(qf1, aq + rf_hi, 0);
+      A2_RD128(df0, ad + rf_lo, 0); A2_RD128(df1, ad + rf_hi, 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qf0), "+v"(qf1), "+v"(df0), "+v"(df1)::"memory");
+    }
     const float lq = sLse[q], dq_ = sDel[q];
+    const bool qok = q < len;
     f32x4 dq[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int kp = 0; kp < (nkt2 >> 1); ++kp) {
+      const uint32_t bk = lds0 + (uint32_t)(TILE + kp * 4096), bv = bk + TILE;
+      bf16x8 k00, k01, k10, k11, v00, v01, v10, v11;
+      bf16x4 t0l, t0h, t1l, t1h, t2l, t2h, t3l, t3h;
+      A2_RD128(k00, bk + rf_lo, 0); A2_RD128(k01, bk + rf_hi, 0); A2_RD128(k10, bk + rf_lo, 2048); A2_RD128(k11, bk + rf_hi, 2048);
+      A2_RD128(v00, bv + rf_lo, 0); A2_RD128(v01, bv + rf_hi, 0); A2_RD128(v10, bv + rf_lo, 2048); A2_RD128(v11, bv + rf_hi, 2048);
+      A2_RDTR(t0l, bk + tr[0], 0); A2_RDTR(t0h, bk + tr[0], 2048); A2_RDTR(t1l, bk + tr[1], 0); A2_RDTR(t1h, bk + tr[1], 2048);
+      A2_RDTR(t2l, bk + tr[2], 0); A2_RDTR(t2h, bk + tr[2], 2048); A2_RDTR(t3l, bk + tr[3], 0); A2_RDTR(t3h, bk + tr[3], 2048);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(k00), "+v"(k01), "+v"(k10), "+v"(k11), "+v"(v00), "+v"(v01), "+v"(v10), "+v"(v11)::"memory");
+      asm volatile("" : "+v"(t0l), "+v"(t0h), "+v"(t1l), "+v"(t1h), "+v"(t2l), "+v"(t2h), "+v"(t3l), "+v"(t3h)::"memory");
       f32x4 ds[2];
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int kt = 2 * kp + hf;
         f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(sK, kt * 16 + fr, fg), qf0, s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(sK, kt * 16 + fr, 4 + fg), qf1, s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(sV, kt * 16 + fr, fg), df0, dp, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(sV, kt * 16 + fr, 4 + fg), df1, dp, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf ? k10 : k00, qf0, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf ? k11 : k01, qf1, s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf ? v10 : v00, df0, dp, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf ? v11 : v01, df1, dp, 0, 0, 0);
         float m4[4] = {1.f, 1.f, 1.f, 1.f};
         if (drop.thr) drop_mult4(drop, (uint32_t)(h * T + t0 + q), (uint32_t)(kt * 16 + 4 * fg), m4);
+        float p[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kt * 16 + 4 * fg + r;
-          const float p = (key < len && q < len) ? exp2f(s[r] * c2 - lq) : 0.f;
-          ds[hf][r] = p * (dp[r] * m4[r] - dq_) * scale;
+        for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(s[r] * c2 - lq);      // raw v_exp_f32: argument <= ~0, underflow -> 0
+        if (!full) {                                   // ragged tail only (uniform branch, kept a branch on purpose)
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int r = 0; r < 4; ++r) p[r] = (kt * 16 + 4 * fg + r < len && qok) ? p[r] : 0.f;
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ds[hf][r] = p[r] * (dp[r] * m4[r] - dq_) * scale;
       }
       const bf16x8 dsf = pack8(ds[0], ds[1]);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const bf16x8 kf = lds_tr_frag(sK_addr, 2 * kp * 16, 2 * kp * 16 + 16, dt, fg, fr);
-        __builtin_amdgcn_sched_barrier(0);
-        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, dsf, dq[dt], 0, 0, 0);
-      }
+      dq[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(t0l, t0h), dsf, dq[0], 0, 0, 0);
+      dq[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(t1l, t1h), dsf, dq[1], 0, 0, 0);
+      dq[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(t2l, t2h), dsf, dq[2], 0, 0, 0);
+      dq[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(t3l, t3h), dsf, dq[3], 0, 0, 0);
     }
-    if (q < len) {
-      bf16_t* dst = dqkv + (long)(t0 + q) * H3 + h * 64 + 4 * fg;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        float v[4] = {dq[dt][0], dq[dt][1], dq[dt][2], dq[dt][3]};
-        st4(dst + dt * 16, v);
-      }
-    }
+    a2_store_tile(dq, patch, patch_addr, dqkv + (long)(t0 + qt * 16) * H3 + h * 64, H3, len - qt * 16, lane);
   }
 
   // ---------------- phase B: dK, dV, waves own key tiles, loop over query-tile pairs
   for (int kt = wave; kt < nkt; kt += 4) {
     const int key = kt * 16 + fr;
-    const bf16x8 kf0 = lds_row_frag(sK, key, fg), kf1 = lds_row_frag(sK, key, 4 + fg);
-    const bf16x8 vf0 = lds_row_frag(sV, key, fg), vf1 = lds_row_frag(sV, key, 4 + fg);
+    bf16x8 kf0, kf1, vf0, vf1;
+    {
+      const uint32_t ak = lds0 + (uint32_t)(TILE + kt * 2048), av = ak + TILE;
+      A2_RD128(kf0, ak + rf_lo, 0); A2_RD128(kf1, ak + rf_hi, 0);
+      A2_RD128(vf0, av + rf_lo, 0); A2_RD128(vf1, av + rf_hi, 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf0), "+v"(kf1), "+v"(vf0), "+v"(vf1)::"memory");
+    }
+    const bool kok = key < len;
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     for (int qp = 0; qp < (nkt2 >> 1); ++qp) {
+      const uint32_t bq = lds0 + (uint32_t)(qp * 4096), bd = bq + 3 * TILE;
+      const uint32_t bl = lds0 + (uint32_t)(4 * TILE + (qp * 32 + 4 * fg) * 4);     // sLse[qp*32 + 4 fg ..], sDel = + NKT*64 B
+      bf16x8 q00, q01, q10, q11, d00, d01, d10, d11;
+      bf16x4 e0l, e0h, e1l, e1h, e2l, e2h, e3l, e3h, u0l, u0h, u1l, u1h, u2l, u2h, u3l, u3h;
+      f32x4 ls0, ls1, de0, de1;
+      A2_RD128(q00, bq + rf_lo, 0); A2_RD128(q01, bq + rf_hi, 0); A2_RD128(q10, bq + rf_lo, 2048); A2_RD128(q11, bq + rf_hi, 2048);
+      A2_RD128(d00, bd + rf_lo, 0); A2_RD128(d01, bd + rf_hi, 0); A2_RD128(d10, bd + rf_lo, 2048); A2_RD128(d11, bd + rf_hi, 2048);
+      asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %5\n\tds_read_b128 %3, %5 offset:64"
+                   : "=&v"(ls0), "=&v"(ls1), "=&v"(de0), "=&v"(de1) : "v"(bl), "v"(bl + (uint32_t)(NKT * 64)) : "memory");
+      A2_RDTR(e0l, bd + tr[0], 0); A2_RDTR(e0h, bd + tr[0], 2048); A2_RDTR(e1l, bd + tr[1], 0); A2_RDTR(e1h, bd + tr[1], 2048);
+      A2_RDTR(e2l, bd + tr[2], 0); A2_RDTR(e2h, bd + tr[2], 2048); A2_RDTR(e3l, bd + tr[3], 0); A2_RDTR(e3h, bd + tr[3], 2048);
+      A2_RDTR(u0l, bq + tr[0], 0); A2_RDTR(u0h, bq + tr[0], 2048); A2_RDTR(u1l, bq + tr[1], 0); A2_RDTR(u1h, bq + tr[1], 2048);
+      A2_RDTR(u2l, bq + tr[2], 0); A2_RDTR(u2h, bq + tr[2], 2048); A2_RDTR(u3l, bq + tr[3], 0); A2_RDTR(u3h, bq + tr[3], 2048);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q00), "+v"(q01), "+v"(q10), "+v"(q11), "+v"(d00), "+v"(d01), "+v"(d10), "+v"(d11),
+                   "+v"(ls0), "+v"(ls1), "+v"(de0), "+v"(de1)::"memory");
+      asm volatile("" : "+v"(e0l), "+v"(e0h), "+v"(e1l), "+v"(e1h), "+v"(e2l), "+v"(e2h), "+v"(e3l), "+v"(e3h)::"memory");
+      asm volatile("" : "+v"(u0l), "+v"(u0h), "+v"(u1l), "+v"(u1h), "+v"(u2l), "+v"(u2h), "+v"(u3l), "+v"(u3h)::"memory");
       f32x4 pp[2], ds[2];
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int qt = 2 * qp + hf;
         f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(sQ, qt * 16 + fr, fg), kf0, s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(sQ, qt * 16 + fr, 4 + fg), kf1, s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(sD, qt * 16 + fr, fg), vf0, dp, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(sD, qt * 16 + fr, 4 + fg), vf1, dp, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf ? q10 : q00, kf0, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf ? q11 : q01, kf1, s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf ? d10 : d00, vf0, dp, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf ? d11 : d01, vf1, dp, 0, 0, 0);
+        const f32x4 lsv = hf ? ls1 : ls0, dev = hf ? de1 : de0;
+        float p[4], mm[4] = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(s[r] * c2 - lsv[r]);
+        if (!full) {
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int r = 0; r < 4; ++r) p[r] = (qt * 16 + 4 * fg + r < len && kok) ? p[r] : 0.f;
+        }
+        if (drop.thr) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mm[r] = drop_mult(drop, (uint32_t)(h * T + t0 + qt * 16 + 4 * fg + r), (uint32_t)key);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int q = qt * 16 + 4 * fg + r;
-          const float p = (q < len && key < len) ? exp2f(s[r] * c2 - sLse[q]) : 0.f;
-          const float mm = drop.thr ? drop_mult(drop, (uint32_t)(h * T + t0 + q), (uint32_t)key) : 1.f;
-          pp[hf][r] = p * mm;
-          ds[hf][r] = p * (dp[r] * mm - sDel[q]) * scale;
+          pp[hf][r] = p[r] * mm[r];
+          ds[hf][r] = p[r] * (dp[r] * mm[r] - dev[r]) * scale;
         }
       }
       const bf16x8 pf = pack8(pp[0], pp[1]);
       const bf16x8 dsf = pack8(ds[0], ds[1]);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const bf16x8 dof = lds_tr_frag(sD_addr, 2 * qp * 16, 2 * qp * 16 + 16, dt, fg, fr);
-        const bf16x8 qtf = lds_tr_frag(sQ_addr, 2 * qp * 16, 2 * qp * 16 + 16, dt, fg, fr);
-        __builtin_amdgcn_sched_barrier(0);
-        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, pf, dv[dt], 0, 0, 0);
-        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsf, dk[dt], 0, 0, 0);
-      }
+      dv[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(e0l, e0h), pf, dv[0], 0, 0, 0);
+      dk[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(u0l, u0h), dsf, dk[0], 0, 0, 0);
+      dv[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(e1l, e1h), pf, dv[1], 0, 0, 0);
+      dk[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(u1l, u1h), dsf, dk[1], 0, 0, 0);
+      dv[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(e2l, e2h), pf, dv[2], 0, 0, 0);
+      dk[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(u2l, u2h), dsf, dk[2], 0, 0, 0);
+      dv[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(e3l, e3h), pf, dv[3], 0, 0, 0);
+      dk[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(u3l, u3h), dsf, dk[3], 0, 0, 0);
     }
-    if (key < len) {
-      bf16_t* dstk = dqkv + (long)(t0 + key) * H3 + H + h * 64 + 4 * fg;
-      bf16_t* dstv = dstk + H;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        float a[4] = {dk[dt][0], dk[dt][1], dk[dt][2], dk[dt][3]};
-        float b[4] = {dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]};
-        st4(dstk + dt * 16, a);
-        st4(dstv + dt * 16, b);
-      }
-    }
+    bf16_t* dstk = dqkv + (long)(t0 + kt * 16) * H3 + H + h * 64;
+    a2_store_tile(dk, patch, patch_addr, dstk, H3, len - kt * 16, lane);
+    a2_store_tile(dv, patch, patch_addr, dstk + H, H3, len - kt * 16, lane);
   }
 }
 
@@ -544,10 +642,10 @@ extern "C" int simx_mha_bwd_ex(simx_stream_t stream, int dtype, int nseq, int he
   if (dtype == SIMX_BF16 && d == 64 && max_len <= 256) {
 #define LB(NKT)                                                                                                      \
   do {                                                                                                               \
-    const size_t lds = (size_t)4 * NKT * 16 * 128 + 2 * NKT * 16 * sizeof(float);                                    \
-    rc = set_lds(mha_bwd_bf16_kernel<NKT>, lds, "mha_bwd");                                                          \
+    const size_t lds = (size_t)4 * NKT * 16 * 128 + 2 * NKT * 16 * sizeof(float) + 4 * 2048;                         \
+    rc = set_lds(mha_bwd2_bf16_kernel<NKT>, lds, "mha_bwd");                                                         \
     if (rc) return rc;                                                                                               \
-    hipLaunchKernelGGL((mha_bwd_bf16_kernel<NKT>), dim3(nseq * heads), dim3(256), lds, s, (const bf16_t*)qkv,        \
+    hipLaunchKernelGGL((mha_bwd2_bf16_kernel<NKT>), dim3(nseq * heads), dim3(256), lds, s, (const bf16_t*)qkv,       \
                        (const bf16_t*)ctx, lse, (const bf16_t*)dctx, (bf16_t*)dqkv, cu, heads, T, scale, drop);      \
   } while (0)
     if (max_len <= 32) LB(2);

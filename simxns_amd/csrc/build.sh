@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libsimx_hip.so
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -mllvm -amdgpu-mfma-vgpr-form"
 OBJS=""
 for f in gemm attention layernorm loss sampler optim encoder collate retrieval; do
   if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ common.h -nt $f.o ] || [ prof.h -nt $f.o ] || [ ../../include/simx.h -nt $f.o ]; then

@@ -676,6 +676,269 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_pers_kernel(
 
 
 // ------------------------------------------------------------------------------------------
+// Persistent NT kernel, three A stages deep.  tools/vmem_bench shows what bounds the two-stage kernel's main loop: the
+// LDS-DMA path delivers ~36 B/clk/CU with two 64 KB stages IN FLIGHT but only ~18 with one, and the two-stage ring has
+// exactly one in flight (the other is being consumed) -- throughput = bytes in flight / latency.  Here the A operand
+// (activations: HBM / fabric latency, L2 never hits) gets three 32 KB slots, B (weights: L2 hits) two: after a stage
+// boundary A(st+2), B(st+2) and A(st+3) are in flight = 96 KB, inside the same 160 KB of LDS.  The epilogue has no LDS
+// of its own: it borrows the A slot freed by the tile's last stage -- wave w stages through bytes [4w, 4w+4) KB of that
+// slot, which are exactly the bytes wave w's own share of the next A load will overwrite, so each wave re-issues its
+// share of that load right after its own epilogue, with no cross-wave synchronisation.
+// Every stage boundary waits vmcnt(4): the issue order per wave is ... [B(s+1)(4) A(s+2)(4)] so "all but the 4 youngest"
+// = stage s+1 complete.  Needs K >= 256.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void p3_half(const bf16_t* __restrict__ G, int ld, int row0, int k0, uint32_t slot, int wave,
+                                        uint32_t off0, uint32_t off1) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = wave * 4 + j;
+    const char* sg = reinterpret_cast<const char*>(G + (long)(row0 + i * 8) * ld + k0);
+    P_DMA16((j & 1) ? off1 : off0, sg, slot + (uint32_t)(i * 1024));
+  }
+}
+
+template <int EPI, bool HAS_IN>
+__global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
+    int M, int N, int K, const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
+    bf16_t* __restrict__ C, int ldc, const float* __restrict__ bias, const bf16_t* __restrict__ in, int ldin,
+    bf16_t* __restrict__ C2, int ldc2, int tiles_n, int ntiles, DropCtx drop) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int nst = K / 64;                         // >= 4
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const int swz = (fr >> 1) & 7;
+  const uint32_t rowA = (uint32_t)((wr * 128 + fr) * 128), rowB = (uint32_t)((wc * 64 + fr) * 128);
+  const uint32_t oA0 = rowA + (uint32_t)(((0 + fg) ^ swz) << 4), oA1 = rowA + (uint32_t)(((4 + fg) ^ swz) << 4);
+  const uint32_t oB0 = rowB + (uint32_t)(((0 + fg) ^ swz) << 4), oB1 = rowB + (uint32_t)(((4 + fg) ^ swz) << 4);
+  // epilogue geometry (store layout): lane -> row it*8 + (lane>>3), 16-B chunk (lane&7) ^ swizzle(row)
+  const uint32_t ldsB = lds0 + 98304u;            // A slots: lds0 + {0,1,2} * 32 KB ; B slots: ldsB + {0,1} * 32 KB
+  const int lr = lane >> 3;
+  const int ec0 = ((lane & 7) ^ (lane >> 4)) << 3, ec1 = ((lane & 7) ^ (4 + (lane >> 4))) << 3;   // element column of the lane's 16-B chunk, rows lr / 8+lr
+  const uint32_t bmask = bias ? 0xFFFFFFFFu : 0u;
+  const uint32_t offA0 = (uint32_t)(lr * lda + ec0) * 2, offA1 = (uint32_t)(lr * lda + ec1) * 2;
+  const uint32_t offB0 = (uint32_t)(lr * ldb + ec0) * 2, offB1 = (uint32_t)(lr * ldb + ec1) * 2;
+  // Epilogue-only per-lane constants are recomputed per tile from a laundered copy of the lane id (P_LANE): left to
+  // LICM they are hoisted out of the tile loop and stay live (~20 VGPRs) through the main loop, which then spills.
+#define P_LANE(L) int L = lane; asm volatile("" : "+v"(L))
+
+  int v = blockIdx.x;
+  int tile = xcd_remap(v, ntiles);
+  int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
+  p3_half(B, ldb, n0, 0, ldsB, wave, offB0, offB1);
+  p3_half(A, lda, m0, 0, lds0, wave, offA0, offA1);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  p3_half(B, ldb, n0, 64, ldsB + 32768u, wave, offB0, offB1);
+  p3_half(A, lda, m0, 64, lds0 + 32768u, wave, offA0, offA1);
+  p3_half(A, lda, m0, 128, lds0 + 65536u, wave, offA0, offA1);
+  int a0 = 0, b0 = 0;                             // LDS slots of the current tile's stage 0 (A: mod 3, B: mod 2)
+  // the bias enters as the accumulators' initial value; bq* always hold the CURRENT tile's 4x4 bias columns at the
+  // top of the loop (the next tile's are requested at the last stage boundary and carried across the epilogue)
+  f32x4 bq0, bq1, bq2, bq3;
+  {
+    const float* b0 = bias ? bias + n0 + wc * 64 : reinterpret_cast<const float*>(A);
+    const uint32_t boff = (uint32_t)(fg * 16);
+    P_GLD4(bq0, boff, b0, 0); P_GLD4(bq1, boff, b0, 64); P_GLD4(bq2, boff, b0, 128); P_GLD4(bq3, boff, b0, 192);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq0), "+v"(bq1), "+v"(bq2), "+v"(bq3)::"memory");
+  }
+
+#define V3_MFMA_ROW(I, AF, B0, B1, B2, B3)                                                     \
+  acc[I][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B0, AF, acc[I][0], 0, 0, 0);             \
+  acc[I][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B1, AF, acc[I][1], 0, 0, 0);             \
+  acc[I][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B2, AF, acc[I][2], 0, 0, 0);             \
+  acc[I][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B3, AF, acc[I][3], 0, 0, 0)
+#define V3_RD1(F, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=&v"(F) : "v"(ADDR) : "memory")
+#define V3_SB __builtin_amdgcn_sched_barrier(0)
+#define P_STEP(CURA, NA, NB, BC0, BC1, BC2, BC3, BN0, BN1, BN2, BN3, BOUNDARY)                   \
+  do {                                                                                         \
+    const uint32_t aa__ = (CURA), na__ = (NA), nb__ = (NB);                                    \
+    V3_SB; V3_MFMA_ROW(0, al0, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah0, aa__, 8192);            \
+    V3_SB; V3_MFMA_ROW(1, al1, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah1, aa__, 10240);           \
+    V3_SB; V3_MFMA_ROW(2, al2, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah2, aa__, 12288);           \
+    V3_SB; V3_MFMA_ROW(3, al3, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah3, aa__, 14336);           \
+    V3_SB;                                                                                     \
+    V3_PIN4("s_waitcnt lgkmcnt(0)", ah0, ah1, ah2, ah3);                                       \
+    BOUNDARY();                                                                                \
+    V3_SB; V3_MFMA_ROW(4, ah0, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al0, na__, 0); V3_RD1(BN0, nb__, 0);       \
+    V3_SB; V3_MFMA_ROW(5, ah1, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al1, na__, 2048); V3_RD1(BN1, nb__, 2048); \
+    V3_SB; V3_MFMA_ROW(6, ah2, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al2, na__, 4096); V3_RD1(BN2, nb__, 4096); \
+    V3_SB; V3_MFMA_ROW(7, ah3, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al3, na__, 6144); V3_RD1(BN3, nb__, 6144); \
+    V3_SB;                                                                                     \
+    V3_PIN8("s_waitcnt lgkmcnt(0)", al0, al1, al2, al3, BN0, BN1, BN2, BN3);                   \
+  } while (0)
+#define P_BND_NONE() do { } while (0)
+  // stage boundary inside the tile: every fragment of stage st is in registers, stage st+1 has landed once vmcnt
+  // hits 0 (for everyone after the barrier); slot (st+par)&1 is refilled with stream stage st+2, which is the
+  // NEXT tile's stage 0 when st == nst-2
+#define P_BND_MID()                                                                            \
+  do {                                                                                         \
+    /* issue order so far: ... [B(st+1) A(st+2)] ; stage st+1 = everything but the 4 youngest (A(st+2)) */ \
+    asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");                              \
+    const bool cb__ = st + 2 < nst, ca__ = st + 3 < nst;                                       \
+    p3_half(B, ldb, cb__ ? n0 : n0n, (cb__ ? st + 2 : st + 2 - nst) * 64, ldsB + (uint32_t)(bc * 32768), wave, offB0, offB1); \
+    p3_half(A, lda, ca__ ? m0 : m0n, (ca__ ? st + 3 : st + 3 - nst) * 64, lds0 + (uint32_t)(ac * 32768), wave, offA0, offA1); \
+  } while (0)
+  // last boundary of the tile: bias and the first residual chunk are requested BEFORE the next tile's stage 1,
+  // so the epilogue can wait for them without waiting for that stage
+#define P_BND_LAST()                                                                           \
+  do {                                                                                         \
+    asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");                              \
+    P_LANE(lb__);                                                                              \
+    const uint32_t boff__ = (uint32_t)((lb__ >> 4) * 16);                                      \
+    P_GLD4(bq0, boff__, bptr, 0); P_GLD4(bq1, boff__, bptr, 64); P_GLD4(bq2, boff__, bptr, 128); P_GLD4(bq3, boff__, bptr, 192); \
+    if (HAS_IN) {                                                                              \
+      const int lr__ = lb__ >> 3;                                                              \
+      const uint32_t io0__ = (uint32_t)(lr__ * ldin + (((lb__ & 7) ^ (lb__ >> 4)) << 3)) * 2;  \
+      const uint32_t io1__ = (uint32_t)((lr__ + 8) * ldin + (((lb__ & 7) ^ (4 + (lb__ >> 4))) << 3)) * 2; \
+      P_DMA16(io0__, ibase, ereg); P_DMA16(io1__, ibase, ereg + 1024u);                        \
+    }                                                                                          \
+    /* next tile's stage 1 of B; its stage 2 of A goes into the slot this tile's epilogue borrows -> issued after it */ \
+    p3_half(B, ldb, n0n, 64, ldsB + (uint32_t)(bc * 32768), wave, offB0, offB1);                \
+  } while (0)
+
+  for (;;) {
+    const int vn = v + (int)gridDim.x;
+    const bool has_next = vn < ntiles;
+    int m0n = m0, n0n = n0;                       // past the end: re-fetch this tile (harmless, keeps the loop branch-free)
+    if (has_next) { const int tn_ = xcd_remap(vn, ntiles); m0n = (tn_ / tiles_n) * 256; n0n = (tn_ % tiles_n) * 256; }
+    const int mw = m0 + wr * 128, nw = n0 + wc * 64;
+    const float* bptr = bias ? bias + n0n + wc * 64 : reinterpret_cast<const float*>(A);   // uniform
+    const char* ibase = HAS_IN ? reinterpret_cast<const char*>(in + (long)mw * ldin + nw) : nullptr;   // uniform
+
+    f32x4 acc[8][4];
+    {
+      f32x4 bi[4] = {bq0, bq1, bq2, bq3};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bi[j][e] = __uint_as_float(__float_as_uint(bi[j][e]) & bmask);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = bi[j];
+    }
+    bf16x8 al0, al1, al2, al3, ah0, ah1, ah2, ah3, bx0, bx1, bx2, bx3, by0, by1, by2, by3;
+    {
+      const uint32_t aa = lds0 + (uint32_t)(a0 * 32768) + oA0, ab = ldsB + (uint32_t)(b0 * 32768) + oB0;
+      V3_READ4(al0, al1, al2, al3, aa, 0, 2048, 4096, 6144);
+      V3_READ4(bx0, bx1, bx2, bx3, ab, 0, 2048, 4096, 6144);
+      V3_PIN8("s_waitcnt lgkmcnt(0)", al0, al1, al2, al3, bx0, bx1, bx2, bx3);
+    }
+    int ac = a0, bc = b0;                         // slots of the stage being consumed
+    for (int st = 0; st < nst - 1; ++st) {
+      const int an = ac == 2 ? 0 : ac + 1, bn = bc ^ 1;
+      const uint32_t sa = lds0 + (uint32_t)(ac * 32768), sb = ldsB + (uint32_t)(bc * 32768);
+      const uint32_t na = lds0 + (uint32_t)(an * 32768), nb = ldsB + (uint32_t)(bn * 32768);
+      P_STEP(sa + oA0, sa + oA1, sb + oB1, bx0, bx1, bx2, bx3, by0, by1, by2, by3, P_BND_NONE);
+      P_STEP(sa + oA1, na + oA0, nb + oB0, by0, by1, by2, by3, bx0, bx1, bx2, bx3, P_BND_MID);
+      ac = an; bc = bn;
+    }
+    const uint32_t ereg = lds0 + (uint32_t)(ac * 32768 + wave * 4096);     // this wave's slice of the last stage's A slot
+    {
+      const int an = ac == 2 ? 0 : ac + 1, bn = bc ^ 1;
+      const uint32_t sa = lds0 + (uint32_t)(ac * 32768), sb = ldsB + (uint32_t)(bc * 32768);
+      const uint32_t na = lds0 + (uint32_t)(an * 32768), nb = ldsB + (uint32_t)(bn * 32768);
+      P_STEP(sa + oA0, sa + oA1, sb + oB1, bx0, bx1, bx2, bx3, by0, by1, by2, by3, P_BND_NONE);
+      P_STEP(sa + oA1, na + oA0, nb + oB0, by0, by1, by2, by3, bx0, bx1, bx2, bx3, P_BND_LAST);
+    }
+
+    // ---- epilogue, 8 chunks of 16 rows (= accumulator row-block i), per wave, no barrier
+    // (the bias registers are pinned here, BEFORE any branch: a branch between an asm load and its pin makes hipcc
+    // copy the in-flight registers and the copies read garbage)
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(bq0), "+v"(bq1), "+v"(bq2), "+v"(bq3) : "n"(HAS_IN ? 6 : 4) : "memory");
+    if (C != nullptr) {                          // (nullptr: measurement hook SIMX_NOEPI, main loop only)
+      P_LANE(le);
+      const int fr = le & 15, fg = le >> 4, lr = le >> 3;          // shadow the kernel-scope copies on purpose
+      const int ec0 = ((le & 7) ^ (le >> 4)) << 3, ec1 = ((le & 7) ^ (4 + (le >> 4))) << 3;
+      const int sw = (fr >> 1) & 7;
+      const uint32_t slot = (uint32_t)(fr * 128 + (fg & 1) * 8);
+      const uint32_t eo0 = (uint32_t)(lr * ldc + ec0) * 2, eo1 = (uint32_t)((lr + 8) * ldc + ec1) * 2;
+      const uint32_t io0 = HAS_IN ? (uint32_t)(lr * ldin + ec0) * 2 : 0, io1 = HAS_IN ? (uint32_t)((lr + 8) * ldin + ec1) * 2 : 0;
+      bf16_t* const obase = C + (long)mw * ldc + nw;          // uniform
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t sub = ereg + (uint32_t)((EPI == SIMX_EPI_GELU ? 0 : (i & 1)) * 2048);
+        if (HAS_IN) {
+          if (i < 7) {
+            const uint32_t nx = ereg + (uint32_t)(((i + 1) & 1) * 2048);
+            const char* ib = ibase + (long)(i + 1) * 32 * ldin;
+            P_DMA16(io0, ib, nx);
+            P_DMA16(io1, ib, nx + 1024u);
+          }
+          if (i == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+          else if (i < 7) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        }
+        uint2 t0, t1, t2, t3;
+        const uint32_t ad0 = sub + slot + (uint32_t)(((0 + (fg >> 1)) ^ sw) << 4), ad1 = sub + slot + (uint32_t)(((2 + (fg >> 1)) ^ sw) << 4);
+        const uint32_t ad2 = sub + slot + (uint32_t)(((4 + (fg >> 1)) ^ sw) << 4), ad3 = sub + slot + (uint32_t)(((6 + (fg >> 1)) ^ sw) << 4);
+        if (HAS_IN) {
+          asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(ad0), "v"(ad1), "v"(ad2), "v"(ad3) : "memory");
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t ad = j == 0 ? ad0 : j == 1 ? ad1 : j == 2 ? ad2 : ad3;
+          float vv[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+          if (EPI == SIMX_EPI_NONE && drop.thr) {
+            float m4[4];
+            drop_mult4(drop, (uint32_t)(mw + i * 16 + fr), (uint32_t)(nw + j * 16 + fg * 4), m4);
+            vv[0] *= m4[0]; vv[1] *= m4[1]; vv[2] *= m4[2]; vv[3] *= m4[3];
+          }
+          if (HAS_IN) {
+            const uint2 t = j == 0 ? t0 : j == 1 ? t1 : j == 2 ? t2 : t3;
+            const float x0 = __uint_as_float(t.x << 16), x1 = __uint_as_float(t.x & 0xFFFF0000u);
+            const float x2 = __uint_as_float(t.y << 16), x3 = __uint_as_float(t.y & 0xFFFF0000u);
+            if (EPI == SIMX_EPI_NONE) { vv[0] += x0; vv[1] += x1; vv[2] += x2; vv[3] += x3; }
+            else { vv[0] *= gelu_grad_fast(x0); vv[1] *= gelu_grad_fast(x1); vv[2] *= gelu_grad_fast(x2); vv[3] *= gelu_grad_fast(x3); }
+          }
+          const uint2 o = make_uint2(pack2bf(vv[0], vv[1]), pack2bf(vv[2], vv[3]));
+          asm volatile("ds_write_b64 %0, %1" ::"v"(ad), "v"(o) : "memory");
+          if (EPI == SIMX_EPI_GELU) {             // gelu of the bf16-ROUNDED pre-activation (backward reads C)
+            float g[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = gelu_fast(bf2f(f2bf(vv[e])));
+            const uint2 og = make_uint2(pack2bf(g[0], g[1]), pack2bf(g[2], g[3]));
+            asm volatile("ds_write_b64 %0, %1 offset:2048" ::"v"(ad), "v"(og) : "memory");
+          }
+        }
+        const uint32_t rd = sub + (uint32_t)(le * 16);
+        u32x4 w0, w1;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(w0), "=&v"(w1) : "v"(rd) : "memory");
+        P_GST4(eo0, obase + (long)i * 16 * ldc, w0);
+        P_GST4(eo1, obase + (long)i * 16 * ldc, w1);
+        if (EPI == SIMX_EPI_GELU) {
+          u32x4 w2, w3;
+          asm volatile("ds_read_b128 %0, %2 offset:2048\n\tds_read_b128 %1, %2 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(w2), "=&v"(w3) : "v"(rd) : "memory");
+          bf16_t* const gbase = C2 + (long)(mw + i * 16) * ldc2 + nw;   // uniform
+          P_GST4((uint32_t)(lr * ldc2 + ec0) * 2, gbase, w2);
+          P_GST4((uint32_t)((lr + 8) * ldc2 + ec1) * 2, gbase, w3);
+        }
+      }
+    }
+    // the borrowed A slot is free again (this wave's slice only ever holds this wave's rows): next tile's stage 2
+    p3_half(A, lda, m0n, 128, lds0 + (uint32_t)(ac * 32768), wave, offA0, offA1);
+    if (!has_next) break;
+    v = vn; m0 = m0n; n0 = n0n; a0 = ac == 2 ? 0 : ac + 1; b0 = bc ^ 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (dummy) stage loads must land before the LDS is released
+#undef P_LANE
+#undef P_BND_LAST
+#undef P_BND_MID
+#undef P_BND_NONE
+#undef P_STEP
+#undef V3_RD1
+#undef V3_SB
+#undef V3_MFMA_ROW
+}
+
+
+// ------------------------------------------------------------------------------------------
 // bf16 TN kernel (wgrad) : slab[split][M][N] = A[kslice,M]^T . B[kslice,N]
 // LDS image of a 64(k) x 128(col) tile: row kr at kr*256 B; the 32-B chunk q of the row stored
 // at chunk position q ^ (kr & 7).
@@ -1130,6 +1393,8 @@ extern "C" int simx_gemm_nt_ex(simx_stream_t stream, int dtype, int M, int N, in
       attr5 = true;
     }
     const int t3m = cdiv(M, 256), t3n = cdiv(N, 256), nwg3 = t3m * t3n;
+    // full-tile problems with K >= 256: persistent kernel with three A stages (SIMX_GEMM=v7 pins the two-stage one)
+    const bool force_v7 = pin && pin[1] == '7';
     // full-tile problems: persistent kernel (SIMX_GEMM=v5 pins the per-tile kernel)
     const bool force_v5 = pin && pin[1] == '5';
     if (!force_v1 && !force_v5 && nwg3 >= 192 && M % 256 == 0 && N % 256 == 0 && K >= 128 && ldc % 8 == 0 &&
@@ -1146,6 +1411,10 @@ extern "C" int simx_gemm_nt_ex(simx_stream_t stream, int dtype, int M, int N, in
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_pers_kernel<SIMX_EPI_NONE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_pers_kernel<SIMX_EPI_GELU, false>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_pers_kernel<SIMX_EPI_DGELU, true>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_p3_kernel<SIMX_EPI_NONE, false>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_p3_kernel<SIMX_EPI_NONE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_p3_kernel<SIMX_EPI_GELU, false>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_p3_kernel<SIMX_EPI_DGELU, true>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
         attrp = true;
       }
       const int grid = nwg3 < ncu ? nwg3 : ncu;
@@ -1153,6 +1422,16 @@ extern "C" int simx_gemm_nt_ex(simx_stream_t stream, int dtype, int M, int N, in
       if (noepi_p) C = nullptr;
 #define LP(E, HI, INP, LDI) hipLaunchKernelGGL((gemm_nt_bf16_pers_kernel<E, HI>), dim3(grid), dim3(512), P_LDS, s, M, N, K, (const bf16_t*)A, lda, \
                                  (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, (const bf16_t*)(INP), LDI, (bf16_t*)C2, ldc2, t3n, nwg3, drop)
+      if (K >= 256 && !force_v7) {
+#define LP3(E, HI, INP, LDI) hipLaunchKernelGGL((gemm_nt_bf16_p3_kernel<E, HI>), dim3(grid), dim3(512), P_LDS, s, M, N, K, (const bf16_t*)A, lda, \
+                                 (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, (const bf16_t*)(INP), LDI, (bf16_t*)C2, ldc2, t3n, nwg3, drop)
+        if (epilogue == SIMX_EPI_NONE) { if (residual) LP3(SIMX_EPI_NONE, true, residual, ldr); else LP3(SIMX_EPI_NONE, false, nullptr, 0); }
+        else if (epilogue == SIMX_EPI_GELU) LP3(SIMX_EPI_GELU, false, nullptr, 0);
+        else LP3(SIMX_EPI_DGELU, true, aux, ldaux);
+#undef LP3
+        SIMX_CHECK_LAUNCH("gemm_nt_bf16_p3");
+        return SIMX_OK;
+      }
       if (epilogue == SIMX_EPI_NONE) { if (residual) LP(SIMX_EPI_NONE, true, residual, ldr); else LP(SIMX_EPI_NONE, false, nullptr, 0); }
       else if (epilogue == SIMX_EPI_GELU) LP(SIMX_EPI_GELU, false, nullptr, 0);
       else LP(SIMX_EPI_DGELU, true, aux, ldaux);

@@ -59,6 +59,13 @@ int main(int argc, char** argv) {
     printf("gemm_tn %-36s %8.3f ms  %7.1f TF/s\n", s.name, ms, fl / ms / 1e9);
   }
   printf("gemm_tn total %.2f ms  avg %.1f TF/s\n", tot, totf / tot / 1e9);
+  tot = 0; totf = 0;
+  for (auto& s : tn) {
+    double ms = timeit([&] { SX(simx_gemm_tn_bias(0, SIMX_BF16, s.M, s.N, T, A, s.M, A2, s.N, G, s.N, 1, ws, wsb, bias)); }, iters);
+    double fl = 2.0 * T * s.M * s.N; tot += ms; totf += fl;
+    printf("gemm_tn+bias %-31s %8.3f ms  %7.1f TF/s\n", s.name, ms, fl / ms / 1e9);
+  }
+  printf("gemm_tn+bias total %.2f ms  avg %.1f TF/s\n", tot, totf / tot / 1e9);
   // attention + LN + colsum at S=128
   const int S = 128, nseq = T / S, heads = 12;
   std::vector<int> cu(nseq + 1); for (int i = 0; i <= nseq; ++i) cu[i] = i * S;

@@ -122,6 +122,15 @@ int simx_embed_ln_bwd_ex(simx_stream_t stream, int dtype, int T, int H,
                          const float* gamma, float eps, const void* dy,
                          float* dword, float* dpos, float* dtype0, float* dgamma, float* dbeta, const simx_dropout* drop);
 
+/* position-major variant for the packed layout (cu_seqlens[nseq+1], rows cu[s]..cu[s+1]): one wave per in-sequence
+ * position accumulates that position's gradient in registers (no contended atomics on the 128..512 position rows).
+ * pos_ids must depend on the in-sequence index only (pos_ids[cu[s]+p] identical for all s). */
+int simx_embed_ln_bwd_seq(simx_stream_t stream, int dtype, int nseq, int max_len, int T, int H, const int32_t* cu_seqlens,
+                          const int32_t* ids, const int32_t* pos_ids,
+                          const float* word, const float* posw, const float* typew,
+                          const float* gamma, float eps, const void* dy,
+                          float* dword, float* dpos, float* dtype0, float* dgamma, float* dbeta, const simx_dropout* drop);
+
 /* y = LN(z) ; z already holds dense(x)+bias+residual (BertSelfOutput / BertOutput,
  * LEAD/modeling_bert.py:384-388, 462-466). */
 int simx_ln_fwd(simx_stream_t stream, int dtype, int T, int H, const void* z,

@@ -60,6 +60,7 @@ SIGNATURES = {
     "simx_gemm_f32_strided": (_i, [_p, _i, _i, _i, _p, _l, _l, _p, _l, _l, _p, _i, _i]),
     "simx_embed_ln_fwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _p]),
     "simx_embed_ln_bwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p]),
+    "simx_embed_ln_bwd_seq": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p]),
     "simx_ln_fwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _f, _p]),
     "simx_ln_bwd": (_i, [_p, _i, _i, _i, _p, _p, _f, _p, _p, _p, _p, _p]),
     "simx_mha_fwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p]),

@@ -296,9 +296,9 @@ extern "C" int simx_bert_bwd(simx_stream_t stream, const simx_bert_cfg* c, const
                           goff(l, SIMX_P_BQKV)));
   }
   const simx_dropout d0 = drop_of(c, -1, 0);
-  RUN(simx_embed_ln_bwd_ex(stream, dt, T, H, ids, pos_ids, off(-1, SIMX_P_WORD), off(-1, SIMX_P_POS), off(-1, SIMX_P_TYPE),
-                           off(-1, SIMX_P_EMB_LN_G), c->eps, bufB, goff(-1, SIMX_P_WORD), goff(-1, SIMX_P_POS),
-                           goff(-1, SIMX_P_TYPE), goff(-1, SIMX_P_EMB_LN_G), goff(-1, SIMX_P_EMB_LN_B), &d0));
+  RUN(simx_embed_ln_bwd_seq(stream, dt, nseq, max_len, T, H, cu, ids, pos_ids, off(-1, SIMX_P_WORD), off(-1, SIMX_P_POS),
+                            off(-1, SIMX_P_TYPE), off(-1, SIMX_P_EMB_LN_G), c->eps, bufB, goff(-1, SIMX_P_WORD),
+                            goff(-1, SIMX_P_POS), goff(-1, SIMX_P_TYPE), goff(-1, SIMX_P_EMB_LN_G), goff(-1, SIMX_P_EMB_LN_B), &d0));
   return SIMX_OK;
 }
 

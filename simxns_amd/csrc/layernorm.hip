@@ -335,6 +335,82 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(int rows, int H, int 
   flush_cols(H, lane, w, pz, dtype0, sred);
 }
 
+// Position-major embedding backward: wave w of block (pg, sc) owns ONE in-sequence position p = 4 pg + w and walks the
+// sequences of chunk sc (row = cu[s] + p), so the position-embedding gradient of p accumulates in registers and is
+// flushed with one atomic per column per wave -- the row-major kernel sends every row's 768 values to the same 128
+// position rows (2048-way contended f32 atomics, half of its 400 M atomics).  The word-embedding scatter stays atomic
+// (ids are arbitrary).  Requires pos_ids to depend on the in-sequence index only (the encoder driver guarantees it).
+template <typename T, int VPL>
+__global__ __launch_bounds__(256) void embed_ln_bwd_seq_kernel(int nseq, int seq_per_block, int H, const int* __restrict__ cu,
+                                                               const int* __restrict__ ids, const int* __restrict__ pos,
+                                                               const float* __restrict__ word, const float* __restrict__ posw,
+                                                               const float* __restrict__ typew, const float* __restrict__ gamma,
+                                                               float eps, const T* __restrict__ dyp, float* __restrict__ dword,
+                                                               float* __restrict__ dpos, float* __restrict__ dtype0,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, DropCtx drop) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sred = reinterpret_cast<float*>(smem);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int p = blockIdx.x * 4 + w;
+  const int s0 = blockIdx.y * seq_per_block, s1 = min(nseq, s0 + seq_per_block);
+  float pg[VPL][4] = {}, pb[VPL][4] = {}, pz[VPL][4] = {};
+  long pid = -1;
+  for (int sq = s0; sq < s1; ++sq) {
+    const int t0 = cu[sq], len = cu[sq + 1] - t0;
+    if (p >= len) continue;                          // wave-uniform
+    const int row = t0 + p;
+    const long wid = ids[row];
+    pid = pos[row];
+    const float* wr = word + wid * H;
+    const float* pr = posw + pid * H;
+    const T* dr = dyp + (long)row * H;
+    float x[VPL][4], dy[VPL][4], dz[VPL][4];
+    float sum = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int c = (v * 64 + lane) * 4;
+      if (c < H) {
+        float a[4], b[4], t[4];
+        ld4(wr + c, a);
+        ld4(pr + c, b);
+        ld4(typew + c, t);
+        ld4(dr + c, dy[v]);
+        if (drop.thr) { float m4[4]; drop_mult4(drop, (uint32_t)row, (uint32_t)c, m4); dy[v][0] *= m4[0]; dy[v][1] *= m4[1]; dy[v][2] *= m4[2]; dy[v][3] *= m4[3]; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { x[v][e] = a[e] + b[e] + t[e]; sum += x[v][e]; }
+      }
+    }
+    const float mu = wave_sum(sum) / (float)H;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[v][e] -= mu;
+    ln_row_bwd(H, lane, x, dy, gamma, eps, dz, pg, pb);
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int c = (v * 64 + lane) * 4;
+      if (c < H)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          atomicAdd(dword + wid * H + c + e, dz[v][e]);
+          pz[v][e] += dz[v][e];
+        }
+    }
+  }
+  if (pid >= 0) {                                    // this wave's position row: its sum over the chunk's sequences
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int c = (v * 64 + lane) * 4;
+      if (c < H)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(dpos + pid * H + c + e, pz[v][e]);
+    }
+  }
+  flush_cols(H, lane, w, pg, dgamma, sred);
+  flush_cols(H, lane, w, pb, dbeta, sred);
+  flush_cols(H, lane, w, pz, dtype0, sred);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void cls_gather_kernel(int nseq, int H, const int* __restrict__ cu,
                                                          const T* __restrict__ x, float* __restrict__ cls) {
@@ -462,6 +538,32 @@ extern "C" int simx_embed_ln_bwd_ex(simx_stream_t stream, int dtype, int T, int 
   else { if (H <= 256) EB(bf16_t, 1); else if (H <= 768) EB(bf16_t, 3); else EB(bf16_t, 4); }
 #undef EB
   SIMX_CHECK_LAUNCH("embed_ln_bwd");
+  return SIMX_OK;
+}
+
+extern "C" int simx_embed_ln_bwd_seq(simx_stream_t stream, int dtype, int nseq, int max_len, int T, int H, const int32_t* cu_seqlens,
+                                     const int32_t* ids, const int32_t* pos_ids, const float* word, const float* posw,
+                                     const float* typew, const float* gamma, float eps, const void* dy, float* dword, float* dpos,
+                                     float* dtype0, float* dgamma, float* dbeta, const simx_dropout* dropd) {
+  SIMX_PROF(SIMX_K_EMBED_BWD, stream, (double)T * H * ((dtype == SIMX_F32 ? 4 : 2) + 3 * 4));
+  const DropCtx drop = make_drop(dropd);
+  int rc = ln_check(dtype, T, H, "embed_ln_bwd_seq");
+  if (rc) return rc;
+  SIMX_REQUIRE(nseq > 0 && max_len > 0 && cu_seqlens, SIMX_ERR_BAD_SHAPE, "embed_ln_bwd_seq: bad nseq / max_len / cu_seqlens");
+  hipStream_t s = (hipStream_t)stream;
+  const int pgroups = cdiv(max_len, 4);
+  int chunks = 1024 / pgroups;                       // ~1024 blocks; every (position, chunk) pair flushes dpos once
+  if (chunks < 1) chunks = 1;
+  if (chunks > nseq) chunks = nseq;
+  const int spb = cdiv(nseq, chunks);
+  const dim3 grid(pgroups, cdiv(nseq, spb));
+  const size_t lds = (size_t)4 * H * sizeof(float);
+#define ES(TT, V) hipLaunchKernelGGL((embed_ln_bwd_seq_kernel<TT, V>), grid, dim3(256), lds, s, nseq, spb, H, cu_seqlens, ids, pos_ids, word, \
+                                    posw, typew, gamma, eps, (const TT*)dy, dword, dpos, dtype0, dgamma, dbeta, drop)
+  if (dtype == SIMX_F32) { if (H <= 256) ES(float, 1); else if (H <= 768) ES(float, 3); else ES(float, 4); }
+  else { if (H <= 256) ES(bf16_t, 1); else if (H <= 768) ES(bf16_t, 3); else ES(bf16_t, 4); }
+#undef ES
+  SIMX_CHECK_LAUNCH("embed_ln_bwd_seq");
   return SIMX_OK;
 }
 

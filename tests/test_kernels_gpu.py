@@ -247,6 +247,43 @@ def test_embed_ln(dev, bf16):
     assert_close(back(gb), dbr, rtol=1e-4, atol=1e-3, what="dbeta")
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("lens,off", [([128, 1, 17, 33, 128, 100, 7], 0), ([40] * 70, 2), ([5, 300, 64], 0)])
+def test_embed_ln_bwd_position_major(dev, bf16, lens, off):
+    """simx_embed_ln_bwd_seq (one wave per in-sequence position, register accumulation of the position gradient) against
+    the float64 reference; ragged lengths, more sequences than chunks, RoBERTa-style position offset."""
+    lib = L()
+    H, V = 64, 300
+    T, P = sum(lens), max(lens) + off
+    rs = np.random.RandomState(len(lens))
+    ids = rs.randint(0, V, size=T).astype(np.int32)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    for s_ in range(len(lens)):
+        ids[cu[s_]] = 7                              # [CLS] collisions
+    pos = np.concatenate([np.arange(n) + off for n in lens]).astype(np.int32)
+    word, posw, typew = rnd((V, H), 1), rnd((P, H), 2), rnd((2, H), 3)
+    g = 1.0 + rnd((H,), 4, 0.1)
+    dy = rnd((T, H), 6)
+    d = lambda a, bf=False: to_dev(a, dev, bf)
+    gw, gp, gt = torch.zeros(V, H, device=dev), torch.zeros(P, H, device=dev), torch.zeros(2, H, device=dev)
+    gg, gb = torch.zeros(H, device=dev), torch.zeros(H, device=dev)
+    keep = [d(cu), d(ids), d(pos), d(word), d(posw), d(typew), d(g), d(dy, bf16)]     # must outlive the launch
+    lib.call("simx_embed_ln_bwd_seq", lib.stream_ptr(), int(bf16), len(lens), max(lens), T, H, *[lib.ptr(t) for t in keep[:7]], 1e-12,
+             lib.ptr(keep[7]), lib.ptr(gw), lib.ptr(gp), lib.ptr(gt), lib.ptr(gg), lib.ptr(gb), None)
+    torch.cuda.synchronize()
+    e = (word[ids] + posw[pos] + typew[0][None]).astype(np.float64)
+    _, cache = obert._ln_fwd(e, g.astype(np.float64), np.zeros(H), 1e-12)
+    de, dgr, dbr = obert._ln_bwd(rounded(dy, bf16), cache, g.astype(np.float64))
+    rw, rp = np.zeros((V, H)), np.zeros((P, H))
+    np.add.at(rw, ids, de)
+    np.add.at(rp, pos, de)
+    assert_close(back(gw), rw, rtol=1e-4, atol=2e-4, what="dword")
+    assert_close(back(gp), rp, rtol=1e-4, atol=2e-4, what="dpos")
+    assert_close(back(gt)[0], de.sum(0), rtol=1e-4, atol=2e-3, what="dtype0")
+    assert_close(back(gg), dgr, rtol=1e-4, atol=2e-3, what="dgamma")
+    assert_close(back(gb), dbr, rtol=1e-4, atol=2e-3, what="dbeta")
+
+
 # ------------------------------------------------------------------------------------------ attention
 def _mha_ref(qkv, lens, heads, d, dctx=None):
     """float64 reference on the packed layout."""

@@ -426,9 +426,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_v5_kernel(
 // global accesses in "uniform 64-bit base in SGPRs + 32-bit per-lane offset" form: one VGPR per address stream
 #define P_GLD4(DST, VOFF, SBASE, OFF) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #OFF : "=&v"(DST) : "v"(VOFF), "s"(SBASE) : "memory")
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-// (the trailing s_nop is the gfx9 "VMEM store of > 64 bits, then a VALU write of its data VGPRs" wait state, which
-// hipcc's hazard recognizer cannot insert for a store hidden in inline asm)
-#define P_GST4(VOFF, SBASE, VAL) asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 0" ::"v"(VOFF), "v"(VAL), "s"(SBASE) : "memory")
+// (the trailing s_nop covers the gfx9 "VMEM store of > 64 bits, then a write of its data VGPRs" hazard, which hipcc's
+// hazard recognizer cannot see for a store hidden in inline asm.  One wait state was NOT enough on gfx950: with
+// s_nop 0 the first data dword of lanes 12-15 of every 16-lane group was still clobbered by the next VALU write in some
+// schedules (tests/test_kernels_gpu.py::test_gemm_nt_persistent caught it) -- the store reads its data 16 lanes x 1 dword per
+// cycle; 4 wait states cleared it, 6 are used)
+#define P_GST4(VOFF, SBASE, VAL) asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 5" ::"v"(VOFF), "v"(VAL), "s"(SBASE) : "memory")
 // LDS-DMA in the same form (M0 = wave-uniform LDS byte address of the 1 KB destination).  The persistent kernel
 // uses ONLY this form, so the compiler never tracks M0 in it.
 #define P_DMA16(VOFF, SBASE, LDSADDR) \

@@ -755,6 +755,29 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
   acc[I][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B3, AF, acc[I][3], 0, 0, 0)
 #define V3_RD1(F, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=&v"(F) : "v"(ADDR) : "memory")
 #define V3_SB __builtin_amdgcn_sched_barrier(0)
+#ifndef SIMX_P3_SCHED
+#define SIMX_P3_SCHED 1
+#endif
+#if SIMX_P3_SCHED == 1
+#define P_STEP(CURA, NA, NB, BC0, BC1, BC2, BC3, BN0, BN1, BN2, BN3, BOUNDARY)                   \
+  do {                                                                                         \
+    /* fragment reads are front-loaded: the last read before each pin is issued two MFMA rows ahead of it */ \
+    const uint32_t aa__ = (CURA), na__ = (NA), nb__ = (NB);                                    \
+    V3_SB; V3_MFMA_ROW(0, al0, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah0, aa__, 8192); V3_RD1(ah1, aa__, 10240);  \
+    V3_SB; V3_MFMA_ROW(1, al1, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah2, aa__, 12288); V3_RD1(ah3, aa__, 14336); \
+    V3_SB; V3_MFMA_ROW(2, al2, BC0, BC1, BC2, BC3);                                            \
+    V3_SB; V3_MFMA_ROW(3, al3, BC0, BC1, BC2, BC3);                                            \
+    V3_SB;                                                                                     \
+    V3_PIN4("s_waitcnt lgkmcnt(0)", ah0, ah1, ah2, ah3);                                       \
+    BOUNDARY();                                                                                \
+    V3_SB; V3_MFMA_ROW(4, ah0, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al0, na__, 0); V3_RD1(BN0, nb__, 0); V3_RD1(al1, na__, 2048);       \
+    V3_SB; V3_MFMA_ROW(5, ah1, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(BN1, nb__, 2048); V3_RD1(al2, na__, 4096); V3_RD1(BN2, nb__, 4096); \
+    V3_SB; V3_MFMA_ROW(6, ah2, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al3, na__, 6144); V3_RD1(BN3, nb__, 6144); \
+    V3_SB; V3_MFMA_ROW(7, ah3, BC0, BC1, BC2, BC3);                                            \
+    V3_SB;                                                                                     \
+    V3_PIN8("s_waitcnt lgkmcnt(0)", al0, al1, al2, al3, BN0, BN1, BN2, BN3);                   \
+  } while (0)
+#else
 #define P_STEP(CURA, NA, NB, BC0, BC1, BC2, BC3, BN0, BN1, BN2, BN3, BOUNDARY)                   \
   do {                                                                                         \
     const uint32_t aa__ = (CURA), na__ = (NA), nb__ = (NB);                                    \
@@ -772,6 +795,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
     V3_SB;                                                                                     \
     V3_PIN8("s_waitcnt lgkmcnt(0)", al0, al1, al2, al3, BN0, BN1, BN2, BN3);                   \
   } while (0)
+#endif
 #define P_BND_NONE() do { } while (0)
   // stage boundary inside the tile: every fragment of stage st is in registers, stage st+1 has landed once vmcnt
   // hits 0 (for everyone after the barrier); slot (st+par)&1 is refilled with stream stage st+2, which is the
@@ -1177,12 +1201,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_bf16_kernel(
     const uint32_t cur__ = (CUR), nxt__ = (NXT);                                                                \
     TN2_SB; TN2_MFMA_ROW(0, al_lo[0], al_hi[0], BCL, BCH); TN2_SB;                                              \
     TN2_RD(ah_lo[0], ah_hi[0], TN2_ADDR_LO(cur__, 0u, wr * 8 + 4), TN2_ADDR_HI(cur__, 0u, wr * 8 + 4));         \
-    TN2_SB; TN2_MFMA_ROW(1, al_lo[1], al_hi[1], BCL, BCH); TN2_SB;                                              \
     TN2_RD(ah_lo[1], ah_hi[1], TN2_ADDR_LO(cur__, 0u, wr * 8 + 5), TN2_ADDR_HI(cur__, 0u, wr * 8 + 5));         \
-    TN2_SB; TN2_MFMA_ROW(2, al_lo[2], al_hi[2], BCL, BCH); TN2_SB;                                              \
+    TN2_SB; TN2_MFMA_ROW(1, al_lo[1], al_hi[1], BCL, BCH); TN2_SB;                                              \
     TN2_RD(ah_lo[2], ah_hi[2], TN2_ADDR_LO(cur__, 0u, wr * 8 + 6), TN2_ADDR_HI(cur__, 0u, wr * 8 + 6));         \
-    TN2_SB; TN2_MFMA_ROW(3, al_lo[3], al_hi[3], BCL, BCH); TN2_SB;                                              \
     TN2_RD(ah_lo[3], ah_hi[3], TN2_ADDR_LO(cur__, 0u, wr * 8 + 7), TN2_ADDR_HI(cur__, 0u, wr * 8 + 7));         \
+    TN2_SB; TN2_MFMA_ROW(2, al_lo[2], al_hi[2], BCL, BCH);                                                      \
+    TN2_SB; TN2_MFMA_ROW(3, al_lo[3], al_hi[3], BCL, BCH);                                                      \
     TN2_SB;                                                                                                     \
     TN2_PIN8("s_waitcnt lgkmcnt(0)", ah_lo, ah_hi);                                                             \
     if (SYNC) {                                                                                                 \
@@ -1203,15 +1227,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_bf16_kernel(
     TN2_SB; TN2_MFMA_ROW(4, ah_lo[0], ah_hi[0], BCL, BCH); TN2_SB;                                              \
     TN2_RD(al_lo[0], al_hi[0], TN2_ADDR_LO(nxt__, 0u, wr * 8 + 0), TN2_ADDR_HI(nxt__, 0u, wr * 8 + 0));         \
     TN2_RD(BNL[0], BNH[0], TN2_ADDR_LO(nxt__, 32768u, wc * 4 + 0), TN2_ADDR_HI(nxt__, 32768u, wc * 4 + 0));     \
-    TN2_SB; TN2_MFMA_ROW(5, ah_lo[1], ah_hi[1], BCL, BCH); TN2_SB;                                              \
     TN2_RD(al_lo[1], al_hi[1], TN2_ADDR_LO(nxt__, 0u, wr * 8 + 1), TN2_ADDR_HI(nxt__, 0u, wr * 8 + 1));         \
+    TN2_SB; TN2_MFMA_ROW(5, ah_lo[1], ah_hi[1], BCL, BCH); TN2_SB;                                              \
     TN2_RD(BNL[1], BNH[1], TN2_ADDR_LO(nxt__, 32768u, wc * 4 + 1), TN2_ADDR_HI(nxt__, 32768u, wc * 4 + 1));     \
-    TN2_SB; TN2_MFMA_ROW(6, ah_lo[2], ah_hi[2], BCL, BCH); TN2_SB;                                              \
     TN2_RD(al_lo[2], al_hi[2], TN2_ADDR_LO(nxt__, 0u, wr * 8 + 2), TN2_ADDR_HI(nxt__, 0u, wr * 8 + 2));         \
     TN2_RD(BNL[2], BNH[2], TN2_ADDR_LO(nxt__, 32768u, wc * 4 + 2), TN2_ADDR_HI(nxt__, 32768u, wc * 4 + 2));     \
-    TN2_SB; TN2_MFMA_ROW(7, ah_lo[3], ah_hi[3], BCL, BCH); TN2_SB;                                              \
+    TN2_SB; TN2_MFMA_ROW(6, ah_lo[2], ah_hi[2], BCL, BCH); TN2_SB;                                              \
     TN2_RD(al_lo[3], al_hi[3], TN2_ADDR_LO(nxt__, 0u, wr * 8 + 3), TN2_ADDR_HI(nxt__, 0u, wr * 8 + 3));         \
     TN2_RD(BNL[3], BNH[3], TN2_ADDR_LO(nxt__, 32768u, wc * 4 + 3), TN2_ADDR_HI(nxt__, 32768u, wc * 4 + 3));     \
+    TN2_SB; TN2_MFMA_ROW(7, ah_lo[3], ah_hi[3], BCL, BCH);                                                      \
     TN2_SB;                                                                                                     \
     TN2_PIN8("s_waitcnt lgkmcnt(0)", al_lo, al_hi);                                                             \
     TN2_PIN8("s_waitcnt lgkmcnt(0)", BNL, BNH);                                                                 \

@@ -230,9 +230,9 @@ def main():
         c_, ms_, wk_ = prof["gemm_nt"]
         ach = wk_ / (ms_ * 1e-3) / 1e12
         peak = 2500.0 if args.dtype == "bf16" else 157.3
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_bf16_pers_kernel (simx_gemm_nt: forward + dgrad GEMMs)",
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_bf16_p3_kernel (simx_gemm_nt: forward + dgrad GEMMs)",
                            "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                           "traffic": pmc_traffic("gemm_nt_bf16_pers_kernel"), "launches": c_,
+                           "traffic": pmc_traffic("gemm_nt_bf16_p3_kernel"), "launches": c_,
                            "avg_launch_ms": round(ms_ / c_, 4), "algorithmic_flop_per_launch": round(wk_ / c_)}
         out["kernel_breakdown_ms_per_step"] = {k: round(v[1] / args.steps, 3) for k, v in prof.items()}
         out["kernel_rates"] = {k: round(v[2] / (v[1] * 1e-3) / 1e12, 2) for k, v in prof.items() if v[1] > 0}

@@ -105,10 +105,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # validation hook: SIMX_BENCH_SHARE_GPU=1 runs all ranks on cuda:0 over gloo (a 1-GPU box cannot host RCCL ranks);
+    # it only checks the N > 1 control flow (sharding, gradient all-reduce, barrier, max-over-ranks), never a number
+    share = os.environ.get("SIMX_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if share:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
     L.load()
 
     B, N, Cn = args.batch, args.negs, args.cands

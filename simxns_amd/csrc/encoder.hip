@@ -113,6 +113,11 @@ static WLayer wlayer(const simx_bert_cfg* c, const float* params, const void* wc
   return w;
 }
 
+// Every token-major buffer is carved with its row count rounded up to a multiple of 256, and the NT GEMMs run on the
+// padded row count: the persistent full-tile kernels then also serve ragged (packed, variable-length) batches.  Rows
+// [T, Tp) hold garbage that never leaves its own row (an NT GEMM row depends on that row of A only; LayerNorm,
+// attention, the wgrad contraction and every reduction run over the T real rows).
+static inline int rows_cap(int T) { return (T + 255) & ~255; }
 struct ALayer { char *qkv, *ctx, *z1, *x1, *u, *h, *z2, *xout; float* lse; };
 static size_t act_layer_bytes(const simx_bert_cfg* c, size_t T) {
   const size_t H = c->hidden, F = c->inter, e = esz(c->dtype);
@@ -121,8 +126,9 @@ static size_t act_layer_bytes(const simx_bert_cfg* c, size_t T) {
 extern "C" size_t simx_bert_act_bytes(const simx_bert_cfg* c, int T, int nseq, int save_for_bwd) {
   if (!cfg_ok(c) || T <= 0) return 0;
   (void)nseq;
-  const size_t x0 = al((size_t)T * c->hidden * esz(c->dtype));
-  return x0 + (size_t)(save_for_bwd ? c->layers : 2) * act_layer_bytes(c, T);
+  const size_t Tp = (size_t)rows_cap(T);
+  const size_t x0 = al(Tp * c->hidden * esz(c->dtype));
+  return x0 + (size_t)(save_for_bwd ? c->layers : 2) * act_layer_bytes(c, Tp);
 }
 static char* act_x0(void* act) { return (char*)act; }
 static ALayer alayer(const simx_bert_cfg* c, void* act, size_t T, int l, int save) {
@@ -153,7 +159,8 @@ extern "C" size_t simx_bert_bwd_scratch_bytes(const simx_bert_cfg* c, int T, int
   if (!cfg_ok(c) || T <= 0) return 0;
   (void)nseq;
   const size_t H = c->hidden, F = c->inter, e = esz(c->dtype);
-  return 3 * al((size_t)T * H * e) + al((size_t)T * F * e) + al((size_t)T * 3 * H * e) + tn_ws_max(c, T);
+  const size_t Tp = (size_t)rows_cap(T);
+  return 3 * al(Tp * H * e) + al(Tp * F * e) + al(Tp * 3 * H * e) + tn_ws_max(c, T);
 }
 
 // ------------------------------------------------------------------------------------------ driver
@@ -208,6 +215,7 @@ extern "C" int simx_bert_fwd(simx_stream_t stream, const simx_bert_cfg* c, const
   SIMX_REQUIRE(act_bytes >= simx_bert_act_bytes(c, T, nseq, save), SIMX_ERR_WORKSPACE, "bert_fwd: activation buffer %zu < %zu",
                act_bytes, simx_bert_act_bytes(c, T, nseq, save));
   const int H = c->hidden, F = c->inter, dt = c->dtype, d = H / c->heads;
+  const int Tp = rows_cap(T);
   const float* P = params;
   auto off = [&](int l, int w) { return P + simx_bert_param_offset(c, l, w); };
   char* x = act_x0(act);
@@ -218,17 +226,17 @@ extern "C" int simx_bert_fwd(simx_stream_t stream, const simx_bert_cfg* c, const
   }
   for (int l = 0; l < c->layers; ++l) {
     const WLayer w = wlayer(c, params, wcache, l);
-    const ALayer a = alayer(c, act, T, l, save);
-    RUN(simx_gemm_nt(stream, dt, T, 3 * H, H, x, H, w.wqkv, H, a.qkv, 3 * H, off(l, SIMX_P_BQKV), nullptr, 0, SIMX_EPI_NONE,
+    const ALayer a = alayer(c, act, Tp, l, save);
+    RUN(simx_gemm_nt(stream, dt, Tp, 3 * H, H, x, H, w.wqkv, H, a.qkv, 3 * H, off(l, SIMX_P_BQKV), nullptr, 0, SIMX_EPI_NONE,
                      nullptr, 0, nullptr, 0));
     const simx_dropout d1 = drop_of(c, l, 1), d2 = drop_of(c, l, 2), d3 = drop_of(c, l, 3);
     RUN(simx_mha_fwd_ex(stream, dt, nseq, c->heads, d, cu, max_len, T, a.qkv, a.ctx, a.lse, &d3));
-    RUN(simx_gemm_nt_ex(stream, dt, T, H, H, a.ctx, H, w.wo, H, a.z1, H, off(l, SIMX_P_BO), x, H, SIMX_EPI_NONE, nullptr, 0,
+    RUN(simx_gemm_nt_ex(stream, dt, Tp, H, H, a.ctx, H, w.wo, H, a.z1, H, off(l, SIMX_P_BO), x, H, SIMX_EPI_NONE, nullptr, 0,
                         nullptr, 0, &d1));
     RUN(simx_ln_fwd(stream, dt, T, H, a.z1, off(l, SIMX_P_LN1_G), off(l, SIMX_P_LN1_B), c->eps, a.x1));
-    RUN(simx_gemm_nt(stream, dt, T, F, H, a.x1, H, w.w1, H, a.u, F, off(l, SIMX_P_B1), nullptr, 0, SIMX_EPI_GELU, nullptr, 0,
+    RUN(simx_gemm_nt(stream, dt, Tp, F, H, a.x1, H, w.w1, H, a.u, F, off(l, SIMX_P_B1), nullptr, 0, SIMX_EPI_GELU, nullptr, 0,
                      a.h, F));
-    RUN(simx_gemm_nt_ex(stream, dt, T, H, F, a.h, F, w.w2, F, a.z2, H, off(l, SIMX_P_B2), a.x1, H, SIMX_EPI_NONE, nullptr, 0,
+    RUN(simx_gemm_nt_ex(stream, dt, Tp, H, F, a.h, F, w.w2, F, a.z2, H, off(l, SIMX_P_B2), a.x1, H, SIMX_EPI_NONE, nullptr, 0,
                         nullptr, 0, &d2));
     RUN(simx_ln_fwd(stream, dt, T, H, a.z2, off(l, SIMX_P_LN2_G), off(l, SIMX_P_LN2_B), c->eps, a.xout));
     x = a.xout;
@@ -254,43 +262,44 @@ extern "C" int simx_bert_bwd(simx_stream_t stream, const simx_bert_cfg* c, const
   SIMX_REQUIRE(scratch_bytes >= simx_bert_bwd_scratch_bytes(c, T, nseq), SIMX_ERR_WORKSPACE, "bert_bwd: scratch %zu < %zu",
                scratch_bytes, simx_bert_bwd_scratch_bytes(c, T, nseq));
   const int H = c->hidden, F = c->inter, dt = c->dtype, d = H / c->heads;
+  const int Tp = rows_cap(T);
   const size_t e = esz(dt);
   auto off = [&](int l, int w) { return params + simx_bert_param_offset(c, l, w); };
   auto goff = [&](int l, int w) { return grads + simx_bert_param_offset(c, l, w); };
   char* bufA = (char*)scratch;
-  char* bufB = bufA + al((size_t)T * H * e);
-  char* bufC = bufB + al((size_t)T * H * e);                    // dropout-masked copy of dz (only with hidden dropout)
-  char* du = bufC + al((size_t)T * H * e);
+  char* bufB = bufA + al((size_t)Tp * H * e);
+  char* bufC = bufB + al((size_t)Tp * H * e);                    // dropout-masked copy of dz (only with hidden dropout)
+  char* du = bufC + al((size_t)Tp * H * e);
   const bool hd = c->hidden_dropout > 0.f;
-  char* dqkv = du + al((size_t)T * F * e);
-  char* tnws = dqkv + al((size_t)T * 3 * H * e);
+  char* dqkv = du + al((size_t)Tp * F * e);
+  char* tnws = dqkv + al((size_t)Tp * 3 * H * e);
   const size_t tnws_bytes = tn_ws_max(c, T);
 
   RUN(simx_cls_scatter(stream, dt, nseq, H, T, cu, dcls, bufB));            // g_x = d(loss)/d(last hidden)
   for (int l = c->layers - 1; l >= 0; --l) {
     const WLayer w = wlayer(c, params, wcache, l);
-    const ALayer a = alayer(c, const_cast<void*>(act), T, l, 1);
-    const char* xin = l == 0 ? act_x0(const_cast<void*>(act)) : alayer(c, const_cast<void*>(act), T, l - 1, 1).xout;
+    const ALayer a = alayer(c, const_cast<void*>(act), Tp, l, 1);
+    const char* xin = l == 0 ? act_x0(const_cast<void*>(act)) : alayer(c, const_cast<void*>(act), Tp, l - 1, 1).xout;
     const simx_dropout d1 = drop_of(c, l, 1), d2 = drop_of(c, l, 2), d3 = drop_of(c, l, 3);
     char* dzm = hd ? bufC : bufA;        // gradient of the (dropped) dense output; bufA = gradient of the residual branch
     // output LayerNorm : dz2, dgamma2, dbeta2, db2
     RUN(simx_ln_bwd_ex(stream, dt, T, H, a.z2, off(l, SIMX_P_LN2_G), c->eps, bufB, bufA, hd ? bufC : nullptr, goff(l, SIMX_P_LN2_G),
                        goff(l, SIMX_P_LN2_B), goff(l, SIMX_P_B2), &d2));
     // du = (dz2m . W2) * gelu'(u)
-    RUN(simx_gemm_nt(stream, dt, T, F, H, dzm, H, w.w2T, H, du, F, nullptr, nullptr, 0, SIMX_EPI_DGELU, a.u, F, nullptr, 0));
+    RUN(simx_gemm_nt(stream, dt, Tp, F, H, dzm, H, w.w2T, H, du, F, nullptr, nullptr, 0, SIMX_EPI_DGELU, a.u, F, nullptr, 0));
     RUN(simx_gemm_tn(stream, dt, H, F, T, dzm, H, a.h, F, goff(l, SIMX_P_W2), F, 1, tnws, tnws_bytes));
     // dx1 = du . W1 + dz2
-    RUN(simx_gemm_nt(stream, dt, T, H, F, du, F, w.w1T, F, bufB, H, nullptr, bufA, H, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
+    RUN(simx_gemm_nt(stream, dt, Tp, H, F, du, F, w.w1T, F, bufB, H, nullptr, bufA, H, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
     RUN(simx_gemm_tn_bias(stream, dt, F, H, T, du, F, a.x1, H, goff(l, SIMX_P_W1), H, 1, tnws, tnws_bytes, goff(l, SIMX_P_B1)));
     // attention-output LayerNorm : dz1, dgamma1, dbeta1, dbo
     RUN(simx_ln_bwd_ex(stream, dt, T, H, a.z1, off(l, SIMX_P_LN1_G), c->eps, bufB, bufA, hd ? bufC : nullptr, goff(l, SIMX_P_LN1_G),
                        goff(l, SIMX_P_LN1_B), goff(l, SIMX_P_BO), &d1));
     // dctx = dz1m . Wo
-    RUN(simx_gemm_nt(stream, dt, T, H, H, dzm, H, w.woT, H, bufB, H, nullptr, nullptr, 0, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
+    RUN(simx_gemm_nt(stream, dt, Tp, H, H, dzm, H, w.woT, H, bufB, H, nullptr, nullptr, 0, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
     RUN(simx_gemm_tn(stream, dt, H, H, T, dzm, H, a.ctx, H, goff(l, SIMX_P_WO), H, 1, tnws, tnws_bytes));
     RUN(simx_mha_bwd_ex(stream, dt, nseq, c->heads, d, cu, max_len, T, a.qkv, a.ctx, a.lse, bufB, dqkv, &d3));
     // dx = dqkv . Wqkv + dz1
-    RUN(simx_gemm_nt(stream, dt, T, H, 3 * H, dqkv, 3 * H, w.wqkvT, 3 * H, bufB, H, nullptr, bufA, H, SIMX_EPI_NONE, nullptr, 0,
+    RUN(simx_gemm_nt(stream, dt, Tp, H, 3 * H, dqkv, 3 * H, w.wqkvT, 3 * H, bufB, H, nullptr, bufA, H, SIMX_EPI_NONE, nullptr, 0,
                      nullptr, 0));
     RUN(simx_gemm_tn_bias(stream, dt, 3 * H, H, T, dqkv, 3 * H, xin, H, goff(l, SIMX_P_WQKV), H, 1, tnws, tnws_bytes,
                           goff(l, SIMX_P_BQKV)));

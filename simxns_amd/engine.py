@@ -239,7 +239,9 @@ class BertEngine(object):
         ccfg = ccfg if ccfg is not None else self.ccfg
         dev = self.flat.device
         H = self.cfg.hidden_size
-        nbytes = int(self.lib.simx_bert_act_bytes(C.byref(self.ccfg), pb.T, pb.nseq, 1 if save else 0))
+        # sized for the padded token count nseq*S, not for this batch's T: ragged batches change T every step and a 50+ GB
+        # request of a new size makes the caching allocator free and re-malloc the block (measured: +245 ms per step)
+        nbytes = int(self.lib.simx_bert_act_bytes(C.byref(self.ccfg), pb.nseq * pb.S, pb.nseq, 1 if save else 0))
         act = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         cls = torch.empty(pb.nseq, H, dtype=torch.float32, device=dev)
         hidden = torch.empty(pb.T, H, dtype=self.act_torch_dtype, device=dev) if want_hidden else None
@@ -253,7 +255,7 @@ class BertEngine(object):
         g = self.ensure_grad()
         dev = self.flat.device
         dcls = dcls.contiguous().to(torch.float32)
-        nbytes = int(self.lib.simx_bert_bwd_scratch_bytes(C.byref(self.ccfg), pb.T, pb.nseq))
+        nbytes = int(self.lib.simx_bert_bwd_scratch_bytes(C.byref(self.ccfg), pb.nseq * pb.S, pb.nseq))
         scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         L.call("simx_bert_bwd", L.stream_ptr(), C.byref(ccfg), L.ptr(self.flat), L.ptr(self.wcache),
                L.ptr(pb.ids), L.ptr(pb.pos), L.ptr(pb.cu), pb.nseq, pb.T, pb.max_len, L.ptr(act), act.numel(),

@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--no-teacher", action="store_true", help="feed fixed teacher logits (student-only flops)")
     ap.add_argument("--no-dropout", action="store_true", help="eval-mode step (the reference trains with dropout 0.1, models.py:70-72)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-realistic", action="store_true", help="skip the extra realistic-length measurement")
     ap.add_argument("--no-prof", action="store_true")
     args = ap.parse_args()
 
@@ -145,11 +146,18 @@ def main():
     # ---- synthetic, PRE-TOKENISED candidate pool in HBM (per rank: B queries x (1 positive + Cn candidates)); the
     # per-step batch (passage rows, masks, cross-encoder rows q + ctx[1:-1]) is assembled on the device by
     # simx_assemble_batch from the sampler's picks -- the reference does this in 15 DataLoader workers per rank.
-    def toks(seed, n, S, mean, std, lo):
-        ids, mask, lens = synth.make_batch(seed, n, S, cfg.vocab_size, mean, std, lo, full=not args.varlen)
+    def toks(seed, n, S, mean, std, lo, full):
+        ids, mask, lens = synth.make_batch(seed, n, S, cfg.vocab_size, mean, std, lo, full=full)
         return torch.from_numpy(ids.astype(np.int32)).to(dev), lens
-    q_tok, q_lens = toks(100 + rank, B, QL, 9, 3, 4)
-    p_tok, p_lens = toks(200 + rank, B * (1 + Cn), PL, 80, 25, 16)
+    pool = {}
+
+    def build_pool(full):
+        """full: every sequence at its maximum length (the padded shapes the reference computes, whatever the text);
+        otherwise SURVEY 8d's length distribution (query ~ N(9,3) in [4,32], passage ~ N(80,25) in [16,128])."""
+        pool["q"], pool["ql"] = toks(100 + rank, B, QL, 9, 3, 4, full)
+        pool["p"], pool["pl"] = toks(200 + rank, B * (1 + Cn), PL, 80, 25, 16, full)
+    build_pool(not args.varlen)
+    q_lens, p_lens = pool["ql"], pool["pl"]
     q_rows = torch.arange(B, dtype=torch.int32, device=dev)
     row_base = (torch.arange(B, device=dev) * (1 + Cn)).unsqueeze(1)
     ce_tokens = int(min(CL, int(np.max(q_lens)) + int(np.max(p_lens)) - 2))     # longest cross-encoder row
@@ -167,7 +175,7 @@ def main():
         # S1+S2 on the GPU, then device-side batch assembly (gather of pre-tokenised passages)
         neg = ops.simans_sample(d_scores, d_spos, N, form=ops.LAPLACE, tau=3.0, seed=42 + rank, offset=step_no[0])
         sel = torch.cat([zero_col, neg.long() + 1], dim=1)                         # [B,1+N] rows of the query's pool
-        batch = ops.assemble_batch(q_tok, p_tok, q_rows, (row_base + sel).to(torch.int32), 1 + N, pad_id=0, sep_id=102, ce_len=CL)
+        batch = ops.assemble_batch(pool["q"], pool["p"], q_rows, (row_base + sel).to(torch.int32), 1 + N, pad_id=0, sep_id=102, ce_len=CL)
         q_ids, q_mask, c_ids, c_mask, _ = batch["student"]
         q, c = bi(q_ids, q_mask, c_ids, c_mask)
         if args.no_teacher:
@@ -210,6 +218,26 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # the same job on SURVEY 8d's realistic length distribution (the packed layout skips pad tokens; the reference pads
+    # to q32/p128 regardless).  Reported beside the headline, never as `value`.
+    real = None
+    if not args.varlen and not args.no_realistic:
+        build_pool(False)
+        for _ in range(2):
+            one_step()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(4):
+            one_step()
+        sync()
+        dr = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([dr], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dr = float(tt.item())
+        real = {"value": round(world * P * 4 / dr, 1), "ms_per_step": round(dr / 4 * 1e3, 2), "steps": 4,
+                "lengths": "query ~ N(9,3) clipped to [4,32], passage ~ N(80,25) clipped to [16,128] (SURVEY 8d)",
+                "real_token_fraction": round(float((np.sum(pool["ql"]) / (B * QL) * B * QL + np.mean(pool["pl"]) * P) / (B * QL + P * PL)), 3)}
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -234,6 +262,8 @@ def main():
            "algorithmic_tflop_per_step_per_gpu": {"student_fwd_bwd": round(stu / 1e12, 2), "teacher_fwd": round(tea / 1e12, 2)},
            "step_mfma_util": round((stu + tea) / (ms_step * 1e-3) / 2.5e15, 4) if args.dtype == "bf16" and not args.varlen else None,
            "final_loss": round(final_loss, 5)}
+    if real is not None:
+        out["realistic_lengths"] = real
     if prof and "gemm_nt" in prof:
         c_, ms_, wk_ = prof["gemm_nt"]
         ach = wk_ / (ms_ * 1e-3) / 1e12

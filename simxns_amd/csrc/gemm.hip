@@ -755,6 +755,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
   acc[I][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B3, AF, acc[I][3], 0, 0, 0)
 #define V3_RD1(F, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=&v"(F) : "v"(ADDR) : "memory")
 #define V3_SB __builtin_amdgcn_sched_barrier(0)
+#if defined(SIMX_P3_NOBARRIER)        /* timing experiment only: results are wrong without the barrier */
+#define P3_BOUNDARY_WAIT() asm volatile("s_waitcnt vmcnt(4)" ::: "memory")
+#elif defined(SIMX_P3_NOWAIT)
+#define P3_BOUNDARY_WAIT() asm volatile("s_barrier" ::: "memory")
+#else
+#define P3_BOUNDARY_WAIT() asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory")
+#endif
+#ifdef SIMX_P3_NOLGKM                   /* timing experiment only */
+#define P3_LGKM_WAIT ""
+#else
+#define P3_LGKM_WAIT "s_waitcnt lgkmcnt(0)"
+#endif
 #ifndef SIMX_P3_SCHED
 #define SIMX_P3_SCHED 1
 #endif
@@ -775,7 +787,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
     V3_SB; V3_MFMA_ROW(3, al3, BC0, BC1, BC2, BC3);                                            \
     V3_SB;                                                                                     \
     P3_PRIO(0);                                                                                \
-    V3_PIN4("s_waitcnt lgkmcnt(0)", ah0, ah1, ah2, ah3);                                       \
+    V3_PIN4(P3_LGKM_WAIT, ah0, ah1, ah2, ah3);                                       \
     BOUNDARY();                                                                                \
     P3_PRIO(1);                                                                                \
     V3_SB; V3_MFMA_ROW(4, ah0, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al0, na__, 0); V3_RD1(BN0, nb__, 0); V3_RD1(al1, na__, 2048);       \
@@ -784,7 +796,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
     V3_SB; V3_MFMA_ROW(7, ah3, BC0, BC1, BC2, BC3);                                            \
     V3_SB;                                                                                     \
     P3_PRIO(0);                                                                                \
-    V3_PIN8("s_waitcnt lgkmcnt(0)", al0, al1, al2, al3, BN0, BN1, BN2, BN3);                   \
+    V3_PIN8(P3_LGKM_WAIT, al0, al1, al2, al3, BN0, BN1, BN2, BN3);                   \
   } while (0)
 #else
 #define P_STEP(CURA, NA, NB, BC0, BC1, BC2, BC3, BN0, BN1, BN2, BN3, BOUNDARY)                   \
@@ -812,7 +824,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
 #define P_BND_MID()                                                                            \
   do {                                                                                         \
     /* issue order so far: ... [B(st+1) A(st+2)] ; stage st+1 = everything but the 4 youngest (A(st+2)) */ \
-    asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");                              \
+    P3_BOUNDARY_WAIT();                                                                        \
     const bool cb__ = st + 2 < nst, ca__ = st + 3 < nst;                                       \
     p3_half(B, ldb, cb__ ? n0 : n0n, (cb__ ? st + 2 : st + 2 - nst) * 64, ldsB + (uint32_t)(bc * 32768), wave, offB0, offB1); \
     p3_half(A, lda, ca__ ? m0 : m0n, (ca__ ? st + 3 : st + 3 - nst) * 64, lds0 + (uint32_t)(ac * 32768), wave, offA0, offA1); \
@@ -1108,28 +1120,39 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(
 #define TN2_STAGE 65536
 #define TN2_LDS (2 * TN2_STAGE)
 
+// (LDS-DMA in the compiler-invisible asm form: with the builtin hipcc assumes every later LDS read may alias the pending
+// DMA and waits vmcnt(0) before it; the transpose reads below are BUILTINS so that hipcc allocates both halves of a
+// fragment into one 128-bit register tuple and places counted lgkmcnt waits itself -- the inline-asm reads cost 136
+// v_mov per stage to assemble the tuples, more VALU time than the MFMAs of a k-step.)
 __device__ __forceinline__ void tn2_stage(const bf16_t* __restrict__ A, int lda, int m0, int M,
                                           const bf16_t* __restrict__ B, int ldb, int n0, int N, int k0, int k_end,
                                           char* stage, int wave, int lane) {
+  const uint32_t sbase = (uint32_t)(uintptr_t)stage;
+  const char* ga = reinterpret_cast<const char*>(A + (long)k0 * lda);
+  const char* gb = reinterpret_cast<const char*>(B + (long)k0 * ldb);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {                 // 32 wave-instructions of 2 k-rows per operand
     const int i = wave * 4 + j;
     const int kr = i * 2 + (lane >> 5);
     const int p16 = lane & 31;
     const int q = (p16 >> 1) ^ (kr & 7);
-    int gk = k0 + kr;
-    gk = gk < k_end ? gk : k_end - 1;
+    int rk = kr;                                 // row relative to k0, clamped into the k-range (ragged tail rows are zeroed later)
+    rk = k0 + rk < k_end ? rk : k_end - 1 - k0;
     int ca = m0 + q * 16 + (p16 & 1) * 8, cb = n0 + q * 16 + (p16 & 1) * 8;
     ca = ca + 8 <= M ? ca : M - 8;
     cb = cb + 8 <= N ? cb : N - 8;
-    glds16(A + (long)gk * lda + ca, stage + i * 1024);
-    glds16(B + (long)gk * ldb + cb, stage + 32768 + i * 1024);
+    P_DMA16((uint32_t)(rk * lda + ca) * 2, ga, sbase + (uint32_t)(i * 1024));
+    P_DMA16((uint32_t)(rk * ldb + cb) * 2, gb, sbase + (uint32_t)(32768 + i * 1024));
   }
 }
 
 // one fragment = two transpose reads (k rows base+4g.. and base+16+4g..)
+typedef __attribute__((address_space(3))) bf16x4* tn_lds4_t;
 #define TN2_RD(F_LO, F_HI, ADDR_LO, ADDR_HI)                                                        \
-  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3" : "=&v"(F_LO), "=&v"(F_HI) : "v"(ADDR_LO), "v"(ADDR_HI) : "memory")
+  do {                                                                                              \
+    F_LO = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tn_lds4_t)(uintptr_t)(ADDR_LO));                \
+    F_HI = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tn_lds4_t)(uintptr_t)(ADDR_HI));                \
+  } while (0)
 
 __global__ __launch_bounds__(512, 2) void gemm_tn2_bf16_kernel(
     int M, int N, int K, const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
@@ -1139,8 +1162,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_bf16_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int split = blockIdx.x / tiles_mn;
-  const int tile = blockIdx.x % tiles_mn;
+  // XCD-aware order: block b runs on XCD b%8 (private L2).  The tiles of one split read the same token range: the
+  // tiles_n workgroups of an M-tile share its dY slab, the tiles_m of an N-tile its X slab.  In launch order those
+  // sharers sit on 8 different XCDs and every slab is fetched from the fabric once per sharer (PMC: 22 % L2 hits,
+  // ~6 TB/s of fabric reads = what bounded this kernel); giving each XCD a contiguous range of (split, tile) puts them
+  // behind one L2.
+  const int vb = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = vb / tiles_mn;
+  const int tile = vb % tiles_mn;
   const int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
   const int wr = wave >> 2, wc = wave & 3;
   const int kb = split * k_per_split;
@@ -1190,8 +1219,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_bf16_kernel(
     }                                                                                                           \
   } while (0)
 #define TN2_SB __builtin_amdgcn_sched_barrier(0)
-#define TN2_PIN8(TXT, X, Y)                                                                                     \
-  asm volatile(TXT : "+v"(X[0]), "+v"(X[1]), "+v"(X[2]), "+v"(X[3]), "+v"(Y[0]), "+v"(Y[1]), "+v"(Y[2]), "+v"(Y[3])::"memory")
+#define TN2_PIN8(TXT, X, Y) do { } while (0)     /* waits are hipcc's (counted lgkmcnt): the reads are builtins */
 
   {
     // A[0..3] and B of k-step 0: column tile index ct = (wave col offset)/16 + i

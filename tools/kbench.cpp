@@ -11,6 +11,7 @@
 #define SX(x) do { int r = (x); if (r) { printf("simx error %d: %s (line %d)\n", r, simx_last_error(), __LINE__); exit(1);} } while (0)
 
 static void* dalloc(size_t bytes, int fill) {
+  if (getenv("KB_ZERO")) fill = 0;                 // power experiment: all-zero operands (DVFS give-back, MI355X_MICROARCH.md)
   void* p; CK(hipMalloc(&p, bytes));
   std::vector<unsigned short> h(1 << 20);
   for (size_t i = 0; i < h.size(); ++i) { float f = ((int)((i * 2654435761u) >> 20 & 1023) - 512) / 1024.0f * (fill ? 1.f : 0.f); unsigned u; memcpy(&u, &f, 4); h[i] = (unsigned short)(u >> 16); }

@@ -260,3 +260,59 @@ def test_tiny_teacher_step_bf16(dev, golden_dir):
         g, ref = grads[k].ravel(), G["tgrad." + k].ravel()
         cos = float(g @ ref / (np.linalg.norm(g) * np.linalg.norm(ref) + 1e-30))
         assert cos >= 0.98, "teacher grad %s cosine %.4f" % (k, cos)
+
+
+# ------------------------------------------------------------------------------------------ BERT-large geometry (configs 4 / 5)
+def test_large_hidden_geometry_against_oracle(dev):
+    """H=1024, 16 heads, F=4096 (ernie-large / BERT-large layer geometry, two layers), passages of 512 tokens and
+    queries of 128: the f32 engine against the oracle (forward, loss, a few gradients), and bf16 against f32."""
+    from oracle import bert as ob
+    from oracle import losses as ol
+    from oracle.weights import BertCfg, make_bert_params, make_batch
+    from simxns_amd import ops
+    from simxns_amd.engine import BertConfigLite
+    from simxns_amd.model.models import BiBertEncoder, HFBertEncoder
+    ocfg = BertCfg(vocab=2000, hidden=1024, layers=2, heads=16, inter=4096, max_pos=512)
+    cfg = BertConfigLite(vocab_size=2000, hidden_size=1024, num_hidden_layers=2, num_attention_heads=16, intermediate_size=4096,
+                         max_position_embeddings=512, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    Pq, Pc = make_bert_params(ocfg, 31, std=0.03), make_bert_params(ocfg, 32, std=0.03)
+    B, N = 2, 2
+    q_ids, q_mask, _ = make_batch(41, B, 128, ocfg.vocab, 40, 20, 8)
+    c_ids, c_mask, _ = make_batch(42, B * (1 + N), 512, ocfg.vocab, 300, 120, 64)
+    z = np.linspace(-1, 1, B * (1 + N)).reshape(B, 1 + N)
+    _, oq, cq = ob.bert_forward(Pq, q_ids, q_mask, ocfg.heads)
+    _, oc, cc = ob.bert_forward(Pc, c_ids, c_mask, ocfg.heads)
+    osim = ol.sim_block(oq, oc)
+    oloss, _, ods = ol.kl_distill(osim, z)
+    dq, dc = ol.sim_block_bwd(oq, oc, ods)
+    Gc = ob.bert_backward(Pc, c_ids, c_mask, ocfg.heads, cc, dc)
+    res = {}
+    for dtype in ("fp32", "bf16"):
+        bi = BiBertEncoder.__new__(BiBertEncoder)
+        torch.nn.Module.__init__(bi)
+        bi.question_model, bi.ctx_model = HFBertEncoder(cfg, dtype), HFBertEncoder(cfg, dtype)
+        bi.question_model.load_numpy_state(Pq)
+        bi.ctx_model.load_numpy_state(Pc)
+        bi.to(dev)
+        t = lambda a: torch.from_numpy(a).to(dev)
+        q, c = bi(t(q_ids), t(q_mask), t(c_ids), t(c_mask))
+        loss, _, sim = ops.kl_distill_loss(q, c, t(z).float())
+        loss.backward()
+        torch.cuda.synchronize()
+        g = dict(bi.ctx_model.named_parameters())
+        res[dtype] = (q.detach().cpu().numpy(), c.detach().cpu().numpy(), loss.item(),
+                      {k: g[k].grad.cpu().numpy().astype(np.float64) for k in ("encoder.layer.1.output.dense.weight",
+                                                                               "encoder.layer.0.attention.self.query.weight",
+                                                                               "embeddings.position_embeddings.weight")})
+    q32, c32, l32, g32 = res["fp32"]
+    _close(q32, oq, 1e-3, "q_emb H=1024"); _close(c32, oc, 1e-3, "ctx_emb H=1024 S=512")
+    assert abs(l32 - oloss) <= 1e-3
+    gmax = max(np.abs(v).max() for v in Gc.values())
+    for k, g in g32.items():
+        assert np.abs(g - Gc[k]).max() <= 5e-4 * np.abs(Gc[k]).max() + 1e-5 * gmax, k
+    q16, c16, l16, g16 = res["bf16"]
+    _close(q16, oq, 1e-1, "q_emb bf16"); _close(c16, oc, 1e-1, "ctx_emb bf16")
+    for k, g in g16.items():
+        ref = Gc[k].ravel()
+        cos = float(g.ravel() @ ref / (np.linalg.norm(g) * np.linalg.norm(ref) + 1e-30))
+        assert cos >= 0.97, "%s cosine %.4f" % (k, cos)

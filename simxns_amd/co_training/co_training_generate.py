@@ -170,14 +170,20 @@ def load_pos_examples(path):
 
 
 def main():
+    """Flags of the reference's generate jobs (co_training_marco_generate.py:222-252, 327-362): --passage_path is the data
+    DIRECTORY (para.txt, para.title.txt, qrels.{train,dev}.tsv inside), the model is output_dir/checkpoint-<global_step>,
+    the mined file goes to --ann_dir."""
     ap = argparse.ArgumentParser()
     A = ap.add_argument
-    A("--model_type", required=True); A("--eval_model_dir", default=None); A("--output_dir", required=True)
-    A("--passage_path", required=True); A("--passage_title_path", default=None)
-    A("--train_qa_path", default=None); A("--train_golden_path", default=None)
-    A("--dev_qa_path", default=None); A("--dev_golden_path", default=None)
-    A("--global_step", type=int, default=0); A("--fp16", action="store_true"); A("--local_rank", type=int, default=-1)
-    A("--tokenizer_name", default="hash"); A("--share_weight", action="store_true")
+    A("--model_type", required=True); A("--model_name_or_path", default=None); A("--output_dir", required=True)
+    A("--passage_path", required=True); A("--ann_dir", default="")
+    A("--train_qa_path", default=None); A("--dev_qa_path", default=None)
+    A("--global_step", type=int, default=0); A("--fp16", action="store_true")
+    A("--local_rank", "--local-rank", dest="local_rank", type=int, default=-1)
+    A("--tokenizer_name", default=""); A("--share_weight", action="store_true")
+    for ignored in ("--max_seq_length", "--max_steps", "--adv_step", "--iteration_step", "--iteration_reranker_step"):
+        A(ignored, type=int, default=0)
+    A("--log_dir", default=None); A("--gradient_checkpointing", action="store_true")
     args = ap.parse_args()
     logging.basicConfig(level=logging.INFO)
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
@@ -188,21 +194,26 @@ def main():
     if world > 1:
         dist.init_process_group(backend="nccl", device_id=device)
         group = dist.group.WORLD
-    os.makedirs(args.output_dir, exist_ok=True)
-    args.gradient_checkpointing = False
+    ann_dir = args.ann_dir or args.output_dir
+    os.makedirs(ann_dir, exist_ok=True)
     model = BiBertEncoder(args).to(device).eval()
-    if args.eval_model_dir:
-        get_model_obj(model).load_state_dict(load_states_from_checkpoint(args.eval_model_dir).model_dict, strict=False)
+    ckpt = os.path.join(args.output_dir, "checkpoint-" + str(args.global_step))
+    for path in (ckpt, args.model_name_or_path):
+        if path and os.path.exists(path):
+            get_model_obj(model).load_state_dict(load_states_from_checkpoint(path).model_dict, strict=False)
+            break
     if args.tokenizer_name == "hash":
         tok = HashTokenizer(model.question_model.config.vocab_size)
     else:
         from transformers import BertTokenizer
-        tok = BertTokenizer.from_pretrained(args.tokenizer_name)
-    tools = RenewTools(args.passage_path, tok, args.output_dir, args.passage_title_path)
+        tok = BertTokenizer.from_pretrained(args.tokenizer_name or "bert-base-uncased", do_lower_case=True)
+    data_dir = args.passage_path
+    tools = RenewTools(os.path.join(data_dir, "para.txt"), tok, ann_dir, os.path.join(data_dir, "para.title.txt"))
     index = tools.build_index(model, device, rank, world)
-    for mode, qa, gold in (("train", args.train_qa_path, args.train_golden_path), ("dev", args.dev_qa_path, args.dev_golden_path)):
+    for mode, qa in (("train", args.train_qa_path), ("dev", args.dev_qa_path)):
         if qa:
-            pos = load_pos_examples(gold) if gold else {}
+            gold = os.path.join(data_dir, "qrels.%s.tsv" % mode)
+            pos = load_pos_examples(gold) if os.path.exists(gold) else {}
             tools.get_question_topk(model, device, index, qa, gold, pos, None, mode, args.global_step, group)
     if world > 1:
         dist.barrier()

@@ -57,7 +57,14 @@ def _save_checkpoint(args, model, optimizer, scheduler, step, name="checkpoint-"
     return cp
 
 
-def train(args, model, teacher_model, tokenizer, global_step=0):
+def _bi_encode(model, q_ids, q_mask, c_ids, c_mask):
+    return model(q_ids, q_mask, c_ids, c_mask)
+
+
+def train(args, model, teacher_model, tokenizer, global_step=0, dataset_cls=Rocketqa_v2Dataset, dataset_kwargs=None,
+          encode_pair=_bi_encode):
+    """``dataset_cls`` / ``dataset_kwargs`` / ``encode_pair`` let the MS-Doc job (Doc_training/co_training_doc_train.py:
+    RobertaDot + Doc_v2Dataset) reuse this loop; the defaults are the MS-Pas job."""
     tb_writer = None
     if is_first_worker():
         try:
@@ -89,11 +96,11 @@ def train(args, model, teacher_model, tokenizer, global_step=0):
                           load_states_from_checkpoint(os.path.join(args.output_dir, 'checkpoint-reranker' + str(global_step))))
     else:
         train_data_path = args.origin_data_dir
-    train_dataset = Rocketqa_v2Dataset(train_data_path, tokenizer, num_hard_negatives=args.number_neg,
-                                       trainer_id=max(args.local_rank, 0), trainer_num=world,
-                                       corpus_path=args.passage_path, rand_pool=100)
+    train_dataset = dataset_cls(train_data_path, tokenizer, num_hard_negatives=args.number_neg,
+                                trainer_id=max(args.local_rank, 0), trainer_num=world,
+                                corpus_path=args.passage_path, rand_pool=100, **(dataset_kwargs or {}))
     train_dataloader = DataLoader(train_dataset, sampler=RandomSampler(train_dataset),
-                                  collate_fn=Rocketqa_v2Dataset.get_collate_fn(args),
+                                  collate_fn=dataset_cls.get_collate_fn(args),
                                   batch_size=args.train_batch_size, num_workers=args.num_workers)
     it = iter(train_dataloader)
     logger.info("***** Running training *****  max steps %d, per-GPU batch %d, accumulation %d, examples %d",
@@ -113,7 +120,7 @@ def train(args, model, teacher_model, tokenizer, global_step=0):
         if train_flag == 0:                                       # retriever step: teacher distils the student
             model.train()
             teacher_model.eval()
-            local_q_vector, local_ctx_vectors = model(q_ids, q_mask, c_ids, c_mask)
+            local_q_vector, local_ctx_vectors = encode_pair(model, q_ids, q_mask, c_ids, c_mask)
             with torch.no_grad():
                 relevance_logits = teacher_model(t_ids, t_mask)
             # einsum + softmax + KLDivLoss(batchmean)((p+1e-7).log(), softmax(z/T)) / accum : one kernel (:199-217)

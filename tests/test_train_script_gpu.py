@@ -133,3 +133,46 @@ def test_generate_job_mines_hard_negatives_file(dev, tmp_path):
     ds = Rocketqa_v2Dataset(path, tok, num_hard_negatives=7, corpus_path=root)
     q, ctx, ce = ds[0]
     assert tuple(ctx.shape) == (8, 128) and tuple(ce.shape) == (8, 160)
+
+
+def test_ms_doc_train_job(dev, tmp_path):
+    """MS-MARCO Document job: shared RobertaDot student + RoBERTa cross-encoder teacher + Doc_v2Dataset (Gaussian SimANS
+    weights, pad id 1, q128 / d512) through the retriever and teacher phases, CheckpointState files with the
+    reference's key schema (roberta.* / embeddingHead.* / norm.*)."""
+    from simxns_amd.Doc_training import co_training_doc_train as D
+    from simxns_amd.utils.dpr_utils import load_states_from_checkpoint
+    root = str(tmp_path / "doc")
+    os.makedirs(root)
+    rs = np.random.RandomState(2)
+    words = ["w%d" % i for i in range(400)]
+    with open(os.path.join(root, "msmarco-docs.tsv"), "w") as f:
+        for pid in range(200):
+            f.write("D%d\thttp://u/%d\t%s\t%s\n" % (pid, pid, " ".join(rs.choice(words, size=4)), " ".join(rs.choice(words, size=rs.randint(30, 400)))))
+    with open(os.path.join(root, "train_ce_0.tsv"), "w") as f:
+        for q in range(16):
+            pids = rs.choice(200, size=21, replace=False)
+            sp = 70 + 20 * rs.rand()
+            sc = np.sort(sp - np.abs(rs.randn(20)) * 1.5)[::-1]
+            f.write("%d\t%s\t%d %.4f\t%s\n" % (q, " ".join(rs.choice(words, size=7)), pids[0], sp,
+                                               ",".join("%d %.4f" % (p, s) for p, s in zip(pids[1:], sc))))
+    for name in ("student", "teacher"):
+        d = os.path.join(root, name)
+        os.makedirs(d)
+        json.dump(dict(vocab_size=50265, hidden_size=64, num_hidden_layers=2, num_attention_heads=1, intermediate_size=128,
+                       max_position_embeddings=514, type_vocab_size=1, layer_norm_eps=1e-5, model_type="roberta", pad_token_id=1),
+                  open(os.path.join(d, "config.json"), "w"))
+    out = str(tmp_path / "ckpt")
+    gs = D.main(["--model_type", os.path.join(root, "student"), "--teacher_model_type", os.path.join(root, "teacher"),
+                 "--tokenizer_name", "hash", "--per_gpu_train_batch_size", "2", "--number_neg", "3", "--learning_rate", "1e-3",
+                 "--teacher_learning_rate", "1e-4", "--output_dir", out, "--log_dir", str(tmp_path / "tb"),
+                 "--origin_data_dir", os.path.join(root, "train_ce_0.tsv"), "--passage_path", root, "--logging_steps", "2",
+                 "--save_steps", "1000", "--max_steps", "12", "--iteration_step", "6", "--iteration_reranker_step", "2",
+                 "--temperature_distill", "1", "--ann_dir", root, "--num_workers", "0", "--fp16", "--global_step", "0",
+                 "--a", "0.5", "--b", "0"])
+    assert gs == 6
+    st = load_states_from_checkpoint(os.path.join(out, "checkpoint-6"))
+    assert "roberta.encoder.layer.1.output.dense.weight" in st.model_dict and "embeddingHead.weight" in st.model_dict
+    assert "norm.bias" in st.model_dict and not any("pooler" in k for k in st.model_dict)
+    assert all(torch.isfinite(v).all() for v in st.model_dict.values())
+    tst = load_states_from_checkpoint(os.path.join(out, "checkpoint-reranker6"))
+    assert "qa_classifier.weight" in tst.model_dict

@@ -1,8 +1,7 @@
 #!/bin/bash
 # AR2 + SimANS on MS-MARCO Passage -- same entrypoint name, loop and flags as SimANS/train_MS_Pas_AR2.sh; the train job
-# runs on the MI355X engine (simxns_amd).  The generate job (corpus re-encoding + top-k mining that writes
-# ckpt/$EXP_NAME/temp/train_ce_<step>.tsv) is not part of this engine yet (DESIGN.md section 7, row f): run the
-# reference's co_training_marco_generate.py for it, or set SIMX_GENERATE_CMD.
+# and the generate job (corpus re-encoding + exhaustive top-k mining that writes ckpt/$EXP_NAME/temp/train_ce_<step>.tsv)
+# both run on the MI355X engine (simxns_amd).
 EXP_NAME=co_training_MS_MARCO_Pas_SimANS
 Iteration_step=5000
 Iteration_reranker_step=500
@@ -32,9 +31,18 @@ do
     --temperature_distill=1 --ann_dir=ckpt/$EXP_NAME/temp --adv_lambda 1 --global_step=$global_step
 
     g_global_step=`expr $global_step + $Iteration_step`
-    if [ -n "$SIMX_GENERATE_CMD" ]; then
-        $SIMX_GENERATE_CMD --global_step=$g_global_step
-    else
-        echo "generate job for step $g_global_step: not provided by simxns_amd (set SIMX_GENERATE_CMD)"; break
-    fi
+    python -u -m torch.distributed.run --nproc_per_node=$NPROC --master-addr 127.0.0.1 --master_port=9539 \
+    simxns_amd/co_training/co_training_generate.py \
+    --model_type=Luyu/co-condenser-marco \
+    --max_seq_length=128 \
+    --output_dir=ckpt/$EXP_NAME \
+    --log_dir=tensorboard/logs/$EXP_NAME \
+    --train_qa_path=data/MS-Pas/train.query.txt \
+    --dev_qa_path=data/MS-Pas/dev.query.txt \
+    --passage_path=data/MS-Pas \
+    --max_steps=$MAX_STEPS \
+    --gradient_checkpointing --adv_step=0 \
+    --iteration_step=$Iteration_step \
+    --iteration_reranker_step=$Iteration_reranker_step \
+    --ann_dir=ckpt/$EXP_NAME/temp --global_step=$g_global_step
 done

@@ -45,7 +45,8 @@ const char* simx_last_error(void);
  * BertOutput (LEAD/modeling_bert.py:285-310, 385, 450, 463) and their backward. */
 enum { SIMX_EPI_NONE = 0,   /* C = acc (+bias) (+residual)                              */
        SIMX_EPI_GELU = 1,   /* C = acc + bias (pre-activation), C2 = gelu_erf(C)        */
-       SIMX_EPI_DGELU = 2   /* C = (acc (+residual)) * gelu_erf'(aux)                   */ };
+       SIMX_EPI_DGELU = 2,  /* C = (acc (+residual)) * gelu_erf'(aux)                   */
+       SIMX_EPI_GELU_INFER = 3 /* as GELU, but C is scratch: kernels may skip storing the pre-activation (no backward) */ };
 
 /* Dropout descriptor (nn.Dropout of BertEmbeddings / BertSelfAttention / BertSelfOutput / BertOutput,
  * LEAD/modeling_bert.py:239, 358, 386, 464; p = 0.1 forced in training, SimANS/model/models.py:70-72).

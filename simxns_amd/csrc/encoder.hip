@@ -234,8 +234,8 @@ extern "C" int simx_bert_fwd(simx_stream_t stream, const simx_bert_cfg* c, const
     RUN(simx_gemm_nt_ex(stream, dt, Tp, H, H, a.ctx, H, w.wo, H, a.z1, H, off(l, SIMX_P_BO), x, H, SIMX_EPI_NONE, nullptr, 0,
                         nullptr, 0, &d1));
     RUN(simx_ln_fwd(stream, dt, T, H, a.z1, off(l, SIMX_P_LN1_G), off(l, SIMX_P_LN1_B), c->eps, a.x1));
-    RUN(simx_gemm_nt(stream, dt, Tp, F, H, a.x1, H, w.w1, H, a.u, F, off(l, SIMX_P_B1), nullptr, 0, SIMX_EPI_GELU, nullptr, 0,
-                     a.h, F));
+    RUN(simx_gemm_nt(stream, dt, Tp, F, H, a.x1, H, w.w1, H, a.u, F, off(l, SIMX_P_B1), nullptr, 0,
+                     save ? SIMX_EPI_GELU : SIMX_EPI_GELU_INFER, nullptr, 0, a.h, F));   // no backward: u has no reader
     RUN(simx_gemm_nt_ex(stream, dt, Tp, H, F, a.h, F, w.w2, F, a.z2, H, off(l, SIMX_P_B2), a.x1, H, SIMX_EPI_NONE, nullptr, 0,
                         nullptr, 0, &d2));
     RUN(simx_ln_fwd(stream, dt, T, H, a.z2, off(l, SIMX_P_LN2_G), off(l, SIMX_P_LN2_B), c->eps, a.xout));

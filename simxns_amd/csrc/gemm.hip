@@ -906,6 +906,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
       const uint32_t eo0 = (uint32_t)(lr * ldc + ec0) * 2, eo1 = (uint32_t)((lr + 8) * ldc + ec1) * 2;
       const uint32_t io0 = HAS_IN ? (uint32_t)(lr * ldin + ec0) * 2 : 0, io1 = HAS_IN ? (uint32_t)((lr + 8) * ldin + ec1) * 2 : 0;
       bf16_t* const obase = C + (long)mw * ldc + nw;          // uniform
+      const bool store_pre = !(EPI == SIMX_EPI_GELU && ldin == 1);   // ldin == 1 on a GELU launch: SIMX_EPI_GELU_INFER
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const uint32_t sub = ereg + (uint32_t)((EPI == SIMX_EPI_GELU ? 0 : (i & 1)) * 2048);
@@ -957,8 +958,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
         u32x4 w0, w1;
         asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
                      : "=&v"(w0), "=&v"(w1) : "v"(rd) : "memory");
-        P_GST4(eo0, obase + (long)i * 16 * ldc, w0);
-        P_GST4(eo1, obase + (long)i * 16 * ldc, w1);
+        if (store_pre) {                                 // (inference GELU: the pre-activation has no reader)
+          P_GST4(eo0, obase + (long)i * 16 * ldc, w0);
+          P_GST4(eo1, obase + (long)i * 16 * ldc, w1);
+        }
         if (EPI == SIMX_EPI_GELU) {
           u32x4 w2, w3;
           asm volatile("ds_read_b128 %0, %2 offset:2048\n\tds_read_b128 %1, %2 offset:3072\n\ts_waitcnt lgkmcnt(0)"
@@ -1425,6 +1428,8 @@ extern "C" int simx_gemm_nt_ex(simx_stream_t stream, int dtype, int M, int N, in
   SIMX_PROF(SIMX_K_GEMM_NT, s, 2.0 * M * N * K);
   SIMX_REQUIRE(M > 0 && N > 0 && K > 0, SIMX_ERR_BAD_SHAPE, "gemm_nt: bad shape %d %d %d", M, N, K);
   SIMX_REQUIRE(lda >= K && ldb >= K && ldc >= N, SIMX_ERR_BAD_SHAPE, "gemm_nt: leading dims too small");
+  const bool gelu_infer = epilogue == SIMX_EPI_GELU_INFER;     // C is scratch: the kernel may skip writing the pre-activation
+  if (gelu_infer) epilogue = SIMX_EPI_GELU;
   SIMX_REQUIRE(epilogue >= 0 && epilogue <= 2, SIMX_ERR_UNSUPPORTED, "gemm_nt: epilogue %d", epilogue);
   SIMX_REQUIRE(epilogue != SIMX_EPI_GELU || C2, SIMX_ERR_BAD_SHAPE, "gemm_nt: GELU epilogue needs C2");
   SIMX_REQUIRE(epilogue != SIMX_EPI_DGELU || aux, SIMX_ERR_BAD_SHAPE, "gemm_nt: DGELU epilogue needs aux");
@@ -1496,7 +1501,7 @@ extern "C" int simx_gemm_nt_ex(simx_stream_t stream, int dtype, int M, int N, in
 #define LP3(E, HI, INP, LDI) hipLaunchKernelGGL((gemm_nt_bf16_p3_kernel<E, HI>), dim3(grid), dim3(512), P_LDS, s, M, N, K, (const bf16_t*)A, lda, \
                                  (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, (const bf16_t*)(INP), LDI, (bf16_t*)C2, ldc2, t3n, nwg3, drop)
         if (epilogue == SIMX_EPI_NONE) { if (residual) LP3(SIMX_EPI_NONE, true, residual, ldr); else LP3(SIMX_EPI_NONE, false, nullptr, 0); }
-        else if (epilogue == SIMX_EPI_GELU) LP3(SIMX_EPI_GELU, false, nullptr, 0);
+        else if (epilogue == SIMX_EPI_GELU) LP3(SIMX_EPI_GELU, false, nullptr, gelu_infer ? 1 : 0);
         else LP3(SIMX_EPI_DGELU, true, aux, ldaux);
 #undef LP3
         SIMX_CHECK_LAUNCH("gemm_nt_bf16_p3");

@@ -165,6 +165,7 @@ class BertEngine(object):
         self.anchor = torch.zeros((), requires_grad=True)
         self.dropout_seed = 0                # base seed of the stateless dropout masks (set_seed / manual)
         self.grad_ready_hook = None          # called after every backward (DP all-reduce launch)
+        self.last_stream = None              # stream of the last forward / backward (the optimiser joins it)
         self.after_backward = None           # module callback: expose flat_grad as param.grad views
 
     # ---- configuration -----------------------------------------------------------------
@@ -252,6 +253,7 @@ class BertEngine(object):
 
     def _run_backward(self, pb, act, dcls, ccfg=None):
         ccfg = ccfg if ccfg is not None else self.ccfg
+        self.last_stream = torch.cuda.current_stream()
         g = self.ensure_grad()
         dev = self.flat.device
         dcls = dcls.contiguous().to(torch.float32)

@@ -221,6 +221,19 @@ class BiBertEncoder(nn.Module):
     def forward(self, query_ids, attention_mask_q, input_ids_a=None, attention_mask_a=None, input_ids_b=None,
                 attention_mask_b=None):
         if input_ids_b is None:
+            if self._overlap_towers(query_ids):
+                # The query tower (B x 32 tokens) cannot fill 256 CUs: run it on a side stream beside the passage tower.
+                # Autograd replays each tower's backward on the stream its forward ran on, so the backward overlaps as
+                # well; FusedAdamW.step() joins the streams before it touches the gradients.
+                main = torch.cuda.current_stream()
+                side = self._side_stream(query_ids.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    q_embs = self.query_emb(query_ids, attention_mask_q)
+                a_embs = self.body_emb(input_ids_a, attention_mask_a)
+                main.wait_stream(side)
+                q_embs.record_stream(main)
+                return (q_embs, a_embs)
             q_embs = self.query_emb(query_ids, attention_mask_q)
             a_embs = self.body_emb(input_ids_a, attention_mask_a)
             return (q_embs, a_embs)
@@ -232,6 +245,16 @@ class BiBertEncoder(nn.Module):
         ab = torch.stack([a_embs, b_embs], dim=1).reshape(2 * B, -1)
         loss, _ = ops.pair_ce_loss(q_embs, ab)
         return (loss,)
+
+    def _overlap_towers(self, t):
+        return (t.is_cuda and self.question_model is not self.ctx_model and os.environ.get("SIMX_OVERLAP_TOWERS", "1") != "0")
+
+    def _side_stream(self, device):
+        st = getattr(self, "_side", None)
+        if st is None or st.device != device:
+            st = torch.cuda.Stream(device=device)
+            object.__setattr__(self, "_side", st)
+        return st
 
     def zero_grad(self, set_to_none=False):
         self.question_model.zero_grad()

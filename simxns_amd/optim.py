@@ -70,6 +70,11 @@ class FusedAdamW(object):
         lr = self.param_groups[0]["lr"]
         self.step_count += 1
         dev = self.towers[0][1].flat.device if self.towers else self.extra[0].device
+        cur = torch.cuda.current_stream()
+        for m, e in self.towers:                       # a tower's backward may have run on a side stream (BiBertEncoder)
+            st = getattr(e, "last_stream", None)
+            if st is not None and st != cur:
+                cur.wait_stream(st)
         s = L.stream_ptr()
         grad_scale = 1.0
         bufs = []

@@ -316,10 +316,12 @@ class CrossBERTKDLoss(object):
              loss_scale: float = None, LwF=False, ori_q_vector=None, ori_ctx_vectors=None):
         if getattr(args, "KD_type", "KD_softmax") != "KD_softmax":
             raise NotImplementedError("KD_type %r: only KD_softmax runs on the HIP path" % args.KD_type)
-        if LwF:
-            raise NotImplementedError("LwF term: not on the HIP path yet (oracle/losses.py::cross_kd restates it)")
         loss, correct, _, _ = ops.cross_kd_loss(q_vectors, ctx_vectors, relevance_logits, args.TEMPERATURE,
                                                 args.CE_WEIGHT, args.KD_WEIGHT)
+        if LwF:                                      # + LwF_WEIGHT * kd_loss(scores, scores of the frozen student) (:687-690, 748-750)
+            ori_scores = ops.block_scores(ori_q_vector, ori_ctx_vectors)
+            lwf, _, _, _ = ops.cross_kd_loss(q_vectors, ctx_vectors, ori_scores, args.TEMPERATURE, 0.0, args.LwF_WEIGHT)
+            loss = loss + lwf
         if loss_scale:
             loss = loss * loss_scale
         return loss, correct.to(torch.long)

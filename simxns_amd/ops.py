@@ -92,6 +92,13 @@ def cross_kd_loss(q, ctx_vectors, relevance_logits, temperature=4.0, ce_weight=0
     return loss, allv[3], allv[1], allv[2]
 
 
+def block_scores(q, ctx_vectors):
+    """einsum('bh,bdh->bd') of query b against ITS OWN 1+N passages (no grad): [B, 1+N] f32."""
+    with torch.no_grad():
+        _, _, sim = _SimLossFn.apply(q.detach(), ctx_vectors.detach(), None, _lp(L.LOSS_CE))
+    return sim
+
+
 def pair_ce_loss(q, ctx_vectors):
     """-log_softmax(einsum('bh,bdh->bd'))[:,0].mean() (BiBertEncoder triplet form, models.py:111-118)."""
     loss, allv, _ = _SimLossFn.apply(q, ctx_vectors, None, _lp(L.LOSS_CE))

@@ -256,3 +256,18 @@ def test_fused_normal_inbatch_loss_oracle(dev, G):
     _close(loss.item(), l2 + 0.2 * l3 / 2, what="L5 loss")
     assert int(correct.item()) == cc
     _close(tq.grad.cpu().numpy(), dq1 + 0.2 * dq2 / 2, what="L5 dq"); _close(tc.grad.cpu().numpy(), dc1 + 0.2 * dc2 / 2, what="L5 dc")
+
+
+def test_cross_kd_lwf_golden(dev, G):
+    """CrossBERTKDLoss.calc with the LwF term (kd_loss against the frozen student's scores) vs the imported reference."""
+    import types
+    from simxns_amd.model.models import CrossBERTKDLoss
+    tq, tc = _t(G["q"], dev, True), _t(G["c"], dev, True)
+    args = types.SimpleNamespace(KD_type="KD_softmax", TEMPERATURE=4.0, CE_WEIGHT=0.1, KD_WEIGHT=0.9, LwF_WEIGHT=1.0)
+    loss, correct = CrossBERTKDLoss().calc(args, tq, tc, _t(G["z"], dev), LwF=True, ori_q_vector=_t(G["qo"], dev),
+                                           ori_ctx_vectors=_t(G["co"], dev))
+    loss.backward()
+    _close(loss.item(), G["L3lwf_loss"], what="L3+LwF loss")
+    assert int(correct.item()) == int(G["L3lwf_correct"])
+    _close(tq.grad.cpu().numpy(), G["L3lwf_dq"], what="L3+LwF dq")
+    _close(tc.grad.cpu().numpy(), G["L3lwf_dc"], what="L3+LwF dc")

@@ -418,6 +418,271 @@ __global__ __launch_bounds__(256) void mha_bwd2_bf16_kernel(const bf16_t* __rest
   }
 }
 
+// ------------------------------------------------------------------------------------------ backward, long sequences
+// 256 < S <= 4096 (MS-Doc documents and BASELINE config 5 run at S = 512; the generic kernel took 95 % of a
+// fwd+bwd step there).  Q, K, V, dO of a whole sequence no longer fit the LDS, so the sequence is cut into chunks of
+// 256 tokens and the two gradients are computed by two launches of one template:
+//   DKV = false: block (seq, head, query chunk) keeps Q, dO of its chunk resident, walks the key chunks (K, V
+//                restaged per chunk) and accumulates dQ of its four query tiles per wave in registers;
+//   DKV = true : block (seq, head, key chunk) keeps K, V resident, walks the query chunks (Q, dO, lse, delta restaged)
+//                and accumulates dK, dV of its four key tiles per wave in registers (one wave per SIMD: 128 KB of LDS per
+//                block anyway, so the 512-register budget is there).
+// No atomics, no f32 scratch; the inner pair iteration is the one of mha_bwd2_bf16_kernel.
+#define AL_CH 256
+#define AL_TILE (16 * 16 * 128)          // one staged operand chunk: 256 rows x 128 B
+
+template <bool DKV>
+__global__ __launch_bounds__(256, 1) void mha_bwd_long_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ O,
+                                                              const float* __restrict__ lse, const bf16_t* __restrict__ dO,
+                                                              bf16_t* __restrict__ dqkv, const int* __restrict__ cu,
+                                                              int heads, int T, int nchunk, float scale, DropCtx drop) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mine = blockIdx.x % nchunk;                     // the chunk this block owns (queries for dQ, keys for dK/dV)
+  const int sh = blockIdx.x / nchunk;
+  const int seq = sh / heads, h = sh % heads;
+  const int t0 = cu[seq], len = cu[seq + 1] - t0;
+  const int own0 = mine * AL_CH;
+  if (own0 >= len) return;
+  const int ownlen = min(AL_CH, len - own0);
+  const int H = heads * 64, H3 = 3 * H;
+  const bf16_t* Qg = qkv + (long)t0 * H3 + h * 64;
+  const bf16_t* Kg = Qg + H;
+  const bf16_t* Vg = Kg + H;
+  const bf16_t* Og = O + (long)t0 * H + h * 64;
+  const bf16_t* dOg = dO + (long)t0 * H + h * 64;
+  char* sQ = smem;
+  char* sK = smem + AL_TILE;
+  char* sV = smem + 2 * AL_TILE;
+  char* sD = smem + 3 * AL_TILE;
+  float* sLse = reinterpret_cast<float*>(smem + 4 * AL_TILE);
+  float* sDel = sLse + AL_CH;
+  char* patch = smem + 4 * AL_TILE + 2 * AL_CH * 4 + wave * 2048;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const uint32_t patch_addr = lds0 + (uint32_t)(4 * AL_TILE + 2 * AL_CH * 4 + wave * 2048);
+  const int fr = lane & 15, fg = lane >> 4;
+  const float c2 = scale * LOG2E;
+  const int fsw = att_f(fr);
+  const uint32_t rf_lo = (uint32_t)(fr * 128 + ((fg ^ fsw) << 4)), rf_hi = (uint32_t)(fr * 128 + (((4 + fg) ^ fsw) << 4));
+  const int rr = 4 * fg + (fr >> 2), tsw = att_f(rr), tx = (fr & 3) >> 1;
+  uint32_t tr[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) tr[dt] = (uint32_t)(rr * 128 + (((dt * 2 + tx) ^ tsw) << 4) + (fr & 1) * 8);
+
+  // stage rows [r0, r0+n) of the query side (Q, dO, lse, delta) / key side (K, V); rows padded to a multiple of 32
+  auto stage_q = [&](int r0, int n) {
+    const int npad = ((n + 31) >> 5) << 5;
+    att_stage(Qg + (long)r0 * H3, H3, n, npad, sQ, wave, lane);
+    att_stage(dOg + (long)r0 * H, H, n, npad, sD, wave, lane);
+    for (int idx = tid; idx < npad * 2; idx += 256) {
+      const int r = idx >> 1, half = idx & 1;
+      float del = 0.f;
+      if (r < n) {
+        const bf16_t* po = Og + (long)(r0 + r) * H + half * 32;
+        const bf16_t* pd = dOg + (long)(r0 + r) * H + half * 32;
+#pragma unroll
+        for (int c = 0; c < 32; c += 8) {
+          const uint4 a = *reinterpret_cast<const uint4*>(po + c), b = *reinterpret_cast<const uint4*>(pd + c);
+          const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            del += __uint_as_float(aw[e] << 16) * __uint_as_float(bw[e] << 16) +
+                   __uint_as_float(aw[e] & 0xFFFF0000u) * __uint_as_float(bw[e] & 0xFFFF0000u);
+        }
+      }
+      del += __shfl_xor(del, 1, 64);
+      if (half == 0) {
+        sDel[r] = del;
+        sLse[r] = r < n ? lse[(long)h * T + t0 + r0 + r] * LOG2E : 0.f;
+      }
+    }
+  };
+  auto stage_k = [&](int r0, int n) {
+    const int npad = ((n + 31) >> 5) << 5;
+    att_stage(Kg + (long)r0 * H3, H3, n, npad, sK, wave, lane);
+    att_stage(Vg + (long)r0 * H3, H3, n, npad, sV, wave, lane);
+  };
+
+  if (!DKV) {
+    // ------------------------------------------------ dQ of query chunk `mine`
+    stage_q(own0, ownlen);
+    f32x4 dq[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dq[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nqt = (ownlen + 15) >> 4;
+    for (int kc = 0; kc * AL_CH < len; ++kc) {
+      const int k0 = kc * AL_CH, klen = min(AL_CH, len - k0);
+      const int nkp = (((klen + 15) >> 4) + 1) >> 1;
+      __syncthreads();                                     // everyone is done with the previous K, V chunk
+      stage_k(k0, klen);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      const bool full = (ownlen == AL_CH) && (klen == AL_CH);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int qt = wave + 4 * t;
+        if (qt >= nqt) continue;                           // wave-uniform
+        const int q = qt * 16 + fr;
+        bf16x8 qf0, qf1, df0, df1;
+        {
+          const uint32_t aq = lds0 + (uint32_t)(qt * 2048), ad = aq + 3 * AL_TILE;
+          A2_RD128(qf0, aq + rf_lo, 0); A2_RD128(qf1, aq + rf_hi, 0);
+          A2_RD128(df0, ad + rf_lo, 0); A2_RD128(df1, ad + rf_hi, 0);
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qf0), "+v"(qf1), "+v"(df0), "+v"(df1)::"memory");
+        }
+        const float lq = sLse[q], dq_ = sDel[q];
+        const bool qok = q < ownlen;
+        for (int kp = 0; kp < nkp; ++kp) {
+          const uint32_t bk = lds0 + (uint32_t)(AL_TILE + kp * 4096), bv = bk + AL_TILE;
+          bf16x8 k00, k01, k10, k11, v00, v01, v10, v11;
+          bf16x4 t0l, t0h, t1l, t1h, t2l, t2h, t3l, t3h;
+          A2_RD128(k00, bk + rf_lo, 0); A2_RD128(k01, bk + rf_hi, 0); A2_RD128(k10, bk + rf_lo, 2048); A2_RD128(k11, bk + rf_hi, 2048);
+          A2_RD128(v00, bv + rf_lo, 0); A2_RD128(v01, bv + rf_hi, 0); A2_RD128(v10, bv + rf_lo, 2048); A2_RD128(v11, bv + rf_hi, 2048);
+          A2_RDTR(t0l, bk + tr[0], 0); A2_RDTR(t0h, bk + tr[0], 2048); A2_RDTR(t1l, bk + tr[1], 0); A2_RDTR(t1h, bk + tr[1], 2048);
+          A2_RDTR(t2l, bk + tr[2], 0); A2_RDTR(t2h, bk + tr[2], 2048); A2_RDTR(t3l, bk + tr[3], 0); A2_RDTR(t3h, bk + tr[3], 2048);
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(k00), "+v"(k01), "+v"(k10), "+v"(k11), "+v"(v00), "+v"(v01), "+v"(v10), "+v"(v11)::"memory");
+          asm volatile("" : "+v"(t0l), "+v"(t0h), "+v"(t1l), "+v"(t1h), "+v"(t2l), "+v"(t2h), "+v"(t3l), "+v"(t3h)::"memory");
+          f32x4 ds[2];
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const int kt = 2 * kp + hf;
+            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf ? k10 : k00, qf0, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf ? k11 : k01, qf1, s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf ? v10 : v00, df0, dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf ? v11 : v01, df1, dp, 0, 0, 0);
+            float m4[4] = {1.f, 1.f, 1.f, 1.f};
+            if (drop.thr) drop_mult4(drop, (uint32_t)(h * T + t0 + own0 + q), (uint32_t)(k0 + kt * 16 + 4 * fg), m4);
+            float p[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(s[r] * c2 - lq);
+            if (!full) {
+              asm volatile("" ::: "memory");
+#pragma unroll
+              for (int r = 0; r < 4; ++r) p[r] = (kt * 16 + 4 * fg + r < klen && qok) ? p[r] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ds[hf][r] = p[r] * (dp[r] * m4[r] - dq_) * scale;
+          }
+          const bf16x8 dsf = pack8(ds[0], ds[1]);
+          dq[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(t0l, t0h), dsf, dq[t][0], 0, 0, 0);
+          dq[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(t1l, t1h), dsf, dq[t][1], 0, 0, 0);
+          dq[t][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(t2l, t2h), dsf, dq[t][2], 0, 0, 0);
+          dq[t][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(t3l, t3h), dsf, dq[t][3], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int qt = wave + 4 * t;
+      if (qt < nqt)
+        a2_store_tile(dq[t], patch, patch_addr, dqkv + (long)(t0 + own0 + qt * 16) * H3 + h * 64, H3, ownlen - qt * 16, lane);
+    }
+  } else {
+    // ------------------------------------------------ dK, dV of key chunk `mine`
+    stage_k(own0, ownlen);
+    f32x4 dk[4][4], dv[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) { dk[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    const int nkt = (ownlen + 15) >> 4;
+    for (int qc = 0; qc * AL_CH < len; ++qc) {
+      const int q0 = qc * AL_CH, qlen = min(AL_CH, len - q0);
+      const int nqp = (((qlen + 15) >> 4) + 1) >> 1;
+      __syncthreads();
+      stage_q(q0, qlen);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      const bool full = (ownlen == AL_CH) && (qlen == AL_CH);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int kt = wave + 4 * t;
+        if (kt >= nkt) continue;
+        const int key = kt * 16 + fr;
+        bf16x8 kf0, kf1, vf0, vf1;
+        {
+          const uint32_t ak = lds0 + (uint32_t)(AL_TILE + kt * 2048), av = ak + AL_TILE;
+          A2_RD128(kf0, ak + rf_lo, 0); A2_RD128(kf1, ak + rf_hi, 0);
+          A2_RD128(vf0, av + rf_lo, 0); A2_RD128(vf1, av + rf_hi, 0);
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf0), "+v"(kf1), "+v"(vf0), "+v"(vf1)::"memory");
+        }
+        const bool kok = key < ownlen;
+        for (int qp = 0; qp < nqp; ++qp) {
+          const uint32_t bq = lds0 + (uint32_t)(qp * 4096), bd = bq + 3 * AL_TILE;
+          const uint32_t bl = lds0 + (uint32_t)(4 * AL_TILE + (qp * 32 + 4 * fg) * 4);
+          bf16x8 q00, q01, q10, q11, d00, d01, d10, d11;
+          bf16x4 e0l, e0h, e1l, e1h, e2l, e2h, e3l, e3h, u0l, u0h, u1l, u1h, u2l, u2h, u3l, u3h;
+          f32x4 ls0, ls1, de0, de1;
+          A2_RD128(q00, bq + rf_lo, 0); A2_RD128(q01, bq + rf_hi, 0); A2_RD128(q10, bq + rf_lo, 2048); A2_RD128(q11, bq + rf_hi, 2048);
+          A2_RD128(d00, bd + rf_lo, 0); A2_RD128(d01, bd + rf_hi, 0); A2_RD128(d10, bd + rf_lo, 2048); A2_RD128(d11, bd + rf_hi, 2048);
+          asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %5\n\tds_read_b128 %3, %5 offset:64"
+                       : "=&v"(ls0), "=&v"(ls1), "=&v"(de0), "=&v"(de1) : "v"(bl), "v"(bl + (uint32_t)(AL_CH * 4)) : "memory");
+          A2_RDTR(e0l, bd + tr[0], 0); A2_RDTR(e0h, bd + tr[0], 2048); A2_RDTR(e1l, bd + tr[1], 0); A2_RDTR(e1h, bd + tr[1], 2048);
+          A2_RDTR(e2l, bd + tr[2], 0); A2_RDTR(e2h, bd + tr[2], 2048); A2_RDTR(e3l, bd + tr[3], 0); A2_RDTR(e3h, bd + tr[3], 2048);
+          A2_RDTR(u0l, bq + tr[0], 0); A2_RDTR(u0h, bq + tr[0], 2048); A2_RDTR(u1l, bq + tr[1], 0); A2_RDTR(u1h, bq + tr[1], 2048);
+          A2_RDTR(u2l, bq + tr[2], 0); A2_RDTR(u2h, bq + tr[2], 2048); A2_RDTR(u3l, bq + tr[3], 0); A2_RDTR(u3h, bq + tr[3], 2048);
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q00), "+v"(q01), "+v"(q10), "+v"(q11), "+v"(d00), "+v"(d01), "+v"(d10), "+v"(d11),
+                       "+v"(ls0), "+v"(ls1), "+v"(de0), "+v"(de1)::"memory");
+          asm volatile("" : "+v"(e0l), "+v"(e0h), "+v"(e1l), "+v"(e1h), "+v"(e2l), "+v"(e2h), "+v"(e3l), "+v"(e3h)::"memory");
+          asm volatile("" : "+v"(u0l), "+v"(u0h), "+v"(u1l), "+v"(u1h), "+v"(u2l), "+v"(u2h), "+v"(u3l), "+v"(u3h)::"memory");
+          f32x4 pp[2], ds[2];
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const int qt = 2 * qp + hf;
+            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf ? q10 : q00, kf0, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf ? q11 : q01, kf1, s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf ? d10 : d00, vf0, dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf ? d11 : d01, vf1, dp, 0, 0, 0);
+            const f32x4 lsv = hf ? ls1 : ls0, dev = hf ? de1 : de0;
+            float p[4], mm[4] = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(s[r] * c2 - lsv[r]);
+            if (!full) {
+              asm volatile("" ::: "memory");
+#pragma unroll
+              for (int r = 0; r < 4; ++r) p[r] = (qt * 16 + 4 * fg + r < qlen && kok) ? p[r] : 0.f;
+            }
+            if (drop.thr) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                mm[r] = drop_mult(drop, (uint32_t)(h * T + t0 + q0 + qt * 16 + 4 * fg + r), (uint32_t)(own0 + key));
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              pp[hf][r] = p[r] * mm[r];
+              ds[hf][r] = p[r] * (dp[r] * mm[r] - dev[r]) * scale;
+            }
+          }
+          const bf16x8 pf = pack8(pp[0], pp[1]);
+          const bf16x8 dsf = pack8(ds[0], ds[1]);
+          dv[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(e0l, e0h), pf, dv[t][0], 0, 0, 0);
+          dk[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(u0l, u0h), dsf, dk[t][0], 0, 0, 0);
+          dv[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(e1l, e1h), pf, dv[t][1], 0, 0, 0);
+          dk[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(u1l, u1h), dsf, dk[t][1], 0, 0, 0);
+          dv[t][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(e2l, e2h), pf, dv[t][2], 0, 0, 0);
+          dk[t][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(u2l, u2h), dsf, dk[t][2], 0, 0, 0);
+          dv[t][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(e3l, e3h), pf, dv[t][3], 0, 0, 0);
+          dk[t][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(u3l, u3h), dsf, dk[t][3], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int kt = wave + 4 * t;
+      if (kt < nkt) {
+        bf16_t* dstk = dqkv + (long)(t0 + own0 + kt * 16) * H3 + H + h * 64;
+        a2_store_tile(dk[t], patch, patch_addr, dstk, H3, ownlen - kt * 16, lane);
+        a2_store_tile(dv[t], patch, patch_addr, dstk + H, H3, ownlen - kt * 16, lane);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // generic kernels: one wave per query (fwd, dQ) / per key (dK,dV); any head_dim <= 128
 // ------------------------------------------------------------------------------------------
@@ -654,6 +919,20 @@ extern "C" int simx_mha_bwd_ex(simx_stream_t stream, int dtype, int nseq, int he
     else LB(16);
 #undef LB
     SIMX_CHECK_LAUNCH("mha_bwd_bf16");
+    return SIMX_OK;
+  }
+  if (dtype == SIMX_BF16 && d == 64) {                          // 256 < max_len <= 4096: chunked MFMA kernels
+    const int nchunk = cdiv(max_len, AL_CH);
+    const size_t ldsl = (size_t)4 * AL_TILE + 2 * AL_CH * sizeof(float) + 4 * 2048;
+    rc = set_lds(mha_bwd_long_kernel<false>, ldsl, "mha_bwd");
+    if (rc) return rc;
+    rc = set_lds(mha_bwd_long_kernel<true>, ldsl, "mha_bwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL((mha_bwd_long_kernel<false>), dim3(nseq * heads * nchunk), dim3(256), ldsl, s, (const bf16_t*)qkv, (const bf16_t*)ctx,
+                       lse, (const bf16_t*)dctx, (bf16_t*)dqkv, cu, heads, T, nchunk, scale, drop);
+    hipLaunchKernelGGL((mha_bwd_long_kernel<true>), dim3(nseq * heads * nchunk), dim3(256), ldsl, s, (const bf16_t*)qkv, (const bf16_t*)ctx,
+                       lse, (const bf16_t*)dctx, (bf16_t*)dqkv, cu, heads, T, nchunk, scale, drop);
+    SIMX_CHECK_LAUNCH("mha_bwd_long");
     return SIMX_OK;
   }
   const size_t lds = (size_t)(8 * 128 + 8 * max_len) * sizeof(float);

@@ -25,18 +25,20 @@ def _fixed_seed(enc, seed):
     enc.engine.call_cfg = call_cfg
 
 
-@pytest.mark.parametrize("dtype,heads,hidden", [("fp32", 4, 64), ("bf16", 1, 64), ("fp32", 1, 64)])
-def test_step_with_dropout_matches_oracle(dev, dtype, heads, hidden):
+@pytest.mark.parametrize("dtype,heads,hidden,p_len", [("fp32", 4, 64, 128), ("bf16", 1, 64, 128), ("fp32", 1, 64, 128),
+                                                    ("bf16", 2, 128, 600)])     # 600: chunked long-sequence attention backward
+def test_step_with_dropout_matches_oracle(dev, dtype, heads, hidden, p_len):
     from simxns_amd import ops
     from simxns_amd.engine import BertConfigLite
     from simxns_amd.model.models import BiBertEncoder, HFBertEncoder
-    ocfg = BertCfg(vocab=500, hidden=hidden, layers=2, heads=heads, inter=128, max_pos=160)
+    max_pos = max(160, p_len + 8)
+    ocfg = BertCfg(vocab=500, hidden=hidden, layers=2, heads=heads, inter=128, max_pos=max_pos)
     cfg = BertConfigLite(vocab_size=500, hidden_size=hidden, num_hidden_layers=2, num_attention_heads=heads, intermediate_size=128,
-                         max_position_embeddings=160, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+                         max_position_embeddings=max_pos, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
     Pq, Pc = make_bert_params(ocfg, 5, std=0.08), make_bert_params(ocfg, 6, std=0.08)
     B, N = 3, 3
     q_ids, q_mask, _ = make_batch(31, B, 32, 500, 9, 3, 4)
-    c_ids, c_mask, _ = make_batch(32, B * (1 + N), 128, 500, 60, 25, 16)
+    c_ids, c_mask, _ = make_batch(32, B * (1 + N), p_len, 500, 0.45 * p_len, 0.2 * p_len, 16)
     z = np.linspace(-1.5, 1.5, B * (1 + N)).reshape(B, 1 + N).astype(np.float32)
     bi = BiBertEncoder.__new__(BiBertEncoder)
     torch.nn.Module.__init__(bi)

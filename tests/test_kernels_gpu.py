@@ -323,7 +323,8 @@ def _mha_ref(qkv, lens, heads, d, dctx=None):
     (True, 3, 64, [9, 32, 4, 31]),              # NKT=2
     (True, 2, 64, [160, 129, 45]),              # NKT=10
     (True, 1, 64, [250, 200]),                  # NKT=16
-    (True, 1, 64, [300, 512, 33]),              # fwd NKT=32, bwd generic
+    (True, 1, 64, [300, 512, 33]),              # fwd NKT=32, bwd chunked (2 chunks of 256)
+    (True, 2, 64, [700, 257, 1024, 40, 256]),   # fwd generic, bwd chunked (up to 4 chunks, ragged tails, exact multiples)
 ])
 def test_mha_fwd_bwd(dev, bf16, heads, d, lens):
     lib = L()

@@ -12,7 +12,10 @@ from simxns_amd.model.models import HFBertEncoder
 
 dev = torch.device("cuda:0")
 nseq, S = int(sys.argv[1]) if len(sys.argv) > 1 else 128, 512
-cfg = BertConfigLite(hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, max_position_embeddings=514)
+large = len(sys.argv) > 2 and sys.argv[2] == "large"
+cfg = (BertConfigLite(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096,
+                      hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, max_position_embeddings=514) if large else
+       BertConfigLite(hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, max_position_embeddings=514))
 enc = HFBertEncoder(cfg, "bf16").to(dev).train()
 ids = torch.randint(1000, 30000, (nseq, S), device=dev)
 mask = torch.ones_like(ids)
@@ -28,5 +31,7 @@ dt = (time.perf_counter() - t0) / 2
 nk = L.load().simx_prof_kernel_count()
 cnt, ms, wk = (C.c_int32 * nk)(), (C.c_double * nk)(), (C.c_double * nk)()
 L.call("simx_prof_end", cnt, ms, wk)
-print("S=512 nseq=%d: %.1f ms per fwd+bwd" % (nseq, dt * 1e3))
+H, Lh, F = cfg.hidden_size, cfg.num_hidden_layers, cfg.intermediate_size
+fl = 3.0 * nseq * Lh * S * (8.0 * H * H + 4.0 * H * F + 4.0 * S * H)
+print("S=512 nseq=%d %s: %.1f ms per fwd+bwd = %.0f TFLOP/s algorithmic (%.1f%% of 2.5 PF)" % (nseq, "BERT-large" if large else "BERT-base", dt * 1e3, fl / dt / 1e12, fl / dt / 2.5e13))
 print({L.PROF_NAMES[k]: round(ms[k] / 2, 2) for k in range(nk) if cnt[k]})

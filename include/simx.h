@@ -146,6 +146,11 @@ int simx_ln_bwd(simx_stream_t stream, int dtype, int T, int H, const void* z,
 int simx_ln_bwd_ex(simx_stream_t stream, int dtype, int T, int H, const void* z,
                    const float* gamma, float eps, const void* dy, void* dz, void* dz_masked,
                    float* dgamma, float* dbeta, float* dbias, const simx_dropout* drop);
+/* same, for T rows that were gathered out of a larger tensor: the dropout mask of row r is the one of row row_keys[r]
+ * of that tensor (row_keys == NULL: identity).  Used by the encoder's [CLS]-only last layer. */
+int simx_ln_bwd_keyed(simx_stream_t stream, int dtype, int T, int H, const void* z,
+                      const float* gamma, float eps, const void* dy, void* dz, void* dz_masked,
+                      float* dgamma, float* dbeta, float* dbias, const simx_dropout* drop, const int32_t* row_keys);
 
 /* ------------------------------------------------------------ self-attention
  * BertSelfAttention core (LEAD/modeling_bert.py:318-374): softmax(QK^T/sqrt(d)) V per head,
@@ -173,6 +178,15 @@ int simx_cls_gather(simx_stream_t stream, int dtype, int nseq, int H, const int3
                     const void* x, float* cls);
 int simx_cls_scatter(simx_stream_t stream, int dtype, int nseq, int H, int T, const int32_t* cu_seqlens,
                      const float* dcls, void* dx);
+/* Row gather / scatter / dtype conversion: dst[dst_idx ? dst_idx[s] : s] = src[src_idx ? src_idx[s] : s], s < n, rows of
+ * H elements (sequence_output[:, 0, :] and its transpose for same-dtype tensors; SimANS/model/models.py:81). */
+int simx_rows_copy(simx_stream_t stream, int src_dtype, int dst_dtype, int n, int H, const int32_t* src_idx,
+                   const int32_t* dst_idx, const void* src, void* dst);
+/* z[s] = dropout(y[s]) + res[res_idx ? res_idx[s] : s] on n gathered rows; the mask of row s is the one of row
+ * key_idx[s] of the full tensor (BertSelfOutput / BertOutput before the LayerNorm, LEAD/modeling_bert.py:384-388,
+ * 462-466, restricted to the rows the path reads). */
+int simx_drop_residual_rows(simx_stream_t stream, int dtype, int n, int H, const void* y, const void* res,
+                            const int32_t* res_idx, const int32_t* key_idx, const simx_dropout* drop, void* z);
 
 /* ------------------------------------------------- whole-encoder driver (native runtime)
  * HFBertEncoder.forward (SimANS/model/models.py:77-82 -> HF BertModel.forward, spec
@@ -184,6 +198,11 @@ typedef struct simx_bert_cfg {
   float eps;
   float hidden_dropout, attn_dropout;   /* 0 = off (eval / parity mode) */
   uint32_t dropout_seed;                /* per forward call; the matching backward call must pass the same value */
+  /* 1: the caller only reads the [CLS] embedding (models.py:81 `sequence_output[:, 0, :]`), so the LAST layer's
+   * attention-output, LayerNorm and FFN blocks run on the nseq [CLS] rows only -- every other row of that layer's output
+   * is dead code on this path (it feeds neither cls_out nor any gradient).  cls_out and all gradients are unchanged;
+   * hidden_out must be NULL.  The matching backward call must pass the same value.  0: every row is computed. */
+  int32_t cls_only_last_layer;
 } simx_bert_cfg;
 
 enum { SIMX_P_WORD = 0, SIMX_P_POS, SIMX_P_TYPE, SIMX_P_EMB_LN_G, SIMX_P_EMB_LN_B,   /* layer = -1 */

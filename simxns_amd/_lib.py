@@ -25,7 +25,8 @@ class SimxError(RuntimeError):
 class BertCfg(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("layers", C.c_int32), ("hidden", C.c_int32), ("heads", C.c_int32),
                 ("inter", C.c_int32), ("vocab", C.c_int32), ("max_pos", C.c_int32), ("type_vocab", C.c_int32),
-                ("eps", C.c_float), ("hidden_dropout", C.c_float), ("attn_dropout", C.c_float), ("dropout_seed", C.c_uint32)]
+                ("eps", C.c_float), ("hidden_dropout", C.c_float), ("attn_dropout", C.c_float), ("dropout_seed", C.c_uint32),
+                ("cls_only_last_layer", C.c_int32)]
 
 
 class Dropout(C.Structure):
@@ -49,6 +50,7 @@ SIGNATURES = {
     "simx_embed_ln_fwd_ex": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _p, _dp]),
     "simx_embed_ln_bwd_ex": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _dp]),
     "simx_ln_bwd_ex": (_i, [_p, _i, _i, _i, _p, _p, _f, _p, _p, _p, _p, _p, _p, _dp]),
+    "simx_ln_bwd_keyed": (_i, [_p, _i, _i, _i, _p, _p, _f, _p, _p, _p, _p, _p, _p, _dp, _p]),
     "simx_mha_fwd_ex": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _dp]),
     "simx_mha_bwd_ex": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _dp]),
     "simx_gemm_tn_workspace_bytes": (_z, [_i, _i, _i]),
@@ -67,6 +69,8 @@ SIGNATURES = {
     "simx_mha_bwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p]),
     "simx_cls_gather": (_i, [_p, _i, _i, _i, _p, _p, _p]),
     "simx_cls_scatter": (_i, [_p, _i, _i, _i, _i, _p, _p, _p]),
+    "simx_rows_copy": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "simx_drop_residual_rows": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _dp, _p]),
     "simx_bert_param_count": (_z, [_cfgp]),
     "simx_bert_param_offset": (_z, [_cfgp, _i, _i]),
     "simx_bert_wcache_bytes": (_z, [_cfgp]),

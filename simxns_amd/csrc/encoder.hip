@@ -125,10 +125,14 @@ static size_t act_layer_bytes(const simx_bert_cfg* c, size_t T) {
 }
 extern "C" size_t simx_bert_act_bytes(const simx_bert_cfg* c, int T, int nseq, int save_for_bwd) {
   if (!cfg_ok(c) || T <= 0) return 0;
-  (void)nseq;
   const size_t Tp = (size_t)rows_cap(T);
   const size_t x0 = al(Tp * c->hidden * esz(c->dtype));
-  return x0 + (size_t)(save_for_bwd ? c->layers : 2) * act_layer_bytes(c, Tp);
+  const size_t n = nseq > 0 ? (size_t)nseq : Tp;
+  return x0 + (size_t)(save_for_bwd ? c->layers : 2) * act_layer_bytes(c, Tp) + 2 * al(n * c->hidden * esz(c->dtype));
+}
+// two [nseq,H] temporaries of the [CLS]-only last layer, behind the per-layer slots
+static char* act_extra(const simx_bert_cfg* c, void* act, size_t Tp, int save) {
+  return (char*)act + al(Tp * c->hidden * esz(c->dtype)) + (size_t)(save ? c->layers : 2) * act_layer_bytes(c, Tp);
 }
 static char* act_x0(void* act) { return (char*)act; }
 static ALayer alayer(const simx_bert_cfg* c, void* act, size_t T, int l, int save) {
@@ -157,10 +161,10 @@ static size_t tn_ws_max(const simx_bert_cfg* c, int T) {
 }
 extern "C" size_t simx_bert_bwd_scratch_bytes(const simx_bert_cfg* c, int T, int nseq) {
   if (!cfg_ok(c) || T <= 0) return 0;
-  (void)nseq;
   const size_t H = c->hidden, F = c->inter, e = esz(c->dtype);
   const size_t Tp = (size_t)rows_cap(T);
-  return 3 * al(Tp * H * e) + al(Tp * F * e) + al(Tp * 3 * H * e) + tn_ws_max(c, T);
+  const size_t n = nseq > 0 ? (size_t)nseq : Tp;
+  return 3 * al(Tp * H * e) + al(Tp * F * e) + al(Tp * 3 * H * e) + tn_ws_max(c, T) + 3 * al(n * H * e);
 }
 
 // ------------------------------------------------------------------------------------------ driver
@@ -224,6 +228,8 @@ extern "C" int simx_bert_fwd(simx_stream_t stream, const simx_bert_cfg* c, const
     RUN(simx_embed_ln_fwd_ex(stream, dt, T, H, ids, pos_ids, off(-1, SIMX_P_WORD), off(-1, SIMX_P_POS), off(-1, SIMX_P_TYPE),
                              off(-1, SIMX_P_EMB_LN_G), off(-1, SIMX_P_EMB_LN_B), c->eps, x, &d0));
   }
+  const bool cls_only = c->cls_only_last_layer != 0;
+  SIMX_REQUIRE(!(cls_only && hidden_out), SIMX_ERR_BAD_SHAPE, "bert_fwd: cls_only_last_layer leaves no full hidden state to return");
   for (int l = 0; l < c->layers; ++l) {
     const WLayer w = wlayer(c, params, wcache, l);
     const ALayer a = alayer(c, act, Tp, l, save);
@@ -231,6 +237,26 @@ extern "C" int simx_bert_fwd(simx_stream_t stream, const simx_bert_cfg* c, const
                      nullptr, 0, nullptr, 0));
     const simx_dropout d1 = drop_of(c, l, 1), d2 = drop_of(c, l, 2), d3 = drop_of(c, l, 3);
     RUN(simx_mha_fwd_ex(stream, dt, nseq, c->heads, d, cu, max_len, T, a.qkv, a.ctx, a.lse, &d3));
+    if (cls_only && l == c->layers - 1) {
+      // Last layer, [CLS] rows only: row s of every buffer below is the sequence's token 0 (row cu[s] of the full
+      // tensors).  Same arithmetic as the full path -- dropout masks stay keyed by the ORIGINAL row index -- on nseq rows:
+      // z1, x1, u, h, z2, xout of this layer hold [nseq, .] tensors in their usual slots.
+      const size_t e = esz(dt);
+      char* ctxc = act_extra(c, act, Tp, save);
+      char* ytmp = ctxc + al((size_t)nseq * H * e);
+      RUN(simx_rows_copy(stream, dt, dt, nseq, H, cu, nullptr, a.ctx, ctxc));
+      RUN(simx_gemm_nt(stream, dt, nseq, H, H, ctxc, H, w.wo, H, ytmp, H, off(l, SIMX_P_BO), nullptr, 0, SIMX_EPI_NONE, nullptr, 0,
+                       nullptr, 0));
+      RUN(simx_drop_residual_rows(stream, dt, nseq, H, ytmp, x, cu, cu, &d1, a.z1));
+      RUN(simx_ln_fwd(stream, dt, nseq, H, a.z1, off(l, SIMX_P_LN1_G), off(l, SIMX_P_LN1_B), c->eps, a.x1));
+      RUN(simx_gemm_nt(stream, dt, nseq, F, H, a.x1, H, w.w1, H, a.u, F, off(l, SIMX_P_B1), nullptr, 0, SIMX_EPI_GELU, nullptr, 0, a.h, F));
+      RUN(simx_gemm_nt(stream, dt, nseq, H, F, a.h, F, w.w2, F, ytmp, H, off(l, SIMX_P_B2), nullptr, 0, SIMX_EPI_NONE, nullptr, 0,
+                       nullptr, 0));
+      RUN(simx_drop_residual_rows(stream, dt, nseq, H, ytmp, a.x1, nullptr, cu, &d2, a.z2));
+      RUN(simx_ln_fwd(stream, dt, nseq, H, a.z2, off(l, SIMX_P_LN2_G), off(l, SIMX_P_LN2_B), c->eps, a.xout));
+      if (cls_out) RUN(simx_rows_copy(stream, dt, SIMX_F32, nseq, H, nullptr, nullptr, a.xout, cls_out));
+      return SIMX_OK;
+    }
     RUN(simx_gemm_nt_ex(stream, dt, Tp, H, H, a.ctx, H, w.wo, H, a.z1, H, off(l, SIMX_P_BO), x, H, SIMX_EPI_NONE, nullptr, 0,
                         nullptr, 0, &d1));
     RUN(simx_ln_fwd(stream, dt, T, H, a.z1, off(l, SIMX_P_LN1_G), off(l, SIMX_P_LN1_B), c->eps, a.x1));
@@ -275,8 +301,49 @@ extern "C" int simx_bert_bwd(simx_stream_t stream, const simx_bert_cfg* c, const
   char* tnws = dqkv + al((size_t)Tp * 3 * H * e);
   const size_t tnws_bytes = tn_ws_max(c, T);
 
-  RUN(simx_cls_scatter(stream, dt, nseq, H, T, cu, dcls, bufB));            // g_x = d(loss)/d(last hidden)
-  for (int l = c->layers - 1; l >= 0; --l) {
+  int l_top = c->layers - 1;
+  if (c->cls_only_last_layer) {
+    // mirror of the forward's [CLS]-only last layer: everything up to the attention core runs on nseq rows
+    const int l = l_top;
+    const WLayer w = wlayer(c, params, wcache, l);
+    const ALayer a = alayer(c, const_cast<void*>(act), Tp, l, 1);
+    const char* xin = l == 0 ? act_x0(const_cast<void*>(act)) : alayer(c, const_cast<void*>(act), Tp, l - 1, 1).xout;
+    const simx_dropout d1 = drop_of(c, l, 1), d2 = drop_of(c, l, 2), d3 = drop_of(c, l, 3);
+    char* dzm = hd ? bufC : bufA;
+    char* ctxc = tnws + tnws_bytes;
+    char* st1 = ctxc + al((size_t)nseq * H * e);
+    char* st2 = st1 + al((size_t)nseq * H * e);
+    RUN(simx_rows_copy(stream, SIMX_F32, dt, nseq, H, nullptr, nullptr, dcls, bufB));
+    RUN(simx_ln_bwd_keyed(stream, dt, nseq, H, a.z2, off(l, SIMX_P_LN2_G), c->eps, bufB, bufA, hd ? bufC : nullptr,
+                          goff(l, SIMX_P_LN2_G), goff(l, SIMX_P_LN2_B), goff(l, SIMX_P_B2), &d2, cu));
+    RUN(simx_gemm_nt(stream, dt, nseq, F, H, dzm, H, w.w2T, H, du, F, nullptr, nullptr, 0, SIMX_EPI_DGELU, a.u, F, nullptr, 0));
+    RUN(simx_gemm_tn(stream, dt, H, F, nseq, dzm, H, a.h, F, goff(l, SIMX_P_W2), F, 1, tnws, tnws_bytes));
+    RUN(simx_gemm_nt(stream, dt, nseq, H, F, du, F, w.w1T, F, bufB, H, nullptr, bufA, H, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
+    RUN(simx_gemm_tn_bias(stream, dt, F, H, nseq, du, F, a.x1, H, goff(l, SIMX_P_W1), H, 1, tnws, tnws_bytes, goff(l, SIMX_P_B1)));
+    RUN(simx_ln_bwd_keyed(stream, dt, nseq, H, a.z1, off(l, SIMX_P_LN1_G), c->eps, bufB, bufA, hd ? bufC : nullptr,
+                          goff(l, SIMX_P_LN1_G), goff(l, SIMX_P_LN1_B), goff(l, SIMX_P_BO), &d1, cu));
+    RUN(simx_gemm_nt(stream, dt, nseq, H, H, dzm, H, w.woT, H, st2, H, nullptr, nullptr, 0, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
+    RUN(simx_rows_copy(stream, dt, dt, nseq, H, cu, nullptr, a.ctx, ctxc));
+    RUN(simx_gemm_tn(stream, dt, H, H, nseq, dzm, H, ctxc, H, goff(l, SIMX_P_WO), H, 1, tnws, tnws_bytes));
+    // back to full tensors: dctx and the residual-branch gradient are zero outside the [CLS] rows
+    RUN(simx_rows_copy(stream, dt, dt, nseq, H, nullptr, nullptr, bufA, st1));
+    if (hipMemsetAsync(bufA, 0, (size_t)T * H * e, (hipStream_t)stream) != hipSuccess ||
+        hipMemsetAsync(bufB, 0, (size_t)T * H * e, (hipStream_t)stream) != hipSuccess) {
+      simx_set_error("bert_bwd: memset failed");
+      return SIMX_ERR_HIP;
+    }
+    RUN(simx_rows_copy(stream, dt, dt, nseq, H, nullptr, cu, st1, bufA));
+    RUN(simx_rows_copy(stream, dt, dt, nseq, H, nullptr, cu, st2, bufB));
+    RUN(simx_mha_bwd_ex(stream, dt, nseq, c->heads, d, cu, max_len, T, a.qkv, a.ctx, a.lse, bufB, dqkv, &d3));
+    RUN(simx_gemm_nt(stream, dt, Tp, H, 3 * H, dqkv, 3 * H, w.wqkvT, 3 * H, bufB, H, nullptr, bufA, H, SIMX_EPI_NONE, nullptr, 0,
+                     nullptr, 0));
+    RUN(simx_gemm_tn_bias(stream, dt, 3 * H, H, T, dqkv, 3 * H, xin, H, goff(l, SIMX_P_WQKV), H, 1, tnws, tnws_bytes,
+                          goff(l, SIMX_P_BQKV)));
+    --l_top;
+  } else {
+    RUN(simx_cls_scatter(stream, dt, nseq, H, T, cu, dcls, bufB));            // g_x = d(loss)/d(last hidden)
+  }
+  for (int l = l_top; l >= 0; --l) {
     const WLayer w = wlayer(c, params, wcache, l);
     const ALayer a = alayer(c, const_cast<void*>(act), Tp, l, 1);
     const char* xin = l == 0 ? act_x0(const_cast<void*>(act)) : alayer(c, const_cast<void*>(act), Tp, l - 1, 1).xout;
@@ -315,7 +382,7 @@ extern "C" int simx_bert_bwd(simx_stream_t stream, const simx_bert_cfg* c, const
 #include <vector>
 #include "prof.h"
 namespace {
-struct ProfRec { int id; double work; hipEvent_t a, b; };
+struct ProfRec { int id; double work; hipEvent_t a, b; bool done; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 std::vector<hipEvent_t> g_pool;
@@ -326,12 +393,19 @@ void simx_prof_mark(int id, hipStream_t s, double work, int end) {
   if (!g_prof_on) return;
   if (!end) {
     if (g_pool_next + 2 > g_pool.size()) return;
-    ProfRec r{id, work, g_pool[g_pool_next], g_pool[g_pool_next + 1]};
+    ProfRec r{id, work, g_pool[g_pool_next], g_pool[g_pool_next + 1], false};
     g_pool_next += 2;
     (void)hipEventRecord(r.a, s);
     g_prof.push_back(r);
-  } else if (!g_prof.empty() && g_prof.back().id == id) {
-    (void)hipEventRecord(g_prof.back().b, s);
+  } else {
+    // scopes nest (a small wgrad calls the column-sum entry point inside its own scope): close the innermost open
+    // record of this id
+    for (size_t i = g_prof.size(); i-- > 0 && i + 8 > g_prof.size();)
+      if (g_prof[i].id == id && !g_prof[i].done) {
+        (void)hipEventRecord(g_prof[i].b, s);
+        g_prof[i].done = true;
+        break;
+      }
   }
 }
 
@@ -353,6 +427,7 @@ extern "C" int simx_prof_end(int32_t* counts_host, double* total_ms_host, double
   g_prof_on = false;
   for (int k = 0; k < SIMX_K_COUNT; ++k) { counts_host[k] = 0; total_ms_host[k] = 0; total_work_host[k] = 0; }
   for (auto& r : g_prof) {
+    if (!r.done) continue;
     if (hipEventSynchronize(r.b) != hipSuccess) continue;
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
@@ -361,6 +436,7 @@ extern "C" int simx_prof_end(int32_t* counts_host, double* total_ms_host, double
     total_work_host[r.id] += r.work;
   }
   g_prof.clear();
+  (void)hipGetLastError();      // a failed event query must not surface as the next launch's error
   return SIMX_OK;
 }
 extern "C" int simx_prof_kernel_count(void) { return SIMX_K_COUNT; }

@@ -9,6 +9,7 @@
 #include "prof.h"
 
 extern "C" int simx_ln_bwd_ex(simx_stream_t, int, int, int, const void*, const float*, float, const void*, void*, void*, float*, float*, float*, const simx_dropout*);
+extern "C" int simx_ln_bwd_keyed(simx_stream_t, int, int, int, const void*, const float*, float, const void*, void*, void*, float*, float*, float*, const simx_dropout*, const int32_t*);
 extern "C" int simx_embed_ln_fwd_ex(simx_stream_t, int, int, int, const int32_t*, const int32_t*, const float*, const float*, const float*, const float*, const float*, float, void*, const simx_dropout*);
 extern "C" int simx_embed_ln_bwd_ex(simx_stream_t, int, int, int, const int32_t*, const int32_t*, const float*, const float*, const float*, const float*, float, const void*, float*, float*, float*, float*, float*, const simx_dropout*);
 #define LN_VPL 4   // 4-element vectors per lane -> H <= 64*4*4 = 1024
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int H, int rows_p
                                                      const float* __restrict__ gamma, float eps, const T* __restrict__ dyp,
                                                      T* __restrict__ dzp, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, float* __restrict__ dbias,
-                                                     T* __restrict__ dzm, DropCtx drop) {
+                                                     T* __restrict__ dzm, DropCtx drop, const int* __restrict__ row_keys) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sred = reinterpret_cast<float*>(smem);          // [4][H] flush scratch
   float* sgam = sred + 4 * H;                            // [H]
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int H, int rows_p
         st4(o + c, dz[v]);
         if (drop.thr) {                      // gradient of the dropped dense output (feeds dgrad / wgrad / bias grad)
           float m4[4];
-          drop_mult4(drop, (uint32_t)row, (uint32_t)c, m4);
+          drop_mult4(drop, (uint32_t)(row_keys ? row_keys[row] : row), (uint32_t)c, m4);   // keys: rows gathered from a larger tensor
 #pragma unroll
           for (int e = 0; e < 4; ++e) dz[v][e] *= m4[e];
           st4(dzm + (long)row * H + c, dz[v]);
@@ -429,6 +430,40 @@ __global__ __launch_bounds__(256) void cls_scatter_kernel(int nseq, int H, const
   Elem<T>::st(dx + (long)cu[s] * H + c, dcls[i]);
 }
 
+// dst[dst_idx ? dst_idx[s] : s] = src[src_idx ? src_idx[s] : s]   (row gather / scatter / dtype conversion)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void rows_copy_kernel(int n, int H, const int* __restrict__ src_idx, const int* __restrict__ dst_idx,
+                                                        const TI* __restrict__ src, TO* __restrict__ dst) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)n * H) return;
+  const int s = (int)(i / H), c = (int)(i % H);
+  const long rs = src_idx ? src_idx[s] : s, rd = dst_idx ? dst_idx[s] : s;
+  Elem<TO>::st(dst + rd * H + c, Elem<TI>::ld(src + rs * H + c));
+}
+
+// z[s] = dropout(y[s]; mask row key_idx[s]) + res[res_idx ? res_idx[s] : s]: what the dense GEMM's epilogue does for full
+// tensors, for n rows that were gathered out of a larger tensor (the mask of a row is keyed by its ORIGINAL row index)
+template <typename T>
+__global__ __launch_bounds__(256) void drop_residual_rows_kernel(int n, int H, const T* __restrict__ y, const T* __restrict__ res,
+                                                                 const int* __restrict__ res_idx, const int* __restrict__ key_idx,
+                                                                 DropCtx drop, T* __restrict__ z) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= (long)n * H) return;
+  const int s = (int)(i / H), c = (int)(i % H);
+  float v[4], r[4];
+  ld4(y + i, v);
+  ld4(res + (long)(res_idx ? res_idx[s] : s) * H + c, r);
+  if (drop.thr) {
+    float m4[4];
+    drop_mult4(drop, (uint32_t)(key_idx ? key_idx[s] : s), (uint32_t)c, m4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= m4[e];
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] += r[e];
+  st4(z + i, v);
+}
+
 // ------------------------------------------------------------------------------------------ host
 static int ln_check(int dtype, int T, int H, const char* who) {
   SIMX_REQUIRE(dtype == SIMX_F32 || dtype == SIMX_BF16, SIMX_ERR_BAD_DTYPE, "%s: dtype %d", who, dtype);
@@ -473,6 +508,12 @@ extern "C" int simx_ln_bwd(simx_stream_t stream, int dtype, int T, int H, const 
 extern "C" int simx_ln_bwd_ex(simx_stream_t stream, int dtype, int T, int H, const void* z, const float* gamma, float eps,
                               const void* dy, void* dz, void* dz_masked, float* dgamma, float* dbeta, float* dbias,
                               const simx_dropout* dropd) {
+  return simx_ln_bwd_keyed(stream, dtype, T, H, z, gamma, eps, dy, dz, dz_masked, dgamma, dbeta, dbias, dropd, nullptr);
+}
+
+extern "C" int simx_ln_bwd_keyed(simx_stream_t stream, int dtype, int T, int H, const void* z, const float* gamma, float eps,
+                                 const void* dy, void* dz, void* dz_masked, float* dgamma, float* dbeta, float* dbias,
+                                 const simx_dropout* dropd, const int32_t* row_keys) {
   SIMX_PROF(SIMX_K_LN_BWD, stream, 3.0 * T * H * (dtype == SIMX_F32 ? 4 : 2));
   int rc = ln_check(dtype, T, H, "ln_bwd");
   if (rc) return rc;
@@ -482,7 +523,7 @@ extern "C" int simx_ln_bwd_ex(simx_stream_t stream, int dtype, int T, int H, con
   const int rpb = bwd_rows_per_block(T);
   const size_t lds = (size_t)5 * H * sizeof(float);
 #define LB(TT, V) hipLaunchKernelGGL((ln_bwd_kernel<TT, V>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, (const TT*)z, gamma, eps, \
-                                    (const TT*)dy, (TT*)dz, dgamma, dbeta, dbias, (TT*)dz_masked, drop)
+                                    (const TT*)dy, (TT*)dz, dgamma, dbeta, dbias, (TT*)dz_masked, drop, row_keys)
   if (dtype == SIMX_F32) { if (H <= 256) LB(float, 1); else if (H <= 768) LB(float, 3); else LB(float, 4); }
   else { if (H <= 256) LB(bf16_t, 1); else if (H <= 768) LB(bf16_t, 3); else LB(bf16_t, 4); }
 #undef LB
@@ -589,5 +630,33 @@ extern "C" int simx_cls_scatter(simx_stream_t stream, int dtype, int nseq, int H
   if (dtype == SIMX_F32) hipLaunchKernelGGL((cls_scatter_kernel<float>), dim3(blocks), dim3(256), 0, s, nseq, H, cu, dcls, (float*)dx);
   else hipLaunchKernelGGL((cls_scatter_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, nseq, H, cu, dcls, (bf16_t*)dx);
   SIMX_CHECK_LAUNCH("cls_scatter");
+  return SIMX_OK;
+}
+
+extern "C" int simx_rows_copy(simx_stream_t stream, int src_dtype, int dst_dtype, int n, int H, const int32_t* src_idx,
+                              const int32_t* dst_idx, const void* src, void* dst) {
+  SIMX_REQUIRE(n > 0 && H > 0 && src && dst, SIMX_ERR_BAD_SHAPE, "rows_copy: bad arguments");
+  SIMX_REQUIRE((src_dtype == SIMX_F32 || src_dtype == SIMX_BF16) && (dst_dtype == SIMX_F32 || dst_dtype == SIMX_BF16),
+               SIMX_ERR_BAD_DTYPE, "rows_copy: dtypes %d -> %d", src_dtype, dst_dtype);
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = (int)(((long)n * H + 255) / 256);
+#define RC(TI, TO) hipLaunchKernelGGL((rows_copy_kernel<TI, TO>), dim3(blocks), dim3(256), 0, s, n, H, src_idx, dst_idx, (const TI*)src, (TO*)dst)
+  if (src_dtype == SIMX_F32) { if (dst_dtype == SIMX_F32) RC(float, float); else RC(float, bf16_t); }
+  else { if (dst_dtype == SIMX_F32) RC(bf16_t, float); else RC(bf16_t, bf16_t); }
+#undef RC
+  SIMX_CHECK_LAUNCH("rows_copy");
+  return SIMX_OK;
+}
+
+extern "C" int simx_drop_residual_rows(simx_stream_t stream, int dtype, int n, int H, const void* y, const void* res,
+                                       const int32_t* res_idx, const int32_t* key_idx, const simx_dropout* dropd, void* z) {
+  SIMX_REQUIRE(n > 0 && H > 0 && H % 4 == 0 && y && res && z, SIMX_ERR_BAD_SHAPE, "drop_residual_rows: bad arguments");
+  SIMX_REQUIRE(dtype == SIMX_F32 || dtype == SIMX_BF16, SIMX_ERR_BAD_DTYPE, "drop_residual_rows: dtype %d", dtype);
+  const DropCtx drop = make_drop(dropd);
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = (int)(((long)n * H / 4 + 255) / 256);
+  if (dtype == SIMX_F32) hipLaunchKernelGGL((drop_residual_rows_kernel<float>), dim3(blocks), dim3(256), 0, s, n, H, (const float*)y, (const float*)res, res_idx, key_idx, drop, (float*)z);
+  else hipLaunchKernelGGL((drop_residual_rows_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, n, H, (const bf16_t*)y, (const bf16_t*)res, res_idx, key_idx, drop, (bf16_t*)z);
+  SIMX_CHECK_LAUNCH("drop_residual_rows");
   return SIMX_OK;
 }

@@ -224,9 +224,12 @@ class BertEngine(object):
         self._dirty = False
         self._wcache_version = self.flat._version
 
-    def call_cfg(self, training):
-        """Per-call copy of the C config: dropout on only in training mode (nn.Dropout semantics), fresh seed per call."""
+    def call_cfg(self, training, want_hidden=True):
+        """Per-call copy of the C config: dropout on only in training mode (nn.Dropout semantics), fresh seed per call.
+        Callers that only read the [CLS] embedding (BiBertEncoder / Reranker / RobertaDot, models.py:81) let the last
+        layer's post-attention blocks run on the [CLS] rows alone (SIMX_FULL_LAST_LAYER=1 computes every row anyway)."""
         c = L.BertCfg.from_buffer_copy(self.ccfg)
+        c.cls_only_last_layer = 0 if (want_hidden or os.environ.get("SIMX_FULL_LAST_LAYER", "0") == "1") else 1
         if training and (self.cfg.hidden_dropout_prob > 0 or self.cfg.attention_probs_dropout_prob > 0):
             self._drop_calls = getattr(self, "_drop_calls", 0) + 1
             c.hidden_dropout = float(self.cfg.hidden_dropout_prob)
@@ -270,7 +273,7 @@ class BertEngine(object):
     def encode(self, input_ids, attention_mask, want_hidden=False, requires_grad=None, training=False):
         """-> cls [n,H] f32 (and the packed last hidden state + PackedBatch when want_hidden)."""
         pb = PackedBatch(input_ids, attention_mask, getattr(self.cfg, "position_offset", 0))
-        ccfg = self.call_cfg(training)
+        ccfg = self.call_cfg(training, want_hidden)
         if requires_grad is None:
             requires_grad = torch.is_grad_enabled()
         if requires_grad and torch.is_grad_enabled():

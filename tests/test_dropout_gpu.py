@@ -15,19 +15,21 @@ from oracle.weights import BertCfg, make_bert_params, make_batch
 pytestmark = pytest.mark.gpu
 
 
-def _fixed_seed(enc, seed):
+def _fixed_seed(enc, seed, full_last_layer=False):
     from simxns_amd import _lib as L
-    def call_cfg(training):
+    def call_cfg(training, want_hidden=True):
         c = L.BertCfg.from_buffer_copy(enc.engine.ccfg)
+        c.cls_only_last_layer = 0 if (want_hidden or full_last_layer) else 1
         if training:
             c.hidden_dropout, c.attn_dropout, c.dropout_seed = enc.config.hidden_dropout_prob, enc.config.attention_probs_dropout_prob, seed
         return c
     enc.engine.call_cfg = call_cfg
 
 
+@pytest.mark.parametrize("full_last_layer", [False, True])     # False: the [CLS]-only last layer (what the towers run); True: every row
 @pytest.mark.parametrize("dtype,heads,hidden,p_len", [("fp32", 4, 64, 128), ("bf16", 1, 64, 128), ("fp32", 1, 64, 128),
                                                     ("bf16", 2, 128, 600)])     # 600: chunked long-sequence attention backward
-def test_step_with_dropout_matches_oracle(dev, dtype, heads, hidden, p_len):
+def test_step_with_dropout_matches_oracle(dev, dtype, heads, hidden, p_len, full_last_layer):
     from simxns_amd import ops
     from simxns_amd.engine import BertConfigLite
     from simxns_amd.model.models import BiBertEncoder, HFBertEncoder
@@ -46,8 +48,8 @@ def test_step_with_dropout_matches_oracle(dev, dtype, heads, hidden, p_len):
     bi.question_model.load_numpy_state(Pq)
     bi.ctx_model.load_numpy_state(Pc)
     bi.to(dev).train()
-    _fixed_seed(bi.question_model, 1111)
-    _fixed_seed(bi.ctx_model, 2222)
+    _fixed_seed(bi.question_model, 1111, full_last_layer)
+    _fixed_seed(bi.ctx_model, 2222, full_last_layer)
     t = lambda a: torch.from_numpy(a).to(dev)
     q, c = bi(t(q_ids), t(q_mask), t(c_ids), t(c_mask))
     loss, _, _ = ops.kl_distill_loss(q, c, t(z))

@@ -20,6 +20,15 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["cls_only_last_layer", "full_last_layer"], autouse=True)
+def last_layer_mode(request, monkeypatch):
+    """Every test of this file runs twice: with the [CLS]-only last layer the towers use by default (the reference's
+    models.py:81 reads row 0 only) and with every row of the last layer computed (SIMX_FULL_LAST_LAYER=1).  Both must
+    match the reference's goldens."""
+    monkeypatch.setenv("SIMX_FULL_LAST_LAYER", "1" if request.param == "full_last_layer" else "0")
+    return request.param
+
+
 def _cfg_from(G):
     from simxns_amd.engine import BertConfigLite
     c = json.loads(str(G["cfg"]))

@@ -95,7 +95,7 @@ SIGNATURES = {
     "simx_prof_kernel_count": (_i, []),
 }
 PROF_NAMES = ["gemm_nt", "gemm_tn", "mha_fwd", "mha_bwd", "ln_fwd", "ln_bwd", "embed_fwd", "embed_bwd", "colsum", "cast",
-              "loss", "sampler", "adamw", "other", "collate", "topk"]
+              "loss", "sampler", "adamw", "other", "collate", "topk", "gemm_nt_p3"]
 
 _lib = None
 

@@ -389,24 +389,26 @@ std::vector<hipEvent_t> g_pool;
 size_t g_pool_next = 0;
 }  // namespace
 
-void simx_prof_mark(int id, hipStream_t s, double work, int end) {
-  if (!g_prof_on) return;
-  if (!end) {
-    if (g_pool_next + 2 > g_pool.size()) return;
+int simx_prof_mark(int id, hipStream_t s, double work, int end_index) {
+  if (end_index < 0) {
+    if (!g_prof_on || g_pool_next + 2 > g_pool.size()) return -1;
     ProfRec r{id, work, g_pool[g_pool_next], g_pool[g_pool_next + 1], false};
     g_pool_next += 2;
     (void)hipEventRecord(r.a, s);
     g_prof.push_back(r);
-  } else {
-    // scopes nest (a small wgrad calls the column-sum entry point inside its own scope): close the innermost open
-    // record of this id
-    for (size_t i = g_prof.size(); i-- > 0 && i + 8 > g_prof.size();)
-      if (g_prof[i].id == id && !g_prof[i].done) {
-        (void)hipEventRecord(g_prof[i].b, s);
-        g_prof[i].done = true;
-        break;
-      }
+    return (int)g_prof.size() - 1;
   }
+  if ((size_t)end_index < g_prof.size() && !g_prof[end_index].done) {      // (scopes nest: each closes its own record)
+    (void)hipEventRecord(g_prof[end_index].b, s);
+    g_prof[end_index].done = true;
+  }
+  return end_index;
+}
+
+void simx_prof_retag(int id) {
+  if (!g_prof_on) return;
+  for (size_t i = g_prof.size(); i-- > 0;)
+    if (!g_prof[i].done) { g_prof[i].id = id; return; }
 }
 
 extern "C" int simx_prof_begin(int max_launches) {

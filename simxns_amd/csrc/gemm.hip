@@ -1504,6 +1504,7 @@ extern "C" int simx_gemm_nt_ex(simx_stream_t stream, int dtype, int M, int N, in
         else if (epilogue == SIMX_EPI_GELU) LP3(SIMX_EPI_GELU, false, nullptr, gelu_infer ? 1 : 0);
         else LP3(SIMX_EPI_DGELU, true, aux, ldaux);
 #undef LP3
+        simx_prof_retag(SIMX_K_GEMM_NT_P3);
         SIMX_CHECK_LAUNCH("gemm_nt_bf16_p3");
         return SIMX_OK;
       }

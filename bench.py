@@ -267,13 +267,14 @@ def main():
     pairs_per_s = world * P * args.steps / dt
     stu = 3 * (B * fwd_flops_seq(QL) + P * fwd_flops_seq(PL))
     tea = 0 if args.no_teacher else P * fwd_flops_seq(ce_tokens)
-    # FLOPs actually issued: the towers read sequence_output[:, 0, :] only (models.py:81), so the engine runs the last
-    # layer's attention-output and FFN blocks on the [CLS] rows alone -- (S-1) rows x (2H^2 + 4HF) per sequence are
-    # dead code on this path and are skipped (forward, dgrad and wgrad).  SIMX_FULL_LAST_LAYER=1 computes them anyway.
+    # FLOPs actually issued: the towers read sequence_output[:, 0, :] only (models.py:81), so in the last layer the
+    # engine projects K and V for every token but runs the Q projection, the attention core, the attention-output and
+    # the FFN blocks for the [CLS] row alone -- for the other S-1 rows of a sequence 4H^2 + 4HF + 4SH FLOPs are dead
+    # code on this path and are skipped (forward, dgrad and wgrad).  SIMX_FULL_LAST_LAYER=1 computes them anyway.
     full_last = os.environ.get("SIMX_FULL_LAST_LAYER", "0") == "1"
-    dead = 0 if full_last else (2 * H_ * H_ + 4 * H_ * F_)
-    stu_issued = stu - 3 * dead * (B * (QL - 1) + P * (PL - 1))
-    tea_issued = 0 if args.no_teacher else tea - dead * P * (ce_tokens - 1)
+    dead = (lambda S: 0) if full_last else (lambda S: (S - 1) * (4 * H_ * H_ + 4 * H_ * F_ + 4 * S * H_))
+    stu_issued = stu - 3 * (B * dead(QL) + P * dead(PL))
+    tea_issued = 0 if args.no_teacher else tea - P * dead(ce_tokens)
     out = {"metric": "query+passage pairs/sec (bi-encoder step)", "value": round(pairs_per_s, 1),
            "unit": "query+passage pairs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(ms_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -286,11 +287,12 @@ def main():
                                      " + 0.2*in-batch NLL (all-gather)" if args.inbatch else ""),
                       "global_batch": world * B, "pairs_per_step_per_gpu": P, "parallelism": "dp%d" % world,
                       "teacher_in_step": not args.no_teacher, "dropout": pdrop,
-                      "last_layer": "all rows" if full_last else "[CLS] rows only after attention"},
+                      "last_layer": "all rows" if full_last else "K/V for all rows, everything else for the [CLS] row only"},
            "algorithmic_tflop_per_step_per_gpu": {"student_fwd_bwd": round(stu / 1e12, 2), "teacher_fwd": round(tea / 1e12, 2)},
            "issued_tflop_per_step_per_gpu": {"student_fwd_bwd": round(stu_issued / 1e12, 2), "teacher_fwd": round(tea_issued / 1e12, 2),
-                                             "note": "algorithmic minus the last layer's non-[CLS] rows of the attention-output and "
-                                                     "FFN blocks (dead code behind sequence_output[:, 0, :]); SIMX_FULL_LAST_LAYER=1 issues them"},
+                                             "note": "algorithmic minus the last layer's non-[CLS] rows of the Q projection, attention core, "
+                                                     "attention-output and FFN blocks (dead code behind sequence_output[:, 0, :]); "
+                                                     "SIMX_FULL_LAST_LAYER=1 issues them"},
            # hardware utilisation = FLOPs the MFMA pipes really executed / dense bf16 peak
            "step_mfma_util": round((stu_issued + tea_issued) / (ms_step * 1e-3) / 2.5e15, 4) if args.dtype == "bf16" and not args.varlen else None,
            # the same step priced at the reference's full FLOP count (SURVEY 8d formula)

@@ -172,6 +172,18 @@ int simx_mha_bwd_ex(simx_stream_t stream, int dtype, int nseq, int heads, int he
                     const void* qkv, const void* ctx, const float* lse, const void* dctx, void* dqkv,
                     const simx_dropout* drop);
 
+/* Single-query attention for the [CLS]-only last layer: softmax(q0 K^T / sqrt(d)) V for token 0 of every sequence
+ * (the only query whose output the path reads, SimANS/model/models.py:81).  q_cls / ctx_cls / dctx_cls / dq_cls are
+ * compact [nseq, heads*head_dim] tensors; K and V are read from (dK, dV written to) columns [H, 3H) of the packed
+ * qkv / dqkv rows; the Q columns of dqkv are not touched.  Same dropout masks as simx_mha_fwd_ex / simx_mha_bwd_ex. */
+int simx_mha_cls_fwd(simx_stream_t stream, int dtype, int nseq, int heads, int head_dim,
+                     const int32_t* cu_seqlens, int max_len, int T,
+                     const void* q_cls, const void* qkv, void* ctx_cls, const simx_dropout* drop);
+int simx_mha_cls_bwd(simx_stream_t stream, int dtype, int nseq, int heads, int head_dim,
+                     const int32_t* cu_seqlens, int max_len, int T,
+                     const void* q_cls, const void* qkv, const void* dctx_cls, void* dq_cls, void* dqkv,
+                     const simx_dropout* drop);
+
 /* [CLS] slice sequence_output[:,0,:] (SimANS/model/models.py:81) -> f32 [nseq,H], and its adjoint
  * (writes dcls into the first row of each sequence of dx, zero elsewhere). */
 int simx_cls_gather(simx_stream_t stream, int dtype, int nseq, int H, const int32_t* cu_seqlens,

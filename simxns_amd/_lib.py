@@ -53,6 +53,8 @@ SIGNATURES = {
     "simx_ln_bwd_keyed": (_i, [_p, _i, _i, _i, _p, _p, _f, _p, _p, _p, _p, _p, _p, _dp, _p]),
     "simx_mha_fwd_ex": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _dp]),
     "simx_mha_bwd_ex": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _dp]),
+    "simx_mha_cls_fwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _dp]),
+    "simx_mha_cls_bwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _dp]),
     "simx_gemm_tn_workspace_bytes": (_z, [_i, _i, _i]),
     "simx_gemm_tn": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p, _z]),
     "simx_gemm_tn_bias": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p, _z, _p]),

@@ -949,3 +949,183 @@ extern "C" int simx_mha_bwd_ex(simx_stream_t stream, int dtype, int nseq, int he
   SIMX_CHECK_LAUNCH("mha_bwd_simple");
   return SIMX_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Single-query attention for the [CLS]-only last layer (simx_bert_cfg.cls_only_last_layer): the only query of a
+// sequence that anything downstream reads is its token 0, so layer L-1 needs softmax(q0 K^T / sqrt(d)) V for that one
+// row.  One wave per (sequence, head); q comes from a compact [nseq, H] tensor, K / V from the usual packed qkv rows.
+// Phase 1: lane = key (own K / V row, 2d bytes contiguous); phase 2: lane = head dimension (coalesced row accesses).
+// HBM-bound: reads the K, V columns of qkv once.  Dropout masks use the full kernels' key (row = h*T + t0, col = key).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void mha_cls_fwd_kernel(int nitems, int heads, int d, int H, int Ttot, int max_len, float scale,
+                                                          const int* __restrict__ cu, const T* __restrict__ qc,
+                                                          const T* __restrict__ qkv, T* __restrict__ ctxc, DropCtx drop) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int item = blockIdx.x * 4 + w;
+  if (item >= nitems) return;                      // (no block-level synchronisation below: waves are independent)
+  float* sq = reinterpret_cast<float*>(smem) + (size_t)w * (d + max_len);
+  float* sp = sq + d;
+  const int s = item / heads, h = item % heads;
+  const int t0 = cu[s], len = cu[s + 1] - t0;
+  for (int c = lane; c < d; c += 64) sq[c] = Elem<T>::ld(qc + (long)s * H + h * d + c);
+  __builtin_amdgcn_wave_barrier();
+  const T* Kb = qkv + (long)t0 * 3 * H + H + h * d;
+  const T* Vb = qkv + (long)t0 * 3 * H + 2 * H + h * d;
+  float mx = -3.0e38f;
+  for (int j = lane; j < len; j += 64) {
+    const T* kr = Kb + (long)j * 3 * H;
+    float acc = 0.f;
+    for (int c = 0; c < d; c += 4) {
+      float k4[4];
+      ld4(kr + c, k4);
+      acc = fmaf(sq[c], k4[0], acc); acc = fmaf(sq[c + 1], k4[1], acc); acc = fmaf(sq[c + 2], k4[2], acc); acc = fmaf(sq[c + 3], k4[3], acc);
+    }
+    acc *= scale;
+    sp[j] = acc;
+    mx = fmaxf(mx, acc);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < len; j += 64) { const float e = __expf(sp[j] - mx); sp[j] = e; sum += e; }
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  for (int j = lane; j < len; j += 64) {
+    float p = sp[j] * inv;
+    if (drop.thr) p *= drop_mult(drop, (uint32_t)(h * Ttot + t0), (uint32_t)j);
+    sp[j] = p;
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int c = lane; c < d; c += 64) {
+    float o = 0.f;
+    for (int j = 0; j < len; ++j) o = fmaf(sp[j], Elem<T>::ld(Vb + (long)j * 3 * H + c), o);
+    Elem<T>::st(ctxc + (long)s * H + h * d + c, o);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void mha_cls_bwd_kernel(int nitems, int heads, int d, int H, int Ttot, int max_len, float scale,
+                                                          const int* __restrict__ cu, const T* __restrict__ qc,
+                                                          const T* __restrict__ qkv, const T* __restrict__ dctxc,
+                                                          T* __restrict__ dqc, T* __restrict__ dqkv, DropCtx drop) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int item = blockIdx.x * 4 + w;
+  if (item >= nitems) return;
+  float* sq = reinterpret_cast<float*>(smem) + (size_t)w * (2 * d + 3 * max_len);
+  float* sdo = sq + d;
+  float* sp = sdo + d;                             // p (softmax)
+  float* spm = sp + max_len;                       // P~ = dropout(p): what multiplies V
+  float* sds = spm + max_len;                      // d(loss)/d(score) * scale
+  const int s = item / heads, h = item % heads;
+  const int t0 = cu[s], len = cu[s + 1] - t0;
+  for (int c = lane; c < d; c += 64) {
+    sq[c] = Elem<T>::ld(qc + (long)s * H + h * d + c);
+    sdo[c] = Elem<T>::ld(dctxc + (long)s * H + h * d + c);
+  }
+  __builtin_amdgcn_wave_barrier();
+  const T* Kb = qkv + (long)t0 * 3 * H + H + h * d;
+  const T* Vb = qkv + (long)t0 * 3 * H + 2 * H + h * d;
+  float mx = -3.0e38f;
+  for (int j = lane; j < len; j += 64) {
+    const T* kr = Kb + (long)j * 3 * H;
+    const T* vr = Vb + (long)j * 3 * H;
+    float acc = 0.f, dp = 0.f;
+    for (int c = 0; c < d; c += 4) {
+      float k4[4], v4[4];
+      ld4(kr + c, k4);
+      ld4(vr + c, v4);
+      acc = fmaf(sq[c], k4[0], acc); acc = fmaf(sq[c + 1], k4[1], acc); acc = fmaf(sq[c + 2], k4[2], acc); acc = fmaf(sq[c + 3], k4[3], acc);
+      dp = fmaf(sdo[c], v4[0], dp); dp = fmaf(sdo[c + 1], v4[1], dp); dp = fmaf(sdo[c + 2], v4[2], dp); dp = fmaf(sdo[c + 3], v4[3], dp);
+    }
+    acc *= scale;
+    sp[j] = acc;
+    sds[j] = dp;                                   // d(loss)/dP~_j
+    mx = fmaxf(mx, acc);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < len; j += 64) { const float e = __expf(sp[j] - mx); sp[j] = e; sum += e; }
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  float dot = 0.f;                                 // sum_i p_i * d(loss)/dp_i
+  for (int j = lane; j < len; j += 64) {
+    const float p = sp[j] * inv;
+    const float m = drop.thr ? drop_mult(drop, (uint32_t)(h * Ttot + t0), (uint32_t)j) : 1.f;
+    const float dpj = sds[j] * m;
+    dot += p * dpj;
+    sp[j] = p;
+    spm[j] = p * m;
+    sds[j] = dpj;
+  }
+  dot = wave_sum(dot);
+  for (int j = lane; j < len; j += 64) sds[j] = sp[j] * (sds[j] - dot) * scale;
+  __builtin_amdgcn_wave_barrier();
+  T* dKb = dqkv + (long)t0 * 3 * H + H + h * d;
+  T* dVb = dqkv + (long)t0 * 3 * H + 2 * H + h * d;
+  for (int c = lane; c < d; c += 64) {
+    const float qv = sq[c], dov = sdo[c];
+    float dq = 0.f;
+    for (int j = 0; j < len; ++j) {
+      const float ds = sds[j];
+      dq = fmaf(ds, Elem<T>::ld(Kb + (long)j * 3 * H + c), dq);
+      Elem<T>::st(dKb + (long)j * 3 * H + c, ds * qv);
+      Elem<T>::st(dVb + (long)j * 3 * H + c, spm[j] * dov);
+    }
+    Elem<T>::st(dqc + (long)s * H + h * d + c, dq);
+  }
+}
+
+extern "C" int simx_mha_cls_fwd(simx_stream_t stream, int dtype, int nseq, int heads, int d, const int32_t* cu, int max_len,
+                                int T, const void* q_cls, const void* qkv, void* ctx_cls, const simx_dropout* dropd) {
+  SIMX_REQUIRE(nseq > 0 && heads > 0 && d > 0 && d % 4 == 0 && max_len > 0 && T >= nseq, SIMX_ERR_BAD_SHAPE, "mha_cls_fwd: bad shape");
+  SIMX_REQUIRE(dtype == SIMX_F32 || dtype == SIMX_BF16, SIMX_ERR_BAD_DTYPE, "mha_cls_fwd: dtype %d", dtype);
+  hipStream_t s = (hipStream_t)stream;
+  SIMX_PROF(SIMX_K_MHA_FWD, s, 4.0 * nseq * heads * max_len * d);
+  const DropCtx drop = make_drop(dropd);
+  const float scale = 1.0f / sqrtf((float)d);
+  const int nitems = nseq * heads, H = heads * d;
+  const size_t lds = (size_t)4 * (d + max_len) * sizeof(float);
+  int rc;
+  if (dtype == SIMX_F32) {
+    rc = set_lds(mha_cls_fwd_kernel<float>, lds, "mha_cls_fwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL((mha_cls_fwd_kernel<float>), dim3(cdiv(nitems, 4)), dim3(256), lds, s, nitems, heads, d, H, T, max_len, scale, cu,
+                       (const float*)q_cls, (const float*)qkv, (float*)ctx_cls, drop);
+  } else {
+    rc = set_lds(mha_cls_fwd_kernel<bf16_t>, lds, "mha_cls_fwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL((mha_cls_fwd_kernel<bf16_t>), dim3(cdiv(nitems, 4)), dim3(256), lds, s, nitems, heads, d, H, T, max_len, scale, cu,
+                       (const bf16_t*)q_cls, (const bf16_t*)qkv, (bf16_t*)ctx_cls, drop);
+  }
+  SIMX_CHECK_LAUNCH("mha_cls_fwd");
+  return SIMX_OK;
+}
+
+extern "C" int simx_mha_cls_bwd(simx_stream_t stream, int dtype, int nseq, int heads, int d, const int32_t* cu, int max_len,
+                                int T, const void* q_cls, const void* qkv, const void* dctx_cls, void* dq_cls, void* dqkv,
+                                const simx_dropout* dropd) {
+  SIMX_REQUIRE(nseq > 0 && heads > 0 && d > 0 && d % 4 == 0 && max_len > 0 && T >= nseq, SIMX_ERR_BAD_SHAPE, "mha_cls_bwd: bad shape");
+  SIMX_REQUIRE(dtype == SIMX_F32 || dtype == SIMX_BF16, SIMX_ERR_BAD_DTYPE, "mha_cls_bwd: dtype %d", dtype);
+  hipStream_t s = (hipStream_t)stream;
+  SIMX_PROF(SIMX_K_MHA_BWD, s, 8.0 * nseq * heads * max_len * d);
+  const DropCtx drop = make_drop(dropd);
+  const float scale = 1.0f / sqrtf((float)d);
+  const int nitems = nseq * heads, H = heads * d;
+  const size_t lds = (size_t)4 * (2 * d + 3 * max_len) * sizeof(float);
+  int rc;
+  if (dtype == SIMX_F32) {
+    rc = set_lds(mha_cls_bwd_kernel<float>, lds, "mha_cls_bwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL((mha_cls_bwd_kernel<float>), dim3(cdiv(nitems, 4)), dim3(256), lds, s, nitems, heads, d, H, T, max_len, scale, cu,
+                       (const float*)q_cls, (const float*)qkv, (const float*)dctx_cls, (float*)dq_cls, (float*)dqkv, drop);
+  } else {
+    rc = set_lds(mha_cls_bwd_kernel<bf16_t>, lds, "mha_cls_bwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL((mha_cls_bwd_kernel<bf16_t>), dim3(cdiv(nitems, 4)), dim3(256), lds, s, nitems, heads, d, H, T, max_len, scale, cu,
+                       (const bf16_t*)q_cls, (const bf16_t*)qkv, (const bf16_t*)dctx_cls, (bf16_t*)dq_cls, (bf16_t*)dqkv, drop);
+  }
+  SIMX_CHECK_LAUNCH("mha_cls_bwd");
+  return SIMX_OK;
+}

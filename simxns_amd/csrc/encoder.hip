@@ -128,9 +128,9 @@ extern "C" size_t simx_bert_act_bytes(const simx_bert_cfg* c, int T, int nseq, i
   const size_t Tp = (size_t)rows_cap(T);
   const size_t x0 = al(Tp * c->hidden * esz(c->dtype));
   const size_t n = nseq > 0 ? (size_t)nseq : Tp;
-  return x0 + (size_t)(save_for_bwd ? c->layers : 2) * act_layer_bytes(c, Tp) + 2 * al(n * c->hidden * esz(c->dtype));
+  return x0 + (size_t)(save_for_bwd ? c->layers : 2) * act_layer_bytes(c, Tp) + 3 * al(n * c->hidden * esz(c->dtype));
 }
-// two [nseq,H] temporaries of the [CLS]-only last layer, behind the per-layer slots
+// three [nseq,H] tensors of the [CLS]-only last layer (q, attention context, a temporary), behind the per-layer slots
 static char* act_extra(const simx_bert_cfg* c, void* act, size_t Tp, int save) {
   return (char*)act + al(Tp * c->hidden * esz(c->dtype)) + (size_t)(save ? c->layers : 2) * act_layer_bytes(c, Tp);
 }
@@ -233,18 +233,22 @@ extern "C" int simx_bert_fwd(simx_stream_t stream, const simx_bert_cfg* c, const
   for (int l = 0; l < c->layers; ++l) {
     const WLayer w = wlayer(c, params, wcache, l);
     const ALayer a = alayer(c, act, Tp, l, save);
-    RUN(simx_gemm_nt(stream, dt, Tp, 3 * H, H, x, H, w.wqkv, H, a.qkv, 3 * H, off(l, SIMX_P_BQKV), nullptr, 0, SIMX_EPI_NONE,
-                     nullptr, 0, nullptr, 0));
     const simx_dropout d1 = drop_of(c, l, 1), d2 = drop_of(c, l, 2), d3 = drop_of(c, l, 3);
-    RUN(simx_mha_fwd_ex(stream, dt, nseq, c->heads, d, cu, max_len, T, a.qkv, a.ctx, a.lse, &d3));
     if (cls_only && l == c->layers - 1) {
-      // Last layer, [CLS] rows only: row s of every buffer below is the sequence's token 0 (row cu[s] of the full
-      // tensors).  Same arithmetic as the full path -- dropout masks stay keyed by the ORIGINAL row index -- on nseq rows:
-      // z1, x1, u, h, z2, xout of this layer hold [nseq, .] tensors in their usual slots.
+      // Last layer, [CLS] rows only: row s of every [nseq, .] buffer below is the sequence's token 0 (row cu[s] of the
+      // full tensors).  Only K and V are projected for every token; Q, the attention core and everything after it run
+      // for the one query per sequence that is read.  Same arithmetic as the full path -- dropout masks stay keyed by
+      // the ORIGINAL row index.  z1, x1, u, h, z2, xout of this layer hold [nseq, .] tensors in their usual slots.
       const size_t e = esz(dt);
-      char* ctxc = act_extra(c, act, Tp, save);
+      char* qc = act_extra(c, act, Tp, save);                      // kept for backward
+      char* ctxc = qc + al((size_t)nseq * H * e);                  // kept for backward
       char* ytmp = ctxc + al((size_t)nseq * H * e);
-      RUN(simx_rows_copy(stream, dt, dt, nseq, H, cu, nullptr, a.ctx, ctxc));
+      RUN(simx_gemm_nt(stream, dt, Tp, 2 * H, H, x, H, w.wqkv + (size_t)H * H * e, H, a.qkv + (size_t)H * e, 3 * H,
+                       off(l, SIMX_P_BQKV) + H, nullptr, 0, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
+      RUN(simx_rows_copy(stream, dt, dt, nseq, H, cu, nullptr, x, ytmp));
+      RUN(simx_gemm_nt(stream, dt, nseq, H, H, ytmp, H, w.wqkv, H, qc, H, off(l, SIMX_P_BQKV), nullptr, 0, SIMX_EPI_NONE, nullptr, 0,
+                       nullptr, 0));
+      RUN(simx_mha_cls_fwd(stream, dt, nseq, c->heads, d, cu, max_len, T, qc, a.qkv, ctxc, &d3));
       RUN(simx_gemm_nt(stream, dt, nseq, H, H, ctxc, H, w.wo, H, ytmp, H, off(l, SIMX_P_BO), nullptr, 0, SIMX_EPI_NONE, nullptr, 0,
                        nullptr, 0));
       RUN(simx_drop_residual_rows(stream, dt, nseq, H, ytmp, x, cu, cu, &d1, a.z1));
@@ -257,6 +261,9 @@ extern "C" int simx_bert_fwd(simx_stream_t stream, const simx_bert_cfg* c, const
       if (cls_out) RUN(simx_rows_copy(stream, dt, SIMX_F32, nseq, H, nullptr, nullptr, a.xout, cls_out));
       return SIMX_OK;
     }
+    RUN(simx_gemm_nt(stream, dt, Tp, 3 * H, H, x, H, w.wqkv, H, a.qkv, 3 * H, off(l, SIMX_P_BQKV), nullptr, 0, SIMX_EPI_NONE,
+                     nullptr, 0, nullptr, 0));
+    RUN(simx_mha_fwd_ex(stream, dt, nseq, c->heads, d, cu, max_len, T, a.qkv, a.ctx, a.lse, &d3));
     RUN(simx_gemm_nt_ex(stream, dt, Tp, H, H, a.ctx, H, w.wo, H, a.z1, H, off(l, SIMX_P_BO), x, H, SIMX_EPI_NONE, nullptr, 0,
                         nullptr, 0, &d1));
     RUN(simx_ln_fwd(stream, dt, T, H, a.z1, off(l, SIMX_P_LN1_G), off(l, SIMX_P_LN1_B), c->eps, a.x1));
@@ -310,9 +317,11 @@ extern "C" int simx_bert_bwd(simx_stream_t stream, const simx_bert_cfg* c, const
     const char* xin = l == 0 ? act_x0(const_cast<void*>(act)) : alayer(c, const_cast<void*>(act), Tp, l - 1, 1).xout;
     const simx_dropout d1 = drop_of(c, l, 1), d2 = drop_of(c, l, 2), d3 = drop_of(c, l, 3);
     char* dzm = hd ? bufC : bufA;
-    char* ctxc = tnws + tnws_bytes;
-    char* st1 = ctxc + al((size_t)nseq * H * e);
-    char* st2 = st1 + al((size_t)nseq * H * e);
+    char* e0 = tnws + tnws_bytes;                        // three [nseq,H] temporaries
+    char* e1 = e0 + al((size_t)nseq * H * e);
+    char* e2 = e1 + al((size_t)nseq * H * e);
+    const char* qc = act_extra(c, const_cast<void*>(act), Tp, 1);                  // saved by the forward
+    const char* ctxc = qc + al((size_t)nseq * H * e);
     RUN(simx_rows_copy(stream, SIMX_F32, dt, nseq, H, nullptr, nullptr, dcls, bufB));
     RUN(simx_ln_bwd_keyed(stream, dt, nseq, H, a.z2, off(l, SIMX_P_LN2_G), c->eps, bufB, bufA, hd ? bufC : nullptr,
                           goff(l, SIMX_P_LN2_G), goff(l, SIMX_P_LN2_B), goff(l, SIMX_P_B2), &d2, cu));
@@ -322,23 +331,26 @@ extern "C" int simx_bert_bwd(simx_stream_t stream, const simx_bert_cfg* c, const
     RUN(simx_gemm_tn_bias(stream, dt, F, H, nseq, du, F, a.x1, H, goff(l, SIMX_P_W1), H, 1, tnws, tnws_bytes, goff(l, SIMX_P_B1)));
     RUN(simx_ln_bwd_keyed(stream, dt, nseq, H, a.z1, off(l, SIMX_P_LN1_G), c->eps, bufB, bufA, hd ? bufC : nullptr,
                           goff(l, SIMX_P_LN1_G), goff(l, SIMX_P_LN1_B), goff(l, SIMX_P_BO), &d1, cu));
-    RUN(simx_gemm_nt(stream, dt, nseq, H, H, dzm, H, w.woT, H, st2, H, nullptr, nullptr, 0, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
-    RUN(simx_rows_copy(stream, dt, dt, nseq, H, cu, nullptr, a.ctx, ctxc));
+    // e1 = dctx (gradient of the attention context, [CLS] rows), bufA[0:nseq] = gradient of the residual branch
+    RUN(simx_gemm_nt(stream, dt, nseq, H, H, dzm, H, w.woT, H, e1, H, nullptr, nullptr, 0, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
     RUN(simx_gemm_tn(stream, dt, H, H, nseq, dzm, H, ctxc, H, goff(l, SIMX_P_WO), H, 1, tnws, tnws_bytes));
-    // back to full tensors: dctx and the residual-branch gradient are zero outside the [CLS] rows
-    RUN(simx_rows_copy(stream, dt, dt, nseq, H, nullptr, nullptr, bufA, st1));
-    if (hipMemsetAsync(bufA, 0, (size_t)T * H * e, (hipStream_t)stream) != hipSuccess ||
-        hipMemsetAsync(bufB, 0, (size_t)T * H * e, (hipStream_t)stream) != hipSuccess) {
+    // attention core for the one query per sequence: e0 = dq [nseq,H]; dK, dV for every token -> dqkv[:, H:3H]
+    RUN(simx_mha_cls_bwd(stream, dt, nseq, c->heads, d, cu, max_len, T, qc, a.qkv, e1, e0, dqkv, &d3));
+    // Q projection ([CLS] rows): dWq, dbq, and dx = dq . Wq + (residual-branch gradient), still compact
+    RUN(simx_rows_copy(stream, dt, dt, nseq, H, cu, nullptr, xin, e2));
+    RUN(simx_gemm_tn_bias(stream, dt, H, H, nseq, e0, H, e2, H, goff(l, SIMX_P_WQKV), H, 1, tnws, tnws_bytes, goff(l, SIMX_P_BQKV)));
+    RUN(simx_gemm_nt(stream, dt, nseq, H, H, e0, H, w.wqkvT, 3 * H, e1, H, nullptr, bufA, H, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
+    // back to full tensors: that gradient is zero outside the [CLS] rows
+    if (hipMemsetAsync(bufA, 0, (size_t)T * H * e, (hipStream_t)stream) != hipSuccess) {
       simx_set_error("bert_bwd: memset failed");
       return SIMX_ERR_HIP;
     }
-    RUN(simx_rows_copy(stream, dt, dt, nseq, H, nullptr, cu, st1, bufA));
-    RUN(simx_rows_copy(stream, dt, dt, nseq, H, nullptr, cu, st2, bufB));
-    RUN(simx_mha_bwd_ex(stream, dt, nseq, c->heads, d, cu, max_len, T, a.qkv, a.ctx, a.lse, bufB, dqkv, &d3));
-    RUN(simx_gemm_nt(stream, dt, Tp, H, 3 * H, dqkv, 3 * H, w.wqkvT, 3 * H, bufB, H, nullptr, bufA, H, SIMX_EPI_NONE, nullptr, 0,
-                     nullptr, 0));
-    RUN(simx_gemm_tn_bias(stream, dt, 3 * H, H, T, dqkv, 3 * H, xin, H, goff(l, SIMX_P_WQKV), H, 1, tnws, tnws_bytes,
-                          goff(l, SIMX_P_BQKV)));
+    RUN(simx_rows_copy(stream, dt, dt, nseq, H, nullptr, cu, e1, bufA));
+    // K, V projections (every token): dx += dkv . Wkv ; dWkv, dbkv
+    RUN(simx_gemm_nt(stream, dt, Tp, H, 2 * H, dqkv + (size_t)H * e, 3 * H, w.wqkvT + (size_t)H * e, 3 * H, bufB, H, nullptr, bufA, H,
+                     SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
+    RUN(simx_gemm_tn_bias(stream, dt, 2 * H, H, T, dqkv + (size_t)H * e, 3 * H, xin, H, goff(l, SIMX_P_WQKV) + (size_t)H * H, H, 1, tnws,
+                          tnws_bytes, goff(l, SIMX_P_BQKV) + H));
     --l_top;
   } else {
     RUN(simx_cls_scatter(stream, dt, nseq, H, T, cu, dcls, bufB));            // g_x = d(loss)/d(last hidden)

@@ -176,8 +176,8 @@ def test_module_api_and_sequence_output(dev, golden_dir):
     assert hs is None and seq.shape == (ids.shape[0], ids.shape[1], 64) and pooled.shape == (ids.shape[0], 64)
     assert torch.equal(seq[:, 0, :], pooled)
     np.testing.assert_allclose(pooled.detach().cpu().numpy(), G["q_emb"], atol=2e-5 * 4)
-    emb = bi.query_emb(ids, mask)
-    assert torch.allclose(emb, pooled)
+    emb = bi.query_emb(ids, mask)        # [CLS]-only last layer: single-query attention sums in a different order
+    assert torch.allclose(emb, pooled, atol=2e-5, rtol=1e-5)
     # share_weight aliasing + state_dict schema
     keys = list(bi.state_dict().keys())
     assert "question_model.encoder.layer.0.attention.self.query.weight" in keys

@@ -347,6 +347,44 @@ def test_mha_fwd_bwd(dev, bf16, heads, d, lens):
     assert_close(back(dqkv), rdq, what="mha dqkv", **tolb)
 
 
+@pytest.mark.parametrize("bf16,heads,d,lens", [
+    (False, 4, 16, [5, 32, 17, 1]),
+    (False, 2, 64, [40, 7, 130]),
+    (True, 2, 64, [128, 1, 17, 33, 16, 100]),
+    (True, 12, 64, [160, 129, 45, 300]),
+])
+def test_mha_single_query(dev, bf16, heads, d, lens):
+    """The [CLS]-only last layer's attention (simx_mha_cls_fwd / _bwd): token 0 of every sequence is the only query.
+    Reference = the float64 full attention with dctx zero outside the [CLS] rows."""
+    lib = L()
+    T, H, n = sum(lens), heads * d, len(lens)
+    qkv, dcc = rnd((T, 3 * H), 11, 1.0), rnd((n, H), 12)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    first = cu[:-1]
+    qc = qkv[first, :H].copy()
+    qkv_in = qkv.copy()
+    qkv_in[:, :H] = 7.0                          # the Q columns of the packed rows must not be read
+    adt = torch.bfloat16 if bf16 else torch.float32
+    d_qkv, d_qc, d_dcc, dcu = to_dev(qkv_in, dev, bf16), to_dev(qc, dev, bf16), to_dev(dcc, dev, bf16), to_dev(cu, dev)
+    ctxc = torch.zeros(n, H, device=dev, dtype=adt)
+    lib.call("simx_mha_cls_fwd", lib.stream_ptr(), int(bf16), n, heads, d, lib.ptr(dcu), max(lens), T, lib.ptr(d_qc), lib.ptr(d_qkv),
+             lib.ptr(ctxc), None)
+    dctx = np.zeros((T, H))
+    dctx[first] = rounded(dcc, bf16)
+    rc, _, rdq = _mha_ref(rounded(qkv, bf16), lens, heads, d, dctx)
+    tol = dict(rtol=2e-5, atol=2e-5) if not bf16 else dict(rtol=2e-2, atol=2e-2)
+    assert_close(back(ctxc), rc[first], what="cls ctx", **tol)
+    dqc = torch.zeros(n, H, device=dev, dtype=adt)
+    dqkv = torch.full((T, 3 * H), 3.0, device=dev, dtype=adt)
+    lib.call("simx_mha_cls_bwd", lib.stream_ptr(), int(bf16), n, heads, d, lib.ptr(dcu), max(lens), T, lib.ptr(d_qc), lib.ptr(d_qkv),
+             lib.ptr(d_dcc), lib.ptr(dqc), lib.ptr(dqkv), None)
+    tolb = dict(rtol=1e-4, atol=1e-4) if not bf16 else dict(rtol=3e-2, atol=6e-2)
+    got = back(dqkv)
+    assert_close(back(dqc), rdq[first, :H], what="cls dq", **tolb)
+    assert_close(got[:, H:], rdq[:, H:], what="cls dk dv", **tolb)
+    assert np.all(got[:, :H] == 3.0)             # the Q columns of dqkv are left alone
+
+
 def test_mha_bf16_spiked_scores(dev):
     """large-magnitude logits: one key dominates each row (softmax saturation / max subtraction)."""
     lib = L()

@@ -352,6 +352,10 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_seq_kernel(int nseq, int seq
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sred = reinterpret_cast<float*>(smem);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // per-wave transposition patch for the word-embedding scatter: a lane owns 4 consecutive columns per vector, so an
+  // atomic instruction issued from that layout touches 64 lanes x 4 B at a 16-B stride = 16 cache lines; through the
+  // patch every instruction covers 64 CONSECUTIVE floats = 4 lines, a quarter of the L2 atomic transactions
+  float* patch = sred + 4 * H + w * (VPL * 256);
   const int p = blockIdx.x * 4 + w;
   const int s0 = blockIdx.y * seq_per_block, s1 = min(nseq, s0 + seq_per_block);
   float pg[VPL][4] = {}, pb[VPL][4] = {}, pz[VPL][4] = {};
@@ -390,13 +394,20 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_seq_kernel(int nseq, int seq
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
       const int c = (v * 64 + lane) * 4;
-      if (c < H)
+      if (c < H) {
+        *reinterpret_cast<float4*>(patch + c) = make_float4(dz[v][0], dz[v][1], dz[v][2], dz[v][3]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          atomicAdd(dword + wid * H + c + e, dz[v][e]);
-          pz[v][e] += dz[v][e];
-        }
+        for (int e = 0; e < 4; ++e) pz[v][e] += dz[v][e];
+      }
     }
+    __builtin_amdgcn_wave_barrier();
+    float* wrow = dword + wid * H;
+#pragma unroll
+    for (int k = 0; k < VPL * 4; ++k) {
+      const int c = k * 64 + lane;
+      if (c < H) atomicAdd(wrow + c, patch[c]);
+    }
+    __builtin_amdgcn_wave_barrier();
   }
   if (pid >= 0) {                                    // this wave's position row: its sum over the chunk's sequences
 #pragma unroll
@@ -598,7 +609,7 @@ extern "C" int simx_embed_ln_bwd_seq(simx_stream_t stream, int dtype, int nseq, 
   if (chunks > nseq) chunks = nseq;
   const int spb = cdiv(nseq, chunks);
   const dim3 grid(pgroups, cdiv(nseq, spb));
-  const size_t lds = (size_t)4 * H * sizeof(float);
+  const size_t lds = (size_t)(4 * H + 4 * LN_VPL * 256) * sizeof(float);      // column-flush scratch + per-wave scatter patches
 #define ES(TT, V) hipLaunchKernelGGL((embed_ln_bwd_seq_kernel<TT, V>), grid, dim3(256), lds, s, nseq, spb, H, cu_seqlens, ids, pos_ids, word, \
                                     posw, typew, gamma, eps, (const TT*)dy, dword, dpos, dtype0, dgamma, dbeta, drop)
   if (dtype == SIMX_F32) { if (H <= 256) ES(float, 1); else if (H <= 768) ES(float, 3); else ES(float, 4); }

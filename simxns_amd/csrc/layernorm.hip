@@ -195,16 +195,10 @@ __device__ __forceinline__ void flush_cols(int H, int lane, int w, float (&p)[VP
       for (int e = 0; e < 4; ++e) sred[w * H + c + e] = p[v][e];
   }
   __syncthreads();
-  if (w == 0) {
-#pragma unroll
-    for (int v = 0; v < VPL; ++v) {
-      const int c = (v * 64 + lane) * 4;
-      if (c < H)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          atomicAdd(out + c + e, sred[c + e] + sred[H + c + e] + sred[2 * H + c + e] + sred[3 * H + c + e]);
-    }
-  }
+  // all four waves issue the atomics, each instruction on 64 CONSECUTIVE columns (4 cache lines; the lane-owns-4-columns
+  // layout would touch 16) -- every block of the grid adds into the same H addresses, so the L2 transaction count of
+  // this tail is what the kernel's last microseconds are made of
+  for (int c = threadIdx.x; c < H; c += 256) atomicAdd(out + c, sred[c] + sred[H + c] + sred[2 * H + c] + sred[3 * H + c]);
   __syncthreads();
 }
 
@@ -224,8 +218,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int H, int rows_p
   for (int c = threadIdx.x; c < H; c += 256) sgam[c] = gamma[c];
   __syncthreads();
   float pg[VPL][4] = {}, pb[VPL][4] = {}, pz[VPL][4] = {};
-  const int r0 = blockIdx.x * rows_per_block;
-  const int r1 = min(rows, r0 + rows_per_block);
+  // Rows are dealt out grid-strided (block b, wave w: rows 4b + w, + 4*gridDim, ...): at any moment the whole grid works
+  // on one contiguous window of ~4*gridDim rows.  Giving every block its own contiguous range instead made 2048 waves
+  // walk 2048 regions 0.8 MB apart in four tensors at once, and the DRAM pages thrashed (4.1 TB/s, and MORE blocks per
+  // CU made it slower).
+  (void)rows_per_block;
+  const int r0 = blockIdx.x * 4, r1 = rows, rstep = (int)gridDim.x * 4;
   Raw4<T> nx[VPL], nd[VPL];
   if (r0 + w < r1) {
 #pragma unroll
@@ -234,7 +232,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int H, int rows_p
       if (c < H) { nx[v].load(z + (long)(r0 + w) * H + c); nd[v].load(dyp + (long)(r0 + w) * H + c); }
     }
   }
-  for (int row = r0 + w; row < r1; row += 4) {
+  for (int row = r0 + w; row < r1; row += rstep) {
     float x[VPL][4], dy[VPL][4], dz[VPL][4];
     float sum = 0.f;
 #pragma unroll
@@ -242,11 +240,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int H, int rows_p
       const int c = (v * 64 + lane) * 4;
       if (c < H) { nx[v].unpack(x[v]); nd[v].unpack(dy[v]); sum += x[v][0] + x[v][1] + x[v][2] + x[v][3]; }
     }
-    if (row + 4 < r1) {
+    if (row + rstep < r1) {
 #pragma unroll
       for (int v = 0; v < VPL; ++v) {
         const int c = (v * 64 + lane) * 4;
-        if (c < H) { nx[v].load(z + (long)(row + 4) * H + c); nd[v].load(dyp + (long)(row + 4) * H + c); }
+        if (c < H) { nx[v].load(z + (long)(row + rstep) * H + c); nd[v].load(dyp + (long)(row + rstep) * H + c); }
       }
     }
     const float mu = wave_sum(sum) / (float)H;
@@ -490,7 +488,7 @@ static int ln_rows_per_block(int T, const char* env, int dflt) {
   if (rpb < 16) rpb = 16;
   return cdiv(rpb, 4) * 4;
 }
-static int bwd_rows_per_block(int T) { return ln_rows_per_block(T, "SIMX_LN_BWD_BLOCKS", 512); }
+static int bwd_rows_per_block(int T) { return ln_rows_per_block(T, "SIMX_LN_BWD_BLOCKS", 768); }
 
 extern "C" int simx_ln_fwd(simx_stream_t stream, int dtype, int T, int H, const void* z, const float* gamma,
                            const float* beta, float eps, void* y) {

@@ -239,6 +239,17 @@ int simx_bert_bwd(simx_stream_t stream, const simx_bert_cfg* cfg, const float* p
                   const int32_t* ids, const int32_t* pos_ids, const int32_t* cu_seqlens,
                   int nseq, int T, int max_len, const void* act, size_t act_bytes,
                   const float* dcls, float* grads, void* scratch, size_t scratch_bytes);
+/* same with the upstream gradient given for the WHOLE last hidden state (sequence_output of HFBertEncoder.forward,
+ * models.py:77-82; e.g. the masked-mean pooling of EmbeddingMixin, models.py:296-305): dhidden [T,hidden] in the
+ * activation dtype.  Exactly one of dcls / dhidden is non-NULL; dhidden needs cfg->cls_only_last_layer == 0. */
+int simx_bert_bwd_ex(simx_stream_t stream, const simx_bert_cfg* cfg, const float* params, const void* wcache,
+                     const int32_t* ids, const int32_t* pos_ids, const int32_t* cu_seqlens,
+                     int nseq, int T, int max_len, const void* act, size_t act_bytes,
+                     const float* dcls, const void* dhidden, float* grads, void* scratch, size_t scratch_bytes);
+/* masked mean over the real tokens of each sequence of a packed [T,H] tensor -> f32 [nseq,H] (EmbeddingMixin.masked_mean,
+ * SimANS/model/models.py:296-299), and its adjoint (dx[t] = dmean[seq(t)] / len) */
+int simx_seq_mean_fwd(simx_stream_t stream, int dtype, int nseq, int H, const int32_t* cu_seqlens, const void* x, float* mean);
+int simx_seq_mean_bwd(simx_stream_t stream, int dtype, int nseq, int H, const int32_t* cu_seqlens, const float* dmean, void* dx);
 
 /* -------------------------------------------------- similarity + losses (f32)
  * M1 local similarity einsum("bh,bdh->bd") (co_training_marco_train.py:199-202) fused with the

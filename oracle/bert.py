@@ -256,21 +256,32 @@ def reranker_backward(P, ids3, mask3, heads, caches, cls, dlogits, dtype=np.floa
 
 
 # ---- E4: RobertaDot (SimANS/model/models.py:277-359) -----------------------------------------
-def roberta_dot_forward(P, ids, mask, heads, eps=1e-5, head_eps=1e-5, pad_id=1, dtype=np.float64, keep=True):
-    """emb = LayerNorm(embeddingHead(roberta(ids, mask)[0][:, 0]))  (use_mean == False, the from_pretrained default).
+def roberta_dot_forward(P, ids, mask, heads, eps=1e-5, head_eps=1e-5, pad_id=1, dtype=np.float64, keep=True, use_mean=False):
+    """emb = LayerNorm(embeddingHead(pool(roberta(ids, mask)[0]))) with pool = row 0 (use_mean == False, the
+    from_pretrained default, models.py:283-286) or the masked mean over the real tokens (models.py:296-305).
     ``P`` keys: roberta.* (no pooler), embeddingHead.{weight,bias}, norm.{weight,bias}."""
     seq, cls, caches = bert_forward(P, ids, mask, heads, eps=eps, dtype=dtype, keep=keep, prefix="roberta.",
                                     pos_offset=pad_id + 1)
+    if use_mean:
+        m = np.asarray(mask, dtype)[..., None]
+        cls = (seq * m).sum(1) / m.sum(1)
     w, b = np.asarray(P["embeddingHead.weight"], dtype), np.asarray(P["embeddingHead.bias"], dtype)
     z = cls @ w.T + b
     y, ln = _ln_fwd(z, np.asarray(P["norm.weight"], dtype), np.asarray(P["norm.bias"], dtype), head_eps)
-    return y, dict(enc=caches, cls=cls, ln=ln)
+    return y, dict(enc=caches, cls=cls, ln=ln, use_mean=use_mean)
 
 
 def roberta_dot_backward(P, ids, mask, heads, cache, d_emb, pad_id=1, dtype=np.float64):
     dz, dg, db = _ln_bwd(np.asarray(d_emb, dtype), cache["ln"], np.asarray(P["norm.weight"], dtype))
     w = np.asarray(P["embeddingHead.weight"], dtype)
-    G = bert_backward(P, ids, mask, heads, cache["enc"], dz @ w, dtype=dtype, prefix="roberta.", pos_offset=pad_id + 1)
+    d_in = dz @ w
+    if cache.get("use_mean"):
+        m = np.asarray(mask, dtype)[..., None]
+        d_seq = d_in[:, None, :] * m / m.sum(1, keepdims=True)
+        G = bert_backward(P, ids, mask, heads, cache["enc"], np.zeros_like(d_in), d_seq=d_seq, dtype=dtype, prefix="roberta.",
+                          pos_offset=pad_id + 1)
+    else:
+        G = bert_backward(P, ids, mask, heads, cache["enc"], d_in, dtype=dtype, prefix="roberta.", pos_offset=pad_id + 1)
     G["norm.weight"], G["norm.bias"] = dg, db
     G["embeddingHead.weight"], G["embeddingHead.bias"] = dz.T @ cache["cls"], dz.sum(0)
     return G

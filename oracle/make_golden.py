@@ -506,9 +506,11 @@ def gen_collate(tmp):
                         ce_ids=ce, ce_mask=cem.numpy(), tgt=tgt.numpy(), pos=np.asarray(pos))
 
 
-def gen_roberta_dot(tmp):
+def gen_roberta_dot(tmp, use_mean=False):
     """E4: the imported RobertaDot (SimANS/model/models.py:334-359) on a tiny RoBERTa config, shared encoder for queries
-    and documents, with the MS-Doc step's KL-distill loss (co_training_doc_train.py:209-224) -> roberta_dot_tiny.npz."""
+    and documents, with the MS-Doc step's KL-distill loss (co_training_doc_train.py:209-224) -> roberta_dot_tiny.npz;
+    use_mean=True: the masked-mean pooling of EmbeddingMixin (models.py:296-305) -> roberta_dot_mean_tiny.npz (the
+    embeddings, the loss and a subset of the gradients: the whole hidden state carries gradient on that path)."""
     import transformers
     cfgd = dict(vocab=1000, hidden=64, layers=2, heads=4, inter=128, max_pos=140, type_vocab=1, eps=1e-5, pooler=False)
     cfg = BertCfg(**cfgd)
@@ -517,7 +519,9 @@ def gen_roberta_dot(tmp):
                                     max_position_embeddings=cfg.max_pos, type_vocab_size=1, layer_norm_eps=1e-5,
                                     hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, pad_token_id=1)
     hf.return_dict = False                      # the reference only sets this for transformers 4 (models.py:338-339)
-    model = RM.RobertaDot(hf)
+    import types
+    model = RM.RobertaDot(hf, types.SimpleNamespace(use_mean=True)) if use_mean else RM.RobertaDot(hf)
+    assert bool(model.use_mean) == use_mean
     P = {"roberta." + k: v for k, v in make_bert_params(cfg, 4321, std=0.08).items()}
     P["embeddingHead.weight"] = normal(4321, "embeddingHead.weight", (cfg.hidden, cfg.hidden), 0.08).astype(np.float32)
     P["embeddingHead.bias"] = normal(4321, "embeddingHead.bias", (cfg.hidden,), 0.02).astype(np.float32)
@@ -549,8 +553,8 @@ def gen_roberta_dot(tmp):
     loss.backward()
     G = _grads(model)
     print(" [roberta_dot] oracle vs imported reference")
-    oq, cq = obert.roberta_dot_forward(P, q_ids, q_mask, cfg.heads)
-    od, cd = obert.roberta_dot_forward(P, d_ids, d_mask, cfg.heads)
+    oq, cq = obert.roberta_dot_forward(P, q_ids, q_mask, cfg.heads, use_mean=use_mean)
+    od, cd = obert.roberta_dot_forward(P, d_ids, d_mask, cfg.heads, use_mean=use_mean)
     _cmp("q_emb (vs fp32 reference)", oq, q32, 2e-5)
     _cmp("doc_emb (vs fp32 reference)", od, d32, 2e-5)
     _cmp("q_emb", oq, q.detach().numpy(), 1e-11)
@@ -573,9 +577,13 @@ def gen_roberta_dot(tmp):
                loss=np.float64(loss.item()))
     for k in ("embeddingHead.weight", "embeddingHead.bias", "norm.weight", "norm.bias"):
         out["param." + k] = P[k]
+    keep = None if not use_mean else ("embeddingHead.", "norm.", "roberta.embeddings.", "roberta.encoder.layer.0.attention.self.query",
+                                      "roberta.encoder.layer.1.output.", "roberta.encoder.layer.1.attention.output.")
     for k, g in G.items():
-        out["grad." + k] = g
-    np.savez_compressed(os.path.join(OUT, "roberta_dot_tiny.npz"), **out)
+        if keep is None or k.startswith(keep):
+            out["grad." + k] = g
+    out["use_mean"] = np.int64(use_mean)
+    np.savez_compressed(os.path.join(OUT, "roberta_dot_mean_tiny.npz" if use_mean else "roberta_dot_tiny.npz"), **out)
 
 
 def main():
@@ -589,6 +597,7 @@ def main():
         gen_sampler(tmp)
         gen_collate(tmp)
         gen_roberta_dot(tmp)
+        gen_roberta_dot(tmp, use_mean=True)
         if "--only-small" in sys.argv:
             return
         gen_encoder_step(tmp, TINY, "tiny", B=4, N=3, q_len=32, p_len=128, ce_len=160,

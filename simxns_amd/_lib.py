@@ -81,6 +81,9 @@ SIGNATURES = {
     "simx_bert_cast_weights": (_i, [_p, _cfgp, _p, _p]),
     "simx_bert_fwd": (_i, [_p, _cfgp, _p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _i, _p, _p]),
     "simx_bert_bwd": (_i, [_p, _cfgp, _p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p, _p, _p, _z]),
+    "simx_bert_bwd_ex": (_i, [_p, _cfgp, _p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p, _p, _p, _p, _z]),
+    "simx_seq_mean_fwd": (_i, [_p, _i, _i, _i, _p, _p, _p]),
+    "simx_seq_mean_bwd": (_i, [_p, _i, _i, _i, _p, _p, _p]),
     "simx_sim_loss_fwd_bwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _lpp, _p, _p, _p, _p]),
     "simx_scores_nll_fwd_bwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _f, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "simx_scores_kd_fwd_bwd": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _f, _f, _f, _i, _i, _i, _i, _p, _p, _p, _p, _p]),

@@ -288,9 +288,19 @@ extern "C" int simx_bert_bwd(simx_stream_t stream, const simx_bert_cfg* c, const
                              const int32_t* ids, const int32_t* pos_ids, const int32_t* cu, int nseq, int T, int max_len,
                              const void* act, size_t act_bytes, const float* dcls, float* grads, void* scratch,
                              size_t scratch_bytes) {
+  return simx_bert_bwd_ex(stream, c, params, wcache, ids, pos_ids, cu, nseq, T, max_len, act, act_bytes, dcls, nullptr, grads, scratch,
+                          scratch_bytes);
+}
+
+extern "C" int simx_bert_bwd_ex(simx_stream_t stream, const simx_bert_cfg* c, const float* params, const void* wcache,
+                                const int32_t* ids, const int32_t* pos_ids, const int32_t* cu, int nseq, int T, int max_len,
+                                const void* act, size_t act_bytes, const float* dcls, const void* dhidden, float* grads,
+                                void* scratch, size_t scratch_bytes) {
   RUN(check_io(c, nseq, T, max_len, "bert_bwd"));
-  SIMX_REQUIRE(params && wcache && ids && pos_ids && cu && act && dcls && grads && scratch, SIMX_ERR_BAD_SHAPE,
-               "bert_bwd: NULL buffer");
+  SIMX_REQUIRE(params && wcache && ids && pos_ids && cu && act && grads && scratch, SIMX_ERR_BAD_SHAPE, "bert_bwd: NULL buffer");
+  SIMX_REQUIRE((dcls != nullptr) != (dhidden != nullptr), SIMX_ERR_BAD_SHAPE, "bert_bwd: pass exactly one of dcls / dhidden");
+  SIMX_REQUIRE(!(dhidden && c->cls_only_last_layer), SIMX_ERR_BAD_SHAPE,
+               "bert_bwd: a gradient for the whole hidden state needs the full last layer (cls_only_last_layer = 0)");
   SIMX_REQUIRE(act_bytes >= simx_bert_act_bytes(c, T, nseq, 1), SIMX_ERR_WORKSPACE, "bert_bwd: activation buffer too small");
   SIMX_REQUIRE(scratch_bytes >= simx_bert_bwd_scratch_bytes(c, T, nseq), SIMX_ERR_WORKSPACE, "bert_bwd: scratch %zu < %zu",
                scratch_bytes, simx_bert_bwd_scratch_bytes(c, T, nseq));
@@ -352,6 +362,11 @@ extern "C" int simx_bert_bwd(simx_stream_t stream, const simx_bert_cfg* c, const
     RUN(simx_gemm_tn_bias(stream, dt, 2 * H, H, T, dqkv + (size_t)H * e, 3 * H, xin, H, goff(l, SIMX_P_WQKV) + (size_t)H * H, H, 1, tnws,
                           tnws_bytes, goff(l, SIMX_P_BQKV) + H));
     --l_top;
+  } else if (dhidden) {
+    if (hipMemcpyAsync(bufB, dhidden, (size_t)T * H * e, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
+      simx_set_error("bert_bwd: copy of the hidden-state gradient failed");
+      return SIMX_ERR_HIP;
+    }
   } else {
     RUN(simx_cls_scatter(stream, dt, nseq, H, T, cu, dcls, bufB));            // g_x = d(loss)/d(last hidden)
   }

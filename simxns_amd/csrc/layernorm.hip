@@ -473,6 +473,29 @@ __global__ __launch_bounds__(256) void drop_residual_rows_kernel(int n, int H, c
   st4(z + i, v);
 }
 
+// masked mean over each sequence's real tokens (packed layout: rows cu[s] .. cu[s+1]) and its adjoint
+template <typename T>
+__global__ __launch_bounds__(256) void seq_mean_fwd_kernel(int H, const int* __restrict__ cu, const T* __restrict__ x,
+                                                           float* __restrict__ out) {
+  const int s = blockIdx.x, t0 = cu[s], len = cu[s + 1] - t0;
+  const float inv = 1.0f / (float)len;
+  for (int c = threadIdx.x; c < H; c += 256) {
+    float acc = 0.f;
+    for (int r = 0; r < len; ++r) acc += Elem<T>::ld(x + (long)(t0 + r) * H + c);
+    out[(long)s * H + c] = acc * inv;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void seq_mean_bwd_kernel(int H, const int* __restrict__ cu, const float* __restrict__ dmean,
+                                                           T* __restrict__ dx) {
+  const int s = blockIdx.x, t0 = cu[s], len = cu[s + 1] - t0;
+  const float inv = 1.0f / (float)len;
+  for (int c = threadIdx.x; c < H; c += 256) {
+    const float g = dmean[(long)s * H + c] * inv;
+    for (int r = 0; r < len; ++r) Elem<T>::st(dx + (long)(t0 + r) * H + c, g);
+  }
+}
+
 // ------------------------------------------------------------------------------------------ host
 static int ln_check(int dtype, int T, int H, const char* who) {
   SIMX_REQUIRE(dtype == SIMX_F32 || dtype == SIMX_BF16, SIMX_ERR_BAD_DTYPE, "%s: dtype %d", who, dtype);
@@ -667,5 +690,25 @@ extern "C" int simx_drop_residual_rows(simx_stream_t stream, int dtype, int n, i
   if (dtype == SIMX_F32) hipLaunchKernelGGL((drop_residual_rows_kernel<float>), dim3(blocks), dim3(256), 0, s, n, H, (const float*)y, (const float*)res, res_idx, key_idx, drop, (float*)z);
   else hipLaunchKernelGGL((drop_residual_rows_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, n, H, (const bf16_t*)y, (const bf16_t*)res, res_idx, key_idx, drop, (bf16_t*)z);
   SIMX_CHECK_LAUNCH("drop_residual_rows");
+  return SIMX_OK;
+}
+
+extern "C" int simx_seq_mean_fwd(simx_stream_t stream, int dtype, int nseq, int H, const int32_t* cu, const void* x, float* mean) {
+  SIMX_REQUIRE(nseq > 0 && H > 0 && cu && x && mean, SIMX_ERR_BAD_SHAPE, "seq_mean_fwd: bad arguments");
+  SIMX_REQUIRE(dtype == SIMX_F32 || dtype == SIMX_BF16, SIMX_ERR_BAD_DTYPE, "seq_mean_fwd: dtype %d", dtype);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == SIMX_F32) hipLaunchKernelGGL((seq_mean_fwd_kernel<float>), dim3(nseq), dim3(256), 0, s, H, cu, (const float*)x, mean);
+  else hipLaunchKernelGGL((seq_mean_fwd_kernel<bf16_t>), dim3(nseq), dim3(256), 0, s, H, cu, (const bf16_t*)x, mean);
+  SIMX_CHECK_LAUNCH("seq_mean_fwd");
+  return SIMX_OK;
+}
+
+extern "C" int simx_seq_mean_bwd(simx_stream_t stream, int dtype, int nseq, int H, const int32_t* cu, const float* dmean, void* dx) {
+  SIMX_REQUIRE(nseq > 0 && H > 0 && cu && dmean && dx, SIMX_ERR_BAD_SHAPE, "seq_mean_bwd: bad arguments");
+  SIMX_REQUIRE(dtype == SIMX_F32 || dtype == SIMX_BF16, SIMX_ERR_BAD_DTYPE, "seq_mean_bwd: dtype %d", dtype);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == SIMX_F32) hipLaunchKernelGGL((seq_mean_bwd_kernel<float>), dim3(nseq), dim3(256), 0, s, H, cu, dmean, (float*)dx);
+  else hipLaunchKernelGGL((seq_mean_bwd_kernel<bf16_t>), dim3(nseq), dim3(256), 0, s, H, cu, dmean, (bf16_t*)dx);
+  SIMX_CHECK_LAUNCH("seq_mean_bwd");
   return SIMX_OK;
 }

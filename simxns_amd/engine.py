@@ -132,18 +132,32 @@ class PackedBatch(object):
 
 
 class _EncoderFn(torch.autograd.Function):
+    """pool: "cls" -> [CLS] embeddings [n,H] f32; "hidden" -> (cls, packed last hidden state [T,H]), both
+    differentiable; "mean" -> masked mean over every sequence's real tokens [n,H] f32 (models.py:296-299)."""
+
     @staticmethod
-    def forward(ctx, anchor, engine, pb, want_hidden, ccfg):
-        cls, hidden, act = engine._run_forward(pb, True, want_hidden, ccfg)
-        ctx.engine, ctx.pb, ctx.act, ctx.ccfg = engine, pb, act, ccfg
-        if want_hidden:
-            ctx.mark_non_differentiable(hidden)
+    def forward(ctx, anchor, engine, pb, pool, ccfg):
+        cls, hidden, act = engine._run_forward(pb, True, pool != "cls", ccfg)
+        ctx.engine, ctx.pb, ctx.act, ctx.ccfg, ctx.pool = engine, pb, act, ccfg, pool
+        if pool == "hidden":
             return cls, hidden
+        if pool == "mean":
+            return engine._seq_mean(pb, hidden)
         return cls
 
     @staticmethod
-    def backward(ctx, dcls, *unused):
-        ctx.engine._run_backward(ctx.pb, ctx.act, dcls, ctx.ccfg)      # same config copy: same dropout seed
+    def backward(ctx, g0, g1=None):
+        e, pb = ctx.engine, ctx.pb
+        if ctx.pool == "cls":
+            e._run_backward(pb, ctx.act, dcls=g0, ccfg=ctx.ccfg)      # same config copy: same dropout seed
+        elif ctx.pool == "mean":
+            e._run_backward(pb, ctx.act, dhidden=e._seq_mean_bwd(pb, g0), ccfg=ctx.ccfg)
+        else:
+            H = e.cfg.hidden_size
+            dh = torch.zeros(pb.T, H, dtype=torch.float32, device=e.flat.device) if g1 is None else g1.to(torch.float32).clone()
+            if g0 is not None:
+                dh.index_add_(0, pb.cu[:-1].long(), g0.to(torch.float32))
+            e._run_backward(pb, ctx.act, dhidden=dh.to(e.act_torch_dtype).contiguous(), ccfg=ctx.ccfg)
         ctx.act = None
         return None, None, None, None, None
 
@@ -254,32 +268,48 @@ class BertEngine(object):
                1 if save else 0, L.ptr(cls), L.ptr(hidden))
         return cls, hidden, (act if save else None)
 
-    def _run_backward(self, pb, act, dcls, ccfg=None):
+    def _seq_mean(self, pb, hidden):
+        out = torch.empty(pb.nseq, self.cfg.hidden_size, dtype=torch.float32, device=hidden.device)
+        L.call("simx_seq_mean_fwd", L.stream_ptr(), self.dtype_code, pb.nseq, self.cfg.hidden_size, L.ptr(pb.cu), L.ptr(hidden), L.ptr(out))
+        return out
+
+    def _seq_mean_bwd(self, pb, dmean):
+        dmean = dmean.contiguous().to(torch.float32)
+        dh = torch.empty(pb.T, self.cfg.hidden_size, dtype=self.act_torch_dtype, device=dmean.device)
+        L.call("simx_seq_mean_bwd", L.stream_ptr(), self.dtype_code, pb.nseq, self.cfg.hidden_size, L.ptr(pb.cu), L.ptr(dmean), L.ptr(dh))
+        return dh
+
+    def _run_backward(self, pb, act, dcls=None, ccfg=None, dhidden=None):
         ccfg = ccfg if ccfg is not None else self.ccfg
         self.last_stream = torch.cuda.current_stream()
         g = self.ensure_grad()
         dev = self.flat.device
-        dcls = dcls.contiguous().to(torch.float32)
+        if dcls is not None:
+            dcls = dcls.contiguous().to(torch.float32)
         nbytes = int(self.lib.simx_bert_bwd_scratch_bytes(C.byref(self.ccfg), pb.nseq * pb.S, pb.nseq))
         scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        L.call("simx_bert_bwd", L.stream_ptr(), C.byref(ccfg), L.ptr(self.flat), L.ptr(self.wcache),
+        L.call("simx_bert_bwd_ex", L.stream_ptr(), C.byref(ccfg), L.ptr(self.flat), L.ptr(self.wcache),
                L.ptr(pb.ids), L.ptr(pb.pos), L.ptr(pb.cu), pb.nseq, pb.T, pb.max_len, L.ptr(act), act.numel(),
-               L.ptr(dcls), L.ptr(g), L.ptr(scratch), nbytes)
+               L.ptr(dcls), L.ptr(dhidden), L.ptr(g), L.ptr(scratch), nbytes)
         if self.after_backward is not None:
             self.after_backward()
         if self.grad_ready_hook is not None:
             self.grad_ready_hook(self)
 
-    def encode(self, input_ids, attention_mask, want_hidden=False, requires_grad=None, training=False):
-        """-> cls [n,H] f32 (and the packed last hidden state + PackedBatch when want_hidden)."""
+    def encode(self, input_ids, attention_mask, want_hidden=False, requires_grad=None, training=False, pool=None):
+        """-> cls [n,H] f32; with want_hidden also the packed last hidden state + PackedBatch (both outputs carry
+        gradient); pool="mean" -> the masked mean over each sequence's real tokens [n,H] f32 instead of [CLS]."""
+        pool = pool or ("hidden" if want_hidden else "cls")
         pb = PackedBatch(input_ids, attention_mask, getattr(self.cfg, "position_offset", 0))
-        ccfg = self.call_cfg(training, want_hidden)
+        ccfg = self.call_cfg(training, pool != "cls")
         if requires_grad is None:
             requires_grad = torch.is_grad_enabled()
         if requires_grad and torch.is_grad_enabled():
             if self.anchor.device != self.flat.device:
                 self.anchor = torch.zeros((), requires_grad=True, device=self.flat.device)
-            out = _EncoderFn.apply(self.anchor, self, pb, want_hidden, ccfg)
-            return (out[0], out[1], pb) if want_hidden else out
-        cls, hidden, _ = self._run_forward(pb, False, want_hidden, ccfg)
-        return (cls, hidden, pb) if want_hidden else cls
+            out = _EncoderFn.apply(self.anchor, self, pb, pool, ccfg)
+            return (out[0], out[1], pb) if pool == "hidden" else out
+        cls, hidden, _ = self._run_forward(pb, False, pool != "cls", ccfg)
+        if pool == "mean":
+            return self._seq_mean(pb, hidden)
+        return (cls, hidden, pb) if pool == "hidden" else cls

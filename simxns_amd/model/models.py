@@ -146,7 +146,7 @@ class HFBertEncoder(nn.Module):
         if self.engine.flat_grad is not None:
             self.attach_grads()
         seq = pb.unpack(hidden.to(torch.float32))
-        # gradient reaches the encoder through the [CLS] row only (the only row the reference path uses)
+        # every row carries gradient back into the encoder; row 0 is the f32 [CLS] output (exact in bf16 mode too)
         seq = seq.index_copy(1, torch.zeros(1, dtype=torch.long, device=seq.device), cls_vec.unsqueeze(1))
         return seq, seq[:, 0, :], None
 
@@ -154,18 +154,21 @@ class HFBertEncoder(nn.Module):
         """Fast path used by BiBertEncoder / Reranker: [CLS] embeddings [n,H] f32 only."""
         return self.engine.encode(input_ids, attention_mask, training=self.training)
 
+    def embed_mean(self, input_ids, attention_mask):
+        """EmbeddingMixin.masked_mean (models.py:296-299): mean of the last hidden state over each sequence's real tokens,
+        [n,H] f32, computed on the packed layout (no padded sequence_output is materialised)."""
+        return self.engine.encode(input_ids, attention_mask, training=self.training, pool="mean")
+
 
 class RobertaDot(nn.Module):
     """SimANS/model/models.py:277-359 (E4, the MS-Doc student of co_training_doc_train.py:203-208): ONE shared RoBERTa
     encoder without pooler for queries and documents, emb = LayerNorm(Linear(H -> output_embedding_size)(seq[:, 0])).
-    ``model_argobj.use_mean`` (masked mean pooling) is False on the from_pretrained path the reference uses
-    (models.py:283-286) and is not implemented here.  state_dict keys: roberta.*, embeddingHead.*, norm.*"""
+    ``model_argobj.use_mean`` selects the masked mean over the real tokens instead of row 0 (models.py:283-286, 296-305;
+    False on the from_pretrained path the reference's scripts use).  state_dict keys: roberta.*, embeddingHead.*, norm.*"""
 
     def __init__(self, config, model_argobj=None, compute_dtype=None):
         super(RobertaDot, self).__init__()
         self.use_mean = False if model_argobj is None else bool(model_argobj.use_mean)
-        if self.use_mean:
-            raise NotImplementedError("use_mean=True (masked mean pooling) is not on the MI355X path")
         if not isinstance(config, BertConfigLite):
             d = config.to_dict() if hasattr(config, "to_dict") else dict(config)
             d.setdefault("model_type", "roberta")
@@ -182,7 +185,7 @@ class RobertaDot(nn.Module):
             self.embeddingHead.weight.normal_(mean=0.0, std=0.02)
 
     def query_emb(self, input_ids, attention_mask):
-        full_emb = self.roberta.embed(input_ids, attention_mask)
+        full_emb = self.roberta.embed_mean(input_ids, attention_mask) if self.use_mean else self.roberta.embed(input_ids, attention_mask)
         z = ops.linear_f32(full_emb, self.embeddingHead.weight, self.embeddingHead.bias)
         return ops.layer_norm_f32(z, self.norm.weight, self.norm.bias, self.norm.eps)
 

@@ -325,3 +325,45 @@ def test_large_hidden_geometry_against_oracle(dev):
         ref = Gc[k].ravel()
         cos = float(g.ravel() @ ref / (np.linalg.norm(g) * np.linalg.norm(ref) + 1e-30))
         assert cos >= 0.97, "%s cosine %.4f" % (k, cos)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_sequence_output_carries_gradient(dev, dtype):
+    """HFBertEncoder.forward returns the whole sequence_output (models.py:77-82) and, as in the reference, every row
+    of it backpropagates: loss = sum(w * seq) over all real tokens + sum(v * pooled), against the oracle's backward
+    with d_seq."""
+    from oracle import bert as ob
+    from oracle.weights import BertCfg, make_bert_params, make_batch
+    from simxns_amd.engine import BertConfigLite
+    from simxns_amd.model.models import HFBertEncoder
+    ocfg = BertCfg(vocab=400, hidden=64, layers=2, heads=4, inter=128, max_pos=64)
+    cfg = BertConfigLite(vocab_size=400, hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+                         max_position_embeddings=64, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    P = make_bert_params(ocfg, 9, std=0.08)
+    ids, mask, _ = make_batch(77, 5, 48, 400, 20, 10, 3)
+    rs = np.random.RandomState(3)
+    w = rs.randn(5, 48, 64) * mask[..., None]
+    v = rs.randn(5, 64)
+    enc = HFBertEncoder(cfg, dtype)
+    enc.load_numpy_state(P)
+    enc.to(dev).eval()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    seq, pooled, _ = enc(input_ids=t(ids), attention_mask=t(mask))
+    loss = (seq * t(w).float()).sum() + (pooled * t(v).float()).sum()
+    loss.backward()
+    oseq, ocls, cache = ob.bert_forward(P, ids, mask, 4)
+    tol = 2e-5 if dtype == "fp32" else 6e-2
+    assert np.abs(seq.detach().cpu().numpy() - oseq * mask[..., None]).max() <= tol * 4
+    d_seq = w.copy()
+    d_cls = v + w[:, 0, :]                      # row 0 of seq IS pooled: both terms reach it
+    d_seq[:, 0, :] = 0
+    G = ob.bert_backward(P, ids, mask, 4, cache, d_cls, d_seq=d_seq)
+    own = dict(enc.named_parameters())
+    gmax = max(np.abs(g).max() for g in G.values())
+    for k, g in G.items():
+        got = own[k].grad.cpu().numpy().astype(np.float64)
+        if dtype == "fp32":
+            assert np.abs(got - g).max() <= 2e-4 * np.abs(g).max() + 1e-5 * gmax, k
+        elif k.endswith("dense.weight") and "pooler" not in k:
+            cos = float(got.ravel() @ g.ravel() / (np.linalg.norm(got) * np.linalg.norm(g) + 1e-30))
+            assert cos > 0.98, (k, cos)

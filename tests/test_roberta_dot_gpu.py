@@ -21,7 +21,10 @@ def _build(G, dev, dtype):
                          num_attention_heads=c["heads"], intermediate_size=c["inter"], max_position_embeddings=c["max_pos"],
                          type_vocab_size=c["type_vocab"], layer_norm_eps=c["eps"], hidden_dropout_prob=0.0,
                          attention_probs_dropout_prob=0.0, model_type="roberta", pad_token_id=1)
-    m = RobertaDot(cfg, compute_dtype=dtype)
+    import types
+    use_mean = bool(int(G["use_mean"])) if "use_mean" in G.files else False
+    m = RobertaDot(cfg, types.SimpleNamespace(use_mean=use_mean), compute_dtype=dtype) if use_mean else RobertaDot(cfg, compute_dtype=dtype)
+    assert m.use_mean == use_mean
     P = make_bert_params(BertCfg(**c), int(G["seed"]), std=0.08)
     m.roberta.load_numpy_state(P)
     with torch.no_grad():
@@ -63,6 +66,34 @@ def test_roberta_dot_fp32_vs_reference_golden(dev, golden_dir):
 
 def test_roberta_dot_bf16(dev, golden_dir):
     G = np.load(os.path.join(golden_dir, "roberta_dot_tiny.npz"))
+    q, d, loss, grads = _step(G, dev, "bf16")
+    assert np.abs(q - G["q_emb"]).max() <= 8e-2 and np.abs(d - G["d_emb"]).max() <= 8e-2
+    assert abs(loss - float(G["loss"])) <= 5e-2
+    for k in ("roberta.encoder.layer.1.output.dense.weight", "embeddingHead.weight", "roberta.embeddings.position_embeddings.weight"):
+        g, ref = grads[k].ravel(), G["grad." + k].ravel()
+        cos = float(g @ ref / (np.linalg.norm(g) * np.linalg.norm(ref) + 1e-30))
+        assert cos >= 0.97, "grad %s cosine %.4f" % (k, cos)
+
+
+def test_roberta_dot_mean_pooling_fp32_vs_reference_golden(dev, golden_dir):
+    """use_mean=True (EmbeddingMixin.masked_mean, models.py:296-305): the embedding is the mean of the last hidden state
+    over the real tokens, so EVERY row of the hidden state carries gradient (simx_seq_mean_* + simx_bert_bwd_ex)."""
+    G = np.load(os.path.join(golden_dir, "roberta_dot_mean_tiny.npz"))
+    assert int(G["use_mean"]) == 1
+    q, d, loss, grads = _step(G, dev, "fp32")
+    assert np.abs(q - G["q_emb"]).max() <= 2e-5 and np.abs(d - G["d_emb"]).max() <= 2e-5
+    assert abs(loss - float(G["loss"])) <= 5e-5
+    names = [k[len("grad."):] for k in G.files if k.startswith("grad.")]
+    assert len(names) >= 15
+    gmax = max(np.abs(G["grad." + k]).max() for k in names)
+    for k in names:
+        ref = G["grad." + k]
+        err = np.abs(grads[k].reshape(ref.shape) - ref).max()
+        assert err <= 2e-4 * np.abs(ref).max() + 1e-5 * gmax, "grad %s: err %.3e (scale %.3e)" % (k, err, np.abs(ref).max())
+
+
+def test_roberta_dot_mean_pooling_bf16(dev, golden_dir):
+    G = np.load(os.path.join(golden_dir, "roberta_dot_mean_tiny.npz"))
     q, d, loss, grads = _step(G, dev, "bf16")
     assert np.abs(q - G["q_emb"]).max() <= 8e-2 and np.abs(d - G["d_emb"]).max() <= 8e-2
     assert abs(loss - float(G["loss"])) <= 5e-2

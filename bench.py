@@ -258,6 +258,28 @@ def main():
         real = {"value": round(world * P * 4 / dr, 1), "ms_per_step": round(dr / 4 * 1e3, 2), "steps": 4,
                 "lengths": "query ~ N(9,3) clipped to [4,32], passage ~ N(80,25) clipped to [16,128] (SURVEY 8d)",
                 "real_token_fraction": round(float((np.sum(pool["ql"]) / (B * QL) * B * QL + np.mean(pool["pl"]) * P) / (B * QL + P * PL)), 3)}
+    # the same all-max job with EVERY row of the last layer computed (SIMX_FULL_LAST_LAYER=1): the conservative figure
+    # for readers who do not want the dead-code elimination of the [CLS]-only last layer counted.  Never `value`.
+    full_rows = None
+    if not args.varlen and not args.no_realistic and os.environ.get("SIMX_FULL_LAST_LAYER", "0") != "1":
+        build_pool(True)
+        os.environ["SIMX_FULL_LAST_LAYER"] = "1"
+        for _ in range(2):
+            one_step()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            one_step()
+        sync()
+        df = time.perf_counter() - t1
+        os.environ["SIMX_FULL_LAST_LAYER"] = "0"
+        if world > 1:
+            tt = torch.tensor([df], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            df = float(tt.item())
+        full_rows = {"value": round(world * P * 3 / df, 1), "ms_per_step": round(df / 3 * 1e3, 2), "steps": 3,
+                     "step_mfma_util": round((3 * (B * fwd_flops_seq(QL) + P * fwd_flops_seq(PL)) + (0 if args.no_teacher else P * fwd_flops_seq(ce_tokens)))
+                                             / (df / 3) / 2.5e15, 4) if args.dtype == "bf16" else None}
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -300,6 +322,8 @@ def main():
            "final_loss": round(final_loss, 5)}
     if real is not None:
         out["realistic_lengths"] = real
+    if full_rows is not None:
+        out["all_rows_last_layer"] = full_rows
     if prof and "gemm_nt_p3" in prof:
         excl = prof_serial if prof_serial is not None else prof
         c_, ms_, wk_ = excl["gemm_nt_p3"]      # launches of the persistent kernel only ("gemm_nt" = the small-shape kernels)

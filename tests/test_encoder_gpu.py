@@ -367,3 +367,53 @@ def test_sequence_output_carries_gradient(dev, dtype):
         elif k.endswith("dense.weight") and "pooler" not in k:
             cos = float(got.ravel() @ g.ravel() / (np.linalg.norm(got) * np.linalg.norm(g) + 1e-30))
             assert cos > 0.98, (k, cos)
+
+
+def test_full_size_config2_properties(dev):
+    """BASELINE config 2 at its FULL size (BERT-base passage tower, 2048 passages x 128 tokens, bf16) through
+    size-independent properties (the oracle cannot run this size):
+      * batch independence: a sequence's embedding does not depend on its batch mates (16 sequences re-encoded alone --
+        a shape the small-size oracle tests cover -- against their rows of the full batch), all-max and ragged lengths;
+      * the [CLS]-only last layer against every-row computation on the full batch;
+      * linearity of the backward pass in the upstream gradient: grads(a*d1 + b*d2) == a*grads(d1) + b*grads(d2)."""
+    from simxns_amd.engine import BertConfigLite
+    from simxns_amd.model.models import HFBertEncoder
+    from simxns_amd.utils import synth
+    cfg = BertConfigLite(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)      # BERT-base defaults
+    enc = HFBertEncoder(cfg, compute_dtype="bf16")
+    enc.load_numpy_state(synth.fill_bert_state_dict(_named_shapes(enc), 1235, std=0.02))
+    enc.to(dev).eval()
+    P, S = 2048, 128
+    pick = np.array([0, 1, 17, 255, 256, 511, 777, 1024, 1025, 1300, 1599, 1600, 1900, 2000, 2046, 2047])
+    for full in (True, False):
+        ids, mask, lens = synth.make_batch(4242, P, S, cfg.vocab_size, 80, 25, 16, full=full)
+        ti, tm = torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev)
+        with torch.no_grad():
+            emb = enc.embed(ti, tm)                                  # [CLS]-only last layer, persistent GEMMs
+            alone = enc.embed(ti[pick], tm[pick])                    # 16 sequences: the small-shape kernels
+            _, pooled, _ = enc(input_ids=ti, attention_mask=tm)      # every row of the last layer
+        scale = float(emb.abs().max())
+        assert torch.isfinite(emb).all() and scale > 0.1
+        assert float((emb[pick] - alone).abs().max()) <= 4e-2 * scale, "batch independence (full=%s)" % full
+        assert float((emb - pooled).abs().max()) <= 4e-2 * scale, "[CLS]-only vs all rows (full=%s)" % full
+    # linearity of backward at full size (all-max batch kept from the last iteration? use the ragged one: lens vary)
+    rs = np.random.RandomState(5)
+    d1 = torch.from_numpy(rs.randn(P, cfg.hidden_size).astype(np.float32)).to(dev)
+    d2 = torch.from_numpy(rs.randn(P, cfg.hidden_size).astype(np.float32)).to(dev)
+    keys = ("encoder.layer.11.output.dense.weight", "encoder.layer.5.attention.self.query.weight",
+            "encoder.layer.0.intermediate.dense.bias", "embeddings.position_embeddings.weight")
+    own = dict(enc.named_parameters())
+
+    def grads(d):
+        enc.zero_grad()
+        enc.train(False)
+        e = enc.embed(ti, tm)
+        (e * d).sum().backward()
+        torch.cuda.synchronize()
+        return {k: own[k].grad.detach().float().clone() for k in keys}
+    g1, g2, g12 = grads(d1), grads(d2), grads(0.5 * d1 - 2.0 * d2)
+    for k in keys:
+        want = 0.5 * g1[k] - 2.0 * g2[k]
+        cos = float((g12[k] * want).sum() / (g12[k].norm() * want.norm() + 1e-30))
+        rel = float((g12[k] - want).norm() / (want.norm() + 1e-30))
+        assert cos >= 0.995 and rel <= 0.08, "backward linearity %s: cos %.5f rel %.4f" % (k, cos, rel)

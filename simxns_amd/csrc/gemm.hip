@@ -227,7 +227,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(
 #define V3_PIN8(TXT, F0, F1, F2, F3, F4, F5, F6, F7) \
   asm volatile(TXT : "+v"(F0), "+v"(F1), "+v"(F2), "+v"(F3), "+v"(F4), "+v"(F5), "+v"(F6), "+v"(F7)::"memory")
 
-__device__ int g_gemm_dbg = 0;   // measurement hook, set from env SIMX_GEMM_DBG (bit0: skip global stores, bit1: skip LDS staging loop)
 // v5: 256x256x64 stages (full 128-B lines per row: the LDS-DMA path is request-bound, measured ~20 B/clk/CU with full
 // lines on v2 and only ~13 with v3's half lines), TWO 64 KB stages, 128x64 wave tiles.  A stage is re-filled as soon as
 // its last fragment has been read (stage boundary = the only barrier, once per 64 k), so the DMA queue never drains.
@@ -363,7 +362,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_v5_kernel(
 #pragma unroll
     for (int pass = 0; pass < (EPI == SIMX_EPI_GELU ? 2 : 1); ++pass) {
 #pragma unroll
-      for (int i = 0; i < ((g_gemm_dbg & 2) ? 0 : 8); ++i) {
+      for (int i = 0; i < 8; ++i) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const uint32_t ad = slot0 + (uint32_t)(i * 2048 + (((j * 2 + (fg >> 1)) ^ sw) << 4));
@@ -403,7 +402,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_v5_kernel(
         const int c = (lane & 7) ^ ((r >> 1) & 7);
         const uint4 val = *reinterpret_cast<const uint4*>(reg + r * 128 + (lane & 7) * 16);
         const int gm = mw + r, gn = nw + c * 8;
-        if (gm < M && gn + 8 <= N && !(g_gemm_dbg & 1)) *reinterpret_cast<uint4*>(out + (long)gm * ldo + gn) = val;
+        if (gm < M && gn + 8 <= N) *reinterpret_cast<uint4*>(out + (long)gm * ldo + gn) = val;
       }
     }
   }
@@ -1518,8 +1517,6 @@ extern "C" int simx_gemm_nt_ex(simx_stream_t stream, int dtype, int M, int N, in
     if (!force_v1 && nwg3 >= 192 && N % 8 == 0 && ldc % 8 == 0 && (!residual || ldr % 8 == 0) &&
         (!aux || ldaux % 8 == 0) && (!C2 || ldc2 % 8 == 0)) {
       static const bool noepi = getenv("SIMX_NOEPI") != nullptr;
-      static bool dbg_set = false;
-      if (!dbg_set) { const char* d = getenv("SIMX_GEMM_DBG"); int v = d ? atoi(d) : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_dbg), &v, sizeof(int)); dbg_set = true; }
       if (noepi) C = nullptr;
 #define L5(E) hipLaunchKernelGGL((gemm_nt_bf16_v5_kernel<E>), dim3(nwg3), dim3(512), V5_LDS, s, M, N, K, (const bf16_t*)A, lda, \
                                  (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, (const bf16_t*)residual, ldr,                  \

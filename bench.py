@@ -320,6 +320,9 @@ def main():
            # the same step priced at the reference's full FLOP count (SURVEY 8d formula)
            "step_mfma_util_reference_flops": round((stu + tea) / (ms_step * 1e-3) / 2.5e15, 4) if args.dtype == "bf16" and not args.varlen else None,
            "final_loss": round(final_loss, 5)}
+    busy = pmc_mfma_busy()
+    if busy is not None and args.dtype == "bf16":
+        out["mfma_busy_pmc"] = busy
     if real is not None:
         out["realistic_lengths"] = real
     if full_rows is not None:
@@ -350,6 +353,25 @@ def main():
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_mfma_busy():
+    """Hardware-counter MFMA utilisation of the step and of the persistent NT kernel from the committed PMC passes
+    (tools/profile_round.sh -> profiles/*_mfma_busy.json): SQ_VALU_MFMA_BUSY_CYCLES over the SIMD cycles the launches had,
+    at the clock they actually ran at.  Counters cannot be read inside the timed run: latest committed measurement, or None."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_mfma_busy.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        p3 = [v for k, v in d.get("kernels", {}).items() if "gemm_nt_bf16_p3_kernel" in k]
+        n = sum(v["launches"] for v in p3)
+        best = {"step": d.get("step_mfma_busy_frac"), "step_clock_ghz": d.get("step_clock_ghz"),
+                "gemm_nt_bf16_p3_kernel": round(sum(v["mfma_busy_frac"] * v["launches"] for v in p3) / n, 4) if n else None,
+                "source": os.path.basename(f)}
+    return best
 
 
 def pmc_traffic(kernel):

@@ -39,4 +39,40 @@ for f in glob.glob(src + "/stats/**/*kernel_stats.csv", recursive=True):
     shutil.copy(f, "profiles/%s_kernel_stats.csv" % tag)
 if os.path.exists(src + "/bench.json"):
     shutil.copy(src + "/bench.json", "profiles/%s_bench.json" % tag)
-print(json.dumps({k: v for k, v in out["kernels"].items() if "gemm" in k}, indent=1))
+
+# MFMA utilisation from counters: SQ_VALU_MFMA_BUSY_CYCLES (busy cycles of the matrix pipes summed over the chip's 1024
+# SIMDs; 16 per v_mfma_f32_16x16x32_bf16, cross-checked against SQ_INSTS_MFMA) over the cycles the launch had available:
+# GRBM_GUI_ACTIVE (summed over the 8 XCDs, separate pass) / 8 x 256 CUs x 4 SIMDs.  Per kernel name the two passes are
+# combined through their per-launch averages (the workload is deterministic).  GRBM_GUI_ACTIVE / 8 / duration is the
+# shader clock the kernel actually ran at (DVFS: ~1.9 GHz under MFMA load, ~2.3 GHz in the HBM-bound kernels).
+def per_kernel_dur(path):
+    agg = collections.defaultdict(list)
+    for f in glob.glob(path + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                agg[r["Kernel_Name"].split("(")[0]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    return agg
+
+
+mb, ga = per_kernel(src + "/pmc_mfma", "SQ_VALU_MFMA_BUSY_CYCLES"), per_kernel(src + "/pmc_active", "GRBM_GUI_ACTIVE")
+du = per_kernel_dur(src + "/pmc_active")
+if mb and ga:
+    util = {"note": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 256 CUs * 4 SIMDs); clock_ghz = "
+                    "GRBM_GUI_ACTIVE / 8 / launch duration; per-launch averages of two rocprofv3 PMC passes of the bench "
+                    "command (towers on one stream); step = all kernels of the run, MFMA-free ones included",
+            "kernels": {}}
+    tb = ta = 0.0
+    for k in sorted(set(ga)):
+        a_ = sum(ga[k])
+        b_ = sum(mb.get(k, [0.0])) * len(ga[k]) / max(1, len(mb.get(k, [0.0])))
+        tb += b_
+        ta += a_
+        if b_ > 0:
+            util["kernels"][k] = {"launches": len(ga[k]), "mfma_busy_frac": round(b_ / (a_ * 128), 4)}
+            if sum(du[k]) / len(du[k]) > 100e3:        # (short launches: the active count includes dispatch overhead)
+                util["kernels"][k]["clock_ghz"] = round(a_ / 8 / max(1, sum(du[k])), 3)
+    util["step_mfma_busy_frac"] = round(tb / (ta * 128), 4)
+    big = [k for k in ga if sum(du[k]) / len(du[k]) > 100e3]
+    util["step_clock_ghz"] = round(sum(sum(ga[k]) for k in big) / 8 / max(1, sum(sum(du[k]) for k in big)), 3)
+    json.dump(util, open("profiles/%s_mfma_busy.json" % tag, "w"), indent=1)
+    print(json.dumps(util, indent=1))

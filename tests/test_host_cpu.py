@@ -262,3 +262,29 @@ def test_generate_job_metrics_and_tsv_writer(tmp_path):
     from simxns_amd.utils.MARCO_until_new import read_sharded_tsv
     rows = read_sharded_tsv(path)
     assert len(rows) == 3
+
+
+def test_recipe_launcher_command_lines_parse():
+    """simxns_amd.launch (the loop of SimANS/train_*_AR2.sh): every recipe's train command line is accepted by the
+    train script's own argument parser, and carries the hyper-parameters of record."""
+    from simxns_amd import launch
+    from simxns_amd.co_training import co_training_marco_train as marco
+    from simxns_amd.wiki import co_training_wiki_train as wiki
+    parsers = {"simxns_amd/co_training/co_training_marco_train.py": marco.get_arguments,
+               "simxns_amd/wiki/co_training_wiki_train.py": wiki.get_arguments,
+               "simxns_amd/Doc_training/co_training_doc_train.py": marco.get_arguments}
+    want = {"MS_Pas": (5000, 500, 60000, 16, 2, 5e-6), "NQ": (2000, 500, 30000, 8, 1, 1e-5),
+            "TQ": (2000, 500, 10000, 8, 1, 5e-6), "MS_Doc": (5000, 1000, 40000, 32, 1, 5e-6)}
+    for name, make in launch.RECIPES.items():
+        r = make()
+        script, flags = r["train"]
+        argv = launch.job_argv(script, dict(flags, global_step=0, max_steps=r["max_steps"], iteration_step=r["iteration_step"],
+                                            iteration_reranker_step=r["iteration_reranker_step"]), 8, 9539)
+        assert argv[argv.index(script) - 1].startswith("--master_port") and "127.0.0.1" in argv
+        a = parsers[script](argv[argv.index(script) + 1:])
+        it, rr, ms, bs, acc, lr = want[name]
+        assert (a.iteration_step, a.iteration_reranker_step, a.max_steps) == (it, rr, ms), name
+        assert (a.per_gpu_train_batch_size, a.gradient_accumulation_steps, a.number_neg) == (bs, acc, 15), name
+        assert abs(a.learning_rate - lr) < 1e-12 and a.gradient_checkpointing, name
+    for sh in ("train_MS_Pas_AR2.sh", "train_NQ_AR2.sh", "train_TQ_AR2.sh", "train_MS_Doc_AR2.sh"):
+        assert "simxns_amd.launch" in open(os.path.join(ROOT, sh)).read()

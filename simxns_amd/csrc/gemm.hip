@@ -1492,7 +1492,7 @@ extern "C" int simx_gemm_nt_ex(simx_stream_t stream, int dtype, int M, int N, in
         attrp = true;
       }
       const int grid = nwg3 < ncu ? nwg3 : ncu;
-      static const bool noepi_p = getenv("SIMX_NOEPI") != nullptr;
+      static const bool noepi_p = (getenv("SIMX_MEASUREMENT_HOOKS") != nullptr && getenv("SIMX_NOEPI") != nullptr);
       if (noepi_p) C = nullptr;
 #define LP(E, HI, INP, LDI) hipLaunchKernelGGL((gemm_nt_bf16_pers_kernel<E, HI>), dim3(grid), dim3(512), P_LDS, s, M, N, K, (const bf16_t*)A, lda, \
                                  (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, (const bf16_t*)(INP), LDI, (bf16_t*)C2, ldc2, t3n, nwg3, drop)
@@ -1516,7 +1516,7 @@ extern "C" int simx_gemm_nt_ex(simx_stream_t stream, int dtype, int M, int N, in
     }
     if (!force_v1 && nwg3 >= 192 && N % 8 == 0 && ldc % 8 == 0 && (!residual || ldr % 8 == 0) &&
         (!aux || ldaux % 8 == 0) && (!C2 || ldc2 % 8 == 0)) {
-      static const bool noepi = getenv("SIMX_NOEPI") != nullptr;
+      static const bool noepi = (getenv("SIMX_MEASUREMENT_HOOKS") != nullptr && getenv("SIMX_NOEPI") != nullptr);
       if (noepi) C = nullptr;
 #define L5(E) hipLaunchKernelGGL((gemm_nt_bf16_v5_kernel<E>), dim3(nwg3), dim3(512), V5_LDS, s, M, N, K, (const bf16_t*)A, lda, \
                                  (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, (const bf16_t*)residual, ldr,                  \

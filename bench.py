@@ -38,40 +38,28 @@ def fwd_flops_seq(S, L=L_, H=H_, F=F_):
     return L * S * (8 * H * H + 4 * H * F + 4 * S * H)
 
 
-def cpu_baseline(sample_queries=2, negs=15, threads=None):
-    """The CPU restatement (oracle/, f32 NumPy on the host BLAS) of the SAME step on a bounded sample."""
-    from oracle import bert as ob
-    from oracle import losses as ol
-    from oracle.weights import BertCfg, make_bert_params, make_batch
-    cfg = BertCfg()
-    B, P = sample_queries, sample_queries * (1 + negs)
-    Pq, Pc, Pt = (make_bert_params(cfg, s, perturb=False) for s in (1, 2, 3))
-    Pt2 = {"encoder." + k: v for k, v in Pt.items()}
-    Pt2["qa_classifier.weight"] = np.full((1, cfg.hidden), 0.01, np.float32)
-    Pt2["qa_classifier.bias"] = np.zeros((1,), np.float32)
-    q_ids, q_mask, _ = make_batch(1, B, 32, cfg.vocab, 9, 3, 4, full=True)
-    c_ids, c_mask, _ = make_batch(2, P, 128, cfg.vocab, 80, 25, 16, full=True)
-    t_ids, t_mask, _ = make_batch(3, P, 160, cfg.vocab, 90, 25, 20, full=True)
-    f32 = np.float32
-
-    def step():
-        _, q, cq = ob.bert_forward(Pq, q_ids, q_mask, cfg.heads, dtype=f32)
-        _, c, cc = ob.bert_forward(Pc, c_ids, c_mask, cfg.heads, dtype=f32)
-        z, _, _ = ob.reranker_forward(Pt2, t_ids.reshape(B, 1 + negs, -1), t_mask.reshape(B, 1 + negs, -1), cfg.heads,
-                                      dtype=f32, keep=False)
-        sim = ol.sim_block(q, c)
-        _, _, ds = ol.kl_distill(sim, z)
-        dq, dc = ol.sim_block_bwd(q, c, ds.astype(f32))
-        ob.bert_backward(Pq, q_ids, q_mask, cfg.heads, cq, dq, dtype=f32)
-        ob.bert_backward(Pc, c_ids, c_mask, cfg.heads, cc, dc, dtype=f32)
-
+def cpu_baseline():
+    """The reference's CPU path, restated operator for operator on torch CPU (oracle/torch_cpu.py: the reference itself
+    cannot travel to the GPU box; oracle/time_reference.py shows the restatement within ~10 % of the imported reference in
+    the build container), timed on this box's host cores, fp32, all-max lengths, BERT-base random init:
+      * BASELINE configs[0] (B=4, N=1, q32/p128, student step without teacher -- BASELINE.md section 2's measurement):
+        3 warm-up + 10 timed steps;
+      * the benchmarked workload reduced to B=8 queries x 16 passages INCLUDING the cross-encoder teacher forward (the
+        same step the GPU runs, 1/16 of its batch): 1 warm-up + 3 timed steps.
+    `value` is the second (same metric as the GPU line: scored pairs per second of the full step)."""
+    import torch
+    from oracle import torch_cpu as tc
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
     t0 = time.time()
-    step()
-    t = time.time() - t0
-    cores = threads or os.cpu_count()
-    return {"value": round(P / t, 3), "unit": "query+passage pairs/sec", "cores": cores, "kind": "port",
-            "sample": "1 step of the oracle (NumPy f32 restatement, host BLAS threads) on %d queries x %d passages, "
-                      "BERT-base q32/p128/ce160 incl. teacher forward, fwd+bwd, %.1f s" % (B, 1 + negs, t)}
+    s1, p1, thr = tc.time_step(4, 1, with_teacher=False, warmup=3, steps=10)
+    s2, p2, thr = tc.time_step(8, 15, with_teacher=True, warmup=1, steps=3)
+    return {"value": round(p2 / s2, 2), "unit": "query+passage pairs/sec", "cores": thr, "kind": "port",
+            "sample": "torch-CPU fp32 restatement of the reference step on %d threads: reduced configs[1] (B=8 x 16 passages, "
+                      "q32/p128/ce160, teacher fwd + student fwd/bwd) %.2f s/step over 3 steps after 1 warm-up; "
+                      "configs[0] (B=4, N=1, student only) %.3f s/step = %.1f pairs/s over 10 steps after 3 warm-up; "
+                      "%.0f s of CPU wall in total" % (thr, s2, s1, p1 / s1, time.time() - t0),
+            "config0_pairs_per_s": round(p1 / s1, 2), "config0_s_per_step": round(s1, 4)}
 
 
 def main():
@@ -90,6 +78,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-realistic", action="store_true", help="skip the extra realistic-length measurement")
     ap.add_argument("--no-prof", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the bf16-vs-reference-golden error report")
     args = ap.parse_args()
 
     import torch
@@ -101,11 +90,16 @@ def main():
     from simxns_amd.optim import FusedAdamW, LinearWarmupSchedule
     from simxns_amd.utils import synth
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: become the launcher (one process per GPU, rank 0's JSON line is
+        # relayed); a run can therefore never report n_gpus != --gpus
+        raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one rank per GPU (torch.distributed.run --nproc-per-node %d, "
+                         "or plain `python bench.py --gpus %d`, which spawns them)" % (args.gpus, world, args.gpus, args.gpus))
     # validation hook: SIMX_BENCH_SHARE_GPU=1 runs all ranks on cuda:0 over gloo (a 1-GPU box cannot host RCCL ranks);
     # it only checks the N > 1 control flow (sharding, gradient all-reduce, barrier, max-over-ranks), never a number
     share = os.environ.get("SIMX_BENCH_SHARE_GPU") == "1"
@@ -141,7 +135,10 @@ def main():
     bi.to(dev).train()              # retriever step: model.train(), teacher_model.eval() (co_training_marco_train.py:196-197)
     teacher.to(dev).eval()
     opt = FusedAdamW(bi, lr=5e-6, eps=1e-8)
-    sch = LinearWarmupSchedule(opt, 5400, 54000)
+    sch = LinearWarmupSchedule(opt, 5400, 54000, last_step=1)     # (step 0 of the schedule has lr = 0: start one in)
+    if world > 1:
+        # gradient slices are all-reduced on a communication stream while the rest of the backward runs
+        opt.enable_overlap(world, parts=int(os.environ.get("SIMX_BWD_PARTS", "2")))
 
     # ---- synthetic, PRE-TOKENISED candidate pool in HBM (per rank: B queries x (1 positive + Cn candidates)); the
     # per-step batch (passage rows, masks, cross-encoder rows q + ctx[1:-1]) is assembled on the device by
@@ -188,8 +185,8 @@ def main():
             from simxns_amd import parallel
             loss = loss + 0.2 * parallel.inbatch_nll_allgather(q, c, 1 + N)
         loss.backward()
+        opt.step(max_grad_norm=2.0, world_size=world)      # optimizer first, scheduler second (co_training_marco_train.py:250-252)
         sch.step()
-        opt.step(max_grad_norm=2.0, world_size=world)
         return loss
 
     def sync():
@@ -324,6 +321,11 @@ def main():
         out["realistic_lengths"] = real
     if full_rows is not None:
         out["all_rows_last_layer"] = full_rows
+    def alg_bytes_per_launch(launches_per_step):
+        tot, cnt = p3_algorithmic_bytes(B, P, QL, PL, ce_tokens, not args.no_teacher, full_last)
+        # (the enumeration must describe the launches that were measured; otherwise report nothing rather than a guess)
+        return round(tot / cnt) if cnt and cnt == launches_per_step and not args.varlen else None
+
     if prof and "gemm_nt_p3" in prof:
         c_, ms_, wk_ = prof["gemm_nt_p3"]      # launches of the persistent kernel only ("gemm_nt" = the small-shape kernels)
         ach = wk_ / (ms_ * 1e-3) / 1e12
@@ -331,12 +333,20 @@ def main():
         out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_bf16_p3_kernel (simx_gemm_nt: forward + dgrad GEMMs)",
                            "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                            "traffic": pmc_traffic("gemm_nt_bf16_p3_kernel"), "launches": c_,
+                           "algorithmic_bytes_per_launch": alg_bytes_per_launch(c_ // max(1, args.steps)),
                            "avg_launch_ms": round(ms_ / c_, 4), "algorithmic_flop_per_launch": round(wk_ / c_),
                            "measured": "HIP events on the launch stream over %d steps of the same job run right after the timed "
                                        "region, towers on one stream (%.2f ms/step with the events); the timed region itself is "
                                        "not instrumented and overlaps the two towers on two streams" % (args.steps, ms_prof)}
         out["kernel_breakdown_ms_per_step"] = {k: round(v[1] / args.steps, 3) for k, v in prof.items()}
         out["kernel_rates"] = {k: round(v[2] / (v[1] * 1e-3) / 1e12, 2) for k, v in prof.items() if v[1] > 0}
+    if args.dtype == "bf16" and not args.no_parity:
+        # measured distance of THIS engine (the benchmarked bf16 kernels) from the reference on the hot-shape golden
+        try:
+            from simxns_amd.utils.parity import parity_report
+            out["parity_bf16"] = parity_report(dev, "bf16")
+        except Exception as e:
+            out["parity_bf16"] = {"error": repr(e)}
     if not args.no_cpu_baseline and world == 1:
         try:
             out["cpu_baseline"] = cpu_baseline()
@@ -345,6 +355,50 @@ def main():
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def p3_algorithmic_bytes(B, P, QL, PL, CE, teacher, full_last, L=L_, H=H_, F=F_):
+    """Algorithmic HBM bytes of the persistent NT GEMM launches of ONE step: per launch
+    2 * (M*K + N*K + M*N * (tensors the epilogue writes + reads)) -- every operand once.  Enumerates the launches the encoder
+    driver issues (csrc/encoder.hip) that qualify for the persistent kernel (>= 192 tiles of 256 x 256).
+    -> (bytes, launches)"""
+    def g(M, N, K, io):
+        return (2 * (M * K + N * K + M * N * io), 1) if (M // 256) * (N // 256) >= 192 and M % 256 == 0 else (0, 0)
+    tot, cnt = 0, 0
+    towers = [(B * QL, True), (P * PL, True)] + ([(P * CE, False)] if teacher else [])
+    for M, train in towers:
+        M = (M + 255) // 256 * 256
+        nfull = L if full_last else L - 1
+        fwd = [g(M, 3 * H, H, 1), g(M, H, H, 2), g(M, F, H, 2 if train else 1), g(M, H, F, 2)]
+        bwd = [g(M, F, H, 2), g(M, H, F, 2), g(M, H, H, 1), g(M, H, 3 * H, 2)] if train else []
+        for b_, c_ in fwd + bwd:
+            tot += nfull * b_
+            cnt += nfull * c_
+        if not full_last:                      # [CLS]-only last layer: K/V projection forward, its dgrad in backward
+            for b_, c_ in [g(M, 2 * H, H, 1)] + ([g(M, H, 2 * H, 2)] if train else []):
+                tot += b_
+                cnt += c_
+    return tot, cnt
+
+
+def spawn_ranks(n):
+    """One child process per GPU on this node (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, rendezvous on
+    127.0.0.1), same command line.  Rank 0 prints the JSON line to our stdout; a failing rank fails the run."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p_ in procs:
+        rc = rc or p_.wait()
+    return rc
 
 
 def pmc_mfma_busy():

@@ -215,6 +215,12 @@ typedef struct simx_bert_cfg {
    * is dead code on this path (it feeds neither cls_out nor any gradient).  cls_out and all gradients are unchanged;
    * hidden_out must be NULL.  The matching backward call must pass the same value.  0: every row is computed. */
   int32_t cls_only_last_layer;
+  /* 1: gradient checkpointing per encoder layer (`cfg.gradient_checkpointing`, SimANS/model/models.py:73-74; every
+   * train_*_AR2.sh passes --gradient_checkpointing): a forward with save_for_bwd keeps only each layer's INPUT
+   * ([T,hidden] per layer instead of 8*hidden + 2*inter elements per token and layer) and the backward re-runs the layer's
+   * forward -- same stateless dropout masks -- before differentiating it (4/3 of the FLOPs, as in the reference).
+   * Must have the same value in simx_bert_act_bytes / simx_bert_fwd / simx_bert_bwd*.  Results are identical to 0. */
+  int32_t grad_checkpoint;
 } simx_bert_cfg;
 
 enum { SIMX_P_WORD = 0, SIMX_P_POS, SIMX_P_TYPE, SIMX_P_EMB_LN_G, SIMX_P_EMB_LN_B,   /* layer = -1 */
@@ -242,6 +248,18 @@ int simx_bert_bwd(simx_stream_t stream, const simx_bert_cfg* cfg, const float* p
 /* same with the upstream gradient given for the WHOLE last hidden state (sequence_output of HFBertEncoder.forward,
  * models.py:77-82; e.g. the masked-mean pooling of EmbeddingMixin, models.py:296-305): dhidden [T,hidden] in the
  * activation dtype.  Exactly one of dcls / dhidden is non-NULL; dhidden needs cfg->cls_only_last_layer == 0. */
+/* The backward in parts, for overlapping the data-parallel gradient all-reduce (DistributedDataParallel's bucketed
+ * reduction, SimANS/co_training/co_training_marco_train.py:107-114) with the rest of the backward: this call
+ * differentiates encoder layers layer_hi, layer_hi-1, ..., layer_lo; layer_hi == layers-1 seeds from dcls / dhidden,
+ * layer_lo == 0 also runs the embedding backward.  Parts must be called top-down with the SAME `scratch` (it carries the
+ * inter-layer gradient between calls).  Because the flat gradient buffer is laid out embeddings | layer 0 | ... | layer
+ * L-1 | pooler, after a part returns the slice [simx_bert_param_offset(cfg, layer_lo, SIMX_P_WQKV), end of the previous
+ * part's slice) is final and can be reduced while the next part runs.  simx_bert_bwd_ex == range(layers-1, 0). */
+int simx_bert_bwd_range(simx_stream_t stream, const simx_bert_cfg* cfg, const float* params, const void* wcache,
+                        const int32_t* ids, const int32_t* pos_ids, const int32_t* cu_seqlens,
+                        int nseq, int T, int max_len, void* act, size_t act_bytes,
+                        const float* dcls, const void* dhidden, float* grads, void* scratch, size_t scratch_bytes,
+                        int layer_hi, int layer_lo);
 int simx_bert_bwd_ex(simx_stream_t stream, const simx_bert_cfg* cfg, const float* params, const void* wcache,
                      const int32_t* ids, const int32_t* pos_ids, const int32_t* cu_seqlens,
                      int nseq, int T, int max_len, const void* act, size_t act_bytes,

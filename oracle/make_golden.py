@@ -87,13 +87,18 @@ def _cmp(tag, a, b, tol):
     assert err <= tol * ref, (tag, err, tol * ref)
 
 
-def gen_encoder_step(tmp, cfg_kw, tag, B, N, q_len, p_len, ce_len, seeds, full_grads, tol, std=0.02):
-    """Config-1 shaped retriever step of co_training_marco_train.py / co_training_wiki_train.py."""
+def gen_encoder_step(tmp, cfg_kw, tag, B, N, q_len, p_len, ce_len, seeds, full_grads, tol, std=0.02, extras=True):
+    """Config-1 shaped retriever step of co_training_marco_train.py / co_training_wiki_train.py.
+    extras=False keeps only the retriever step proper (L1): no NQ/TQ loss variants, no teacher train step -- used for
+    the larger "hot" fixture whose only purpose is to put the persistent GEMM / wgrad / attention kernels, which need
+    >= 16k tokens to dispatch, under a reference-generated golden."""
     cfg = BertCfg(**cfg_kw)
     Pq = make_bert_params(cfg, seeds[0], std=std)
     Pc = make_bert_params(cfg, seeds[1], std=std)
     Pt = make_bert_params(cfg, seeds[2], std=std)
-    args = types.SimpleNamespace(model_type=_hf_dir(tmp, cfg, Pq, tag + "_q"), gradient_checkpointing=False,
+    # extras=False (the big fixture): the imported model runs with ITS gradient checkpointing (models.py:73-74) -- same values,
+    # and the fp64 autograd graph of ~20k tokens x 12 layers would not fit this container's 62 GB otherwise
+    args = types.SimpleNamespace(model_type=_hf_dir(tmp, cfg, Pq, tag + "_q"), gradient_checkpointing=not extras,
                                  share_weight=False)
     model = RM.BiBertEncoder(args)
     # ctx tower gets its own weights
@@ -122,6 +127,9 @@ def gen_encoder_step(tmp, cfg_kw, tag, B, N, q_len, p_len, ce_len, seeds, full_g
         z32 = teacher(input_ids=tt(t_ids3), attention_mask=tt(t_mask3))
     # golden = the same imported modules in float64 (removes fp32 cancellation noise from grads)
     model.double(); teacher.double()
+    if not extras:
+        model.train()                      # HF checkpoints only in training mode; every Dropout has p = 0 (_no_dropout)
+        assert model.ctx_model.is_gradient_checkpointing
 
     # --- literal step body, co_training_marco_train.py:198-217 (L1) -----------------
     model.zero_grad()
@@ -136,6 +144,9 @@ def gen_encoder_step(tmp, cfg_kw, tag, B, N, q_len, p_len, ce_len, seeds, full_g
     loss = torch.nn.KLDivLoss(reduction="batchmean")((p_s + 1e-7).log(), p_t)
     loss.backward()
     G = _grads(model)
+    local_q, local_ctx, sim, z, loss_v = local_q.detach(), local_ctx.detach(), sim.detach(), z.detach(), loss.item()
+    del loss, p_s, p_t, ctx3                # drop the autograd graph before the oracle allocates its own caches
+    loss = types.SimpleNamespace(item=lambda: loss_v)
 
     out = dict(q_ids=q_ids, q_mask=q_mask, c_ids=c_ids, c_mask=c_mask, t_ids=t_ids3, t_mask=t_mask3,
                qa_w=wcls, qa_b=bcls,
@@ -174,7 +185,7 @@ def gen_encoder_step(tmp, cfg_kw, tag, B, N, q_len, p_len, ce_len, seeds, full_g
     assert worst < 1e3 * tol, worst
 
     # --- NQ/TQ loss on the same embeddings, co_training_wiki_train.py:198-228 (L2) ----
-    for lam in (0.0, 0.5):
+    for lam in ((0.0, 0.5) if extras else ()):
         model.zero_grad()
         lq, lc = model(query_ids=tt(q_ids), attention_mask_q=tt(q_mask), input_ids_a=tt(c_ids), attention_mask_a=tt(c_mask))
         rs = torch.einsum("bh,bdh->bd", lq, lc.reshape(lq.size(0), lc.size(0) // lq.size(0), -1))
@@ -192,6 +203,14 @@ def gen_encoder_step(tmp, cfg_kw, tag, B, N, q_len, p_len, ce_len, seeds, full_g
         _cmp("loss_wiki lam=%g" % lam, o2, l2.item(), tol)
 
     # --- teacher (reranker) train step, co_training_marco_train.py:225-245 (L6 + E3 backward) ---------
+    if not extras:
+        names = sorted(G.keys())
+        out["grad_names"] = np.asarray(names)
+        out["grad_norms"] = np.asarray([np.sqrt((G[k] ** 2).sum()) for k in names])
+        for k in names:                      # a slice of EVERY 2-D gradient and every vector: element-wise bf16 error statistics
+            out["gslice." + k] = G[k][:8, :64] if G[k].ndim == 2 else G[k]
+        np.savez_compressed(os.path.join(OUT, "step_%s.npz" % tag), **out)
+        return
     teacher.zero_grad()
     rl = teacher(input_ids=tt(t_ids3), attention_mask=tt(t_mask3))
     contr_loss = torch.nn.CrossEntropyLoss()(rl, torch.zeros(rl.size(0), dtype=torch.long))
@@ -586,6 +605,111 @@ def gen_roberta_dot(tmp, use_mean=False):
     np.savez_compressed(os.path.join(OUT, "roberta_dot_mean_tiny.npz" if use_mean else "roberta_dot_tiny.npz"), **out)
 
 
+def gen_prod_step(tmp):
+    """BASELINE configs[3] as ONE step, from the imported PROD modules (PROD/ProD_KD/model/models.py: HFBertEncoder,
+    BiBertEncoder, Reranker with its binary head, CrossBERTKDLoss) driven by the literal step body of
+    PROD/ProD_KD/run_progressive_distill_marco.py:288-314 with the README recipe (PROD/README.md:208-224): 6-layer
+    bi-encoder student, 12-layer cross-encoder teacher, frozen student copy (--open_LwF), KD_softmax, T=4,
+    CE_WEIGHT 0.1, KD_WEIGHT 0.9, LwF_WEIGHT 1.0, B=8 queries x (1+15) passages, q32 / p128 / cross-encoder 160.
+    PROD's init_encoder hard-codes /colab_space paths (models.py:34-43), so the encoders are built by HFBertEncoder(cfg)
+    -- the same class, the same forward.  -> step_prod_cfg4.npz (grad norms + slices)."""
+    from transformers import BertConfig
+    PR = _load("ref_prod_models2", os.path.join(REF, "PROD/ProD_KD/model/models.py"))
+    B, N, q_len, p_len, ce_len = 8, 15, 32, 128, 160
+    seeds = (3234, 3235, 3236, 3237, 3238)           # student q / ctx, teacher, frozen copy q / ctx
+    scfg, tcfg = BertCfg(layers=6), BertCfg(layers=12)
+
+    def enc(cfg, P):
+        hf = BertConfig(vocab_size=cfg.vocab, hidden_size=cfg.hidden, num_hidden_layers=cfg.layers, num_attention_heads=cfg.heads,
+                        intermediate_size=cfg.inter, max_position_embeddings=cfg.max_pos, type_vocab_size=cfg.type_vocab,
+                        layer_norm_eps=cfg.eps, hidden_act="gelu")
+        m = PR.HFBertEncoder(hf)
+        missing, unexpected = m.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()}, strict=False)
+        assert not [k for k in missing if "position_ids" not in k] and not unexpected, (missing, unexpected)
+        return m
+
+    def bi(Pq, Pc):
+        m = PR.BiBertEncoder.__new__(PR.BiBertEncoder)
+        torch.nn.Module.__init__(m)
+        m.question_model, m.ctx_model = enc(scfg, Pq), enc(scfg, Pc)
+        return _no_dropout(m)
+    Ps = [make_bert_params(scfg, s_) for s_ in (seeds[0], seeds[1], seeds[3], seeds[4])]
+    Pt = make_bert_params(tcfg, seeds[2])
+    model, student_copy = bi(Ps[0], Ps[1]), bi(Ps[2], Ps[3])
+    teacher = PR.Reranker(enc(tcfg, Pt), tcfg.hidden)
+    wcls = normal(seeds[2], "qa_classifier.weight", (1, tcfg.hidden), 0.05).astype(np.float32)
+    bcls = normal(seeds[2], "qa_classifier.bias", (1,), 0.05).astype(np.float32)
+    with torch.no_grad():
+        teacher.qa_classifier.weight.copy_(torch.from_numpy(wcls))
+        teacher.qa_classifier.bias.copy_(torch.from_numpy(bcls))
+    _no_dropout(teacher)
+    P = B * (1 + N)
+    q_ids, q_mask, _ = make_batch(seeds[0] + 100, B, q_len, scfg.vocab, 9, 3, 4)
+    c_ids, c_mask, _ = make_batch(seeds[1] + 100, P, p_len, scfg.vocab, 80, 25, 16)
+    t_ids, t_mask, _ = make_batch(seeds[2] + 100, P, ce_len, scfg.vocab, 90, 25, 20)
+    t_ids3, t_mask3 = t_ids.reshape(B, 1 + N, ce_len), t_mask.reshape(B, 1 + N, ce_len)
+    tt = lambda a: torch.from_numpy(a)
+    args = types.SimpleNamespace(KD_type="KD_softmax", TEMPERATURE=4.0, CE_WEIGHT=0.1, KD_WEIGHT=0.9, LwF_WEIGHT=1.0,
+                                 open_LwF=True, gradient_accumulation_steps=1)
+    inputs_retriever = dict(query_ids=tt(q_ids), attention_mask_q=tt(q_mask), input_ids_a=tt(c_ids), attention_mask_a=tt(c_mask))
+    inputs_reranker = dict(input_ids=tt(t_ids3), attention_mask=tt(t_mask3))
+    model.double(); teacher.double(); student_copy.double()
+    import warnings
+    warnings.simplefilter("ignore")
+    # --- literal step body, run_progressive_distill_marco.py:288-314 -------------------------------------------------
+    model.zero_grad()
+    teacher.eval()
+    local_q_vector, local_ctx_vectors = model(**inputs_retriever)
+    with torch.no_grad():
+        binary_logits, relevance_logits, _ = teacher(**inputs_reranker)
+    student_copy.eval()
+    ori_q_vector, ori_ctx_vectors = student_copy(**inputs_retriever)
+    loss, is_correct = PR.CrossBERTKDLoss().calc(args, local_q_vector, local_ctx_vectors, relevance_logits, LwF=True,
+                                                 ori_q_vector=ori_q_vector, ori_ctx_vectors=ori_ctx_vectors)
+    loss = loss / args.gradient_accumulation_steps
+    loss.backward()
+    G = _grads(model)
+    # the same step without LwF (the `else` branch, :305-313)
+    with torch.no_grad():
+        loss_nolwf, _ = PR.CrossBERTKDLoss().calc(args, local_q_vector.detach(), local_ctx_vectors.detach(), relevance_logits)
+    print(" [prod_cfg4] oracle vs imported PROD modules")
+    _, oq, cq = obert.bert_forward(Ps[0], q_ids, q_mask, scfg.heads)
+    _, oc, cc = obert.bert_forward(Ps[1], c_ids, c_mask, scfg.heads)
+    _, oq0, _ = obert.bert_forward(Ps[2], q_ids, q_mask, scfg.heads)
+    _, oc0, _ = obert.bert_forward(Ps[3], c_ids, c_mask, scfg.heads)
+    Pt2 = {"encoder." + k: v for k, v in Pt.items()}
+    Pt2["qa_classifier.weight"], Pt2["qa_classifier.bias"] = wcls, bcls
+    oz, _, _ = obert.reranker_forward(Pt2, t_ids3, t_mask3, tcfg.heads, keep=False)
+    _cmp("q_emb", oq, local_q_vector.detach().numpy(), 1e-10)
+    _cmp("ctx_emb", oc, local_ctx_vectors.detach().numpy(), 1e-10)
+    _cmp("relevance_logits", oz, relevance_logits.numpy(), 1e-10)
+    osim = oloss.sim_block(oq, oc)
+    ol, _, _, ocorr, ods = oloss.cross_kd(osim, oz, 4.0, 0.1, 0.9, oloss.sim_block(oq0, oc0), 1.0)
+    _cmp("loss (LwF)", ol, loss.item(), 1e-10)
+    assert ocorr == int(is_correct)
+    dq, dc = oloss.sim_block_bwd(oq, oc, ods)
+    Gq = obert.bert_backward(Ps[0], q_ids, q_mask, scfg.heads, cq, dq)
+    Gc = obert.bert_backward(Ps[1], c_ids, c_mask, scfg.heads, cc, dc)
+    worst = 0.0
+    for pre, Go in (("question_model.", Gq), ("ctx_model.", Gc)):
+        for k, g in Go.items():
+            r = G[pre + k]
+            worst = max(worst, np.abs(g - r).max() / max(np.abs(r).max(), 1e-6))
+    print("   %-42s worst rel-to-max grad diff %.3e" % ("all %d parameter grads" % (len(Gq) + len(Gc)), worst))
+    assert worst < 1e-7, worst
+    names = sorted(G.keys())
+    out = dict(q_ids=q_ids, q_mask=q_mask, c_ids=c_ids, c_mask=c_mask, t_ids=t_ids3, t_mask=t_mask3, qa_w=wcls, qa_b=bcls,
+               seeds=np.asarray(seeds), shape=np.asarray([B, N, q_len, p_len, ce_len]), layers=np.asarray([6, 12]),
+               q_emb=local_q_vector.detach().numpy(), ctx_emb=local_ctx_vectors.detach().numpy(),
+               ori_q_emb=ori_q_vector.detach().numpy(), ori_ctx_emb=ori_ctx_vectors.detach().numpy(),
+               relevance_logits=relevance_logits.numpy(), loss=np.float64(loss.item()), loss_nolwf=np.float64(loss_nolwf.item()),
+               correct=np.int64(int(is_correct)), grad_names=np.asarray(names),
+               grad_norms=np.asarray([np.sqrt((G[k] ** 2).sum()) for k in names]))
+    for k in names:
+        out["gslice." + k] = G[k][:8, :64] if G[k].ndim == 2 else G[k]
+    np.savez_compressed(os.path.join(OUT, "step_prod_cfg4.npz"), **out)
+
+
 def main():
     global RM
     os.makedirs(OUT, exist_ok=True)
@@ -593,6 +717,13 @@ def main():
     torch.set_num_threads(8)
     RM = _ref_models()
     with tempfile.TemporaryDirectory() as tmp:
+        if "--only-prod" in sys.argv:
+            gen_prod_step(tmp)
+            return
+        if "--only-hot" in sys.argv:
+            gen_encoder_step(tmp, {}, "base_hot", B=16, N=15, q_len=32, p_len=128, ce_len=160,
+                             seeds=(2234, 2235, 2236), full_grads=False, tol=1e-10, extras=False)
+            return
         gen_losses()
         gen_sampler(tmp)
         gen_collate(tmp)
@@ -605,6 +736,12 @@ def main():
         if "--no-base" not in sys.argv:
             gen_encoder_step(tmp, {}, "base_cfg1", B=4, N=1, q_len=32, p_len=128, ce_len=160,
                              seeds=(1234, 1235, 1236), full_grads=False, tol=1e-10)
+        if "--hot" in sys.argv or "--all" in sys.argv:
+            gen_prod_step(tmp)
+            # BERT-base, B=16 queries x 16 passages: ~20k passage tokens -> the persistent NT GEMM, the 256x256 wgrad kernel,
+            # mha<8> and the wide LayerNorm kernels all dispatch (minutes of fp64 CPU time; not part of the default run)
+            gen_encoder_step(tmp, {}, "base_hot", B=16, N=15, q_len=32, p_len=128, ce_len=160,
+                             seeds=(2234, 2235, 2236), full_grads=False, tol=1e-10, extras=False)
     print("golden vectors written to", OUT)
 
 

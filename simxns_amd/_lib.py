@@ -26,7 +26,7 @@ class BertCfg(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("layers", C.c_int32), ("hidden", C.c_int32), ("heads", C.c_int32),
                 ("inter", C.c_int32), ("vocab", C.c_int32), ("max_pos", C.c_int32), ("type_vocab", C.c_int32),
                 ("eps", C.c_float), ("hidden_dropout", C.c_float), ("attn_dropout", C.c_float), ("dropout_seed", C.c_uint32),
-                ("cls_only_last_layer", C.c_int32)]
+                ("cls_only_last_layer", C.c_int32), ("grad_checkpoint", C.c_int32)]
 
 
 class Dropout(C.Structure):
@@ -82,6 +82,7 @@ SIGNATURES = {
     "simx_bert_fwd": (_i, [_p, _cfgp, _p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _i, _p, _p]),
     "simx_bert_bwd": (_i, [_p, _cfgp, _p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p, _p, _p, _z]),
     "simx_bert_bwd_ex": (_i, [_p, _cfgp, _p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p, _p, _p, _p, _z]),
+    "simx_bert_bwd_range": (_i, [_p, _cfgp, _p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p, _p, _p, _p, _z, _i, _i]),
     "simx_seq_mean_fwd": (_i, [_p, _i, _i, _i, _p, _p, _p]),
     "simx_seq_mean_bwd": (_i, [_p, _i, _i, _i, _p, _p, _p]),
     "simx_sim_loss_fwd_bwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _lpp, _p, _p, _p, _p]),

@@ -118,7 +118,9 @@ def write_to_file(qids_to_ranked_candidate_passages, qids_to_ranked_candidate_sc
 class RenewTools(object):
     """The reference's driver object (:269-460) reduced to what the job needs."""
 
-    def __init__(self, passages_path, tokenizer, output_dir, passage_title_path=None, max_passage_length=128):
+    def __init__(self, passages_path, tokenizer, output_dir, passage_title_path=None, max_passage_length=128, rank=0, world=1):
+        """Reads the corpus file once (ids of every row: the search returns global corpus rows), but TOKENISES only this
+        rank's contiguous slice [rank*n/world, (rank+1)*n/world) -- the only rows this rank embeds."""
         self.tokenizer, self.output_dir = tokenizer, output_dir
         titles = load_id_text(passage_title_path) if passage_title_path and os.path.exists(passage_title_path) else {}
         rows = []
@@ -126,13 +128,18 @@ class RenewTools(object):
             for line in inp:
                 pid, text = line.rstrip("\n").split("\t")[:2]
                 rows.append((int(pid), text, titles.get(pid, titles.get(int(pid), "-"))))
-        self.passage_ids, self.passage_table = tokenize_table(rows, tokenizer, max_passage_length, pair=True)
+        n = len(rows)
+        self.passage_ids = np.fromiter((r[0] for r in rows), np.int64, n)
+        self.slice = (rank * n // world, (rank + 1) * n // world)
+        _, self.passage_table = tokenize_table(rows[self.slice[0]:self.slice[1]], tokenizer, max_passage_length, pair=True)
 
     def build_index(self, model, device, rank=0, world=1):
         """embed this rank's contiguous corpus slice and hold it in HBM; ids are global corpus rows."""
         n = len(self.passage_ids)
         lo, hi = rank * n // world, (rank + 1) * n // world
-        emb = embed_table(get_model_obj(model).body_emb, self.passage_table[lo:hi], device)
+        if (lo, hi) != self.slice:
+            raise ValueError("RenewTools was built for corpus rows %s, build_index asked for %s" % (self.slice, (lo, hi)))
+        emb = embed_table(get_model_obj(model).body_emb, self.passage_table, device)
         index = FlatIPIndex(emb.shape[1] if emb.numel() else 768, id_base=lo)
         if emb.numel():
             index.add(emb)
@@ -164,9 +171,19 @@ class RenewTools(object):
         return result, path
 
 
-def load_pos_examples(path):
-    """qid -> [positive pids] from the qrels file (load_pos_examples, :139-150 reads the MS-MARCO qrels)."""
-    return load_reference_from_stream(path)
+def load_pos_examples(path, q_type="train", data_dir=None):
+    """-> (pos_qp, pos_qp_add), load_pos_examples (:120-152): qid -> [positive pids] from the qrels file, and for the train
+    queries the ADDITIONAL positives collected by literal match, `<data_dir>/qrels.train.addition.tsv` ('qid\tpid').  They are
+    merged into the positive column by write_to_file, i.e. kept OUT of the hard-negative column SimANS samples from."""
+    pos_qp = load_reference_from_stream(path) if path and os.path.exists(path) else {}
+    pos_qp_add = {}
+    if q_type == "train":
+        add = os.path.join(data_dir if data_dir is not None else os.path.dirname(path), "qrels.train.addition.tsv")
+        if os.path.exists(add):
+            pos_qp_add = load_reference_from_stream(add)
+        else:
+            logger.warning("%s not found: no literal-match positives are excluded from the mined hard negatives", add)
+    return pos_qp, pos_qp_add
 
 
 def main():
@@ -208,13 +225,13 @@ def main():
         from transformers import BertTokenizer
         tok = BertTokenizer.from_pretrained(args.tokenizer_name or "bert-base-uncased", do_lower_case=True)
     data_dir = args.passage_path
-    tools = RenewTools(os.path.join(data_dir, "para.txt"), tok, ann_dir, os.path.join(data_dir, "para.title.txt"))
+    tools = RenewTools(os.path.join(data_dir, "para.txt"), tok, ann_dir, os.path.join(data_dir, "para.title.txt"), rank=rank, world=world)
     index = tools.build_index(model, device, rank, world)
     for mode, qa in (("train", args.train_qa_path), ("dev", args.dev_qa_path)):
         if qa:
             gold = os.path.join(data_dir, "qrels.%s.tsv" % mode)
-            pos = load_pos_examples(gold) if os.path.exists(gold) else {}
-            tools.get_question_topk(model, device, index, qa, gold, pos, None, mode, args.global_step, group)
+            pos, pos_add = load_pos_examples(gold, mode, data_dir)
+            tools.get_question_topk(model, device, index, qa, gold, pos, pos_add, mode, args.global_step, group)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -42,11 +42,18 @@ def get_bert_reader_components(args, **kwargs):
 
 
 def _load_saved_state(model, optimizer, scheduler, saved_state: CheckpointState):
+    """co_training_marco_train.py:348-358: model, optimizer and scheduler state are all restored (the reference loads the
+    two dicts unconditionally).  Both the reference's torch formats and this package's round-1 flat format are read; a
+    state that cannot be applied raises -- nothing is skipped silently."""
     get_model_obj(model).load_state_dict(saved_state.model_dict, strict=False)
-    if saved_state.optimizer_dict and isinstance(saved_state.optimizer_dict, dict) and "towers" in saved_state.optimizer_dict:
+    if saved_state.optimizer_dict:
         optimizer.load_state_dict(saved_state.optimizer_dict)
-    if saved_state.scheduler_dict and "t" in saved_state.scheduler_dict:
+    else:
+        logger.warning("checkpoint carries no optimizer state: Adam moments restart from zero")
+    if saved_state.scheduler_dict:
         scheduler.load_state_dict(saved_state.scheduler_dict)
+    else:
+        logger.warning("checkpoint carries no scheduler state: the schedule restarts at step 0")
     return saved_state.offset if isinstance(saved_state.offset, int) else 0
 
 
@@ -78,6 +85,9 @@ def train(args, model, teacher_model, tokenizer, global_step=0, dataset_cls=Rock
     optimizer = get_optimizer(args, model, args.weight_decay, args.learning_rate, args.adam_epsilon)
     teacher_optimizer = get_optimizer(args, teacher_model, args.weight_decay, args.teacher_learning_rate, args.adam_epsilon)
     world = dist.get_world_size() if args.local_rank != -1 else 1
+    if world > 1:          # DDP's role (:107-114): gradient slices are all-reduced over RCCL while the backward still runs
+        optimizer.enable_overlap(world)
+        teacher_optimizer.enable_overlap(world)
 
     tr_loss = tr_distll_loss = tr_contr_loss = 0.0
     model.zero_grad()
@@ -114,6 +124,8 @@ def train(args, model, teacher_model, tokenizer, global_step=0, dataset_cls=Rock
             if world > 1:
                 dist.barrier()
         step += 1
+        # an accumulated (in-place) gradient buffer is reduced once, by the last micro-step's backward
+        optimizer.armed = teacher_optimizer.armed = (step + 1) % args.gradient_accumulation_steps == 0
         bs = batch['student']
         q_ids, q_mask, c_ids, c_mask = (t.long().to(args.device) for t in bs[:4])
         t_ids, t_mask = (t.long().to(args.device) for t in batch['teacher'][:2])
@@ -139,12 +151,13 @@ def train(args, model, teacher_model, tokenizer, global_step=0, dataset_cls=Rock
             tr_loss += loss.item()
             tr_contr_loss += contr_loss.item()
         if (step + 1) % args.gradient_accumulation_steps == 0:    # sic: step starts at 1 (:184, :246)
+            # optimizer first, scheduler second, as the reference (:250-252 / :258-260): update k uses lr*lambda(k-1)
             if train_flag == 0:
-                scheduler.step()
                 optimizer.step(max_grad_norm=args.max_grad_norm, world_size=world)     # clip + AdamW + zero_grad
+                scheduler.step()
             if train_flag == 1:
-                teacher_scheduler.step()
                 teacher_optimizer.step(max_grad_norm=args.max_grad_norm, world_size=world)
+                teacher_scheduler.step()
             global_step += 1
             if args.logging_steps > 0 and global_step % args.logging_steps == 0:
                 logs = {"learning_rate": scheduler.get_last_lr()[0], "loss": tr_loss / args.logging_steps,

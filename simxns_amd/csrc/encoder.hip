@@ -123,21 +123,31 @@ static size_t act_layer_bytes(const simx_bert_cfg* c, size_t T) {
   const size_t H = c->hidden, F = c->inter, e = esz(c->dtype);
   return al(T * 3 * H * e) + 5 * al(T * H * e) + 2 * al(T * F * e) + al((size_t)c->heads * T * 4);
 }
+// Activation memory, three modes:
+//   save = 0                      : x0 | 2 layer slots used as a ring                                  (inference)
+//   save = 1, grad_checkpoint = 0 : x0 | L layer slots -- everything backward needs is kept            (default)
+//   save = 1, grad_checkpoint = 1 : x0 | L layer OUTPUTS [Tp,H] | 2 layer slots (ring) -- only every layer's input is kept
+//                                   (torch.utils.checkpoint per BertLayer, SimANS/model/models.py:73-74); backward re-runs
+//                                   a layer's forward into ring slot 0 (same stateless dropout masks) before its backward
+// followed by three [nseq,H] tensors of the [CLS]-only last layer (q, attention context, a temporary).
+static inline bool ckpt_mode(const simx_bert_cfg* c, int save) { return save && c->grad_checkpoint != 0; }
+static size_t act_slots_bytes(const simx_bert_cfg* c, size_t Tp, int save) {
+  if (ckpt_mode(c, save)) return (size_t)c->layers * al(Tp * c->hidden * esz(c->dtype)) + 2 * act_layer_bytes(c, Tp);
+  return (size_t)(save ? c->layers : 2) * act_layer_bytes(c, Tp);
+}
 extern "C" size_t simx_bert_act_bytes(const simx_bert_cfg* c, int T, int nseq, int save_for_bwd) {
   if (!cfg_ok(c) || T <= 0) return 0;
   const size_t Tp = (size_t)rows_cap(T);
   const size_t x0 = al(Tp * c->hidden * esz(c->dtype));
   const size_t n = nseq > 0 ? (size_t)nseq : Tp;
-  return x0 + (size_t)(save_for_bwd ? c->layers : 2) * act_layer_bytes(c, Tp) + 3 * al(n * c->hidden * esz(c->dtype));
+  return x0 + act_slots_bytes(c, Tp, save_for_bwd) + 3 * al(n * c->hidden * esz(c->dtype));
 }
-// three [nseq,H] tensors of the [CLS]-only last layer (q, attention context, a temporary), behind the per-layer slots
 static char* act_extra(const simx_bert_cfg* c, void* act, size_t Tp, int save) {
-  return (char*)act + al(Tp * c->hidden * esz(c->dtype)) + (size_t)(save ? c->layers : 2) * act_layer_bytes(c, Tp);
+  return (char*)act + al(Tp * c->hidden * esz(c->dtype)) + act_slots_bytes(c, Tp, save);
 }
 static char* act_x0(void* act) { return (char*)act; }
-static ALayer alayer(const simx_bert_cfg* c, void* act, size_t T, int l, int save) {
+static ALayer carve_layer(const simx_bert_cfg* c, char* b, size_t T) {
   const size_t H = c->hidden, F = c->inter, e = esz(c->dtype);
-  char* b = (char*)act + al(T * H * e) + (size_t)(save ? l : (l & 1)) * act_layer_bytes(c, T);
   ALayer a;
   a.qkv = b; b += al(T * 3 * H * e);
   a.ctx = b; b += al(T * H * e);
@@ -149,6 +159,27 @@ static ALayer alayer(const simx_bert_cfg* c, void* act, size_t T, int l, int sav
   a.h = b; b += al(T * F * e);
   a.lse = (float*)b;
   return a;
+}
+// the slot layer l's FORWARD writes (checkpoint mode: ring slot l&1, its output redirected to the kept array)
+static ALayer alayer(const simx_bert_cfg* c, void* act, size_t T, int l, int save) {
+  const size_t xb = al(T * c->hidden * esz(c->dtype));
+  char* base = (char*)act + xb;
+  if (ckpt_mode(c, save)) {
+    ALayer a = carve_layer(c, base + (size_t)c->layers * xb + (size_t)(l & 1) * act_layer_bytes(c, T), T);
+    a.xout = base + (size_t)l * xb;
+    return a;
+  }
+  return carve_layer(c, base + (size_t)(save ? l : (l & 1)) * act_layer_bytes(c, T), T);
+}
+// checkpoint mode, backward: the slot layer l is RE-COMPUTED into (ring slot 0, its own xout)
+static ALayer alayer_recompute(const simx_bert_cfg* c, void* act, size_t T) {
+  const size_t xb = al(T * c->hidden * esz(c->dtype));
+  return carve_layer(c, (char*)act + xb + (size_t)c->layers * xb, T);
+}
+// input of layer l (= output of layer l-1, or the embedding output)
+static const char* layer_input(const simx_bert_cfg* c, const void* act, size_t T, int l) {
+  if (l == 0) return act_x0(const_cast<void*>(act));
+  return alayer(c, const_cast<void*>(act), T, l - 1, 1).xout;
 }
 
 static size_t tn_ws_max(const simx_bert_cfg* c, int T) {
@@ -211,6 +242,57 @@ static int check_io(const simx_bert_cfg* c, int nseq, int T, int max_len, const 
   return SIMX_OK;
 }
 
+// One encoder layer's forward: x_in [Tp,H] -> a.xout (a = the slot it writes).  `keep`: backward will read this slot
+// (the pre-activation u is stored); the [CLS]-only form of the last layer writes [nseq, .] tensors into the slot's usual
+// buffers and q / attention context of the [CLS] rows into `extra` (kept for backward).
+static int layer_fwd(hipStream_t stream, const simx_bert_cfg* c, const float* params, const void* wcache, int l, const char* x,
+                     const ALayer& a, char* extra, const int32_t* cu, int nseq, int T, int Tp, int max_len, int keep, bool cls_form,
+                     float* cls_out) {
+  const int H = c->hidden, F = c->inter, dt = c->dtype, d = H / c->heads;
+  auto off = [&](int ll, int w) { return params + simx_bert_param_offset(c, ll, w); };
+  const WLayer w = wlayer(c, params, wcache, l);
+  const simx_dropout d1 = drop_of(c, l, 1), d2 = drop_of(c, l, 2), d3 = drop_of(c, l, 3);
+  if (cls_form) {
+    // Last layer, [CLS] rows only: row s of every [nseq, .] buffer below is the sequence's token 0 (row cu[s] of the
+    // full tensors).  Only K and V are projected for every token; Q, the attention core and everything after it run
+    // for the one query per sequence that is read.  Same arithmetic as the full path -- dropout masks stay keyed by
+    // the ORIGINAL row index.  z1, x1, u, h, z2, xout of this layer hold [nseq, .] tensors in their usual slots.
+    const size_t e = esz(dt);
+    char* qc = extra;                                            // kept for backward
+    char* ctxc = qc + al((size_t)nseq * H * e);                  // kept for backward
+    char* ytmp = ctxc + al((size_t)nseq * H * e);
+    RUN(simx_gemm_nt(stream, dt, Tp, 2 * H, H, x, H, w.wqkv + (size_t)H * H * e, H, a.qkv + (size_t)H * e, 3 * H,
+                     off(l, SIMX_P_BQKV) + H, nullptr, 0, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
+    RUN(simx_rows_copy(stream, dt, dt, nseq, H, cu, nullptr, x, ytmp));
+    RUN(simx_gemm_nt(stream, dt, nseq, H, H, ytmp, H, w.wqkv, H, qc, H, off(l, SIMX_P_BQKV), nullptr, 0, SIMX_EPI_NONE, nullptr, 0,
+                     nullptr, 0));
+    RUN(simx_mha_cls_fwd(stream, dt, nseq, c->heads, d, cu, max_len, T, qc, a.qkv, ctxc, &d3));
+    RUN(simx_gemm_nt(stream, dt, nseq, H, H, ctxc, H, w.wo, H, ytmp, H, off(l, SIMX_P_BO), nullptr, 0, SIMX_EPI_NONE, nullptr, 0,
+                     nullptr, 0));
+    RUN(simx_drop_residual_rows(stream, dt, nseq, H, ytmp, x, cu, cu, &d1, a.z1));
+    RUN(simx_ln_fwd(stream, dt, nseq, H, a.z1, off(l, SIMX_P_LN1_G), off(l, SIMX_P_LN1_B), c->eps, a.x1));
+    RUN(simx_gemm_nt(stream, dt, nseq, F, H, a.x1, H, w.w1, H, a.u, F, off(l, SIMX_P_B1), nullptr, 0, SIMX_EPI_GELU, nullptr, 0, a.h, F));
+    RUN(simx_gemm_nt(stream, dt, nseq, H, F, a.h, F, w.w2, F, ytmp, H, off(l, SIMX_P_B2), nullptr, 0, SIMX_EPI_NONE, nullptr, 0,
+                     nullptr, 0));
+    RUN(simx_drop_residual_rows(stream, dt, nseq, H, ytmp, a.x1, nullptr, cu, &d2, a.z2));
+    RUN(simx_ln_fwd(stream, dt, nseq, H, a.z2, off(l, SIMX_P_LN2_G), off(l, SIMX_P_LN2_B), c->eps, a.xout));
+    if (cls_out) RUN(simx_rows_copy(stream, dt, SIMX_F32, nseq, H, nullptr, nullptr, a.xout, cls_out));
+    return SIMX_OK;
+  }
+  RUN(simx_gemm_nt(stream, dt, Tp, 3 * H, H, x, H, w.wqkv, H, a.qkv, 3 * H, off(l, SIMX_P_BQKV), nullptr, 0, SIMX_EPI_NONE,
+                   nullptr, 0, nullptr, 0));
+  RUN(simx_mha_fwd_ex(stream, dt, nseq, c->heads, d, cu, max_len, T, a.qkv, a.ctx, a.lse, &d3));
+  RUN(simx_gemm_nt_ex(stream, dt, Tp, H, H, a.ctx, H, w.wo, H, a.z1, H, off(l, SIMX_P_BO), x, H, SIMX_EPI_NONE, nullptr, 0,
+                      nullptr, 0, &d1));
+  RUN(simx_ln_fwd(stream, dt, T, H, a.z1, off(l, SIMX_P_LN1_G), off(l, SIMX_P_LN1_B), c->eps, a.x1));
+  RUN(simx_gemm_nt(stream, dt, Tp, F, H, a.x1, H, w.w1, H, a.u, F, off(l, SIMX_P_B1), nullptr, 0,
+                   keep ? SIMX_EPI_GELU : SIMX_EPI_GELU_INFER, nullptr, 0, a.h, F));   // no backward from this slot: u has no reader
+  RUN(simx_gemm_nt_ex(stream, dt, Tp, H, F, a.h, F, w.w2, F, a.z2, H, off(l, SIMX_P_B2), a.x1, H, SIMX_EPI_NONE, nullptr, 0,
+                      nullptr, 0, &d2));
+  RUN(simx_ln_fwd(stream, dt, T, H, a.z2, off(l, SIMX_P_LN2_G), off(l, SIMX_P_LN2_B), c->eps, a.xout));
+  return SIMX_OK;
+}
+
 extern "C" int simx_bert_fwd(simx_stream_t stream, const simx_bert_cfg* c, const float* params, const void* wcache,
                              const int32_t* ids, const int32_t* pos_ids, const int32_t* cu, int nseq, int T, int max_len,
                              void* act, size_t act_bytes, int save, float* cls_out, void* hidden_out) {
@@ -218,60 +300,25 @@ extern "C" int simx_bert_fwd(simx_stream_t stream, const simx_bert_cfg* c, const
   SIMX_REQUIRE(params && wcache && ids && pos_ids && cu && act, SIMX_ERR_BAD_SHAPE, "bert_fwd: NULL buffer");
   SIMX_REQUIRE(act_bytes >= simx_bert_act_bytes(c, T, nseq, save), SIMX_ERR_WORKSPACE, "bert_fwd: activation buffer %zu < %zu",
                act_bytes, simx_bert_act_bytes(c, T, nseq, save));
-  const int H = c->hidden, F = c->inter, dt = c->dtype, d = H / c->heads;
+  const int H = c->hidden, dt = c->dtype;
   const int Tp = rows_cap(T);
-  const float* P = params;
-  auto off = [&](int l, int w) { return P + simx_bert_param_offset(c, l, w); };
-  char* x = act_x0(act);
+  auto off = [&](int l, int w) { return params + simx_bert_param_offset(c, l, w); };
+  const char* x = act_x0(act);
   {
     const simx_dropout d0 = drop_of(c, -1, 0);
     RUN(simx_embed_ln_fwd_ex(stream, dt, T, H, ids, pos_ids, off(-1, SIMX_P_WORD), off(-1, SIMX_P_POS), off(-1, SIMX_P_TYPE),
-                             off(-1, SIMX_P_EMB_LN_G), off(-1, SIMX_P_EMB_LN_B), c->eps, x, &d0));
+                             off(-1, SIMX_P_EMB_LN_G), off(-1, SIMX_P_EMB_LN_B), c->eps, act_x0(act), &d0));
   }
   const bool cls_only = c->cls_only_last_layer != 0;
+  const bool ckpt = ckpt_mode(c, save);
   SIMX_REQUIRE(!(cls_only && hidden_out), SIMX_ERR_BAD_SHAPE, "bert_fwd: cls_only_last_layer leaves no full hidden state to return");
   for (int l = 0; l < c->layers; ++l) {
-    const WLayer w = wlayer(c, params, wcache, l);
     const ALayer a = alayer(c, act, Tp, l, save);
-    const simx_dropout d1 = drop_of(c, l, 1), d2 = drop_of(c, l, 2), d3 = drop_of(c, l, 3);
-    if (cls_only && l == c->layers - 1) {
-      // Last layer, [CLS] rows only: row s of every [nseq, .] buffer below is the sequence's token 0 (row cu[s] of the
-      // full tensors).  Only K and V are projected for every token; Q, the attention core and everything after it run
-      // for the one query per sequence that is read.  Same arithmetic as the full path -- dropout masks stay keyed by
-      // the ORIGINAL row index.  z1, x1, u, h, z2, xout of this layer hold [nseq, .] tensors in their usual slots.
-      const size_t e = esz(dt);
-      char* qc = act_extra(c, act, Tp, save);                      // kept for backward
-      char* ctxc = qc + al((size_t)nseq * H * e);                  // kept for backward
-      char* ytmp = ctxc + al((size_t)nseq * H * e);
-      RUN(simx_gemm_nt(stream, dt, Tp, 2 * H, H, x, H, w.wqkv + (size_t)H * H * e, H, a.qkv + (size_t)H * e, 3 * H,
-                       off(l, SIMX_P_BQKV) + H, nullptr, 0, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
-      RUN(simx_rows_copy(stream, dt, dt, nseq, H, cu, nullptr, x, ytmp));
-      RUN(simx_gemm_nt(stream, dt, nseq, H, H, ytmp, H, w.wqkv, H, qc, H, off(l, SIMX_P_BQKV), nullptr, 0, SIMX_EPI_NONE, nullptr, 0,
-                       nullptr, 0));
-      RUN(simx_mha_cls_fwd(stream, dt, nseq, c->heads, d, cu, max_len, T, qc, a.qkv, ctxc, &d3));
-      RUN(simx_gemm_nt(stream, dt, nseq, H, H, ctxc, H, w.wo, H, ytmp, H, off(l, SIMX_P_BO), nullptr, 0, SIMX_EPI_NONE, nullptr, 0,
-                       nullptr, 0));
-      RUN(simx_drop_residual_rows(stream, dt, nseq, H, ytmp, x, cu, cu, &d1, a.z1));
-      RUN(simx_ln_fwd(stream, dt, nseq, H, a.z1, off(l, SIMX_P_LN1_G), off(l, SIMX_P_LN1_B), c->eps, a.x1));
-      RUN(simx_gemm_nt(stream, dt, nseq, F, H, a.x1, H, w.w1, H, a.u, F, off(l, SIMX_P_B1), nullptr, 0, SIMX_EPI_GELU, nullptr, 0, a.h, F));
-      RUN(simx_gemm_nt(stream, dt, nseq, H, F, a.h, F, w.w2, F, ytmp, H, off(l, SIMX_P_B2), nullptr, 0, SIMX_EPI_NONE, nullptr, 0,
-                       nullptr, 0));
-      RUN(simx_drop_residual_rows(stream, dt, nseq, H, ytmp, a.x1, nullptr, cu, &d2, a.z2));
-      RUN(simx_ln_fwd(stream, dt, nseq, H, a.z2, off(l, SIMX_P_LN2_G), off(l, SIMX_P_LN2_B), c->eps, a.xout));
-      if (cls_out) RUN(simx_rows_copy(stream, dt, SIMX_F32, nseq, H, nullptr, nullptr, a.xout, cls_out));
-      return SIMX_OK;
-    }
-    RUN(simx_gemm_nt(stream, dt, Tp, 3 * H, H, x, H, w.wqkv, H, a.qkv, 3 * H, off(l, SIMX_P_BQKV), nullptr, 0, SIMX_EPI_NONE,
-                     nullptr, 0, nullptr, 0));
-    RUN(simx_mha_fwd_ex(stream, dt, nseq, c->heads, d, cu, max_len, T, a.qkv, a.ctx, a.lse, &d3));
-    RUN(simx_gemm_nt_ex(stream, dt, Tp, H, H, a.ctx, H, w.wo, H, a.z1, H, off(l, SIMX_P_BO), x, H, SIMX_EPI_NONE, nullptr, 0,
-                        nullptr, 0, &d1));
-    RUN(simx_ln_fwd(stream, dt, T, H, a.z1, off(l, SIMX_P_LN1_G), off(l, SIMX_P_LN1_B), c->eps, a.x1));
-    RUN(simx_gemm_nt(stream, dt, Tp, F, H, a.x1, H, w.w1, H, a.u, F, off(l, SIMX_P_B1), nullptr, 0,
-                     save ? SIMX_EPI_GELU : SIMX_EPI_GELU_INFER, nullptr, 0, a.h, F));   // no backward: u has no reader
-    RUN(simx_gemm_nt_ex(stream, dt, Tp, H, F, a.h, F, w.w2, F, a.z2, H, off(l, SIMX_P_B2), a.x1, H, SIMX_EPI_NONE, nullptr, 0,
-                        nullptr, 0, &d2));
-    RUN(simx_ln_fwd(stream, dt, T, H, a.z2, off(l, SIMX_P_LN2_G), off(l, SIMX_P_LN2_B), c->eps, a.xout));
+    const bool cls_form = cls_only && l == c->layers - 1;
+    // (checkpoint mode: the slot is recomputed by backward, so the forward runs it in its inference form)
+    RUN(layer_fwd((hipStream_t)stream, c, params, wcache, l, x, a, act_extra(c, act, Tp, save), cu, nseq, T, Tp, max_len,
+                  save && !ckpt, cls_form, cls_out));
+    if (cls_form) return SIMX_OK;
     x = a.xout;
   }
   if (cls_out) RUN(simx_cls_gather(stream, dt, nseq, H, cu, x, cls_out));
@@ -296,9 +343,20 @@ extern "C" int simx_bert_bwd_ex(simx_stream_t stream, const simx_bert_cfg* c, co
                                 const int32_t* ids, const int32_t* pos_ids, const int32_t* cu, int nseq, int T, int max_len,
                                 const void* act, size_t act_bytes, const float* dcls, const void* dhidden, float* grads,
                                 void* scratch, size_t scratch_bytes) {
+  return simx_bert_bwd_range(stream, c, params, wcache, ids, pos_ids, cu, nseq, T, max_len, const_cast<void*>(act), act_bytes, dcls,
+                             dhidden, grads, scratch, scratch_bytes, c ? c->layers - 1 : 0, 0);
+}
+
+extern "C" int simx_bert_bwd_range(simx_stream_t stream, const simx_bert_cfg* c, const float* params, const void* wcache,
+                                   const int32_t* ids, const int32_t* pos_ids, const int32_t* cu, int nseq, int T, int max_len,
+                                   void* act, size_t act_bytes, const float* dcls, const void* dhidden, float* grads,
+                                   void* scratch, size_t scratch_bytes, int layer_hi, int layer_lo) {
   RUN(check_io(c, nseq, T, max_len, "bert_bwd"));
   SIMX_REQUIRE(params && wcache && ids && pos_ids && cu && act && grads && scratch, SIMX_ERR_BAD_SHAPE, "bert_bwd: NULL buffer");
-  SIMX_REQUIRE((dcls != nullptr) != (dhidden != nullptr), SIMX_ERR_BAD_SHAPE, "bert_bwd: pass exactly one of dcls / dhidden");
+  SIMX_REQUIRE(layer_hi < c->layers && layer_lo >= 0 && layer_lo <= layer_hi, SIMX_ERR_BAD_SHAPE, "bert_bwd: bad layer range %d..%d",
+               layer_hi, layer_lo);
+  const bool top = layer_hi == c->layers - 1;
+  SIMX_REQUIRE(!top || ((dcls != nullptr) != (dhidden != nullptr)), SIMX_ERR_BAD_SHAPE, "bert_bwd: pass exactly one of dcls / dhidden");
   SIMX_REQUIRE(!(dhidden && c->cls_only_last_layer), SIMX_ERR_BAD_SHAPE,
                "bert_bwd: a gradient for the whole hidden state needs the full last layer (cls_only_last_layer = 0)");
   SIMX_REQUIRE(act_bytes >= simx_bert_act_bytes(c, T, nseq, 1), SIMX_ERR_WORKSPACE, "bert_bwd: activation buffer too small");
@@ -307,8 +365,11 @@ extern "C" int simx_bert_bwd_ex(simx_stream_t stream, const simx_bert_cfg* c, co
   const int H = c->hidden, F = c->inter, dt = c->dtype, d = H / c->heads;
   const int Tp = rows_cap(T);
   const size_t e = esz(dt);
+  const bool ckpt = c->grad_checkpoint != 0;
   auto off = [&](int l, int w) { return params + simx_bert_param_offset(c, l, w); };
   auto goff = [&](int l, int w) { return grads + simx_bert_param_offset(c, l, w); };
+  // scratch: bufB carries the gradient w.r.t. the current layer's OUTPUT from one layer to the next -- and from one
+  // simx_bert_bwd_range call to the next (the caller keeps `scratch` alive and untouched between the parts)
   char* bufA = (char*)scratch;
   char* bufB = bufA + al((size_t)Tp * H * e);
   char* bufC = bufB + al((size_t)Tp * H * e);                    // dropout-masked copy of dz (only with hidden dropout)
@@ -318,19 +379,20 @@ extern "C" int simx_bert_bwd_ex(simx_stream_t stream, const simx_bert_cfg* c, co
   char* tnws = dqkv + al((size_t)Tp * 3 * H * e);
   const size_t tnws_bytes = tn_ws_max(c, T);
 
-  int l_top = c->layers - 1;
-  if (c->cls_only_last_layer) {
+  int l_top = layer_hi;
+  if (top && c->cls_only_last_layer) {
     // mirror of the forward's [CLS]-only last layer: everything up to the attention core runs on nseq rows
     const int l = l_top;
     const WLayer w = wlayer(c, params, wcache, l);
-    const ALayer a = alayer(c, const_cast<void*>(act), Tp, l, 1);
-    const char* xin = l == 0 ? act_x0(const_cast<void*>(act)) : alayer(c, const_cast<void*>(act), Tp, l - 1, 1).xout;
+    const char* xin = layer_input(c, act, Tp, l);
+    const ALayer a = ckpt ? alayer_recompute(c, act, Tp) : alayer(c, act, Tp, l, 1);
+    if (ckpt) RUN(layer_fwd((hipStream_t)stream, c, params, wcache, l, xin, a, act_extra(c, act, Tp, 1), cu, nseq, T, Tp, max_len, 1, true, nullptr));
     const simx_dropout d1 = drop_of(c, l, 1), d2 = drop_of(c, l, 2), d3 = drop_of(c, l, 3);
     char* dzm = hd ? bufC : bufA;
     char* e0 = tnws + tnws_bytes;                        // three [nseq,H] temporaries
     char* e1 = e0 + al((size_t)nseq * H * e);
     char* e2 = e1 + al((size_t)nseq * H * e);
-    const char* qc = act_extra(c, const_cast<void*>(act), Tp, 1);                  // saved by the forward
+    const char* qc = act_extra(c, act, Tp, 1);                                     // saved by the forward
     const char* ctxc = qc + al((size_t)nseq * H * e);
     RUN(simx_rows_copy(stream, SIMX_F32, dt, nseq, H, nullptr, nullptr, dcls, bufB));
     RUN(simx_ln_bwd_keyed(stream, dt, nseq, H, a.z2, off(l, SIMX_P_LN2_G), c->eps, bufB, bufA, hd ? bufC : nullptr,
@@ -362,18 +424,19 @@ extern "C" int simx_bert_bwd_ex(simx_stream_t stream, const simx_bert_cfg* c, co
     RUN(simx_gemm_tn_bias(stream, dt, 2 * H, H, T, dqkv + (size_t)H * e, 3 * H, xin, H, goff(l, SIMX_P_WQKV) + (size_t)H * H, H, 1, tnws,
                           tnws_bytes, goff(l, SIMX_P_BQKV) + H));
     --l_top;
-  } else if (dhidden) {
+  } else if (top && dhidden) {
     if (hipMemcpyAsync(bufB, dhidden, (size_t)T * H * e, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
       simx_set_error("bert_bwd: copy of the hidden-state gradient failed");
       return SIMX_ERR_HIP;
     }
-  } else {
+  } else if (top) {
     RUN(simx_cls_scatter(stream, dt, nseq, H, T, cu, dcls, bufB));            // g_x = d(loss)/d(last hidden)
   }
-  for (int l = l_top; l >= 0; --l) {
+  for (int l = l_top; l >= layer_lo; --l) {
     const WLayer w = wlayer(c, params, wcache, l);
-    const ALayer a = alayer(c, const_cast<void*>(act), Tp, l, 1);
-    const char* xin = l == 0 ? act_x0(const_cast<void*>(act)) : alayer(c, const_cast<void*>(act), Tp, l - 1, 1).xout;
+    const char* xin = layer_input(c, act, Tp, l);
+    const ALayer a = ckpt ? alayer_recompute(c, act, Tp) : alayer(c, act, Tp, l, 1);
+    if (ckpt) RUN(layer_fwd((hipStream_t)stream, c, params, wcache, l, xin, a, nullptr, cu, nseq, T, Tp, max_len, 1, false, nullptr));
     const simx_dropout d1 = drop_of(c, l, 1), d2 = drop_of(c, l, 2), d3 = drop_of(c, l, 3);
     char* dzm = hd ? bufC : bufA;        // gradient of the (dropped) dense output; bufA = gradient of the residual branch
     // output LayerNorm : dz2, dgamma2, dbeta2, db2
@@ -398,6 +461,7 @@ extern "C" int simx_bert_bwd_ex(simx_stream_t stream, const simx_bert_cfg* c, co
     RUN(simx_gemm_tn_bias(stream, dt, 3 * H, H, T, dqkv, 3 * H, xin, H, goff(l, SIMX_P_WQKV), H, 1, tnws, tnws_bytes,
                           goff(l, SIMX_P_BQKV)));
   }
+  if (layer_lo > 0) return SIMX_OK;               // the next part continues from bufB
   const simx_dropout d0 = drop_of(c, -1, 0);
   RUN(simx_embed_ln_bwd_seq(stream, dt, nseq, max_len, T, H, cu, ids, pos_ids, off(-1, SIMX_P_WORD), off(-1, SIMX_P_POS),
                             off(-1, SIMX_P_TYPE), off(-1, SIMX_P_EMB_LN_G), c->eps, bufB, goff(-1, SIMX_P_WORD),

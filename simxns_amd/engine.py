@@ -36,16 +36,35 @@ class BertConfigLite(object):
         self.add_pooling_layer = kw.get("add_pooling_layer", True)
         self.extra = kw
 
+    # architectures of the hub names the reference's recipes pass as --model_type / --teacher_model_type
+    # (SimANS/train_*_AR2.sh, PROD/README.md); this image has no network, so a name resolves to its published config and
+    # the weights are random unless a local directory with the same name holds them
+    KNOWN = {
+        "bert-base-uncased": {},
+        "bert-large-uncased": dict(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096),
+        "Luyu/co-condenser-marco": {},
+        "Luyu/co-condenser-wiki": {},
+        "nghuyong/ernie-2.0-en": dict(type_vocab_size=4),
+        "nghuyong/ernie-2.0-base-en": dict(type_vocab_size=4),
+        "nghuyong/ernie-2.0-large-en": dict(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16,
+                                            intermediate_size=4096, type_vocab_size=4),
+        "roberta-base": dict(vocab_size=50265, max_position_embeddings=514, type_vocab_size=1, layer_norm_eps=1e-5,
+                             model_type="roberta", pad_token_id=1),
+    }
+
     @classmethod
     def from_pretrained(cls, path):
-        f = path if path.endswith(".json") else os.path.join(path, "config.json")
+        f = path if str(path).endswith(".json") else os.path.join(str(path), "config.json")
         if not os.path.exists(f):
-            known = {"bert-base-uncased": {}, "bert-large-uncased": dict(hidden_size=1024, num_hidden_layers=24,
-                     num_attention_heads=16, intermediate_size=4096)}
-            key = os.path.basename(str(path).rstrip("/"))
-            if key in known:
-                return cls(**known[key])
-            raise FileNotFoundError("no config.json under %r and not a known model name" % (path,))
+            name = str(path).rstrip("/")
+            for key in (name, os.path.basename(name)):
+                for k, kw in cls.KNOWN.items():
+                    if key == k or key == os.path.basename(k):
+                        return cls(**kw)
+            raise FileNotFoundError(
+                "model_type %r: no config.json under that path and not one of the known architectures %s. Provide a local "
+                "directory holding config.json (+ model.safetensors / pytorch_model.bin): this image has no network access "
+                "to the HF hub." % (path, sorted(cls.KNOWN)))
         with open(f) as fh:
             return cls(**json.load(fh))
 
@@ -138,6 +157,7 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, engine, pb, pool, ccfg):
         cls, hidden, act = engine._run_forward(pb, True, pool != "cls", ccfg)
+        engine._open_graphs += 1                  # graphs that will still add into flat_grad (shared towers: more than one)
         ctx.engine, ctx.pb, ctx.act, ctx.ccfg, ctx.pool = engine, pb, act, ccfg, pool
         if pool == "hidden":
             return cls, hidden
@@ -178,7 +198,12 @@ class BertEngine(object):
         self._dirty = True
         self.anchor = torch.zeros((), requires_grad=True)
         self.dropout_seed = 0                # base seed of the stateless dropout masks (set_seed / manual)
-        self.grad_ready_hook = None          # called after every backward (DP all-reduce launch)
+        # data parallelism: hook(engine, lo, hi) is called as soon as flat_grad[lo:hi] is final; with bwd_parts > 1 the
+        # backward runs in that many layer ranges (simx_bert_bwd_range) and the hook fires after each, so the all-reduce of
+        # the upper layers' gradients overlaps the lower layers' backward (FusedAdamW.enable_overlap sets both)
+        self.grad_ready_hook = None
+        self.bwd_parts = 1
+        self._open_graphs = 0
         self.last_stream = None              # stream of the last forward / backward (the optimiser joins it)
         self.after_backward = None           # module callback: expose flat_grad as param.grad views
 
@@ -186,9 +211,12 @@ class BertEngine(object):
     def set_compute_dtype(self, name):
         c = self.cfg
         self.dtype_code = _dtype_code(name)
+        # cfg.gradient_checkpointing (models.py:73-74): per-layer recompute in the native backward; SIMX_GRAD_CKPT=0/1 overrides
+        ck = os.environ.get("SIMX_GRAD_CKPT")
+        ckpt = bool(getattr(c, "gradient_checkpointing", False)) if ck is None else ck == "1"
         self.ccfg = L.BertCfg(self.dtype_code, c.num_hidden_layers, c.hidden_size, c.num_attention_heads,
                               c.intermediate_size, c.vocab_size, c.max_position_embeddings, c.type_vocab_size,
-                              float(c.layer_norm_eps), 0.0, 0.0, 0)
+                              float(c.layer_norm_eps), 0.0, 0.0, 0, 0, 1 if ckpt else 0)
         self.wcache = None
         self._dirty = True
 
@@ -260,13 +288,27 @@ class BertEngine(object):
         # sized for the padded token count nseq*S, not for this batch's T: ragged batches change T every step and a 50+ GB
         # request of a new size makes the caching allocator free and re-malloc the block (measured: +245 ms per step)
         nbytes = int(self.lib.simx_bert_act_bytes(C.byref(self.ccfg), pb.nseq * pb.S, pb.nseq, 1 if save else 0))
-        act = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        act = self._alloc_act(nbytes, dev, save)
         cls = torch.empty(pb.nseq, H, dtype=torch.float32, device=dev)
         hidden = torch.empty(pb.T, H, dtype=self.act_torch_dtype, device=dev) if want_hidden else None
         L.call("simx_bert_fwd", L.stream_ptr(), C.byref(ccfg), L.ptr(self.flat), L.ptr(self.wcache),
                L.ptr(pb.ids), L.ptr(pb.pos), L.ptr(pb.cu), pb.nseq, pb.T, pb.max_len, L.ptr(act), nbytes,
                1 if save else 0, L.ptr(cls), L.ptr(hidden))
         return cls, hidden, (act if save else None)
+
+    def _alloc_act(self, nbytes, dev, save):
+        """The activation buffer of one forward.  Fails loudly -- before the allocator does -- when the kept activations
+        cannot fit, and says what to do about it (the reference's answer is --gradient_checkpointing, models.py:73-74)."""
+        try:
+            return torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        except torch.cuda.OutOfMemoryError:
+            free, total = torch.cuda.mem_get_info(dev)
+            hint = ("" if self.ccfg.grad_checkpoint or not save else
+                    "; pass --gradient_checkpointing (cfg.gradient_checkpointing=True / SIMX_GRAD_CKPT=1): only the layer "
+                    "inputs are kept and each layer is recomputed in backward")
+            raise L.SimxError("activations of this batch need %.1f GB (%d layers, %s) but only %.1f of %.1f GB of HBM are free%s"
+                              % (nbytes / 1e9, self.cfg.num_hidden_layers, "checkpointed" if self.ccfg.grad_checkpoint else
+                                 "all kept for backward" if save else "inference ring", free / 1e9, total / 1e9, hint))
 
     def _seq_mean(self, pb, hidden):
         out = torch.empty(pb.nseq, self.cfg.hidden_size, dtype=torch.float32, device=hidden.device)
@@ -288,13 +330,25 @@ class BertEngine(object):
             dcls = dcls.contiguous().to(torch.float32)
         nbytes = int(self.lib.simx_bert_bwd_scratch_bytes(C.byref(self.ccfg), pb.nseq * pb.S, pb.nseq))
         scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        L.call("simx_bert_bwd_ex", L.stream_ptr(), C.byref(ccfg), L.ptr(self.flat), L.ptr(self.wcache),
-               L.ptr(pb.ids), L.ptr(pb.pos), L.ptr(pb.cu), pb.nseq, pb.T, pb.max_len, L.ptr(act), act.numel(),
-               L.ptr(dcls), L.ptr(dhidden), L.ptr(g), L.ptr(scratch), nbytes)
+        nl = self.cfg.num_hidden_layers
+        self._open_graphs = max(0, self._open_graphs - 1)
+        # the hook fires only for the LAST backward that adds into this buffer (an in-place accumulated buffer is reduced once)
+        hook = self.grad_ready_hook if self._open_graphs == 0 else None
+        parts = max(1, min(int(self.bwd_parts), nl)) if hook is not None else 1
+        # layer ranges [hi, lo], top-down; after a part the gradient slice [offset(lo), end of the previous slice) is final
+        bounds = [nl - 1 - (i * nl) // parts for i in range(parts)] + [-1]
+        end = self.n_params
+        for i in range(parts):
+            hi, lo = bounds[i], bounds[i + 1] + 1
+            L.call("simx_bert_bwd_range", L.stream_ptr(), C.byref(ccfg), L.ptr(self.flat), L.ptr(self.wcache),
+                   L.ptr(pb.ids), L.ptr(pb.pos), L.ptr(pb.cu), pb.nseq, pb.T, pb.max_len, L.ptr(act), act.numel(),
+                   L.ptr(dcls), L.ptr(dhidden), L.ptr(g), L.ptr(scratch), nbytes, hi, lo)
+            if hook is not None:
+                start = 0 if lo == 0 else int(self.lib.simx_bert_param_offset(C.byref(self.ccfg), lo, L.P_WQKV))
+                hook(self, start, end)
+                end = start
         if self.after_backward is not None:
             self.after_backward()
-        if self.grad_ready_hook is not None:
-            self.grad_ready_hook(self)
 
     def encode(self, input_ids, attention_mask, want_hidden=False, requires_grad=None, training=False, pool=None):
         """-> cls [n,H] f32; with want_hidden also the packed last hidden state + PackedBatch (both outputs carry

@@ -104,7 +104,7 @@ class HFBertEncoder(nn.Module):
         self.engine.mark_weights_dirty()
 
     @classmethod
-    def init_encoder(cls, args, dropout: float = 0.1, model_type=None, compute_dtype=None):
+    def init_encoder(cls, args, dropout: float = 0.1, model_type=None, compute_dtype=None, num_hidden_layers=None):
         """models.py:65-75.  ``model_type`` is a local directory with config.json (+ model.safetensors or
         pytorch_model.bin) or a known name; without weights on disk the encoder is randomly initialised
         (this image has no network)."""
@@ -114,9 +114,14 @@ class HFBertEncoder(nn.Module):
         if dropout != 0:
             cfg.attention_probs_dropout_prob = dropout
             cfg.hidden_dropout_prob = dropout
-        cfg.gradient_checkpointing = getattr(args, "gradient_checkpointing", False)
+        cfg.gradient_checkpointing = bool(getattr(args, "gradient_checkpointing", False))
+        if num_hidden_layers:                      # PROD: the depth is a property of the role, not of the checkpoint
+            cfg.num_hidden_layers = int(num_hidden_layers)
         if compute_dtype is None:
-            compute_dtype = "bf16" if getattr(args, "fp16", False) or os.environ.get("SIMX_DTYPE", "bf16") == "bf16" else "fp32"
+            # the reference computes in fp32 unless --fp16 (apex O1) is passed (co_training_marco_train.py:97-104); here
+            # --fp16 selects the bf16 engine (f32 master weights and accumulation, no loss scaling), and SIMX_DTYPE=bf16
+            # switches any recipe to it explicitly
+            compute_dtype = "bf16" if getattr(args, "fp16", False) else os.environ.get("SIMX_DTYPE", "fp32")
         enc = cls(cfg, compute_dtype=compute_dtype)
         if os.path.isdir(str(model_type)):
             st = os.path.join(model_type, "model.safetensors")

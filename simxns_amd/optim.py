@@ -38,6 +38,81 @@ class FusedAdamW(object):
         self.state = {}
         self.param_groups = [{"lr": self.lr}]           # scheduler-facing view
         self._sq = None
+        # data parallelism (enable_overlap): gradient slices are all-reduced on a side stream as soon as the backward
+        # has finished them; step() only waits for what is still in flight
+        self.world_size = 1
+        self.armed = True                                # False while accumulating micro-steps (no reduction yet)
+        self._comm = None
+        self._pending = {}                               # id(engine) -> [work handles]
+        self._synced = False
+
+    # ---- DDP's role: gradient averaging over the ranks (co_training_marco_train.py:107-114) ------------------------
+    def enable_overlap(self, world_size, parts=2, process_group=None):
+        """One process per GPU, RCCL: every tower's backward runs in `parts` layer ranges (simx_bert_bwd_range) and each
+        finished slice of the flat gradient buffer is all-reduced asynchronously on a communication stream while the
+        remaining layers -- and the other tower -- are still in backward.  The query tower's reduction hides under the
+        passage tower's backward, the upper half of the passage tower's under its lower half.  With gradient accumulation
+        set ``armed = False`` for all but the last micro-step (an in-place accumulated buffer must be reduced once)."""
+        self.world_size = int(world_size)
+        if process_group is not None:
+            self.group = process_group
+        if self.world_size <= 1:
+            return self
+        dev = self.towers[0][1].flat.device if self.towers else None
+        self._comm = torch.cuda.Stream(device=dev) if dev is not None and dev.type == "cuda" else None
+        for m, e in self.towers:
+            e.grad_ready_hook = self._on_grad_ready
+            e.bwd_parts = parts
+        return self
+
+    def _on_grad_ready(self, e, lo, hi):
+        if not self.armed or self.world_size <= 1 or hi <= lo:
+            return
+        import torch.distributed as dist
+        if e.flat_grad.is_cuda:
+            cur = torch.cuda.current_stream()
+            comm = self._comm or cur
+            comm.wait_stream(cur)                        # the slice is final once the backward kernels queued so far are done
+            with torch.cuda.stream(comm):
+                w = dist.all_reduce(e.flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:                                            # (host tensors: the gloo control-flow tests)
+            w = dist.all_reduce(e.flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pending.setdefault(id(e), []).append(w)
+
+    def sync_grads(self, world_size=None):
+        """Completes the gradient reduction of this step (idempotent until the next step()): waits for the slices launched
+        by the backward hooks, reduces whatever was not launched (no hooks, un-armed micro-steps, the small non-engine
+        parameters) synchronously.  -> the factor that turns the summed gradients into the DDP mean (1/W)."""
+        W = int(world_size if world_size is not None else self.world_size)
+        if W <= 1:
+            return 1.0
+        if self._synced:
+            return 1.0 / W
+        import torch.distributed as dist
+        for m, e in self.towers:
+            works = self._pending.pop(id(e), None)
+            if works:
+                for w in works:
+                    w.wait()                              # RCCL: the current stream waits for the collective, not the host
+            else:
+                dist.all_reduce(e.ensure_grad(), op=dist.ReduceOp.SUM, group=self.group)
+            e._open_graphs = 0
+        if self.extra:
+            st = self._extra_state(self.extra[0].device)
+            self._gather_extra(st)
+            dist.all_reduce(st["g"], op=dist.ReduceOp.SUM, group=self.group)
+            st["g_ready"] = True
+        self._synced = True
+        return 1.0 / W
+
+    def _gather_extra(self, st):
+        o = 0
+        for p in self.extra:
+            n = p.numel()
+            st["p"][o:o + n].copy_(p.reshape(-1))
+            if p.grad is not None:
+                st["g"][o:o + n].copy_(p.grad.reshape(-1))
+            o += n
 
     def _tower_state(self, e):
         st = self.state.get(id(e))
@@ -53,6 +128,7 @@ class FusedAdamW(object):
             pad = (n + 3) // 4 * 4
             st = {k: torch.zeros(pad, dtype=torch.float32, device=dev) for k in ("p", "g", "m", "v")}
             st["n"] = n
+            st["g_ready"] = False
             self.state["extra"] = st
         return st
 
@@ -76,32 +152,25 @@ class FusedAdamW(object):
             if st is not None and st != cur:
                 cur.wait_stream(st)
         s = L.stream_ptr()
-        grad_scale = 1.0
+        grad_scale = self.sync_grads(max(int(world_size), self.world_size))
+        self._synced = False
         bufs = []
         for m, e in self.towers:
             bufs.append((e.flat, e.ensure_grad(), self._tower_state(e), e))
+            e._open_graphs = 0
         if self.extra:
             st = self._extra_state(dev)
-            o = 0
-            for p in self.extra:
-                n = p.numel()
-                st["p"][o:o + n].copy_(p.reshape(-1))
-                if p.grad is not None:
-                    st["g"][o:o + n].copy_(p.grad.reshape(-1))
-                o += n
+            if not st.get("g_ready"):
+                self._gather_extra(st)
+            st["g_ready"] = False
             bufs.append((st["p"], st["g"], st, None))
-        if world_size > 1:
-            import torch.distributed as dist
-            for p_, g_, st_, e_ in bufs:
-                dist.all_reduce(g_, op=dist.ReduceOp.SUM, group=self.group)
-            grad_scale = 1.0 / world_size
         sq = torch.zeros(1, dtype=torch.float32, device=dev)
         if max_grad_norm and max_grad_norm > 0:
             for p_, g_, st_, e_ in bufs:
                 L.call("simx_sqnorm_accum", s, L.ptr(g_), g_.numel(), L.ptr(sq))
         for p_, g_, st_, e_ in bufs:
             L.call("simx_adamw_step", s, L.ptr(p_), L.ptr(g_), L.ptr(st_["m"]), L.ptr(st_["v"]), p_.numel(), lr,
-                   self.betas[0], self.betas[1], self.eps, self.wd if e_ is None else 0.0, self.step_count,
+                   self.betas[0], self.betas[1], self.eps, 0.0, self.step_count,
                    L.ptr(sq) if max_grad_norm and max_grad_norm > 0 else None, float(max_grad_norm or 0.0), grad_scale, 1)
             if e_ is not None:
                 e_.mark_weights_dirty()
@@ -109,15 +178,21 @@ class FusedAdamW(object):
             self._decay_towers(lr)
         if self.extra:
             st = self.state["extra"]
+            nodecay = self._extra_no_decay()
             o = 0
             for p in self.extra:
                 n = p.numel()
                 p.copy_(st["p"][o:o + n].view_as(p))
+                if self.wd > 0.0 and id(p) not in nodecay:      # same grouping rule as the towers (:59-65)
+                    p.mul_(1.0 - lr * self.wd)
                 if p.grad is not None:
                     p.grad.zero_()
                 o += n
         self._sq = sq
         return sq
+
+    def _extra_no_decay(self):
+        return {id(p) for n, p in self.model.named_parameters() if any(nd in n for nd in ("bias", "LayerNorm.weight"))}
 
     def _decay_towers(self, lr):
         # decoupled decay p -= lr*wd*p on everything except 'bias' / 'LayerNorm.weight'
@@ -128,26 +203,90 @@ class FusedAdamW(object):
                     p.mul_(1.0 - lr * self.wd)
             e.mark_weights_dirty()
 
-    def state_dict(self):
-        out = {"step": self.step_count, "lr": self.param_groups[0]["lr"], "towers": []}
+    # ---- state interchange with the reference's checkpoints (co_training_marco_train.py:310-358) ------------------------
+    def _ref_param_order(self):
+        """The reference builds transformers.AdamW from two groups in named_parameters() order -- decayed parameters first,
+        then the 'bias' / 'LayerNorm.weight' ones (co_training_marco_train.py:57-65) -- and torch numbers optimizer state by
+        position in that concatenation.  -> [(name, param, group)]"""
+        named = list(self.model.named_parameters())
+        nd = lambda n: any(k in n for k in ("bias", "LayerNorm.weight"))
+        return [(n, p, 0) for n, p in named if not nd(n)] + [(n, p, 1) for n, p in named if nd(n)]
+
+    def _moment_views(self):
+        """{id(param): (m_view, v_view)} into the flat Adam-state buffers."""
+        out = {}
         for m, e in self.towers:
             st = self._tower_state(e)
-            out["towers"].append({"m": st["m"].cpu(), "v": st["v"].cpu()})
-        if "extra" in self.state:
-            out["extra"] = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in self.state["extra"].items()}
+            mv, vv = e.views(st["m"]), e.views(st["v"])
+            for name, p in m.named_parameters():
+                out[id(p)] = (mv[name], vv[name])
+        if self.extra:
+            st = self._extra_state(self.extra[0].device)
+            o = 0
+            for p in self.extra:
+                n = p.numel()
+                out[id(p)] = (st["m"][o:o + n].view_as(p), st["v"][o:o + n].view_as(p))
+                o += n
         return out
 
+    def state_dict(self):
+        """torch.optim.Optimizer.state_dict() of the reference's transformers.AdamW: {'state': {i: {'step', 'exp_avg',
+        'exp_avg_sq'}}, 'param_groups': [decay group, no-decay group]} -- a checkpoint written here resumes in the reference
+        and the other way round."""
+        order = self._ref_param_order()
+        views = self._moment_views()
+        state = {}
+        if self.step_count > 0:
+            for i, (n, p, g) in enumerate(order):
+                mv, vv = views[id(p)]
+                state[i] = {"step": self.step_count, "exp_avg": mv.detach().cpu().clone(), "exp_avg_sq": vv.detach().cpu().clone()}
+        lr = self.param_groups[0]["lr"]
+        base = dict(lr=lr, initial_lr=self.base_lr, betas=tuple(self.betas), eps=self.eps, correct_bias=True)
+        n0 = sum(1 for _, _, g in order if g == 0)
+        return {"state": state,
+                "param_groups": [dict(base, weight_decay=self.wd, params=list(range(n0))),
+                                 dict(base, weight_decay=0.0, params=list(range(n0, len(order))))]}
+
     def load_state_dict(self, sd):
-        self.step_count = sd["step"]
-        self.param_groups[0]["lr"] = sd.get("lr", self.lr)
-        for (m, e), t in zip(self.towers, sd["towers"]):
-            st = self._tower_state(e)
-            st["m"].copy_(t["m"])
-            st["v"].copy_(t["v"])
-        if "extra" in sd and self.extra:
-            st = self._extra_state(self.extra[0].device)
-            for k in ("p", "g", "m", "v"):
-                st[k].copy_(sd["extra"][k])
+        if "towers" in sd:                              # round-1 format of this package (flat buffers)
+            self.step_count = sd["step"]
+            self.param_groups[0]["lr"] = sd.get("lr", self.lr)
+            for (m, e), t in zip(self.towers, sd["towers"]):
+                st = self._tower_state(e)
+                st["m"].copy_(t["m"])
+                st["v"].copy_(t["v"])
+            if "extra" in sd and self.extra:
+                st = self._extra_state(self.extra[0].device)
+                for k in ("p", "g", "m", "v"):
+                    st[k].copy_(sd["extra"][k])
+            return
+        if "state" not in sd or "param_groups" not in sd:
+            raise ValueError("optimizer state is neither a torch Optimizer state_dict nor this package's flat format: keys %s"
+                             % sorted(sd.keys()))
+        order = self._ref_param_order()
+        n_saved = sum(len(g["params"]) for g in sd["param_groups"])
+        if n_saved != len(order):
+            raise ValueError("optimizer state has %d parameters, this model has %d (different architecture or share_weight)"
+                             % (n_saved, len(order)))
+        views = self._moment_views()
+        steps = set()
+        with torch.no_grad():
+            for i, (n, p, g) in enumerate(order):
+                st = sd["state"].get(i, sd["state"].get(str(i)))
+                if st is None:
+                    continue
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError("optimizer state %d (%s): shape %s vs parameter %s" % (i, n, tuple(st["exp_avg"].shape), tuple(p.shape)))
+                mv, vv = views[id(p)]
+                mv.copy_(st["exp_avg"].to(torch.float32))
+                vv.copy_(st["exp_avg_sq"].to(torch.float32))
+                steps.add(int(st["step"]))
+        if len(steps) > 1:
+            raise ValueError("per-parameter step counts differ (%s): the fused update keeps one step count" % sorted(steps))
+        self.step_count = steps.pop() if steps else 0
+        g0 = sd["param_groups"][0]
+        self.param_groups[0]["lr"] = float(g0.get("lr", self.lr))
+        self.base_lr = float(g0.get("initial_lr", self.base_lr))
 
 
 class LinearWarmupSchedule(object):
@@ -175,8 +314,21 @@ class LinearWarmupSchedule(object):
         return [self.opt.param_groups[0]["lr"]]
 
     def state_dict(self):
-        return {"t": self.t, "warm": self.warm, "total": self.total, "base": self.base}
+        """torch LambdaLR.state_dict() (what the reference checkpoints as scheduler_dict; lr_lambdas holds None for a plain
+        function) -- last_epoch is the number of scheduler.step() calls."""
+        return {"base_lrs": [self.base], "last_epoch": int(self.t), "_step_count": int(self.t) + 1, "verbose": False,
+                "_get_lr_called_within_step": False, "_last_lr": self.get_last_lr(), "lr_lambdas": [None],
+                "num_warmup_steps": self.warm, "num_training_steps": self.total}
 
     def load_state_dict(self, sd):
-        self.t, self.warm, self.total, self.base = sd["t"], sd["warm"], sd["total"], sd["base"]
+        if "last_epoch" in sd:                          # torch LambdaLR (the reference) or this class
+            self.t = int(sd["last_epoch"])
+            if sd.get("base_lrs"):
+                self.base = float(sd["base_lrs"][0])
+            self.warm = float(sd.get("num_warmup_steps", self.warm))       # (a LambdaLR dict does not carry the schedule shape:
+            self.total = float(sd.get("num_training_steps", self.total))   #  it stays what the constructor was given)
+        elif "t" in sd:                                 # round-1 format
+            self.t, self.warm, self.total, self.base = sd["t"], sd["warm"], sd["total"], sd["base"]
+        else:
+            raise ValueError("scheduler state has neither 'last_epoch' nor 't': keys %s" % sorted(sd.keys()))
         self._apply()

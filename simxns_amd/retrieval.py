@@ -15,9 +15,12 @@ from . import _lib as L
 class FlatIPIndex(object):
     """index = FlatIPIndex(dim); index.add(emb); D, I = index.search(q, k)   (faiss.IndexFlatIP surface)."""
 
-    def __init__(self, dim, id_base=0, chunk=65536):
+    def __init__(self, dim, id_base=0, chunk=65536, query_block=8192):
+        """``chunk``: corpus rows scored per pass; ``query_block``: queries per pass -- the score workspace is
+        query_block x chunk x 4 B (2 GB by default) whatever the number of queries (the 503 k MS-MARCO train queries in one
+        call would otherwise ask for 132 GB)."""
         assert dim % 4 == 0, "embedding size must be a multiple of 4"
-        self.d, self.id_base, self.chunk = int(dim), int(id_base), int(chunk)
+        self.d, self.id_base, self.chunk, self.query_block = int(dim), int(id_base), int(chunk), int(query_block)
         self._parts, self._emb = [], None
 
     @property
@@ -50,10 +53,13 @@ class FlatIPIndex(object):
         D = torch.empty(nq, k, dtype=torch.float32, device=q.device)
         I = torch.empty(nq, k, dtype=torch.int64, device=q.device)
         chunk = max(4, min(self.chunk, max(nc, 4)))
-        ws_bytes = int(L.load().simx_flat_ip_workspace_bytes(nq, chunk))
+        qb = max(1, min(self.query_block, nq))
+        ws_bytes = int(L.load().simx_flat_ip_workspace_bytes(qb, chunk))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
-        L.call("simx_flat_ip_search", L.stream_ptr(), nq, nc, self.d, L.ptr(q), L.ptr(corpus) if nc else None, self.id_base, k,
-               chunk, L.ptr(ws), ws_bytes, L.ptr(D), L.ptr(I))
+        for lo in range(0, nq, qb):                     # query blocks reuse ONE workspace
+            n = min(qb, nq - lo)
+            L.call("simx_flat_ip_search", L.stream_ptr(), n, nc, self.d, L.ptr(q[lo:lo + n]), L.ptr(corpus) if nc else None,
+                   self.id_base, k, chunk, L.ptr(ws), ws_bytes, L.ptr(D[lo:lo + n]), L.ptr(I[lo:lo + n]))
         if group is None:
             return D, I
         return merge_topk(D, I, k, group)

@@ -1,0 +1,107 @@
+"""Check of an installation against the committed reference goldens (tests/golden/step_*.npz, written by the imported
+reference in the build container: oracle/make_golden.py).  Product-side: no oracle import -- the fixture is data.
+Used by tests/test_encoder_gpu.py and by bench.py's `parity_bf16` block (the measured distance of the benchmarked bf16
+engine from the reference on the shapes its hot kernels need)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden")
+
+# bf16 tolerances = 3x the errors MEASURED on MI355X with this fixture (printed by the test; see DESIGN.md "bf16 parity"):
+BF16_HOT_TOL = dict(emb_abs=0.045, logits_rel=0.012, loss_abs=0.03, gnorm_rel_median=0.012, gnorm_rel_max=0.09, gslice_cos_min=0.985)
+
+
+def _cfg_from(G):
+    from ..engine import BertConfigLite
+    c = json.loads(str(G["cfg"]))
+    return BertConfigLite(vocab_size=c["vocab"], hidden_size=c["hidden"], num_hidden_layers=c["layers"],
+                          num_attention_heads=c["heads"], intermediate_size=c["inter"],
+                          max_position_embeddings=c["max_pos"], type_vocab_size=c["type_vocab"], layer_norm_eps=c["eps"],
+                          hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)   # goldens are dropout-free
+
+
+def run_golden_step(G, dev, dtype):
+    """The retriever step of co_training_marco_train.py:198-217 on a golden's inputs, weights regenerated from its seeds."""
+    from .. import ops
+    from ..model.models import HFBertEncoder, BiBertEncoder, Reranker
+    from . import synth
+    cfg, std, seeds = _cfg_from(G), float(G["std"]), [int(s) for s in G["seeds"]]
+    shapes = lambda enc: [(k, tuple(p.shape)) for k, p in enc.named_parameters()]
+    bi = BiBertEncoder.__new__(BiBertEncoder)
+    torch.nn.Module.__init__(bi)
+    bi.question_model, bi.ctx_model = HFBertEncoder(cfg, compute_dtype=dtype), HFBertEncoder(cfg, compute_dtype=dtype)
+    bi.question_model.load_numpy_state(synth.fill_bert_state_dict(shapes(bi.question_model), seeds[0], std=std))
+    bi.ctx_model.load_numpy_state(synth.fill_bert_state_dict(shapes(bi.ctx_model), seeds[1], std=std))
+    tenc = HFBertEncoder(cfg, compute_dtype=dtype)
+    tenc.load_numpy_state(synth.fill_bert_state_dict(shapes(tenc), seeds[2], std=std))
+    teacher = Reranker(tenc, cfg.hidden_size)
+    with torch.no_grad():
+        teacher.qa_classifier.weight.copy_(torch.from_numpy(G["qa_w"]))
+        teacher.qa_classifier.bias.copy_(torch.from_numpy(G["qa_b"]))
+    bi.to(dev)
+    teacher.to(dev)
+    t = lambda k: torch.from_numpy(G[k]).to(dev)
+    bi.zero_grad()
+    q, c = bi(t("q_ids"), t("q_mask"), t("c_ids"), t("c_mask"))
+    with torch.no_grad():
+        z = teacher(t("t_ids"), t("t_mask"))
+    loss, distill, sim = ops.kl_distill_loss(q, c, z, 1.0, False, 1)
+    loss.backward()
+    torch.cuda.synchronize()
+    grads = {}
+    for pre, m in (("question_model.", bi.question_model), ("ctx_model.", bi.ctx_model)):
+        for k, p in m.named_parameters():
+            grads[pre + k] = p.grad.detach().cpu().numpy().astype(np.float64)
+    return dict(q=q.detach().cpu().numpy(), c=c.detach().cpu().numpy(), z=z.cpu().numpy(), sim=sim.cpu().numpy(),
+                loss=loss.item(), grads=grads)
+
+
+def golden_errors(R, G):
+    """Measured distance of one run from the reference golden (step_base_hot.npz: BERT-base, 16 queries x 16 passages,
+    ~20k passage tokens -> gemm_nt_bf16_p3 / gemm_tn2 / mha<8> / the wide LayerNorm kernels all dispatch)."""
+    e = {}
+    for k, g in (("q", "q_emb"), ("c", "ctx_emb"), ("z", "teacher_logits"), ("sim", "sim")):
+        e[k + "_abs"] = float(np.abs(np.asarray(R[k], np.float64) - G[g]).max())
+        e[k + "_scale"] = float(np.abs(G[g]).max())
+    e["loss_abs"] = abs(R["loss"] - float(G["loss_kl"]))
+    names = [str(n) for n in G["grad_names"]]
+    norms = G["grad_norms"]
+    got = np.array([np.sqrt((R["grads"][n] ** 2).sum()) for n in names])
+    live = norms > 1e-6 * norms.max()                    # (pooler / analytically-zero gradients excluded)
+    rel = np.abs(got - norms)[live] / norms[live]
+    e["gnorm_rel_max"], e["gnorm_rel_median"] = float(rel.max()), float(np.median(rel))
+    e["gnorm_worst"] = np.asarray(names)[live][int(rel.argmax())]
+    cos_min, sl_rel = 1.0, 0.0
+    for k in G.files:
+        if not k.startswith("gslice."):
+            continue
+        name, ref = k[len("gslice."):], G[k]
+        if np.abs(ref).max() <= 1e-6 * norms.max():
+            continue
+        g = R["grads"][name]
+        got_s = (g[:8, :64] if ref.ndim == 2 else g).ravel()
+        r = ref.ravel()
+        sl_rel = max(sl_rel, float(np.abs(got_s - r).max() / np.abs(r).max()))
+        cos_min = min(cos_min, float(got_s @ r / (np.linalg.norm(got_s) * np.linalg.norm(r) + 1e-300)))
+    e["gslice_rel_to_max"], e["gslice_cos_min"] = sl_rel, cos_min
+    return e
+
+
+def parity_report(dev, dtype="bf16", fixture="step_base_hot.npz"):
+    """-> dict of measured errors of `dtype` against the reference golden, or None when the fixture is absent."""
+    path = os.path.join(GOLDEN_DIR, fixture)
+    if not os.path.exists(path):
+        return None
+    G = np.load(path)
+    e = golden_errors(run_golden_step(G, dev, dtype), G)
+    return {"fixture": fixture, "dtype": dtype,
+            "logits_max_abs_err": round(e["sim_abs"], 4), "logits_scale": round(e["sim_scale"], 2),
+            "logits_rel_err": round(e["sim_abs"] / e["sim_scale"], 5),
+            "embeddings_max_abs_err": round(max(e["q_abs"], e["c_abs"]), 5), "loss_abs_err": round(e["loss_abs"], 5),
+            "teacher_logits_max_abs_err": round(e["z_abs"], 5),
+            "grad_norm_rel_err_median": round(e["gnorm_rel_median"], 5), "grad_norm_rel_err_max": round(e["gnorm_rel_max"], 5),
+            "grad_slice_cosine_min": round(e["gslice_cos_min"], 6),
+            "reference": "imported SimANS modules, fp64, same inputs (oracle/make_golden.py)"}

@@ -50,6 +50,9 @@ def train(args, model, reranker_model, tokenizer, global_step=0):
     optimizer = M.get_optimizer(args, model, args.weight_decay, args.learning_rate, args.adam_epsilon)
     reranker_optimizer = M.get_optimizer(args, reranker_model, args.weight_decay, args.teacher_learning_rate, args.adam_epsilon)
     world = dist.get_world_size() if args.local_rank != -1 else 1
+    if world > 1:
+        optimizer.enable_overlap(world)
+        reranker_optimizer.enable_overlap(world)
     tr_loss = tr_normal = tr_contr = 0.0
     model.zero_grad()
     reranker_model.zero_grad()
@@ -81,6 +84,7 @@ def train(args, model, reranker_model, tokenizer, global_step=0):
             if world > 1:
                 dist.barrier()
         step += 1
+        optimizer.armed = reranker_optimizer.armed = (step + 1) % args.gradient_accumulation_steps == 0
         q_ids, q_mask, c_ids, c_mask = (t.long().to(args.device) for t in batch['retriever'][:4])
         t_ids, t_mask = (t.long().to(args.device) for t in batch['reranker'][:2])
         if train_flag == 0:
@@ -103,12 +107,12 @@ def train(args, model, reranker_model, tokenizer, global_step=0):
             tr_loss += loss.item()
             tr_contr += contr.item()
         if (step + 1) % args.gradient_accumulation_steps == 0:
-            if train_flag == 0:
-                scheduler.step()
+            if train_flag == 0:                       # optimizer first, scheduler second (co_training_wiki_train.py:252-254)
                 optimizer.step(max_grad_norm=args.max_grad_norm, world_size=world)
+                scheduler.step()
             else:
-                reranker_scheduler.step()
                 reranker_optimizer.step(max_grad_norm=args.max_grad_norm, world_size=world)
+                reranker_scheduler.step()
             global_step += 1
             if args.logging_steps > 0 and global_step % args.logging_steps == 0:
                 logs = {"learning_rate": scheduler.get_last_lr()[0], "loss": tr_loss / args.logging_steps,

@@ -164,7 +164,43 @@ def test_base_cfg1_step_bf16(dev, golden_dir):
     sel = [i for i, n in enumerate(names) if n.endswith("dense.weight") and "pooler" not in n]
     got = np.array([np.sqrt((R["grads"][names[i]] ** 2).sum()) for i in sel])
     ref = G["grad_norms"][sel]
-    assert np.median(np.abs(got - ref) / ref) < 0.15
+    rel = np.abs(got - ref) / ref
+    print("cfg1 bf16 grad-norm rel err: median %.4f max %.4f" % (np.median(rel), rel.max()))
+    assert np.median(rel) < 0.02 and rel.max() < 0.12          # (measured on MI355X: median 0.004, max 0.03)
+
+
+# ------------------------------------------------------------------------------------------ the HOT kernels under the reference golden
+from simxns_amd.utils.parity import golden_errors as hot_errors, BF16_HOT_TOL  # noqa: E402
+
+
+
+
+def test_base_hot_step_fp32_vs_reference_golden(dev, golden_dir):
+    """The shapes the benchmarked kernels need (>= 16k tokens) in the f32 parity mode: loss / logits / embeddings within
+    1e-3 (north_star), all 398 gradient norms and a slice of every gradient within 2e-4 / 1e-3 of their scale."""
+    G = np.load(os.path.join(golden_dir, "step_base_hot.npz"))
+    R = run_step(G, dev, "fp32")
+    e = hot_errors(R, G)
+    print("hot fp32 errors:", json.dumps(e))
+    assert e["q_abs"] <= 1e-3 and e["c_abs"] <= 1e-3 and e["loss_abs"] <= 1e-3
+    assert e["z_abs"] <= 1e-3 * max(1.0, e["z_scale"]) and e["sim_abs"] <= 1e-3 * max(1.0, e["sim_scale"])
+    assert e["gnorm_rel_max"] <= 5e-4, e
+    assert e["gslice_rel_to_max"] <= 2e-3 and e["gslice_cos_min"] >= 0.99999, e
+
+
+def test_base_hot_step_bf16_vs_reference_golden(dev, golden_dir):
+    """The BENCHMARKED kernels end to end against the reference: bf16 engine on the hot fixture.  Tolerances are three
+    times the measured errors (BF16_HOT_TOL), not a generic bf16 allowance."""
+    G = np.load(os.path.join(golden_dir, "step_base_hot.npz"))
+    R = run_step(G, dev, "bf16")
+    e = hot_errors(R, G)
+    print("hot bf16 errors:", json.dumps(e))
+    t = BF16_HOT_TOL
+    assert e["q_abs"] <= t["emb_abs"] and e["c_abs"] <= t["emb_abs"], e
+    assert e["sim_abs"] <= t["logits_rel"] * e["sim_scale"] and e["z_abs"] <= t["logits_rel"] * max(1.0, e["z_scale"]), e
+    assert e["loss_abs"] <= t["loss_abs"], e
+    assert e["gnorm_rel_median"] <= t["gnorm_rel_median"] and e["gnorm_rel_max"] <= t["gnorm_rel_max"], e
+    assert e["gslice_cos_min"] >= t["gslice_cos_min"], e
 
 
 def test_module_api_and_sequence_output(dev, golden_dir):
@@ -194,7 +230,7 @@ def test_training_step_fused_optimizer(dev, golden_dir):
     G = np.load(os.path.join(golden_dir, "step_tiny.npz"))
     bi, teacher = build_models(G, dev, "fp32")
     opt = FusedAdamW(bi, lr=1e-3, eps=1e-8)
-    sch = LinearWarmupSchedule(opt, 1, 10)
+    sch = LinearWarmupSchedule(opt, 1, 10, last_step=1)
     t = lambda k: torch.from_numpy(G[k]).to(dev)
     pool0 = bi.question_model.pooler.dense.weight.detach().clone()
     losses = []
@@ -204,8 +240,8 @@ def test_training_step_fused_optimizer(dev, golden_dir):
         q, c = bi(t("q_ids"), t("q_mask"), t("c_ids"), t("c_mask"))
         loss, _, _ = ops.kl_distill_loss(q, c, z)
         loss.backward()
-        sch.step()
         sq = opt.step(max_grad_norm=2.0)
+        sch.step()
         losses.append(loss.item())
         assert float(bi.ctx_model.engine.flat_grad.abs().max()) == 0.0
     assert losses[2] < losses[0]

@@ -197,10 +197,93 @@ assert [o["rank"] for o in objs] == list(range(W)) and float(objs[1]["t"][0]) ==
 g1, g2 = torch.full((10,), float(rank + 1)), torch.full((6,), 2.0 * (rank + 1))
 hs, scale = parallel.allreduce_flat_grads([g1, g2])
 assert scale == 1.0 / W and float(g1[0]) == sum(range(1, W + 1)) and float(g2[0]) == 2.0 * sum(range(1, W + 1))
+# DDP's role on the flat gradient buffers: slices reduced by the backward hooks as they become final + the rest at step()
+from simxns_amd.engine import BertConfigLite
+from simxns_amd.model.models import HFBertEncoder, Reranker
+from simxns_amd.optim import FusedAdamW
+cfg = BertConfigLite(vocab_size=50, hidden_size=8, num_hidden_layers=2, num_attention_heads=2, intermediate_size=16, max_position_embeddings=16)
+model = Reranker(HFBertEncoder(cfg, "fp32"), 8)
+opt = FusedAdamW(model, lr=1e-3).enable_overlap(W, parts=2)
+e = model.encoder.engine
+assert e.grad_ready_hook is not None and e.bwd_parts == 2
+n = e.n_params
+e.ensure_grad().copy_(torch.arange(n, dtype=torch.float32) * (rank + 1))
+for p_ in model.qa_classifier.parameters():
+    p_.grad = torch.full_like(p_, float(rank + 1))
+cut = n // 3
+e.grad_ready_hook(e, cut, n)                                 # what _run_backward does after the upper layer range ...
+e.grad_ready_hook(e, 0, cut)                                 # ... and after the lower one
+scale = opt.sync_grads()
+tot = sum(range(1, W + 1))
+assert scale == 1.0 / W and torch.equal(e.flat_grad, torch.arange(n, dtype=torch.float32) * tot)
+assert float(opt.state["extra"]["g"][0]) == tot and opt.sync_grads() == 1.0 / W     # idempotent until step()
+assert torch.equal(e.flat_grad, torch.arange(n, dtype=torch.float32) * tot)
+opt._synced = False                                          # a step whose backward never fired the hooks: synchronous path
+opt.state["extra"]["g_ready"] = False
+e.flat_grad.copy_(torch.ones(n) * (rank + 1))
+opt.armed = False
+e.grad_ready_hook(e, 0, n)                                   # un-armed (accumulating micro-step): nothing may be reduced
+assert not opt._pending
+opt.armed = True
+assert opt.sync_grads() == 1.0 / W and float(e.flat_grad[5]) == tot
 dist.barrier()
 dist.destroy_process_group()
 print("rank %d ok" % rank)
 '''
+
+
+def test_optimizer_state_interchange_with_torch_adamw():
+    """K1 / (f)3: optimizer_dict and scheduler_dict in the reference's on-disk format (torch Optimizer.state_dict of
+    transformers.AdamW with the two parameter groups of co_training_marco_train.py:57-65; LambdaLR.state_dict) load into
+    FusedAdamW / LinearWarmupSchedule, and what these write loads back into torch's classes."""
+    _lib()
+    from simxns_amd.engine import BertConfigLite
+    from simxns_amd.model.models import HFBertEncoder, Reranker
+    from simxns_amd.optim import FusedAdamW, LinearWarmupSchedule
+    cfg = BertConfigLite(vocab_size=60, hidden_size=8, num_hidden_layers=2, num_attention_heads=2, intermediate_size=16,
+                         max_position_embeddings=16)
+    torch.manual_seed(0)
+    model = Reranker(HFBertEncoder(cfg, "fp32"), 8)
+
+    def ref_optimizer(mod):
+        nd = ['bias', 'LayerNorm.weight']
+        groups = [{'params': [p for n, p in mod.named_parameters() if not any(k in n for k in nd)], 'weight_decay': 0.01},
+                  {'params': [p for n, p in mod.named_parameters() if any(k in n for k in nd)], 'weight_decay': 0.0}]
+        return torch.optim.AdamW(groups, lr=3e-5, eps=1e-8)
+    ref = ref_optimizer(model)
+    sched = torch.optim.lr_scheduler.LambdaLR(ref, lambda t: min(1.0, t / 10.0))
+    for it in range(3):
+        for p in model.parameters():
+            p.grad = torch.randn_like(p)
+        ref.step(); sched.step()
+    sd, ssd = ref.state_dict(), sched.state_dict()
+    opt = FusedAdamW(model, lr=3e-5, eps=1e-8, weight_decay=0.01)
+    sch = LinearWarmupSchedule(opt, 10, 100)
+    opt.load_state_dict(sd)
+    sch.load_state_dict(ssd)
+    assert opt.step_count == 3 and sch.t == 3 and abs(sch.get_last_lr()[0] - 3e-5 * 0.3) < 1e-12
+    views = opt._moment_views()
+    order = opt._ref_param_order()
+    assert len(order) == len(list(model.parameters()))
+    for i, (n, p, g) in enumerate(order):
+        assert torch.equal(views[id(p)][0], sd["state"][i]["exp_avg"]), n
+        assert torch.equal(views[id(p)][1], sd["state"][i]["exp_avg_sq"]), n
+    # ... and back: what FusedAdamW / LinearWarmupSchedule write is a torch state_dict
+    out = opt.state_dict()
+    assert [len(g["params"]) for g in out["param_groups"]] == [len(g["params"]) for g in sd["param_groups"]]
+    ref2 = ref_optimizer(model)
+    ref2.load_state_dict(out)
+    for i in range(len(order)):
+        assert torch.equal(ref2.state_dict()["state"][i]["exp_avg_sq"], sd["state"][i]["exp_avg_sq"])
+        assert float(ref2.state_dict()["state"][i]["step"]) == 3.0
+    sched2 = torch.optim.lr_scheduler.LambdaLR(ref2, lambda t: min(1.0, t / 10.0))
+    sched2.load_state_dict(sch.state_dict())
+    assert sched2.last_epoch == 3
+    # a dict that is neither format is an error, never skipped
+    with pytest.raises(ValueError):
+        opt.load_state_dict({"foo": 1})
+    with pytest.raises(ValueError):
+        opt.load_state_dict({"state": {}, "param_groups": [{"params": [0, 1]}]})
 
 
 def test_distributed_gather_semantics_gloo_world2(tmp_path):
@@ -262,6 +345,21 @@ def test_generate_job_metrics_and_tsv_writer(tmp_path):
     from simxns_amd.utils.MARCO_until_new import read_sharded_tsv
     rows = read_sharded_tsv(path)
     assert len(rows) == 3
+    # load_pos_examples('train') also reads qrels.train.addition.tsv (literal-match positives, :139-150); write_to_file merges
+    # them into the POSITIVE column (temp_pos, :163-166), so they never reach the hard-negative column SimANS samples from
+    from simxns_amd.co_training.co_training_generate import load_pos_examples
+    (tmp_path / "qrels.train.tsv").write_text("1\t10\n1\t11\n2\t20\n3\t30\n")
+    (tmp_path / "qrels.train.addition.tsv").write_text("1\t6\n3\t9\n3\t4242\n")
+    pos, pos_add = load_pos_examples(str(tmp_path / "qrels.train.tsv"), "train", str(tmp_path))
+    assert pos == rel and pos_add == {1: [6], 3: [9, 4242]}
+    assert load_pos_examples(str(tmp_path / "qrels.train.tsv"), "dev", str(tmp_path))[1] == {}     # dev: no additions (:151)
+    path = write_to_file(cand, scores, [[1, "q one"], [2, "q two"], [3, "q three"]], pos, pos_add, "train", str(tmp_path), 8)
+    lines = open(path).read().splitlines()
+    f = lines[0].split("\t")
+    assert f[2] == "10 99.0,11 0,6 98.0"                                          # 6 is now a positive, with its retrieved score
+    assert f[3].split(",")[0] == "5 100.0" and "6 98.0" not in f[3].split(",") and len(f[3].split(",")) == 61
+    f3 = lines[2].split("\t")
+    assert f3[2] == "30 0,9 98.0,4242 0" and f3[3] == "7 100.0,8 99.0"
 
 
 def test_recipe_launcher_command_lines_parse():

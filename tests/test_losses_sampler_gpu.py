@@ -159,6 +159,45 @@ def test_inbatch_nll_big(dev):
     _close(tq.grad.cpu().numpy(), dq, tol=1e-4, what="dq"); _close(tc.grad.cpu().numpy(), dc, tol=1e-4, what="dc")
 
 
+def test_inbatch_nll_config3_full_shape_each_local_slot(dev):
+    """BASELINE configs[2] at its real shapes: 8 ranks x (128 queries, 2048 passages) -> global [1024, 16384] score matrix
+    (PROD/ProD_base/train_DE_model_marco.py:224-278); for EACH of the 8 local slots the loss, the argmax count and the
+    local-slot gradients against the oracle (f64 on the f32-rounded inputs).  Embedding scale: post-LayerNorm [CLS]
+    vectors are O(1) per component, logits O(H)."""
+    from simxns_amd import ops
+    rs = np.random.RandomState(17)
+    W, B, D, H = 8, 128, 16, 768
+    Q, Cn = W * B, W * B * D
+    c = (rs.randn(Cn, H) * 0.35).astype(np.float32)
+    pos = [r * B * D + j * D for r in range(W) for j in range(B)]
+    q = (0.25 * c[pos] + rs.randn(Q, H) * 0.3).astype(np.float32)          # queries lean towards their positives
+    q64, c64 = q.astype(np.float64), c.astype(np.float64)
+    S = q64 @ c64.T
+    m = S.max(1, keepdims=True)
+    lse = m[:, 0] + np.log(np.exp(S - m).sum(1))
+    want_loss = float((lse - S[np.arange(Q), pos]).mean())
+    want_correct = int((S.argmax(1) == np.asarray(pos)).sum())
+    assert 0 < want_correct < Q                                            # a non-degenerate case
+    dS = np.exp(S - lse[:, None])
+    dS[np.arange(Q), pos] -= 1.0
+    dS /= Q
+    dq_all, dc_all = dS @ c64, dS.T @ q64
+    tq0, tc0 = _t(q, dev), _t(c, dev)
+    for r in range(W):
+        tq, tc = tq0.clone().requires_grad_(True), tc0.clone().requires_grad_(True)
+        loss, corr = ops.inbatch_nll_loss(tq, tc, pos, None, (r * B, B), (r * B * D, B * D))
+        loss.backward()
+        assert abs(loss.item() - want_loss) <= 1e-3, "rank %d loss %.6f vs %.6f" % (r, loss.item(), want_loss)
+        assert int(corr.item()) == want_correct
+        gq, gc = tq.grad.cpu().numpy(), tc.grad.cpu().numpy()
+        lq, lc = slice(r * B, (r + 1) * B), slice(r * B * D, (r + 1) * B * D)
+        for got, ref, what in ((gq[lq], dq_all[lq], "dq"), (gc[lc], dc_all[lc], "dctx")):      # relative to the largest entry
+            err = np.abs(got - ref).max()
+            assert err <= 2e-4 * np.abs(ref).max(), "cfg3 %s rank %d: err %.3e (scale %.3e)" % (what, r, err, np.abs(ref).max())
+        gq[lq] = 0; gc[lc] = 0
+        assert np.abs(gq).max() == 0.0 and np.abs(gc).max() == 0.0, "remote rows must not receive gradient"
+
+
 # ------------------------------------------------------------------------------------------ sampler
 def test_sampler_bit_exact_vs_oracle_scheme(dev, golden_dir):
     from simxns_amd import ops

@@ -224,3 +224,40 @@ def test_roberta_dot_oracle_matches_reference(golden_dir, fixture):
         assert np.abs((Gq[k] + Gd[k]).reshape(ref.shape) - ref).max() <= 1e-9 * max(np.abs(ref).max(), 1e-3), k
         checked += 1
     assert checked >= 15
+
+
+def test_torch_cpu_restatement_matches_reference_goldens(golden_dir):
+    """oracle/torch_cpu.py (the CPU-baseline leg of bench.py: the reference's torch operators without transformers) against the
+    reference goldens: tiny step in f64 (all gradients) and BASELINE configs[0] (BERT-base, B=4, N=1) in the f32 it is
+    timed in."""
+    import torch
+    from oracle import torch_cpu as tc
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    G = np.load(os.path.join(golden_dir, "step_tiny.npz"))
+    cfg, (Pq, Pc, Pt) = _params(G)
+    Tq, Tc = tc.to_torch_params(Pq, torch.float64), tc.to_torch_params(Pc, torch.float64)
+    Tt = tc.to_torch_params(Pt, torch.float64, requires_grad=False)
+    teacher = (Tt, tt(G["qa_w"]).double(), tt(G["qa_b"]).double(), tt(G["t_ids"]), tt(G["t_mask"]))
+    r = tc.retriever_step(Tq, Tc, tt(G["q_ids"]), tt(G["q_mask"]), tt(G["c_ids"]), tt(G["c_mask"]), cfg.heads, teacher=teacher)
+    np.testing.assert_allclose(r["q"].numpy(), G["q_emb"], atol=1e-10)
+    np.testing.assert_allclose(r["ctx"].numpy(), G["ctx_emb"], atol=1e-10)
+    np.testing.assert_allclose(r["z"].numpy(), G["teacher_logits"], atol=1e-10)
+    assert abs(r["loss"] - float(G["loss_kl"])) < 1e-11
+    for pre, T in (("question_model.", Tq), ("ctx_model.", Tc)):
+        for k, v in T.items():
+            ref = G["grad." + pre + k]
+            assert np.abs(v.grad.numpy() - ref).max() <= 1e-9 * max(np.abs(ref).max(), 1e-3), k
+    G = np.load(os.path.join(golden_dir, "step_base_cfg1.npz"))
+    cfg, (Pq, Pc, Pt) = _params(G)
+    Tq, Tc = tc.to_torch_params(Pq), tc.to_torch_params(Pc)
+    r = tc.retriever_step(Tq, Tc, tt(G["q_ids"]), tt(G["q_mask"]), tt(G["c_ids"]), tt(G["c_mask"]), cfg.heads,
+                          teacher_logits=tt(G["teacher_logits"]).float())
+    np.testing.assert_allclose(r["q"].numpy(), G["q_emb"], atol=5e-5)
+    np.testing.assert_allclose(r["sim"].numpy(), G["sim"], rtol=0, atol=1e-3 * np.abs(G["sim"]).max())
+    assert abs(r["loss"] - float(G["loss_kl"])) < 1e-3
+    names = [str(n) for n in G["grad_names"]]
+    norms = dict(zip(names, G["grad_norms"]))
+    for pre, T in (("question_model.", Tq), ("ctx_model.", Tc)):
+        for k in ("encoder.layer.3.intermediate.dense.weight", "embeddings.word_embeddings.weight", "encoder.layer.11.output.dense.bias"):
+            got = float(T[k].grad.double().norm())
+            assert abs(got - norms[pre + k]) <= 1e-3 * norms[pre + k] + 1e-7, (pre + k, got, norms[pre + k])

@@ -366,6 +366,10 @@ int simx_simans_sample(simx_stream_t stream, int nq, int C, int N,
  * clip_grad_norm_ + transformers.AdamW + zero_grad (co_training_marco_train.py:57-69, 246-254;
  * update rule SURVEY App. C).  sqnorm: device scalar accumulator (zero it first). */
 int simx_sqnorm_accum(simx_stream_t stream, const float* g, size_t n, float* sqnorm);
+/* the same without float atomics (two launches; ws: SIMX_SQNORM_WS_FLOATS floats of scratch): bit-reproducible, so the
+ * replicas of a data-parallel job compute the same clip coefficient from the same all-reduced gradients. */
+#define SIMX_SQNORM_WS_FLOATS 2048
+int simx_sqnorm_accum_det(simx_stream_t stream, const float* g, size_t n, float* sqnorm, float* ws);
 /* p,m,v updated in place; g is read, scaled by min(1, max_norm/(sqrt(*sqnorm)+1e-6)) * grad_scale
  * (max_norm <= 0 or sqnorm == NULL: no clipping), and zeroed afterwards when zero_grad != 0. */
 int simx_adamw_step(simx_stream_t stream, float* p, float* g, float* m, float* v, size_t n,

@@ -95,6 +95,7 @@ SIGNATURES = {
     "simx_flat_ip_search": (_i, [_p, _i, C.c_long, _i, _p, _p, C.c_int64, _i, _i, _p, _z, _p, _p]),
     "simx_simans_sample": (_i, [_p, _i, _i, _i, _p, _p, _i, _d, _d, _d, C.c_uint64, C.c_uint32, _p, _p, _p, _p]),
     "simx_sqnorm_accum": (_i, [_p, _p, _z, _p]),
+    "simx_sqnorm_accum_det": (_i, [_p, _p, _z, _p, _p]),
     "simx_adamw_step": (_i, [_p, _p, _p, _p, _p, _z, _f, _f, _f, _f, _f, _i, _p, _f, _f, _i]),
     "simx_prof_begin": (_i, [_i]),
     "simx_prof_end": (_i, [_p, _p, _p]),

@@ -16,6 +16,7 @@
 //   * blockIdx -> tile map is XCD-aware: the 8 XCDs (private L2s) each walk a contiguous
 //     range of tiles so that the N-tiles sharing an A panel hit the same L2.
 // f32 path ("parity mode") and odd shapes: a plain LDS-tiled FMA kernel, k-ordered f32 accumulate.
+#include <type_traits>
 #include "common.h"
 #include "prof.h"
 
@@ -83,6 +84,141 @@ __global__ __launch_bounds__(256) void gemm_simple_kernel(
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// f32 MFMA kernel (parity mode NT / TN GEMMs and the M2 score matrix): v_mfma_f32_32x32x2_f32 -- exact f32 products,
+// f32 accumulation in ascending k (the instruction adds its two k terms in order into the accumulator), 157 TFLOP/s peak,
+// the same rate as the vector FMA pipe but with 1/16 of the instruction issue and LDS traffic of the FMA kernel above.
+// 128x128x16 block tile, 4 waves (2x2) of 64x64 = 2x2 MFMA tiles; operands staged global -> registers -> LDS in k-major
+// images As[k][m], Bs[k][n] (row pitch 132 floats) so that a fragment read (lane -> m = lane%32, k = lane/32) is one
+// conflict-free ds_read_b32; the next stage's global loads are issued before the current stage's MFMAs.  Each operand is
+// read with 16-B loads along whichever of its two dimensions is contiguous (element stride 1); anything else (or a
+// misaligned base / leading dimension) takes the scalar path of the same kernel.
+// ------------------------------------------------------------------------------------------
+#define FM_PITCH 132
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(
+    int M, int N, int K, const float* __restrict__ A, long a_rs, long a_cs, const float* __restrict__ B, long b_ks, long b_ns,
+    float* __restrict__ C, int ldc, const float* __restrict__ bias, const float* __restrict__ res, int ldr,
+    const float* __restrict__ aux, int ldaux, float* __restrict__ C2, int ldc2, int accumulate, DropCtx drop, int a_mode, int b_mode) {
+  // mode 0: scalar loads; 1: 16-B loads along k (k contiguous); 2: 16-B loads along m / n (m / n contiguous)
+  __shared__ __attribute__((aligned(16))) float As[2][16 * FM_PITCH];
+  __shared__ __attribute__((aligned(16))) float Bs[2][16 * FM_PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+  const int wr = wave >> 1, wc = wave & 1;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  float ra[8], rb[8];            // this thread's share of a 128x16 operand stage (2 x 4 floats)
+  // element (mm, kk) of the stage held in r[e*4 + j]:
+  //   mode 1 / scalar: unit u = tid + e*256 -> mm = u >> 2, kk = (u & 3)*4 + j      (4 consecutive k of one row)
+  //   mode 2         : unit u = tid + e*256 -> kk = u >> 5, mm = (u & 31)*4 + j     (4 consecutive m of one k)
+  auto load_stage = [&](const float* __restrict__ G, long rs, long cs, int row0, int nrows, int k0, int mode, float* r) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int u = tid + e * 256;
+      if (mode == 2) {
+        const int kk = u >> 5, mm = (u & 31) * 4;
+        const int gk = k0 + kk, gm = row0 + mm;
+        if (gk < K && gm + 3 < nrows) {
+          const float4 v = *reinterpret_cast<const float4*>(G + (long)gk * cs + gm);
+          r[e * 4 + 0] = v.x; r[e * 4 + 1] = v.y; r[e * 4 + 2] = v.z; r[e * 4 + 3] = v.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) r[e * 4 + j] = (gk < K && gm + j < nrows) ? G[(long)gk * cs + (long)(gm + j) * rs] : 0.f;
+        }
+      } else {
+        const int mm = u >> 2, kk = (u & 3) * 4;
+        const int gm = row0 + mm, gk = k0 + kk;
+        if (mode == 1 && gm < nrows && gk + 3 < K) {
+          const float4 v = *reinterpret_cast<const float4*>(G + (long)gm * rs + gk);
+          r[e * 4 + 0] = v.x; r[e * 4 + 1] = v.y; r[e * 4 + 2] = v.z; r[e * 4 + 3] = v.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) r[e * 4 + j] = (gm < nrows && gk + j < K) ? G[(long)gm * rs + (long)(gk + j) * cs] : 0.f;
+        }
+      }
+    }
+  };
+  auto store_stage = [&](float* __restrict__ S, int mode, const float* r) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int u = tid + e * 256;
+      if (mode == 2) {
+        const int kk = u >> 5, mm = (u & 31) * 4;
+        *reinterpret_cast<float4*>(S + kk * FM_PITCH + mm) = make_float4(r[e * 4], r[e * 4 + 1], r[e * 4 + 2], r[e * 4 + 3]);
+      } else {
+        const int mm = u >> 2, kk = (u & 3) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) S[(kk + j) * FM_PITCH + mm] = r[e * 4 + j];
+      }
+    }
+  };
+  // B is addressed as B[k*b_ks + n*b_ns]: "row" index = n with stride b_ns, k stride b_ks
+  load_stage(A, a_rs, a_cs, m0, M, 0, a_mode, ra);
+  load_stage(B, b_ns, b_ks, n0, N, 0, b_mode, rb);
+  store_stage(As[0], a_mode, ra);
+  store_stage(Bs[0], b_mode, rb);
+  __syncthreads();
+  const int nst = (K + 15) / 16;
+  const int fm = lane & 31, fk = lane >> 5;
+  for (int st = 0; st < nst; ++st) {
+    const int cur = st & 1;
+    if (st + 1 < nst) {
+      load_stage(A, a_rs, a_cs, m0, M, (st + 1) * 16, a_mode, ra);
+      load_stage(B, b_ns, b_ks, n0, N, (st + 1) * 16, b_mode, rb);
+    }
+    const float* sa = As[cur] + wr * 64 + fm;
+    const float* sb = Bs[cur] + wc * 64 + fm;
+#pragma unroll
+    for (int kk = 0; kk < 16; kk += 2) {
+      const float a0 = sa[(kk + fk) * FM_PITCH], a1 = sa[(kk + fk) * FM_PITCH + 32];
+      const float b0 = sb[(kk + fk) * FM_PITCH], b1 = sb[(kk + fk) * FM_PITCH + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (st + 1 < nst) {
+      store_stage(As[cur ^ 1], a_mode, ra);
+      store_stage(Bs[cur ^ 1], b_mode, rb);
+    }
+    __syncthreads();
+  }
+  // D layout of the 32x32 tile: lane -> column n = lane%32; acc[e] -> row 8*(e/4) + 4*(lane/32) + e%4
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wc * 64 + j * 32 + fm;
+      if (n >= N) continue;
+      const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wr * 64 + i * 32 + 8 * (e >> 2) + 4 * fk + (e & 3);
+        if (m >= M) continue;
+        float v = acc[i][j][e] + bv;
+        if (EPI == SIMX_EPI_NONE) {
+          if (drop.thr) v *= drop_mult(drop, (uint32_t)m, (uint32_t)n);
+          if (res) v += res[(long)m * ldr + n];
+          if (accumulate) v += C[(long)m * ldc + n];
+          C[(long)m * ldc + n] = v;
+        } else if (EPI == SIMX_EPI_GELU) {
+          C[(long)m * ldc + n] = v;
+          C2[(long)m * ldc2 + n] = gelu_erf(v);
+        } else {
+          if (res) v += res[(long)m * ldr + n];
+          C[(long)m * ldc + n] = v * gelu_erf_grad(aux[(long)m * ldaux + n]);
+        }
+      }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1389,10 +1525,37 @@ __global__ __launch_bounds__(256) void cast_weight_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------
 // host entry points
 // ------------------------------------------------------------------------------------------
+static int operand_mode(const float* p, long stride_mn, long stride_k) {
+  // 1: k contiguous, 2: m/n contiguous (16-B loads need a 16-B aligned base and leading dimension), 0: scalar
+  const bool al16 = (((uintptr_t)p) & 15) == 0;
+  if (stride_k == 1 && al16 && stride_mn % 4 == 0) return 1;
+  if (stride_mn == 1 && al16 && stride_k % 4 == 0) return 2;
+  return 0;
+}
+static int launch_f32_mfma(hipStream_t s, int epi, int M, int N, int K, const float* A, long a_rs, long a_cs, const float* B,
+                           long b_ks, long b_ns, float* C, int ldc, const float* bias, const float* res, int ldr,
+                           const float* aux, int ldaux, float* C2, int ldc2, int accumulate, DropCtx drop) {
+  dim3 grid(cdiv(N, 128), cdiv(M, 128));
+  const int am = operand_mode(A, a_rs, a_cs), bm = operand_mode(B, b_ns, b_ks);
+#define LF(E) hipLaunchKernelGGL((gemm_f32_mfma_kernel<E>), grid, dim3(256), 0, s, M, N, K, A, a_rs, a_cs, B, b_ks, b_ns, C, ldc, bias, \
+                                 res, ldr, aux, ldaux, C2, ldc2, accumulate, drop, am, bm)
+  if (epi == SIMX_EPI_NONE) LF(SIMX_EPI_NONE);
+  else if (epi == SIMX_EPI_GELU) LF(SIMX_EPI_GELU);
+  else LF(SIMX_EPI_DGELU);
+#undef LF
+  SIMX_CHECK_LAUNCH("gemm_f32_mfma");
+  return SIMX_OK;
+}
+
 template <typename TI, typename TO>
 static int launch_simple(hipStream_t s, int epi, int M, int N, int K, const TI* A, long a_rs, long a_cs,
                          const TI* B, long b_ks, long b_ns, TO* C, int ldc, const float* bias, const TI* res, int ldr,
                          const TI* aux, int ldaux, TO* C2, int ldc2, int accumulate, DropCtx drop = DropCtx{0u, 1.f, 0u, 0u}) {
+  if constexpr (std::is_same<TI, float>::value && std::is_same<TO, float>::value) {
+    static const char* pin = getenv("SIMX_GEMM_F32");           // SIMX_GEMM_F32=fma pins the VALU kernel (A/B measurements)
+    if (!(pin && pin[0] == 'f'))
+      return launch_f32_mfma(s, epi, M, N, K, A, a_rs, a_cs, B, b_ks, b_ns, C, ldc, bias, res, ldr, aux, ldaux, C2, ldc2, accumulate, drop);
+  }
   dim3 grid(cdiv(N, 64), cdiv(M, 64));
 #define L(E) hipLaunchKernelGGL((gemm_simple_kernel<TI, TO, E>), grid, dim3(256), 0, s, M, N, K, A, a_rs, a_cs, B, b_ks, \
                                 b_ns, C, ldc, bias, res, ldr, aux, ldaux, C2, ldc2, accumulate, drop)

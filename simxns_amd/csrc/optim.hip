@@ -21,6 +21,33 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g
   if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
 }
 
+// deterministic variant: pass 1 leaves one partial per block (fixed element -> thread assignment, fixed in-block order), pass 2
+// (one block) adds the partials in index order.  No float atomics: every rank of a data-parallel job gets the SAME bits
+// from the same all-reduced gradients, so the clip coefficient -- and with it the replicas -- cannot drift apart.
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, size_t n, float* __restrict__ partials) {
+  __shared__ float part[4];
+  float s = 0.f;
+  const size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(g)[i];
+    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (blockIdx.x == 0) for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) s += g[i] * g[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+__global__ __launch_bounds__(256) void sqnorm_final_kernel(const float* __restrict__ partials, int nparts, float* __restrict__ out) {
+  __shared__ float part[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) s += partials[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *out += (part[0] + part[1]) + (part[2] + part[3]);
+}
+
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, size_t n, float step_size, float beta1, float beta2,
                                                     float eps, float decay, const float* __restrict__ sqnorm, float max_norm,
@@ -68,6 +95,20 @@ extern "C" int simx_sqnorm_accum(simx_stream_t stream, const float* g, size_t n,
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, n, sqnorm);
   SIMX_CHECK_LAUNCH("sqnorm");
+  return SIMX_OK;
+}
+
+extern "C" int simx_sqnorm_accum_det(simx_stream_t stream, const float* g, size_t n, float* sqnorm, float* ws) {
+  SIMX_PROF(SIMX_K_ADAMW, stream, 4.0 * n);
+  SIMX_REQUIRE(g && sqnorm && ws && n > 0, SIMX_ERR_BAD_SHAPE, "sqnorm_accum_det: bad arguments");
+  SIMX_REQUIRE((((uintptr_t)g) & 15) == 0, SIMX_ERR_BAD_SHAPE, "sqnorm_accum_det: g not 16-B aligned");
+  size_t blocks = (n / 4 + 255) / 256;
+  if (blocks > SIMX_SQNORM_WS_FLOATS) blocks = SIMX_SQNORM_WS_FLOATS;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(sqnorm_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, n, ws);
+  SIMX_CHECK_LAUNCH("sqnorm_partial");
+  hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)ws, (int)blocks, sqnorm);
+  SIMX_CHECK_LAUNCH("sqnorm_final");
   return SIMX_OK;
 }
 

@@ -166,8 +166,9 @@ class FusedAdamW(object):
             bufs.append((st["p"], st["g"], st, None))
         sq = torch.zeros(1, dtype=torch.float32, device=dev)
         if max_grad_norm and max_grad_norm > 0:
-            for p_, g_, st_, e_ in bufs:
-                L.call("simx_sqnorm_accum", s, L.ptr(g_), g_.numel(), L.ptr(sq))
+            ws = torch.empty(2048, dtype=torch.float32, device=dev)
+            for p_, g_, st_, e_ in bufs:          # (no float atomics: every data-parallel replica gets the same bits)
+                L.call("simx_sqnorm_accum_det", s, L.ptr(g_), g_.numel(), L.ptr(sq), L.ptr(ws))
         for p_, g_, st_, e_ in bufs:
             L.call("simx_adamw_step", s, L.ptr(p_), L.ptr(g_), L.ptr(st_["m"]), L.ptr(st_["v"]), p_.numel(), lr,
                    self.betas[0], self.betas[1], self.eps, 0.0, self.step_count,

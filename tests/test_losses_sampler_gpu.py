@@ -170,7 +170,7 @@ def test_inbatch_nll_config3_full_shape_each_local_slot(dev):
     Q, Cn = W * B, W * B * D
     c = (rs.randn(Cn, H) * 0.35).astype(np.float32)
     pos = [r * B * D + j * D for r in range(W) for j in range(B)]
-    q = (0.25 * c[pos] + rs.randn(Q, H) * 0.3).astype(np.float32)          # queries lean towards their positives
+    q = (0.12 * c[pos] + rs.randn(Q, H) * 0.3).astype(np.float32)          # queries lean towards their positives (~half are top-1)
     q64, c64 = q.astype(np.float64), c.astype(np.float64)
     S = q64 @ c64.T
     m = S.max(1, keepdims=True)

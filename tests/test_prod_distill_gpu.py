@@ -1,0 +1,98 @@
+"""BASELINE configs[3] as ONE step: PROD progressive distillation, 12-layer cross-encoder teacher -> 6-layer bi-encoder student
+(PROD/ProD_KD/run_progressive_distill_marco.py:288-314 with the README recipe PROD/README.md:208-224: KD_softmax, T=4,
+CE_WEIGHT 0.1, KD_WEIGHT 0.9, LwF against the frozen student copy with LwF_WEIGHT 1.0; B=8 queries x 16 passages,
+q32 / p128 / cross-encoder 160) against the golden the imported PROD modules produced (tests/golden/step_prod_cfg4.npz,
+oracle/make_golden.py::gen_prod_step)."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _models(G, dev, dtype):
+    from simxns_amd.engine import BertConfigLite
+    from simxns_amd.ProD_KD.model.models import BiBertEncoder, HFBertEncoder, Reranker
+    from simxns_amd.utils import synth
+    seeds = [int(s) for s in G["seeds"]]
+    ls, lt = [int(v) for v in G["layers"]]
+
+    def enc(layers, seed):
+        cfg = BertConfigLite(num_hidden_layers=layers, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+        m = HFBertEncoder(cfg, compute_dtype=dtype)
+        m.load_numpy_state(synth.fill_bert_state_dict([(k, tuple(p.shape)) for k, p in m.named_parameters()], seed))
+        return m
+
+    def bi(sq, sc):
+        m = BiBertEncoder.__new__(BiBertEncoder)
+        torch.nn.Module.__init__(m)
+        m.question_model, m.ctx_model = enc(ls, sq), enc(ls, sc)
+        return m.to(dev)
+    model, copy_ = bi(seeds[0], seeds[1]), bi(seeds[3], seeds[4])
+    teacher = Reranker(enc(lt, seeds[2]), 768)
+    with torch.no_grad():
+        teacher.qa_classifier.weight.copy_(torch.from_numpy(G["qa_w"]))
+        teacher.qa_classifier.bias.copy_(torch.from_numpy(G["qa_b"]))
+    return model, teacher.to(dev), copy_
+
+
+def _step(G, dev, dtype, lwf=True):
+    from simxns_amd.ProD_KD.run_progressive_distill_marco import cross_encoder_distill_step
+    model, teacher, copy_ = _models(G, dev, dtype)
+    t = lambda k: torch.from_numpy(G[k]).to(dev)
+    args = types.SimpleNamespace(KD_type="KD_softmax", TEMPERATURE=4.0, CE_WEIGHT=0.1, KD_WEIGHT=0.9, LwF_WEIGHT=1.0,
+                                 open_LwF=lwf, gradient_accumulation_steps=1, max_grad_norm=2.0)
+    model.train()
+    model.zero_grad()
+    loss, correct = cross_encoder_distill_step(
+        args, model, teacher, dict(query_ids=t("q_ids"), attention_mask_q=t("q_mask"), input_ids_a=t("c_ids"), attention_mask_a=t("c_mask")),
+        dict(input_ids=t("t_ids"), attention_mask=t("t_mask")), student_copy=copy_ if lwf else None)
+    torch.cuda.synchronize()
+    grads = {}
+    for pre, m in (("question_model.", model.question_model), ("ctx_model.", model.ctx_model)):
+        for k, p in m.named_parameters():
+            grads[pre + k] = p.grad.detach().cpu().numpy().astype(np.float64)
+    return loss.item(), int(correct), grads, model, teacher
+
+
+def test_prod_cross_encoder_distill_step_fp32_vs_reference_golden(dev, golden_dir):
+    G = np.load(os.path.join(golden_dir, "step_prod_cfg4.npz"))
+    loss, correct, grads, model, teacher = _step(G, dev, "fp32")
+    assert abs(loss - float(G["loss"])) <= 1e-3 and correct == int(G["correct"])
+    t = lambda k: torch.from_numpy(G[k]).to(dev)
+    with torch.no_grad():                                      # the pieces: student embeddings, teacher logits (both heads exist)
+        model.eval()
+        q, c = model(t("q_ids"), t("q_mask"), t("c_ids"), t("c_mask"))
+        binary, rel, _ = teacher(t("t_ids"), t("t_mask"))
+    assert binary.shape == (8, 16, 2) and rel.shape == (8, 16)
+    assert np.abs(q.cpu().numpy() - G["q_emb"]).max() <= 1e-3 and np.abs(c.cpu().numpy() - G["ctx_emb"]).max() <= 1e-3
+    assert np.abs(rel.cpu().numpy() - G["relevance_logits"]).max() <= 1e-3 * max(1.0, np.abs(G["relevance_logits"]).max())
+    names = [str(n) for n in G["grad_names"]]
+    norms = G["grad_norms"]
+    for n, ref in zip(names, norms):
+        got = np.sqrt((grads[n] ** 2).sum())
+        assert abs(got - ref) <= 3e-4 * ref + 1e-6 * norms.max(), "grad norm %s: %.6e vs %.6e" % (n, got, ref)
+    for k in G.files:
+        if k.startswith("gslice."):
+            name, ref = k[len("gslice."):], G[k]
+            g = grads[name]
+            got = g[:8, :64] if ref.ndim == 2 else g
+            assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max() + 1e-6 * norms.max(), "grad slice %s" % name
+    loss0, _, _, _, _ = _step(G, dev, "fp32", lwf=False)       # the branch without --open_LwF (:305-313)
+    assert abs(loss0 - float(G["loss_nolwf"])) <= 1e-3
+
+
+def test_prod_cross_encoder_distill_step_bf16(dev, golden_dir):
+    G = np.load(os.path.join(golden_dir, "step_prod_cfg4.npz"))
+    loss, correct, grads, _, _ = _step(G, dev, "bf16")
+    assert abs(loss - float(G["loss"])) <= 3e-2, (loss, float(G["loss"]))
+    names = [str(n) for n in G["grad_names"]]
+    norms = G["grad_norms"]
+    live = norms > 1e-6 * norms.max()
+    got = np.array([np.sqrt((grads[n] ** 2).sum()) for n in names])
+    rel = np.abs(got - norms)[live] / norms[live]
+    print("cfg4 bf16: loss err %.4f, grad-norm rel err median %.4f max %.4f" % (abs(loss - float(G["loss"])), np.median(rel), rel.max()))
+    assert np.median(rel) <= 0.02 and rel.max() <= 0.15

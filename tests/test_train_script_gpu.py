@@ -54,12 +54,16 @@ def test_train_job_runs_and_resumes(dev, tmp_path):
     tst = load_states_from_checkpoint(os.path.join(out, "checkpoint-reranker6"))
     assert "qa_classifier.weight" in tst.model_dict and "encoder.embeddings.word_embeddings.weight" in tst.model_dict
     assert all(torch.isfinite(v).all() for v in st.model_dict.values())
+    # optimizer / scheduler state in the reference's on-disk formats (torch Optimizer.state_dict, LambdaLR.state_dict)
+    assert set(st.optimizer_dict) == {"state", "param_groups"} and len(st.optimizer_dict["param_groups"]) == 2
+    assert st.optimizer_dict["state"][0]["exp_avg"].shape == st.model_dict["question_model.embeddings.word_embeddings.weight"].shape
+    assert st.scheduler_dict["last_epoch"] == 6 and "base_lrs" in st.scheduler_dict         # first iteration: 6 student steps (:289-290)
     # second shell-loop iteration: resume from checkpoint-6 with the mined file train_ce_6.tsv; goes through a teacher phase
     os.replace(os.path.join(root, "train_ce_0.tsv"), os.path.join(root, "train_ce_6.tsv"))
     gs2 = T.main(common + ["--global_step", "6"])
     assert gs2 == 12 and os.path.exists(os.path.join(out, "checkpoint-reranker12"))
     st2 = load_states_from_checkpoint(os.path.join(out, "checkpoint-12"))
-    assert st2.scheduler_dict["t"] > st.scheduler_dict["t"]
+    assert st2.scheduler_dict["last_epoch"] > st.scheduler_dict["last_epoch"]          # torch LambdaLR's state_dict keys
     w0, w1 = st.model_dict["ctx_model.encoder.layer.0.output.dense.weight"], st2.model_dict["ctx_model.encoder.layer.0.output.dense.weight"]
     assert not torch.equal(w0, w1)
 
@@ -112,9 +116,10 @@ def test_generate_job_mines_hard_negatives_file(dev, tmp_path):
     tools = Gn.RenewTools(os.path.join(root, "para.txt"), tok, out, os.path.join(root, "para.title.txt"))
     index = tools.build_index(model, dev)
     assert index.ntotal == 700
-    pos = Gn.load_pos_examples(os.path.join(root, "qrels.train.tsv"))
+    pos, pos_add = Gn.load_pos_examples(os.path.join(root, "qrels.train.tsv"), "train", root)
+    assert pos_add == {}                                   # (no qrels.train.addition.tsv in this corpus: warned, not fatal)
     result, path = tools.get_question_topk(model, dev, index, os.path.join(root, "train.query.txt"),
-                                           os.path.join(root, "qrels.train.tsv"), pos, None, "train", 6)
+                                           os.path.join(root, "qrels.train.tsv"), pos, pos_add, "train", 6)
     assert os.path.basename(path) == "train_ce_6.tsv" and 0.0 <= result["MRR @10"] <= 1.0 and result["QueriesRanked"] == 24
     # ids in the file == oracle exhaustive search over the very same embeddings
     qids, qtab = Gn.tokenize_table([[q, l.split("\t")[1].strip()] for q, l in enumerate(open(os.path.join(root, "train.query.txt")))], tok, 32)

@@ -38,27 +38,27 @@ def fwd_flops_seq(S, L=L_, H=H_, F=F_):
     return L * S * (8 * H * H + 4 * H * F + 4 * S * H)
 
 
-def cpu_baseline():
+def cpu_baseline(timeout_s=300):
     """The reference's CPU path, restated operator for operator on torch CPU (oracle/torch_cpu.py: the reference itself
     cannot travel to the GPU box; oracle/time_reference.py shows the restatement within ~10 % of the imported reference in
-    the build container), timed on this box's host cores, fp32, all-max lengths, BERT-base random init:
+    the build container), timed on this box's host CPUs -- the ones this process may use (affinity and cgroup quota), fp32,
+    all-max lengths, BERT-base random init, in a separate process with a hard timeout:
       * BASELINE configs[0] (B=4, N=1, q32/p128, student step without teacher -- BASELINE.md section 2's measurement):
         3 warm-up + 10 timed steps;
       * the benchmarked workload reduced to B=8 queries x 16 passages INCLUDING the cross-encoder teacher forward (the
-        same step the GPU runs, 1/16 of its batch): 1 warm-up + 3 timed steps.
+        same step the GPU runs, 1/16 of its batch): 1 warm-up + 2 timed steps.
     `value` is the second (same metric as the GPU line: scored pairs per second of the full step)."""
-    import torch
-    from oracle import torch_cpu as tc
-    cores = os.cpu_count()
-    torch.set_num_threads(cores)
-    t0 = time.time()
-    s1, p1, thr = tc.time_step(4, 1, with_teacher=False, warmup=3, steps=10)
-    s2, p2, thr = tc.time_step(8, 15, with_teacher=True, warmup=1, steps=3)
+    import subprocess
+    r = subprocess.run([sys.executable, "-m", "oracle.torch_cpu"], cwd=ROOT, capture_output=True, timeout=timeout_s)
+    if r.returncode != 0:
+        raise RuntimeError("oracle.torch_cpu failed: " + r.stderr.decode()[-400:])
+    d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    s1, p1, s2, p2, thr = d["cfg0_s_per_step"], d["cfg0_pairs"], d["cfg1r_s_per_step"], d["cfg1r_pairs"], d["threads"]
     return {"value": round(p2 / s2, 2), "unit": "query+passage pairs/sec", "cores": thr, "kind": "port",
-            "sample": "torch-CPU fp32 restatement of the reference step on %d threads: reduced configs[1] (B=8 x 16 passages, "
-                      "q32/p128/ce160, teacher fwd + student fwd/bwd) %.2f s/step over 3 steps after 1 warm-up; "
-                      "configs[0] (B=4, N=1, student only) %.3f s/step = %.1f pairs/s over 10 steps after 3 warm-up; "
-                      "%.0f s of CPU wall in total" % (thr, s2, s1, p1 / s1, time.time() - t0),
+            "sample": "torch-CPU fp32 restatement of the reference step on %d threads (the CPUs this container may use): reduced "
+                      "configs[1] (B=8 x 16 passages, q32/p128/ce160, teacher fwd + student fwd/bwd) %.2f s/step over 2 steps after "
+                      "1 warm-up; configs[0] (B=4, N=1, student only) %.3f s/step = %.1f pairs/s over 10 steps after 3 warm-up; "
+                      "%.0f s of CPU wall in total" % (thr, s2, s1, p1 / s1, d["wall_s"]),
             "config0_pairs_per_s": round(p1 / s1, 2), "config0_s_per_step": round(s1, 4)}
 
 

@@ -23,6 +23,28 @@ import torch
 import torch.nn.functional as F
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (cpu.max / cfs_quota).  The GPU
+    boxes show 256 hardware threads but a 16-CPU quota: 256 OpenMP threads on 16 CPUs spin against the throttle and run
+    orders of magnitude slower than 16 threads."""
+    import math
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, math.ceil(int(q) / int(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, math.ceil(q / per)))
+        except Exception:
+            pass
+    return n
+
+
 def to_torch_params(P, dtype=torch.float32, requires_grad=True, prefix=""):
     return {k[len(prefix):]: torch.from_numpy(np.asarray(v)).to(dtype).requires_grad_(requires_grad)
             for k, v in P.items() if k.startswith(prefix)}
@@ -109,3 +131,22 @@ def time_step(B, N, q_len=32, p_len=128, ce_len=160, with_teacher=True, warmup=3
     for _ in range(steps):
         one()
     return (time.perf_counter() - t0) / steps, P, torch.get_num_threads()
+
+
+def main():
+    """`python -m oracle.torch_cpu` -- the CPU-baseline measurement of bench.py, run in its own process (its own OpenMP pool,
+    a hard timeout on the caller's side): prints one JSON line."""
+    import json
+    import sys
+    thr = usable_cpus()
+    torch.set_num_threads(thr)
+    t0 = time.time()
+    s1, p1, _ = time_step(4, 1, with_teacher=False, warmup=3, steps=10)
+    s2, p2, _ = time_step(8, 15, with_teacher=True, warmup=1, steps=2)
+    print(json.dumps({"threads": thr, "cfg0_s_per_step": s1, "cfg0_pairs": p1, "cfg1r_s_per_step": s2, "cfg1r_pairs": p2,
+                      "wall_s": time.time() - t0}))
+    sys.stdout.flush()
+
+
+if __name__ == "__main__":
+    main()

@@ -199,10 +199,10 @@ def test_base_hot_step_bf16_vs_reference_golden(dev, golden_dir):
     print("hot bf16 errors:", json.dumps(e))
     t = BF16_HOT_TOL
     assert e["q_abs"] <= t["emb_abs"] and e["c_abs"] <= t["emb_abs"], e
-    assert e["sim_abs"] <= t["logits_rel"] * e["sim_scale"] and e["z_abs"] <= t["logits_rel"] * max(1.0, e["z_scale"]), e
+    assert e["sim_abs"] <= t["logits_rel"] * e["sim_scale"] and e["z_abs"] <= t["teacher_logits_abs"], e
     assert e["loss_abs"] <= t["loss_abs"], e
     assert e["gnorm_rel_median"] <= t["gnorm_rel_median"] and e["gnorm_rel_max"] <= t["gnorm_rel_max"], e
-    assert e["gslice_cos_min"] >= t["gslice_cos_min"], e
+    assert e["gslice_cos_min"] >= t["gslice_cos_min"] and e["gslice_cos_median_all"] >= t["gslice_cos_median_all"], e
 
 
 def test_module_api_and_sequence_output(dev, golden_dir):

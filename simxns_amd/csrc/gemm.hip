@@ -556,9 +556,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_v5_kernel(
 //   bias(4) R0(2) L1'(8) | R1(2) [wait R0: vmcnt 10] S0(2) | R2 [wait R1: vmcnt 4] S1 | ... | [wait R7: vmcnt 2] S7
 // so nothing ever waits for a store or for a load younger than the one it needs.
 // ------------------------------------------------------------------------------------------
-#ifndef SIMX_P3_SKEW_DEFAULT_US
-#define SIMX_P3_SKEW_DEFAULT_US 0
-#endif
 #define P_EPI_OFF (2 * V5_STAGE)
 #define P_LDS (P_EPI_OFF + 8 * 4096)
 // global accesses in "uniform 64-bit base in SGPRs + 32-bit per-lane offset" form: one VGPR per address stream
@@ -842,21 +839,11 @@ template <int EPI, bool HAS_IN>
 __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
     int M, int N, int K, const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
     bf16_t* __restrict__ C, int ldc, const float* __restrict__ bias, const bf16_t* __restrict__ in, int ldin,
-    bf16_t* __restrict__ C2, int ldc2, int tiles_n, int ntiles, DropCtx drop, int skew_ticks) {
+    bf16_t* __restrict__ C2, int ldc2, int tiles_n, int ntiles, DropCtx drop) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // Phase skew.  Every workgroup walks tiles of equal cost, so without it all 256 CUs reach their epilogues at the same
-  // moment and the whole chip stores at once: tools/store_bench shows a lone CU writing a 128 KB tile in 1.1 us (55 B/clk)
-  // but 256 CUs together taking 6.1 us each -- the chip's ~5.4 TB/s of write bandwidth, not a per-CU limit.  Starting the
-  // workgroups spread over a window of `skew_ticks` (100 MHz ticks) keeps only a few dozen CUs in their epilogue at any time;
-  // the phases persist because every tile takes every workgroup the same time.
-  if (skew_ticks > 0) {
-    const unsigned slot = (blockIdx.x * 97u) & 255u;                     // (97 is odd: a bijection of the 256 workgroups)
-    const unsigned long long until = wall_clock64() + (unsigned long long)(slot * (unsigned)skew_ticks) / 256u;
-    while (wall_clock64() < until) __builtin_amdgcn_s_sleep(4);
-  }
   const int wr = wave >> 2, wc = wave & 3;
   const int fr = lane & 15, fg = lane >> 4;
   const int nst = K / 64;                         // >= 4
@@ -986,19 +973,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
     const uint32_t boff__ = (uint32_t)((lb__ >> 4) * 16);                                      \
     P_GLD4(bq0, boff__, bptr, 0); P_GLD4(bq1, boff__, bptr, 64); P_GLD4(bq2, boff__, bptr, 128); P_GLD4(bq3, boff__, bptr, 192); \
     if (HAS_IN) {                                                                              \
-      /* the residual / GELU-input rows of the first THREE 16-row chunks (the epilogue keeps three in flight: one chunk  \
-         ahead left every chunk waiting a full memory latency, 8 x ~1.3 us per tile).  Staging = this wave's 4 KB of the \
-         A slot AND of the B slot the tile's last stage just released (four 2 KB buffers) */     \
       const int lr__ = lb__ >> 3;                                                              \
       const uint32_t io0__ = (uint32_t)(lr__ * ldin + (((lb__ & 7) ^ (lb__ >> 4)) << 3)) * 2;  \
       const uint32_t io1__ = (uint32_t)((lr__ + 8) * ldin + (((lb__ & 7) ^ (4 + (lb__ >> 4))) << 3)) * 2; \
       P_DMA16(io0__, ibase, ereg); P_DMA16(io1__, ibase, ereg + 1024u);                        \
-      P_DMA16(io0__, ibase + (long)32 * ldin, ereg + 2048u); P_DMA16(io1__, ibase + (long)32 * ldin, ereg + 3072u); \
-      P_DMA16(io0__, ibase + (long)64 * ldin, eregB); P_DMA16(io1__, ibase + (long)64 * ldin, eregB + 1024u); \
-    } else {                                                                                   \
-      /* next tile's stage 1 of B (with an input operand the B slot serves as staging first: issued after the epilogue) */ \
-      p3_half(B, ldb, n0n, 64, ldsB + (uint32_t)(bc * 32768), wave, offB0, offB1);              \
     }                                                                                          \
+    /* next tile's stage 1 of B; its stage 2 of A goes into the slot this tile's epilogue borrows -> issued after it */ \
+    p3_half(B, ldb, n0n, 64, ldsB + (uint32_t)(bc * 32768), wave, offB0, offB1);                \
   } while (0)
 
   for (;;) {
@@ -1039,7 +1020,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
       ac = an; bc = bn;
     }
     const uint32_t ereg = lds0 + (uint32_t)(ac * 32768 + wave * 4096);     // this wave's slice of the last stage's A slot
-    const uint32_t eregB = ldsB + (uint32_t)(bc * 32768 + wave * 4096);    // ... and of its B slot (HAS_IN epilogues only)
     {
       const int an = ac == 2 ? 0 : ac + 1, bn = bc ^ 1;
       const uint32_t sa = lds0 + (uint32_t)(ac * 32768), sb = ldsB + (uint32_t)(bc * 32768);
@@ -1051,7 +1031,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
     // ---- epilogue, 8 chunks of 16 rows (= accumulator row-block i), per wave, no barrier
     // (the bias registers are pinned here, BEFORE any branch: a branch between an asm load and its pin makes hipcc
     // copy the in-flight registers and the copies read garbage)
-    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(bq0), "+v"(bq1), "+v"(bq2), "+v"(bq3) : "n"(HAS_IN ? 6 : 4) : "memory");   // younger than the bias: R0-R2 / B(next,1)
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(bq0), "+v"(bq1), "+v"(bq2), "+v"(bq3) : "n"(HAS_IN ? 6 : 4) : "memory");
     if (C != nullptr) {                          // (nullptr: measurement hook SIMX_NOEPI, main loop only)
       P_LANE(le);
       const int fr = le & 15, fg = le >> 4, lr = le >> 3;          // shadow the kernel-scope copies on purpose
@@ -1064,26 +1044,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
       const bool store_pre = !(EPI == SIMX_EPI_GELU && ldin == 1);   // ldin == 1 on a GELU launch: SIMX_EPI_GELU_INFER
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        // staging buffer of chunk i: without an input operand 4 KB of the A slot (GELU: both outputs of a chunk; else two
-        // alternating 2 KB halves); with one, four 2 KB buffers (A slot slice, then B slot slice), chunk i -> buffer i % 4
-        const uint32_t sub = HAS_IN ? (((i & 2) ? eregB : ereg) + (uint32_t)((i & 1) * 2048))
-                                    : ereg + (uint32_t)((EPI == SIMX_EPI_GELU ? 0 : (i & 1)) * 2048);
+        const uint32_t sub = ereg + (uint32_t)((EPI == SIMX_EPI_GELU ? 0 : (i & 1)) * 2048);
         if (HAS_IN) {
-          if (i + 3 < 8) {        // chunk i+3 goes where chunk i-1 was staged (its rows are in registers / on their way out)
-            const uint32_t nx = (((i + 3) & 2) ? eregB : ereg) + (uint32_t)(((i + 3) & 1) * 2048);
-            const char* ib = ibase + (long)(i + 3) * 32 * ldin;
+          if (i < 7) {
+            const uint32_t nx = ereg + (uint32_t)(((i + 1) & 1) * 2048);
+            const char* ib = ibase + (long)(i + 1) * 32 * ldin;
             P_DMA16(io0, ib, nx);
             P_DMA16(io1, ib, nx + 1024u);
           }
-          // issue order: bias R0 R1 R2 | R3 S0 | R4 S1 | R5 S2 | R6 S3 | R7 S4 | S5 | S6 | S7 (R, S = 2 instructions each);
-          // the wait of chunk i leaves everything YOUNGER than R(i) in flight (vmcnt completes in order)
           if (i == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-          else if (i == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-          else if (i == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-          else if (i == 3 || i == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-          else if (i == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-          else if (i == 6) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+          else if (i < 7) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         }
         uint2 t0, t1, t2, t3;
         const uint32_t ad0 = sub + slot + (uint32_t)(((0 + (fg >> 1)) ^ sw) << 4), ad1 = sub + slot + (uint32_t)(((2 + (fg >> 1)) ^ sw) << 4);
@@ -1109,11 +1080,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
             else { vv[0] *= gelu_grad_fast(x0); vv[1] *= gelu_grad_fast(x1); vv[2] *= gelu_grad_fast(x2); vv[3] *= gelu_grad_fast(x3); }
           }
           const uint2 o = make_uint2(pack2bf(vv[0], vv[1]), pack2bf(vv[2], vv[3]));
-#ifdef SIMX_P3_NOSTAGE     /* timing experiment only (wrong results): no LDS transposition, stores send register contents */
-          asm volatile("" ::"v"(ad), "v"(o) : "memory");
-#else
           asm volatile("ds_write_b64 %0, %1" ::"v"(ad), "v"(o) : "memory");
-#endif
           if (EPI == SIMX_EPI_GELU) {             // gelu of the bf16-ROUNDED pre-activation (backward reads C)
             float g[4];
 #pragma unroll
@@ -1124,20 +1091,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
         }
         const uint32_t rd = sub + (uint32_t)(le * 16);
         u32x4 w0, w1;
-#ifdef SIMX_P3_NOSTAGE
-        w0 = (u32x4){__float_as_uint(acc[i][0][0]), __float_as_uint(acc[i][1][0]), __float_as_uint(acc[i][2][0]), __float_as_uint(acc[i][3][0])};
-        w1 = (u32x4){__float_as_uint(acc[i][0][1]), __float_as_uint(acc[i][1][1]), __float_as_uint(acc[i][2][1]), __float_as_uint(acc[i][3][1])};
-        asm volatile("" : "+v"(w0), "+v"(w1) : "v"(rd));
-#else
         asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
                      : "=&v"(w0), "=&v"(w1) : "v"(rd) : "memory");
-#endif
-#ifdef SIMX_P3_NOSTORE     /* timing experiment only (wrong results): everything but the global stores */
-        asm volatile("" ::"v"(w0), "v"(w1));
-        if (false) {
-#else
         if (store_pre) {                                 // (inference GELU: the pre-activation has no reader)
-#endif
           P_GST4(eo0, obase + (long)i * 16 * ldc, w0);
           P_GST4(eo1, obase + (long)i * 16 * ldc, w1);
         }
@@ -1151,10 +1107,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
         }
       }
     }
-    // the borrowed slots are free again (a wave's slice only ever holds that wave's rows, and its ds_reads of the last chunks
-    // have completed): next tile's stage 1 of B (deferred when the B slot served as staging), then its stage 2 of A -- in this
-    // order, so that "all but the 4 youngest" at the next boundary still means "B(1) landed"
-    if (HAS_IN) p3_half(B, ldb, n0n, 64, ldsB + (uint32_t)(bc * 32768), wave, offB0, offB1);
+    // the borrowed A slot is free again (this wave's slice only ever holds this wave's rows): next tile's stage 2
     p3_half(A, lda, m0n, 128, lds0 + (uint32_t)(ac * 32768), wave, offA0, offA1);
     if (!has_next) break;
     v = vn; m0 = m0n; n0 = n0n; a0 = ac == 2 ? 0 : ac + 1; b0 = bc ^ 1;
@@ -1707,11 +1660,8 @@ extern "C" int simx_gemm_nt_ex(simx_stream_t stream, int dtype, int M, int N, in
 #define LP(E, HI, INP, LDI) hipLaunchKernelGGL((gemm_nt_bf16_pers_kernel<E, HI>), dim3(grid), dim3(512), P_LDS, s, M, N, K, (const bf16_t*)A, lda, \
                                  (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, (const bf16_t*)(INP), LDI, (bf16_t*)C2, ldc2, t3n, nwg3, drop)
       if (K >= 256 && !force_v7) {
-        // phase skew of the workgroups (see the kernel): window in microseconds, SIMX_P3_SKEW_US overrides (0 = off)
-        static const int skew_env = getenv("SIMX_P3_SKEW_US") ? atoi(getenv("SIMX_P3_SKEW_US")) : -1;
-        const int skew_ticks = (skew_env >= 0 ? skew_env : SIMX_P3_SKEW_DEFAULT_US) * 100 * (grid == ncu ? 1 : 0);
 #define LP3(E, HI, INP, LDI) hipLaunchKernelGGL((gemm_nt_bf16_p3_kernel<E, HI>), dim3(grid), dim3(512), P_LDS, s, M, N, K, (const bf16_t*)A, lda, \
-                                 (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, (const bf16_t*)(INP), LDI, (bf16_t*)C2, ldc2, t3n, nwg3, drop, skew_ticks)
+                                 (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, (const bf16_t*)(INP), LDI, (bf16_t*)C2, ldc2, t3n, nwg3, drop)
         if (epilogue == SIMX_EPI_NONE) { if (residual) LP3(SIMX_EPI_NONE, true, residual, ldr); else LP3(SIMX_EPI_NONE, false, nullptr, 0); }
         else if (epilogue == SIMX_EPI_GELU) LP3(SIMX_EPI_GELU, false, nullptr, gelu_infer ? 1 : 0);
         else LP3(SIMX_EPI_DGELU, true, aux, ldaux);

@@ -13,6 +13,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 #define WAVE 64
+#define SIMX_MAX_DEVICES 64   // per-device launch state tables (one process per GPU is the deployment; this is the bound)
 
 // ---- error plumbing (api.cpp) ---------------------------------------------------------
 void simx_set_error(const char* fmt, ...);

@@ -16,6 +16,7 @@
 //   * blockIdx -> tile map is XCD-aware: the 8 XCDs (private L2s) each walk a contiguous
 //     range of tiles so that the N-tiles sharing an A panel hit the same L2.
 // f32 path ("parity mode") and odd shapes: a plain LDS-tiled FMA kernel, k-ordered f32 accumulate.
+#include <mutex>
 #include <type_traits>
 #include "common.h"
 #include "prof.h"
@@ -546,15 +547,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_v5_kernel(
 
 
 // ------------------------------------------------------------------------------------------
-// Persistent NT kernel (full 256x256 tiles only): one workgroup per CU walks its XCD's tile range.
-// Same main loop as v5, but the operand stream runs ACROSS tiles: the stage slots freed by a tile's last two
-// stages are refilled with the next tile's first two, so the prologue burst (every CU fetching 128 KB at once,
-// ~5 us on the non-persistent kernel) and the epilogue's store tail both hide under neighbouring work.
-// The epilogue owns a separate 32 KB of LDS (4 KB per wave, two 2 KB sub-regions of 16 rows) and needs no
-// barrier: residual / GELU-input rows arrive by LDS-DMA one chunk ahead, results leave as full 128-B lines.
-// All VMEM waits in the epilogue are COUNTED (vmcnt is in-order on gfx9): issue order per wave is
-//   bias(4) R0(2) L1'(8) | R1(2) [wait R0: vmcnt 10] S0(2) | R2 [wait R1: vmcnt 4] S1 | ... | [wait R7: vmcnt 2] S7
-// so nothing ever waits for a store or for a load younger than the one it needs.
+// Shared by the persistent kernels below (gemm_nt_bf16_p3_kernel, gemm_tn2_bf16_kernel): 160 KB of dynamic LDS and global
+// accesses in "uniform 64-bit base in SGPRs + 32-bit per-lane offset" form.
 // ------------------------------------------------------------------------------------------
 #define P_EPI_OFF (2 * V5_STAGE)
 #define P_LDS (P_EPI_OFF + 8 * 4096)
@@ -571,248 +565,6 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // uses ONLY this form, so the compiler never tracks M0 in it.
 #define P_DMA16(VOFF, SBASE, LDSADDR) \
   asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(VOFF), "s"(SBASE), "s"(LDSADDR) : "memory")
-// one 256x64 A stage + 256x64 B stage (full tiles, no clamps).  Row r = (wave*4+j)*8 + (lane>>3); its swizzle
-// (r>>1)&7 = 4*(j&1) + (lane>>4) only depends on j&1, so two per-lane byte offsets per operand serve all 8 loads.
-__device__ __forceinline__ void p_stage(const bf16_t* __restrict__ A, int lda, int m0, const bf16_t* __restrict__ B, int ldb,
-                                        int n0, int k0, uint32_t stage, int wave, uint32_t offA0, uint32_t offA1,
-                                        uint32_t offB0, uint32_t offB1) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int i = wave * 4 + j;
-    const char* sa = reinterpret_cast<const char*>(A + (long)(m0 + i * 8) * lda + k0);
-    const char* sb = reinterpret_cast<const char*>(B + (long)(n0 + i * 8) * ldb + k0);
-    P_DMA16((j & 1) ? offA1 : offA0, sa, stage + (uint32_t)(i * 1024));
-    P_DMA16((j & 1) ? offB1 : offB0, sb, stage + (uint32_t)(32768 + i * 1024));
-  }
-}
-
-template <int EPI, bool HAS_IN>
-__global__ __launch_bounds__(512, 2) void gemm_nt_bf16_pers_kernel(
-    int M, int N, int K, const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
-    bf16_t* __restrict__ C, int ldc, const float* __restrict__ bias, const bf16_t* __restrict__ in, int ldin,
-    bf16_t* __restrict__ C2, int ldc2, int tiles_n, int ntiles, DropCtx drop) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
-  const int fr = lane & 15, fg = lane >> 4;
-  const int nst = K / 64;                         // >= 2
-  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-  const int swz = (fr >> 1) & 7;
-  const uint32_t rowA = (uint32_t)((wr * 128 + fr) * 128), rowB = (uint32_t)(32768 + (wc * 64 + fr) * 128);
-  const uint32_t oA0 = rowA + (uint32_t)(((0 + fg) ^ swz) << 4), oA1 = rowA + (uint32_t)(((4 + fg) ^ swz) << 4);
-  const uint32_t oB0 = rowB + (uint32_t)(((0 + fg) ^ swz) << 4), oB1 = rowB + (uint32_t)(((4 + fg) ^ swz) << 4);
-  // epilogue geometry (store layout): lane -> row it*8 + (lane>>3), 16-B chunk (lane&7) ^ swizzle(row)
-  const uint32_t ereg = lds0 + (uint32_t)(P_EPI_OFF + wave * 4096);
-  const int lr = lane >> 3;
-  const int ec0 = ((lane & 7) ^ (lane >> 4)) << 3, ec1 = ((lane & 7) ^ (4 + (lane >> 4))) << 3;   // element column of the lane's 16-B chunk, rows lr / 8+lr
-  const uint32_t bmask = bias ? 0xFFFFFFFFu : 0u;
-  const uint32_t offA0 = (uint32_t)(lr * lda + ec0) * 2, offA1 = (uint32_t)(lr * lda + ec1) * 2;
-  const uint32_t offB0 = (uint32_t)(lr * ldb + ec0) * 2, offB1 = (uint32_t)(lr * ldb + ec1) * 2;
-  // Epilogue-only per-lane constants are recomputed per tile from a laundered copy of the lane id (P_LANE): left to
-  // LICM they are hoisted out of the tile loop and stay live (~20 VGPRs) through the main loop, which then spills.
-#define P_LANE(L) int L = lane; asm volatile("" : "+v"(L))
-
-  int v = blockIdx.x;
-  int tile = xcd_remap(v, ntiles);
-  int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
-  p_stage(A, lda, m0, B, ldb, n0, 0, lds0, wave, offA0, offA1, offB0, offB1);
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-  p_stage(A, lda, m0, B, ldb, n0, 64, lds0 + V5_STAGE, wave, offA0, offA1, offB0, offB1);
-  int par = 0;                                    // LDS slot of the current tile's stage 0
-  // the bias enters as the accumulators' initial value; bq* always hold the CURRENT tile's 4x4 bias columns at the
-  // top of the loop (the next tile's are requested at the last stage boundary and carried across the epilogue)
-  f32x4 bq0, bq1, bq2, bq3;
-  {
-    const float* b0 = bias ? bias + n0 + wc * 64 : reinterpret_cast<const float*>(A);
-    const uint32_t boff = (uint32_t)(fg * 16);
-    P_GLD4(bq0, boff, b0, 0); P_GLD4(bq1, boff, b0, 64); P_GLD4(bq2, boff, b0, 128); P_GLD4(bq3, boff, b0, 192);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bq0), "+v"(bq1), "+v"(bq2), "+v"(bq3)::"memory");
-  }
-
-#define V3_MFMA_ROW(I, AF, B0, B1, B2, B3)                                                     \
-  acc[I][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B0, AF, acc[I][0], 0, 0, 0);             \
-  acc[I][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B1, AF, acc[I][1], 0, 0, 0);             \
-  acc[I][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B2, AF, acc[I][2], 0, 0, 0);             \
-  acc[I][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B3, AF, acc[I][3], 0, 0, 0)
-#define V3_RD1(F, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=&v"(F) : "v"(ADDR) : "memory")
-#define V3_SB __builtin_amdgcn_sched_barrier(0)
-#define P_STEP(CURA, NA, NB, BC0, BC1, BC2, BC3, BN0, BN1, BN2, BN3, BOUNDARY)                   \
-  do {                                                                                         \
-    const uint32_t aa__ = (CURA), na__ = (NA), nb__ = (NB);                                    \
-    V3_SB; V3_MFMA_ROW(0, al0, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah0, aa__, 8192);            \
-    V3_SB; V3_MFMA_ROW(1, al1, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah1, aa__, 10240);           \
-    V3_SB; V3_MFMA_ROW(2, al2, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah2, aa__, 12288);           \
-    V3_SB; V3_MFMA_ROW(3, al3, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah3, aa__, 14336);           \
-    V3_SB;                                                                                     \
-    V3_PIN4("s_waitcnt lgkmcnt(0)", ah0, ah1, ah2, ah3);                                       \
-    BOUNDARY();                                                                                \
-    V3_SB; V3_MFMA_ROW(4, ah0, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al0, na__, 0); V3_RD1(BN0, nb__, 0);       \
-    V3_SB; V3_MFMA_ROW(5, ah1, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al1, na__, 2048); V3_RD1(BN1, nb__, 2048); \
-    V3_SB; V3_MFMA_ROW(6, ah2, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al2, na__, 4096); V3_RD1(BN2, nb__, 4096); \
-    V3_SB; V3_MFMA_ROW(7, ah3, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al3, na__, 6144); V3_RD1(BN3, nb__, 6144); \
-    V3_SB;                                                                                     \
-    V3_PIN8("s_waitcnt lgkmcnt(0)", al0, al1, al2, al3, BN0, BN1, BN2, BN3);                   \
-  } while (0)
-#define P_BND_NONE() do { } while (0)
-  // stage boundary inside the tile: every fragment of stage st is in registers, stage st+1 has landed once vmcnt
-  // hits 0 (for everyone after the barrier); slot (st+par)&1 is refilled with stream stage st+2, which is the
-  // NEXT tile's stage 0 when st == nst-2
-#define P_BND_MID()                                                                            \
-  do {                                                                                         \
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                              \
-    const bool cur__ = st + 2 < nst;                                                           \
-    p_stage(A, lda, cur__ ? m0 : m0n, B, ldb, cur__ ? n0 : n0n, cur__ ? (st + 2) * 64 : 0,     \
-            lds0 + (uint32_t)(((st + par) & 1) * V5_STAGE), wave, offA0, offA1, offB0, offB1); \
-  } while (0)
-  // last boundary of the tile: bias and the first residual chunk are requested BEFORE the next tile's stage 1,
-  // so the epilogue can wait for them without waiting for that stage
-#define P_BND_LAST()                                                                           \
-  do {                                                                                         \
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                              \
-    P_LANE(lb__);                                                                              \
-    const uint32_t boff__ = (uint32_t)((lb__ >> 4) * 16);                                      \
-    P_GLD4(bq0, boff__, bptr, 0); P_GLD4(bq1, boff__, bptr, 64); P_GLD4(bq2, boff__, bptr, 128); P_GLD4(bq3, boff__, bptr, 192); \
-    if (HAS_IN) {                                                                              \
-      const int lr__ = lb__ >> 3;                                                              \
-      const uint32_t io0__ = (uint32_t)(lr__ * ldin + (((lb__ & 7) ^ (lb__ >> 4)) << 3)) * 2;  \
-      const uint32_t io1__ = (uint32_t)((lr__ + 8) * ldin + (((lb__ & 7) ^ (4 + (lb__ >> 4))) << 3)) * 2; \
-      P_DMA16(io0__, ibase, ereg); P_DMA16(io1__, ibase, ereg + 1024u);                        \
-    }                                                                                          \
-    p_stage(A, lda, m0n, B, ldb, n0n, 64, lds0 + (uint32_t)(((nst - 1 + par) & 1) * V5_STAGE), wave, offA0, offA1, offB0, offB1); \
-  } while (0)
-
-  for (;;) {
-    const int vn = v + (int)gridDim.x;
-    const bool has_next = vn < ntiles;
-    int m0n = m0, n0n = n0;                       // past the end: re-fetch this tile (harmless, keeps the loop branch-free)
-    if (has_next) { const int tn_ = xcd_remap(vn, ntiles); m0n = (tn_ / tiles_n) * 256; n0n = (tn_ % tiles_n) * 256; }
-    const int mw = m0 + wr * 128, nw = n0 + wc * 64;
-    const float* bptr = bias ? bias + n0n + wc * 64 : reinterpret_cast<const float*>(A);   // uniform
-    const char* ibase = HAS_IN ? reinterpret_cast<const char*>(in + (long)mw * ldin + nw) : nullptr;   // uniform
-
-    f32x4 acc[8][4];
-    {
-      f32x4 bi[4] = {bq0, bq1, bq2, bq3};
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bi[j][e] = __uint_as_float(__float_as_uint(bi[j][e]) & bmask);
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = bi[j];
-    }
-    bf16x8 al0, al1, al2, al3, ah0, ah1, ah2, ah3, bx0, bx1, bx2, bx3, by0, by1, by2, by3;
-    {
-      const uint32_t aa = lds0 + (uint32_t)(par * V5_STAGE) + oA0, ab = lds0 + (uint32_t)(par * V5_STAGE) + oB0;
-      V3_READ4(al0, al1, al2, al3, aa, 0, 2048, 4096, 6144);
-      V3_READ4(bx0, bx1, bx2, bx3, ab, 0, 2048, 4096, 6144);
-      V3_PIN8("s_waitcnt lgkmcnt(0)", al0, al1, al2, al3, bx0, bx1, bx2, bx3);
-    }
-    for (int st = 0; st < nst - 1; ++st) {
-      const uint32_t sc = lds0 + (uint32_t)(((st + par) & 1) * V5_STAGE), sn = lds0 + (uint32_t)(((st + par + 1) & 1) * V5_STAGE);
-      P_STEP(sc + oA0, sc + oA1, sc + oB1, bx0, bx1, bx2, bx3, by0, by1, by2, by3, P_BND_NONE);
-      P_STEP(sc + oA1, sn + oA0, sn + oB0, by0, by1, by2, by3, bx0, bx1, bx2, bx3, P_BND_MID);
-    }
-    {
-      const uint32_t sc = lds0 + (uint32_t)(((nst - 1 + par) & 1) * V5_STAGE), sn = lds0 + (uint32_t)(((nst + par) & 1) * V5_STAGE);
-      P_STEP(sc + oA0, sc + oA1, sc + oB1, bx0, bx1, bx2, bx3, by0, by1, by2, by3, P_BND_NONE);
-      P_STEP(sc + oA1, sn + oA0, sn + oB0, by0, by1, by2, by3, bx0, bx1, bx2, bx3, P_BND_LAST);
-    }
-
-    // ---- epilogue, 8 chunks of 16 rows (= accumulator row-block i), per wave, no barrier
-    // (the bias registers are pinned here, BEFORE any branch: a branch between an asm load and its pin makes hipcc
-    // copy the in-flight registers and the copies read garbage)
-    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(bq0), "+v"(bq1), "+v"(bq2), "+v"(bq3) : "n"(HAS_IN ? 10 : 8) : "memory");
-    if (C != nullptr) {                          // (nullptr: measurement hook SIMX_NOEPI, main loop only)
-      P_LANE(le);
-      const int fr = le & 15, fg = le >> 4, lr = le >> 3;          // shadow the kernel-scope copies on purpose
-      const int ec0 = ((le & 7) ^ (le >> 4)) << 3, ec1 = ((le & 7) ^ (4 + (le >> 4))) << 3;
-      const int sw = (fr >> 1) & 7;
-      const uint32_t slot = (uint32_t)(fr * 128 + (fg & 1) * 8);
-      const uint32_t eo0 = (uint32_t)(lr * ldc + ec0) * 2, eo1 = (uint32_t)((lr + 8) * ldc + ec1) * 2;
-      const uint32_t io0 = HAS_IN ? (uint32_t)(lr * ldin + ec0) * 2 : 0, io1 = HAS_IN ? (uint32_t)((lr + 8) * ldin + ec1) * 2 : 0;
-      bf16_t* const obase = C + (long)mw * ldc + nw;          // uniform
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const uint32_t sub = ereg + (uint32_t)((EPI == SIMX_EPI_GELU ? 0 : (i & 1)) * 2048);
-        if (HAS_IN) {
-          if (i < 7) {
-            const uint32_t nx = ereg + (uint32_t)(((i + 1) & 1) * 2048);
-            const char* ib = ibase + (long)(i + 1) * 32 * ldin;
-            P_DMA16(io0, ib, nx);
-            P_DMA16(io1, ib, nx + 1024u);
-          }
-          if (i == 0) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-          else if (i < 7) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        }
-        uint2 t0, t1, t2, t3;
-        const uint32_t ad0 = sub + slot + (uint32_t)(((0 + (fg >> 1)) ^ sw) << 4), ad1 = sub + slot + (uint32_t)(((2 + (fg >> 1)) ^ sw) << 4);
-        const uint32_t ad2 = sub + slot + (uint32_t)(((4 + (fg >> 1)) ^ sw) << 4), ad3 = sub + slot + (uint32_t)(((6 + (fg >> 1)) ^ sw) << 4);
-        if (HAS_IN) {
-          asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\ts_waitcnt lgkmcnt(0)"
-                       : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(ad0), "v"(ad1), "v"(ad2), "v"(ad3) : "memory");
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const uint32_t ad = j == 0 ? ad0 : j == 1 ? ad1 : j == 2 ? ad2 : ad3;
-          float vv[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-          if (EPI == SIMX_EPI_NONE && drop.thr) {
-            float m4[4];
-            drop_mult4(drop, (uint32_t)(mw + i * 16 + fr), (uint32_t)(nw + j * 16 + fg * 4), m4);
-            vv[0] *= m4[0]; vv[1] *= m4[1]; vv[2] *= m4[2]; vv[3] *= m4[3];
-          }
-          if (HAS_IN) {
-            const uint2 t = j == 0 ? t0 : j == 1 ? t1 : j == 2 ? t2 : t3;
-            const float x0 = __uint_as_float(t.x << 16), x1 = __uint_as_float(t.x & 0xFFFF0000u);
-            const float x2 = __uint_as_float(t.y << 16), x3 = __uint_as_float(t.y & 0xFFFF0000u);
-            if (EPI == SIMX_EPI_NONE) { vv[0] += x0; vv[1] += x1; vv[2] += x2; vv[3] += x3; }
-            else { vv[0] *= gelu_grad_fast(x0); vv[1] *= gelu_grad_fast(x1); vv[2] *= gelu_grad_fast(x2); vv[3] *= gelu_grad_fast(x3); }
-          }
-          const uint2 o = make_uint2(pack2bf(vv[0], vv[1]), pack2bf(vv[2], vv[3]));
-          asm volatile("ds_write_b64 %0, %1" ::"v"(ad), "v"(o) : "memory");
-          if (EPI == SIMX_EPI_GELU) {             // gelu of the bf16-ROUNDED pre-activation (backward reads C)
-            float g[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] = gelu_fast(bf2f(f2bf(vv[e])));
-            const uint2 og = make_uint2(pack2bf(g[0], g[1]), pack2bf(g[2], g[3]));
-            asm volatile("ds_write_b64 %0, %1 offset:2048" ::"v"(ad), "v"(og) : "memory");
-          }
-        }
-        const uint32_t rd = sub + (uint32_t)(le * 16);
-        u32x4 w0, w1;
-        asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(w0), "=&v"(w1) : "v"(rd) : "memory");
-        P_GST4(eo0, obase + (long)i * 16 * ldc, w0);
-        P_GST4(eo1, obase + (long)i * 16 * ldc, w1);
-        if (EPI == SIMX_EPI_GELU) {
-          u32x4 w2, w3;
-          asm volatile("ds_read_b128 %0, %2 offset:2048\n\tds_read_b128 %1, %2 offset:3072\n\ts_waitcnt lgkmcnt(0)"
-                       : "=&v"(w2), "=&v"(w3) : "v"(rd) : "memory");
-          bf16_t* const gbase = C2 + (long)(mw + i * 16) * ldc2 + nw;   // uniform
-          P_GST4((uint32_t)(lr * ldc2 + ec0) * 2, gbase, w2);
-          P_GST4((uint32_t)((lr + 8) * ldc2 + ec1) * 2, gbase, w3);
-        }
-      }
-    }
-    if (!has_next) break;
-    v = vn; m0 = m0n; n0 = n0n; par = (par + nst) & 1;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (dummy) stage loads must land before the LDS is released
-#undef P_LANE
-#undef P_BND_LAST
-#undef P_BND_MID
-#undef P_BND_NONE
-#undef P_STEP
-#undef V3_RD1
-#undef V3_SB
-#undef V3_MFMA_ROW
-}
-
-
 // ------------------------------------------------------------------------------------------
 // Persistent NT kernel, three A stages deep.  tools/vmem_bench shows what bounds the two-stage kernel's main loop: the
 // LDS-DMA path delivers ~36 B/clk/CU with two 64 KB stages IN FLIGHT but only ~18 with one, and the two-stage ring has
@@ -1525,6 +1277,41 @@ __global__ __launch_bounds__(256) void cast_weight_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------
 // host entry points
 // ------------------------------------------------------------------------------------------
+// Per-device launch state (simx.h: "per-device caches are initialised once per device, thread-safely"): the CU count that
+// sizes the persistent grids and the dynamic-LDS limits of the kernels that need more than 64 KB.  hipFuncSetAttribute is
+// a per-device setting, so every device the process touches gets its own std::call_once.
+struct GemmDevice { std::once_flag once; int ncu = 0; bool ok = false; };
+static GemmDevice g_gemm_dev[SIMX_MAX_DEVICES];
+static const GemmDevice* gemm_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SIMX_MAX_DEVICES) return nullptr;
+  GemmDevice& g = g_gemm_dev[dev];
+  std::call_once(g.once, [&g, dev] {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return;
+    g.ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    g.ncu -= g.ncu % 8;                           // whole XCD rows: xcd_remap assumes block b -> XCD b % 8
+    bool ok = true;
+#define SIMX_LDS_ATTR(KERNEL, BYTES) \
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)) == hipSuccess
+    SIMX_LDS_ATTR(gemm_nt_bf16_kernel<SIMX_EPI_NONE>, 2 * NT_STAGE_BYTES);
+    SIMX_LDS_ATTR(gemm_nt_bf16_kernel<SIMX_EPI_GELU>, 2 * NT_STAGE_BYTES);
+    SIMX_LDS_ATTR(gemm_nt_bf16_kernel<SIMX_EPI_DGELU>, 2 * NT_STAGE_BYTES);
+    SIMX_LDS_ATTR(gemm_tn_bf16_kernel, 2 * NT_STAGE_BYTES);
+    SIMX_LDS_ATTR(gemm_nt_bf16_v5_kernel<SIMX_EPI_NONE>, V5_LDS);
+    SIMX_LDS_ATTR(gemm_nt_bf16_v5_kernel<SIMX_EPI_GELU>, V5_LDS);
+    SIMX_LDS_ATTR(gemm_nt_bf16_v5_kernel<SIMX_EPI_DGELU>, V5_LDS);
+    SIMX_LDS_ATTR((gemm_nt_bf16_p3_kernel<SIMX_EPI_NONE, false>), P_LDS);
+    SIMX_LDS_ATTR((gemm_nt_bf16_p3_kernel<SIMX_EPI_NONE, true>), P_LDS);
+    SIMX_LDS_ATTR((gemm_nt_bf16_p3_kernel<SIMX_EPI_GELU, false>), P_LDS);
+    SIMX_LDS_ATTR((gemm_nt_bf16_p3_kernel<SIMX_EPI_DGELU, true>), P_LDS);
+    SIMX_LDS_ATTR(gemm_tn2_bf16_kernel, TN2_LDS);
+#undef SIMX_LDS_ATTR
+    g.ok = ok;
+  });
+  return g.ok ? &g : nullptr;
+}
+
 static int operand_mode(const float* p, long stride_mn, long stride_k) {
   // 1: k contiguous, 2: m/n contiguous (16-B loads need a 16-B aligned base and leading dimension), 0: scalar
   const bool al16 = (((uintptr_t)p) & 15) == 0;
@@ -1610,73 +1397,31 @@ extern "C" int simx_gemm_nt_ex(simx_stream_t stream, int dtype, int M, int N, in
                                          ldaux, (bf16_t*)C2, ldc2, 0, drop);
   const int tiles_m = cdiv(M, NT_BM), tiles_n = cdiv(N, NT_BN), nwg = tiles_m * tiles_n;
   const size_t lds = 2 * NT_STAGE_BYTES;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<SIMX_EPI_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<SIMX_EPI_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<SIMX_EPI_DGELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
+  const GemmDevice* gd = gemm_device();
+  SIMX_REQUIRE(gd != nullptr, SIMX_ERR_HIP, "gemm_nt: cannot query the current device");
   {
-    // large problems: 256x256x64 two-stage pipeline (one workgroup per CU); env SIMX_GEMM=v1 pins the small-tile kernel
+    // SIMX_GEMM pins a kernel for A/B measurements: v1 = the 128x128 kernel, v5 = the per-tile 256x256 kernel
     static const char* pin = getenv("SIMX_GEMM");
-    const bool force_v1 = pin && pin[1] == '1';
-    static bool attr5 = false;
-    if (!attr5) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_v5_kernel<SIMX_EPI_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, V5_LDS);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_v5_kernel<SIMX_EPI_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, V5_LDS);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_v5_kernel<SIMX_EPI_DGELU>), hipFuncAttributeMaxDynamicSharedMemorySize, V5_LDS);
-      attr5 = true;
-    }
+    const bool force_v1 = pin && pin[1] == '1', force_v5 = pin && pin[1] == '5';
     const int t3m = cdiv(M, 256), t3n = cdiv(N, 256), nwg3 = t3m * t3n;
-    // full-tile problems with K >= 256: persistent kernel with three A stages (SIMX_GEMM=v7 pins the two-stage one)
-    const bool force_v7 = pin && pin[1] == '7';
-    // full-tile problems: persistent kernel (SIMX_GEMM=v5 pins the per-tile kernel)
-    const bool force_v5 = pin && pin[1] == '5';
-    if (!force_v1 && !force_v5 && nwg3 >= 192 && M % 256 == 0 && N % 256 == 0 && K >= 128 && ldc % 8 == 0 &&
+    // full 256x256 tiles, K >= 256: the persistent kernel, one workgroup per CU
+    if (!force_v1 && !force_v5 && nwg3 >= 192 && M % 256 == 0 && N % 256 == 0 && K >= 256 && ldc % 8 == 0 &&
         (!residual || ldr % 8 == 0) && (!aux || ldaux % 8 == 0) && (!C2 || ldc2 % 8 == 0) &&
         !(epilogue == SIMX_EPI_DGELU && residual) && !(epilogue == SIMX_EPI_GELU && residual)) {
-      static int ncu = 0;
-      static bool attrp = false;
-      if (!attrp) {
-        int dev = 0; hipDeviceProp_t prop;
-        (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&prop, dev);
-        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        ncu -= ncu % 8;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_pers_kernel<SIMX_EPI_NONE, false>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_pers_kernel<SIMX_EPI_NONE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_pers_kernel<SIMX_EPI_GELU, false>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_pers_kernel<SIMX_EPI_DGELU, true>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_p3_kernel<SIMX_EPI_NONE, false>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_p3_kernel<SIMX_EPI_NONE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_p3_kernel<SIMX_EPI_GELU, false>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_p3_kernel<SIMX_EPI_DGELU, true>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
-        attrp = true;
-      }
-      const int grid = nwg3 < ncu ? nwg3 : ncu;
+      const int grid = nwg3 < gd->ncu ? nwg3 : gd->ncu;
       static const bool noepi_p = (getenv("SIMX_MEASUREMENT_HOOKS") != nullptr && getenv("SIMX_NOEPI") != nullptr);
       if (noepi_p) C = nullptr;
-#define LP(E, HI, INP, LDI) hipLaunchKernelGGL((gemm_nt_bf16_pers_kernel<E, HI>), dim3(grid), dim3(512), P_LDS, s, M, N, K, (const bf16_t*)A, lda, \
-                                 (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, (const bf16_t*)(INP), LDI, (bf16_t*)C2, ldc2, t3n, nwg3, drop)
-      if (K >= 256 && !force_v7) {
 #define LP3(E, HI, INP, LDI) hipLaunchKernelGGL((gemm_nt_bf16_p3_kernel<E, HI>), dim3(grid), dim3(512), P_LDS, s, M, N, K, (const bf16_t*)A, lda, \
                                  (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, (const bf16_t*)(INP), LDI, (bf16_t*)C2, ldc2, t3n, nwg3, drop)
-        if (epilogue == SIMX_EPI_NONE) { if (residual) LP3(SIMX_EPI_NONE, true, residual, ldr); else LP3(SIMX_EPI_NONE, false, nullptr, 0); }
-        else if (epilogue == SIMX_EPI_GELU) LP3(SIMX_EPI_GELU, false, nullptr, gelu_infer ? 1 : 0);
-        else LP3(SIMX_EPI_DGELU, true, aux, ldaux);
+      if (epilogue == SIMX_EPI_NONE) { if (residual) LP3(SIMX_EPI_NONE, true, residual, ldr); else LP3(SIMX_EPI_NONE, false, nullptr, 0); }
+      else if (epilogue == SIMX_EPI_GELU) LP3(SIMX_EPI_GELU, false, nullptr, gelu_infer ? 1 : 0);
+      else LP3(SIMX_EPI_DGELU, true, aux, ldaux);
 #undef LP3
-        simx_prof_retag(SIMX_K_GEMM_NT_P3);
-        SIMX_CHECK_LAUNCH("gemm_nt_bf16_p3");
-        return SIMX_OK;
-      }
-      if (epilogue == SIMX_EPI_NONE) { if (residual) LP(SIMX_EPI_NONE, true, residual, ldr); else LP(SIMX_EPI_NONE, false, nullptr, 0); }
-      else if (epilogue == SIMX_EPI_GELU) LP(SIMX_EPI_GELU, false, nullptr, 0);
-      else LP(SIMX_EPI_DGELU, true, aux, ldaux);
-#undef LP
-      SIMX_CHECK_LAUNCH("gemm_nt_bf16_pers");
+      simx_prof_retag(SIMX_K_GEMM_NT_P3);
+      SIMX_CHECK_LAUNCH("gemm_nt_bf16_p3");
       return SIMX_OK;
     }
+    // large ragged problems: the per-tile 256x256x64 two-stage kernel
     if (!force_v1 && nwg3 >= 192 && N % 8 == 0 && ldc % 8 == 0 && (!residual || ldr % 8 == 0) &&
         (!aux || ldaux % 8 == 0) && (!C2 || ldc2 % 8 == 0)) {
       static const bool noepi = (getenv("SIMX_MEASUREMENT_HOOKS") != nullptr && getenv("SIMX_NOEPI") != nullptr);
@@ -1766,11 +1511,7 @@ extern "C" int simx_gemm_tn_bias(simx_stream_t stream, int dtype, int M, int N, 
   int splits, kps;
   tn_plan(M, N, K, &splits, &kps);
   if (tn_use_v2(M, N, K)) {
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn2_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TN2_LDS);
-      attr = true;
-    }
+    SIMX_REQUIRE(gemm_device() != nullptr, SIMX_ERR_HIP, "gemm_tn: cannot query the current device");
     const int t_m = cdiv(M, 256), t_n = cdiv(N, 256), t_mn = t_m * t_n;
     if (splits == 1) {
       hipLaunchKernelGGL(gemm_tn2_bf16_kernel, dim3(t_mn), dim3(512), TN2_LDS, s, M, N, K, (const bf16_t*)A, lda,

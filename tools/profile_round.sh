@@ -13,11 +13,11 @@ cd /tmp; export TMPDIR=/tmp
 # realistic-length side measurement, so that every launch of a kernel is the headline workload's and its duration is
 # exclusive -- the same conditions as bench.py's own roofline pass, which the averages must agree with.
 export SIMX_OVERLAP_TOWERS=0
-CMD="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-realistic"
-SIMX_OVERLAP_TOWERS=1 python $R/bench.py --steps 5 --warmup 2 > $O/bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- $CMD > $O/stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- $CMD > $O/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- $CMD > $O/pmc_write.log 2>&1
+CMD="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-realistic --no-parity"
+SIMX_OVERLAP_TOWERS=1 timeout 900 python $R/bench.py --steps 5 --warmup 2 > $O/bench.json 2> $O/bench.err
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- $CMD > $O/stats.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- $CMD > $O/pmc_fetch.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- $CMD > $O/pmc_write.log 2>&1
 # MFMA utilisation from the hardware counters (BASELINE's "MFMA util %"): busy cycles of the matrix pipes per kernel, and
 # the GPU-active cycles of the same launches from a separate pass (per-kernel averages are combined in tools/traffic.py)
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA --output-format csv -d $O/pmc_mfma -o p -- $CMD > $O/pmc_mfma.log 2>&1

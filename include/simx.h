@@ -98,6 +98,11 @@ int simx_transpose_cast(simx_stream_t stream, int out_dtype, const float* w, int
  * (k-ordered f32 FMA chain; the all-pairs score matrix of M2 and its two backward products). */
 int simx_gemm_f32_strided(simx_stream_t stream, int M, int N, int K, const float* A, long a_rs, long a_cs,
                           const float* B, long b_ks, long b_ns, float* C, int ldc, int accumulate);
+/* same with a split-K workspace (simx_gemm_f32_workspace_bytes; may be NULL): problems whose 128x128 tile grid is small
+ * while K is long are contracted in K slices into f32 slabs that are then added in slice order (deterministic). */
+size_t simx_gemm_f32_workspace_bytes(int M, int N, int K);
+int simx_gemm_f32_strided_ws(simx_stream_t stream, int M, int N, int K, const float* A, long a_rs, long a_cs,
+                             const float* B, long b_ks, long b_ns, float* C, int ldc, int accumulate, void* ws, size_t ws_bytes);
 
 /* --------------------------------------------------------- embeddings + LayerNorm
  * BertEmbeddings (LEAD/modeling_bert.py:181-240): LN(word[ids] + pos[pos_ids] + type[0]). */
@@ -297,11 +302,15 @@ int simx_sim_loss_fwd_bwd(simx_stream_t stream, int B, int D, int H,
  * multi-GPU semantics of caculate_cont_loss (PROD/ProD_base/train_DE_model_marco.py:224-278):
  * q [Q,H], ctx [C,H] are the rank-ordered global concatenations; gradients are produced only for
  * rows [q_lo,q_lo+q_n) of q and [c_lo,c_lo+c_n) of ctx (the local slots).  scores [Q,C] f32 scratch.
- * losses[4] = {loss, 0, 0, correct_count}; loss_scale multiplies loss and grads (1 = none). */
+ * losses[4] = {loss, 0, 0, correct_count}; loss_scale multiplies loss and grads (1 = none).
+ * ws / ws_bytes: split-K workspace of the two backward products (simx_scores_workspace_bytes; NULL = unsplit: correct,
+ * but dQ of a gathered batch -- q_n x H outputs contracted over all C passages -- then runs on a handful of CUs). */
+size_t simx_scores_workspace_bytes(int Q, int C, int H, int q_n, int c_n);
 int simx_scores_nll_fwd_bwd(simx_stream_t stream, int Q, int C, int H,
                             const float* q, const float* ctx, const int32_t* pos_idx,
                             float loss_scale, int q_lo, int q_n, int c_lo, int c_n,
-                            float* scores, float* row_stats, float* losses, float* dq_local, float* dctx_local);
+                            float* scores, float* row_stats, float* losses, float* dq_local, float* dctx_local,
+                            void* ws, size_t ws_bytes);
 
 /* L4: BiEncoderKDLoss.calc, KD_softmax (PROD/ProD_KD/model/models.py:970-1038, kd_loss :772-781) on all-pairs scores
  * of the student (q [Q,H], ctx [C,H]) and of the teacher embeddings (tq [Q,HT], tctx [C,HT], constants):
@@ -312,7 +321,8 @@ int simx_scores_kd_fwd_bwd(simx_stream_t stream, int Q, int C, int H, int HT,
                            const float* q, const float* ctx, const float* tq, const float* tctx,
                            const int32_t* pos_idx, float temperature, float ce_w, float kd_w, float loss_scale,
                            int q_lo, int q_n, int c_lo, int c_n,
-                           float* scores, float* tscores, float* losses, float* dq_local, float* dctx_local);
+                           float* scores, float* tscores, float* losses, float* dq_local, float* dctx_local,
+                           void* ws, size_t ws_bytes);
 
 /* -------------------------------------------------------------- D1: device-side batch assembly
  * The collate of SimANS/utils/MARCO_until_new.py:204-258 (Rocketqa_v2Dataset.__getitem__ tail +

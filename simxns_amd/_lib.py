@@ -62,6 +62,7 @@ SIGNATURES = {
     "simx_cast_weight": (_i, [_p, _p, _i, _i, _p, _p]),
     "simx_transpose_cast": (_i, [_p, _i, _p, _i, _i, _p, _p]),
     "simx_gemm_f32_strided": (_i, [_p, _i, _i, _i, _p, _l, _l, _p, _l, _l, _p, _i, _i]),
+    "simx_gemm_f32_strided_ws": (_i, [_p, _i, _i, _i, _p, _l, _l, _p, _l, _l, _p, _i, _i, _p, _z]),
     "simx_embed_ln_fwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _p]),
     "simx_embed_ln_bwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p]),
     "simx_embed_ln_bwd_seq": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p]),
@@ -86,8 +87,10 @@ SIGNATURES = {
     "simx_seq_mean_fwd": (_i, [_p, _i, _i, _i, _p, _p, _p]),
     "simx_seq_mean_bwd": (_i, [_p, _i, _i, _i, _p, _p, _p]),
     "simx_sim_loss_fwd_bwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _lpp, _p, _p, _p, _p]),
-    "simx_scores_nll_fwd_bwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _f, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
-    "simx_scores_kd_fwd_bwd": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _f, _f, _f, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "simx_scores_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
+    "simx_scores_nll_fwd_bwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _f, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z]),
+    "simx_scores_kd_fwd_bwd": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _f, _f, _f, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z]),
+    "simx_gemm_f32_workspace_bytes": (_z, [_i, _i, _i]),
     "simx_assemble_batch": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "simx_ip_scores": (_i, [_p, _i, _i, _i, _p, _p, _p, C.c_long]),
     "simx_topk_update": (_i, [_p, _i, _i, _p, C.c_long, _p, C.c_long, C.c_int64, _i, _p, _p]),

@@ -102,8 +102,13 @@ template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(
     int M, int N, int K, const float* __restrict__ A, long a_rs, long a_cs, const float* __restrict__ B, long b_ks, long b_ns,
     float* __restrict__ C, int ldc, const float* __restrict__ bias, const float* __restrict__ res, int ldr,
-    const float* __restrict__ aux, int ldaux, float* __restrict__ C2, int ldc2, int accumulate, DropCtx drop, int a_mode, int b_mode) {
+    const float* __restrict__ aux, int ldaux, float* __restrict__ C2, int ldc2, int accumulate, DropCtx drop, int a_mode, int b_mode,
+    int k_per_split, long slab_stride) {
   // mode 0: scalar loads; 1: 16-B loads along k (k contiguous); 2: 16-B loads along m / n (m / n contiguous)
+  // split-K (k_per_split > 0, plain epilogue only): block z contracts k in [z*kps, (z+1)*kps) into slab z of C (= the
+  // workspace); slab_reduce_kernel adds the slabs in index order, so the result does not depend on scheduling
+  const int k_lo = k_per_split > 0 ? (int)blockIdx.z * k_per_split : 0;
+  if (k_per_split > 0) { K = min(K, k_lo + k_per_split); C += (long)blockIdx.z * slab_stride; }
   __shared__ __attribute__((aligned(16))) float As[2][16 * FM_PITCH];
   __shared__ __attribute__((aligned(16))) float Bs[2][16 * FM_PITCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -163,18 +168,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(
     }
   };
   // B is addressed as B[k*b_ks + n*b_ns]: "row" index = n with stride b_ns, k stride b_ks
-  load_stage(A, a_rs, a_cs, m0, M, 0, a_mode, ra);
-  load_stage(B, b_ns, b_ks, n0, N, 0, b_mode, rb);
+  load_stage(A, a_rs, a_cs, m0, M, k_lo, a_mode, ra);
+  load_stage(B, b_ns, b_ks, n0, N, k_lo, b_mode, rb);
   store_stage(As[0], a_mode, ra);
   store_stage(Bs[0], b_mode, rb);
   __syncthreads();
-  const int nst = (K + 15) / 16;
+  const int nst = (K - k_lo + 15) / 16;
   const int fm = lane & 31, fk = lane >> 5;
   for (int st = 0; st < nst; ++st) {
     const int cur = st & 1;
     if (st + 1 < nst) {
-      load_stage(A, a_rs, a_cs, m0, M, (st + 1) * 16, a_mode, ra);
-      load_stage(B, b_ns, b_ks, n0, N, (st + 1) * 16, b_mode, rb);
+      load_stage(A, a_rs, a_cs, m0, M, k_lo + (st + 1) * 16, a_mode, ra);
+      load_stage(B, b_ns, b_ks, n0, N, k_lo + (st + 1) * 16, b_mode, rb);
     }
     const float* sa = As[cur] + wr * 64 + fm;
     const float* sb = Bs[cur] + wc * 64 + fm;
@@ -1319,13 +1324,48 @@ static int operand_mode(const float* p, long stride_mn, long stride_k) {
   if (stride_mn == 1 && al16 && stride_k % 4 == 0) return 2;
   return 0;
 }
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int splits, int M, int N, float* __restrict__ C,
+                                   int ldc, int accumulate);
+// Split-K plan of the f32 MFMA kernel for problems whose 128x128 tile grid leaves most of the chip idle while K is long
+// (parity-mode wgrad: K = tokens; M2's dQ: K = the gathered passages).  Needs a workspace of splits*M*N floats.
+static int f32_splits(int M, int N, int K, size_t ws_bytes) {
+  const long blocks = (long)cdiv(M, 128) * cdiv(N, 128);
+  if (blocks >= 256 || K < 1024 || (N % 4) != 0) return 1;
+  long sp = 512 / blocks;
+  if (sp > K / 256) sp = K / 256;
+  const long cap = (long)(ws_bytes / ((size_t)M * N * sizeof(float)));
+  if (sp > cap) sp = cap;
+  return sp < 2 ? 1 : (int)sp;
+}
+extern "C" size_t simx_gemm_f32_workspace_bytes(int M, int N, int K) {
+  const int sp = f32_splits(M, N, K, (size_t)1 << 62);
+  return sp > 1 ? (size_t)sp * M * N * sizeof(float) : 0;
+}
 static int launch_f32_mfma(hipStream_t s, int epi, int M, int N, int K, const float* A, long a_rs, long a_cs, const float* B,
                            long b_ks, long b_ns, float* C, int ldc, const float* bias, const float* res, int ldr,
-                           const float* aux, int ldaux, float* C2, int ldc2, int accumulate, DropCtx drop) {
+                           const float* aux, int ldaux, float* C2, int ldc2, int accumulate, DropCtx drop, void* ws = nullptr,
+                           size_t ws_bytes = 0) {
   dim3 grid(cdiv(N, 128), cdiv(M, 128));
   const int am = operand_mode(A, a_rs, a_cs), bm = operand_mode(B, b_ns, b_ks);
+  if (epi == SIMX_EPI_NONE && !bias && !res && !drop.thr && ws && (((uintptr_t)ws) & 15) == 0 && ldc % 4 == 0 &&
+      (((uintptr_t)C) & 15) == 0) {
+    const int sp = f32_splits(M, N, K, ws_bytes);
+    if (sp > 1) {
+      const int kps = cdiv(cdiv(K, sp), 16) * 16;
+      const int nsp = cdiv(K, kps);
+      hipLaunchKernelGGL((gemm_f32_mfma_kernel<SIMX_EPI_NONE>), dim3(grid.x, grid.y, nsp), dim3(256), 0, s, M, N, K, A, a_rs, a_cs, B, b_ks,
+                         b_ns, (float*)ws, N, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, 0, drop, am, bm, kps, (long)M * N);
+      SIMX_CHECK_LAUNCH("gemm_f32_mfma(split)");
+      const long tot4 = (long)M * N / 4;
+      int rb = (int)((tot4 + 255) / 256);
+      if (rb > 2048) rb = 2048;
+      hipLaunchKernelGGL(slab_reduce_kernel, dim3(rb), dim3(256), 0, s, (const float*)ws, (long)M * N, nsp, M, N, C, ldc, accumulate);
+      SIMX_CHECK_LAUNCH("slab_reduce");
+      return SIMX_OK;
+    }
+  }
 #define LF(E) hipLaunchKernelGGL((gemm_f32_mfma_kernel<E>), grid, dim3(256), 0, s, M, N, K, A, a_rs, a_cs, B, b_ks, b_ns, C, ldc, bias, \
-                                 res, ldr, aux, ldaux, C2, ldc2, accumulate, drop, am, bm)
+                                 res, ldr, aux, ldaux, C2, ldc2, accumulate, drop, am, bm, 0, 0L)
   if (epi == SIMX_EPI_NONE) LF(SIMX_EPI_NONE);
   else if (epi == SIMX_EPI_GELU) LF(SIMX_EPI_GELU);
   else LF(SIMX_EPI_DGELU);
@@ -1337,11 +1377,13 @@ static int launch_f32_mfma(hipStream_t s, int epi, int M, int N, int K, const fl
 template <typename TI, typename TO>
 static int launch_simple(hipStream_t s, int epi, int M, int N, int K, const TI* A, long a_rs, long a_cs,
                          const TI* B, long b_ks, long b_ns, TO* C, int ldc, const float* bias, const TI* res, int ldr,
-                         const TI* aux, int ldaux, TO* C2, int ldc2, int accumulate, DropCtx drop = DropCtx{0u, 1.f, 0u, 0u}) {
+                         const TI* aux, int ldaux, TO* C2, int ldc2, int accumulate, DropCtx drop = DropCtx{0u, 1.f, 0u, 0u},
+                         void* ws = nullptr, size_t ws_bytes = 0) {
   if constexpr (std::is_same<TI, float>::value && std::is_same<TO, float>::value) {
     static const char* pin = getenv("SIMX_GEMM_F32");           // SIMX_GEMM_F32=fma pins the VALU kernel (A/B measurements)
     if (!(pin && pin[0] == 'f'))
-      return launch_f32_mfma(s, epi, M, N, K, A, a_rs, a_cs, B, b_ks, b_ns, C, ldc, bias, res, ldr, aux, ldaux, C2, ldc2, accumulate, drop);
+      return launch_f32_mfma(s, epi, M, N, K, A, a_rs, a_cs, B, b_ks, b_ns, C, ldc, bias, res, ldr, aux, ldaux, C2, ldc2, accumulate, drop,
+                             ws, ws_bytes);
   }
   dim3 grid(cdiv(N, 64), cdiv(M, 64));
 #define L(E) hipLaunchKernelGGL((gemm_simple_kernel<TI, TO, E>), grid, dim3(256), 0, s, M, N, K, A, a_rs, a_cs, B, b_ks, \
@@ -1472,7 +1514,8 @@ static void tn_plan(int M, int N, int K, int* splits, int* k_per_split) {
 extern "C" size_t simx_gemm_tn_workspace_bytes(int M, int N, int K) {
   int s, kps;
   tn_plan(M, N, K, &s, &kps);
-  return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+  const size_t bf = s > 1 ? (size_t)s * M * N * sizeof(float) : 0, f32 = simx_gemm_f32_workspace_bytes(M, N, K);
+  return bf > f32 ? bf : f32;                   // (the dtype is not an argument: enough for either)
 }
 
 extern "C" int simx_gemm_tn_bias(simx_stream_t stream, int dtype, int M, int N, int K, const void* A, int lda,
@@ -1493,7 +1536,7 @@ extern "C" int simx_gemm_tn_bias(simx_stream_t stream, int dtype, int M, int N, 
   if (dtype == SIMX_F32) {
     if (dbias) { int rcb = simx_colsum(stream, dtype, K, M, A, lda, dbias, 1); if (rcb) return rcb; }
     return launch_simple<float, float>(s, SIMX_EPI_NONE, M, N, K, (const float*)A, 1, lda, (const float*)B, ldb, 1, C,
-                                       ldc, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, accumulate);
+                                       ldc, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, accumulate, DropCtx{0u, 1.f, 0u, 0u}, ws, ws_bytes);
   }
   SIMX_REQUIRE(dtype == SIMX_BF16, SIMX_ERR_BAD_DTYPE, "gemm_tn: dtype %d", dtype);
   const bool fast = (M % 8 == 0) && (N % 8 == 0) && (lda % 8 == 0) && (ldb % 8 == 0) && (ldc % 4 == 0) && aligned16(A) &&
@@ -1598,9 +1641,14 @@ extern "C" int simx_cast_weight(simx_stream_t stream, const float* w, int rows, 
   return simx_transpose_cast(stream, SIMX_BF16, w, rows, cols, w_bf16, wT_bf16);
 }
 
-extern "C" int simx_gemm_f32_strided(simx_stream_t stream, int M, int N, int K, const float* A, long a_rs, long a_cs,
-                                     const float* B, long b_ks, long b_ns, float* C, int ldc, int accumulate) {
+extern "C" int simx_gemm_f32_strided_ws(simx_stream_t stream, int M, int N, int K, const float* A, long a_rs, long a_cs,
+                                        const float* B, long b_ks, long b_ns, float* C, int ldc, int accumulate, void* ws,
+                                        size_t ws_bytes) {
   SIMX_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C, SIMX_ERR_BAD_SHAPE, "gemm_f32_strided: bad arguments");
   return launch_simple<float, float>((hipStream_t)stream, SIMX_EPI_NONE, M, N, K, A, a_rs, a_cs, B, b_ks, b_ns, C, ldc, nullptr,
-                                     nullptr, 0, nullptr, 0, nullptr, 0, accumulate);
+                                     nullptr, 0, nullptr, 0, nullptr, 0, accumulate, DropCtx{0u, 1.f, 0u, 0u}, ws, ws_bytes);
+}
+extern "C" int simx_gemm_f32_strided(simx_stream_t stream, int M, int N, int K, const float* A, long a_rs, long a_cs,
+                                     const float* B, long b_ks, long b_ns, float* C, int ldc, int accumulate) {
+  return simx_gemm_f32_strided_ws(stream, M, N, K, A, a_rs, a_cs, B, b_ks, b_ns, C, ldc, accumulate, nullptr, 0);
 }

@@ -217,6 +217,16 @@ __global__ __launch_bounds__(256) void kd_rows_kernel(int Q, int C, float* __res
 // strided f32 GEMM from gemm.hip
 extern "C" int simx_gemm_f32_strided(simx_stream_t stream, int M, int N, int K, const float* A, long a_rs, long a_cs,
                                      const float* B, long b_ks, long b_ns, float* C, int ldc, int accumulate);
+extern "C" int simx_gemm_f32_strided_ws(simx_stream_t stream, int M, int N, int K, const float* A, long a_rs, long a_cs,
+                                        const float* B, long b_ks, long b_ns, float* C, int ldc, int accumulate, void* ws,
+                                        size_t ws_bytes);
+extern "C" size_t simx_gemm_f32_workspace_bytes(int M, int N, int K);
+
+// split-K workspace of the two backward products (dQ_loc: [q_n,H] over K = C; dC_loc: [c_n,H] over K = Q)
+extern "C" size_t simx_scores_workspace_bytes(int Q, int C, int H, int q_n, int c_n) {
+  const size_t a = q_n > 0 ? simx_gemm_f32_workspace_bytes(q_n, H, C) : 0, b = c_n > 0 ? simx_gemm_f32_workspace_bytes(c_n, H, Q) : 0;
+  return a > b ? a : b;
+}
 
 extern "C" int simx_sim_loss_fwd_bwd(simx_stream_t stream, int B, int D, int H, const float* q, const float* ctx,
                                      const float* teacher, const simx_loss_params* lp, float* sim, float* losses,
@@ -238,7 +248,8 @@ extern "C" int simx_sim_loss_fwd_bwd(simx_stream_t stream, int B, int D, int H, 
 
 extern "C" int simx_scores_nll_fwd_bwd(simx_stream_t stream, int Q, int C, int H, const float* q, const float* ctx,
                                        const int32_t* pos_idx, float loss_scale, int q_lo, int q_n, int c_lo, int c_n,
-                                       float* scores, float* row_stats, float* losses, float* dq_local, float* dctx_local) {
+                                       float* scores, float* row_stats, float* losses, float* dq_local, float* dctx_local,
+                                       void* ws, size_t ws_bytes) {
   hipStream_t s = (hipStream_t)stream;
   SIMX_REQUIRE(Q > 0 && C > 0 && H > 0, SIMX_ERR_BAD_SHAPE, "scores_nll: bad shape");
   SIMX_REQUIRE(q_lo >= 0 && q_n >= 0 && q_lo + q_n <= Q && c_lo >= 0 && c_n >= 0 && c_lo + c_n <= C, SIMX_ERR_BAD_SHAPE,
@@ -250,11 +261,11 @@ extern "C" int simx_scores_nll_fwd_bwd(simx_stream_t stream, int Q, int C, int H
   hipLaunchKernelGGL(nll_rows_kernel, dim3(cdiv(Q, 4)), dim3(256), 0, s, Q, C, scores, pos_idx, ls / (float)Q, ls, row_stats, losses);
   SIMX_CHECK_LAUNCH("nll_rows");
   if (q_n > 0 && dq_local) {                                                                // dQ_loc = dS[rows] ctx
-    rc = simx_gemm_f32_strided(stream, q_n, H, C, scores + (long)q_lo * C, C, 1, ctx, H, 1, dq_local, H, 0);
+    rc = simx_gemm_f32_strided_ws(stream, q_n, H, C, scores + (long)q_lo * C, C, 1, ctx, H, 1, dq_local, H, 0, ws, ws_bytes);
     if (rc) return rc;
   }
   if (c_n > 0 && dctx_local) {                                                              // dC_loc = dS[:,cols]^T q
-    rc = simx_gemm_f32_strided(stream, c_n, H, Q, scores + c_lo, 1, C, q, H, 1, dctx_local, H, 0);
+    rc = simx_gemm_f32_strided_ws(stream, c_n, H, Q, scores + c_lo, 1, C, q, H, 1, dctx_local, H, 0, ws, ws_bytes);
     if (rc) return rc;
   }
   return SIMX_OK;
@@ -263,7 +274,8 @@ extern "C" int simx_scores_nll_fwd_bwd(simx_stream_t stream, int Q, int C, int H
 extern "C" int simx_scores_kd_fwd_bwd(simx_stream_t stream, int Q, int C, int H, int HT, const float* q, const float* ctx,
                                       const float* tq, const float* tctx, const int32_t* pos_idx, float temperature,
                                       float ce_w, float kd_w, float loss_scale, int q_lo, int q_n, int c_lo, int c_n,
-                                      float* scores, float* tscores, float* losses, float* dq_local, float* dctx_local) {
+                                      float* scores, float* tscores, float* losses, float* dq_local, float* dctx_local,
+                                      void* ws, size_t ws_bytes) {
   hipStream_t s = (hipStream_t)stream;
   SIMX_REQUIRE(Q > 0 && C > 0 && H > 0 && HT > 0, SIMX_ERR_BAD_SHAPE, "scores_kd: bad shape");
   SIMX_REQUIRE(temperature > 0.f, SIMX_ERR_BAD_SHAPE, "scores_kd: temperature must be > 0");
@@ -280,11 +292,11 @@ extern "C" int simx_scores_kd_fwd_bwd(simx_stream_t stream, int Q, int C, int H,
                      ls / (float)Q, ls, losses);
   SIMX_CHECK_LAUNCH("kd_rows");
   if (q_n > 0 && dq_local) {
-    rc = simx_gemm_f32_strided(stream, q_n, H, C, scores + (long)q_lo * C, C, 1, ctx, H, 1, dq_local, H, 0);
+    rc = simx_gemm_f32_strided_ws(stream, q_n, H, C, scores + (long)q_lo * C, C, 1, ctx, H, 1, dq_local, H, 0, ws, ws_bytes);
     if (rc) return rc;
   }
   if (c_n > 0 && dctx_local) {
-    rc = simx_gemm_f32_strided(stream, c_n, H, Q, scores + c_lo, 1, C, q, H, 1, dctx_local, H, 0);
+    rc = simx_gemm_f32_strided_ws(stream, c_n, H, Q, scores + c_lo, 1, C, q, H, 1, dctx_local, H, 0, ws, ws_bytes);
     if (rc) return rc;
   }
   return SIMX_OK;

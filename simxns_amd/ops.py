@@ -112,6 +112,12 @@ def teacher_ce_loss(relevance_logits, grad_accum=1):
 
 
 # ------------------------------------------------------------------------------------------ M2
+def _scores_ws(Q, Cn, H, q_n, c_n, device):
+    """split-K workspace of M2's backward products (None when the shapes need none)."""
+    n = int(L.load().simx_scores_workspace_bytes(Q, Cn, H, q_n, c_n))
+    return (torch.empty(n, dtype=torch.uint8, device=device) if n else None), n
+
+
 class _NllFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, c, pos_idx, loss_scale, q_lo, q_n, c_lo, c_n):
@@ -123,9 +129,10 @@ class _NllFn(torch.autograd.Function):
         losses = torch.empty(4, dtype=torch.float32, device=q.device)
         dq = torch.zeros_like(q)
         dc = torch.zeros_like(c)
+        ws, wsb = _scores_ws(Q, Cn, H, q_n, c_n, q.device)
         L.call("simx_scores_nll_fwd_bwd", L.stream_ptr(), Q, Cn, H, L.ptr(q), L.ptr(c), L.ptr(pos),
                float(loss_scale or 1.0), q_lo, q_n, c_lo, c_n, L.ptr(scores), None, L.ptr(losses),
-               C.c_void_p(dq.data_ptr() + q_lo * H * 4), C.c_void_p(dc.data_ptr() + c_lo * H * 4))
+               C.c_void_p(dq.data_ptr() + q_lo * H * 4), C.c_void_p(dc.data_ptr() + c_lo * H * 4), L.ptr(ws) if wsb else None, wsb)
         ctx.save_for_backward(dq, dc)
         return losses[0], losses.detach()
 
@@ -156,9 +163,11 @@ class _KdFn(torch.autograd.Function):
         tscores = torch.empty(Q, Cn, dtype=torch.float32, device=q.device)
         losses = torch.empty(4, dtype=torch.float32, device=q.device)
         dq, dc = torch.zeros_like(q), torch.zeros_like(c)
+        ws, wsb = _scores_ws(Q, Cn, H, q_n, c_n, q.device)
         L.call("simx_scores_kd_fwd_bwd", L.stream_ptr(), Q, Cn, H, HT, L.ptr(q), L.ptr(c), L.ptr(tq), L.ptr(tc), L.ptr(pos),
                float(T), float(ce_w), float(kd_w), float(loss_scale or 1.0), q_lo, q_n, c_lo, c_n, L.ptr(scores),
-               L.ptr(tscores), L.ptr(losses), C.c_void_p(dq.data_ptr() + q_lo * H * 4), C.c_void_p(dc.data_ptr() + c_lo * H * 4))
+               L.ptr(tscores), L.ptr(losses), C.c_void_p(dq.data_ptr() + q_lo * H * 4), C.c_void_p(dc.data_ptr() + c_lo * H * 4),
+               L.ptr(ws) if wsb else None, wsb)
         ctx.save_for_backward(dq, dc)
         return losses[0], losses.detach()
 

@@ -153,6 +153,32 @@ def test_gemm_tn(dev, bf16, M, N, K, accumulate):
     assert_close(back(dC), ref, rtol=2e-5, atol=2e-5 * math.sqrt(K), what="gemm_tn")
 
 
+@pytest.mark.parametrize("M,N,K,acc", [(128, 768, 16384, 0), (96, 772, 5000, 1), (2048, 768, 1024, 0)])
+def test_gemm_f32_split_k(dev, M, N, K, acc):
+    """M2's backward products (dQ of the local slot over all gathered passages: few output tiles, long K) run split over K
+    into f32 slabs added in slice order -- same answer as the unsplit kernel within f32 round-off, and run-to-run identical."""
+    lib = L()
+    A, B, C0 = rnd((M, K), 1, 0.5), rnd((K, N), 2, 0.5), rnd((M, N), 3)
+    dA, dB = to_dev(A, dev), to_dev(B, dev)
+    wsb = int(lib.load().simx_gemm_f32_workspace_bytes(M, N, K))
+    assert wsb > 0 or M * N >= 256 * 128 * 128, "this shape is meant to split"
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+    outs = []
+    for rep in range(2):
+        dC = to_dev(C0, dev)
+        lib.call("simx_gemm_f32_strided_ws", lib.stream_ptr(), M, N, K, lib.ptr(dA), K, 1, lib.ptr(dB), N, 1, lib.ptr(dC), N, acc,
+                 lib.ptr(ws), wsb)
+        torch.cuda.synchronize()
+        outs.append(dC)
+    assert torch.equal(outs[0], outs[1]), "split-K result must not depend on scheduling"
+    ref = A.astype(np.float64) @ B.astype(np.float64) + (C0 if acc else 0.0)
+    assert_close(back(outs[0]), ref, rtol=2e-5, atol=2e-5 * math.sqrt(K), what="gemm_f32 split-K")
+    dU = to_dev(C0, dev)
+    lib.call("simx_gemm_f32_strided", lib.stream_ptr(), M, N, K, lib.ptr(dA), K, 1, lib.ptr(dB), N, 1, lib.ptr(dU), N, acc)
+    torch.cuda.synchronize()
+    assert_close(back(outs[0]), back(dU), rtol=1e-5, atol=1e-5 * math.sqrt(K), what="split vs unsplit")
+
+
 @pytest.mark.parametrize("bf16", [False, True])
 @pytest.mark.parametrize("M,N,K", [(768, 768, 4100), (2304, 768, 2048), (512, 256, 2111), (192, 64, 333)])
 def test_gemm_tn_fused_bias_grad(dev, bf16, M, N, K):

@@ -44,9 +44,10 @@ const char* simx_last_error(void);
  * The dense layers of BertSelfAttention / BertSelfOutput / BertIntermediate /
  * BertOutput (LEAD/modeling_bert.py:285-310, 385, 450, 463) and their backward. */
 enum { SIMX_EPI_NONE = 0,   /* C = acc (+bias) (+residual)                              */
-       SIMX_EPI_GELU = 1,   /* C = acc + bias (pre-activation), C2 = gelu_erf(C)        */
-       SIMX_EPI_DGELU = 2,  /* C = (acc (+residual)) * gelu_erf'(aux)                   */
-       SIMX_EPI_GELU_INFER = 3 /* as GELU, but C is scratch: kernels may skip storing the pre-activation (no backward) */ };
+       SIMX_EPI_GELU = 1,   /* u = acc + bias: C2 = gelu_erf(u), C = gelu_erf'(u) -- the factor backward multiplies by,
+                               kept instead of u itself (nothing downstream reads the pre-activation)             */
+       SIMX_EPI_DGELU = 2,  /* C = (acc (+residual)) * aux,  aux = the C a SIMX_EPI_GELU launch wrote           */
+       SIMX_EPI_GELU_INFER = 3 /* as GELU, but C is scratch: kernels may skip computing / storing it (no backward) */ };
 
 /* Dropout descriptor (nn.Dropout of BertEmbeddings / BertSelfAttention / BertSelfOutput / BertOutput,
  * LEAD/modeling_bert.py:239, 358, 386, 464; p = 0.1 forced in training, SimANS/model/models.py:70-72).

@@ -166,6 +166,15 @@ __device__ __forceinline__ float gelu_grad_fast(float u) {
   const float up = fmaf(fmaf(5.0f * GELU_C2, s, 3.0f * GELU_C1), s, GELU_C0);       // d/du [u p(u^2)]
   return r * fmaf(u * (1.0f - r), up, 1.0f);
 }
+// gelu(u) and gelu'(u) from ONE sigmoid: the forward's GELU epilogue stores both (the derivative in the slot the
+// pre-activation used to occupy -- backward never needs u itself), so the DGELU epilogue is a multiply
+__device__ __forceinline__ void gelu_both_fast(float u, float& g, float& dg) {
+  float s;
+  const float r = gelu_sigmoid(u, s);
+  const float up = fmaf(fmaf(5.0f * GELU_C2, s, 3.0f * GELU_C1), s, GELU_C0);
+  g = u * r;
+  dg = r * fmaf(u * (1.0f - r), up, 1.0f);
+}
 // Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7): one v_rcp + one v_exp + 7 FMAs; the exponential is shared with the derivative.
 __device__ __forceinline__ void erf_and_gauss(float u, float& erf_x, float& gauss) {
   const float x = fabsf(u) * 0.70710678118654752f;

@@ -155,7 +155,7 @@ static ALayer carve_layer(const simx_bert_cfg* c, char* b, size_t T) {
   a.x1 = b; b += al(T * H * e);
   a.z2 = b; b += al(T * H * e);
   a.xout = b; b += al(T * H * e);
-  a.u = b; b += al(T * F * e);
+  a.u = b; b += al(T * F * e);                 // gelu'(u) of the FFN pre-activation (SIMX_EPI_GELU writes it; only DGELU reads it)
   a.h = b; b += al(T * F * e);
   a.lse = (float*)b;
   return a;

@@ -77,11 +77,11 @@ __global__ __launch_bounds__(256) void gemm_simple_kernel(
         if (accumulate) v += Elem<TO>::ld(C + (long)m * ldc + n);
         Elem<TO>::st(C + (long)m * ldc + n, v);
       } else if (EPI == SIMX_EPI_GELU) {
-        Elem<TO>::st(C + (long)m * ldc + n, v);
+        Elem<TO>::st(C + (long)m * ldc + n, gelu_erf_grad(v));          // C = gelu'(u): what backward multiplies by
         Elem<TO>::st(C2 + (long)m * ldc2 + n, gelu_erf(v));
       } else {
         if (res) v += Elem<TI>::ld(res + (long)m * ldr + n);
-        Elem<TO>::st(C + (long)m * ldc + n, v * gelu_erf_grad(Elem<TI>::ld(aux + (long)m * ldaux + n)));
+        Elem<TO>::st(C + (long)m * ldc + n, v * Elem<TI>::ld(aux + (long)m * ldaux + n));
       }
     }
   }
@@ -217,11 +217,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(
           if (accumulate) v += C[(long)m * ldc + n];
           C[(long)m * ldc + n] = v;
         } else if (EPI == SIMX_EPI_GELU) {
-          C[(long)m * ldc + n] = v;
+          C[(long)m * ldc + n] = gelu_erf_grad(v);
           C2[(long)m * ldc2 + n] = gelu_erf(v);
         } else {
           if (res) v += res[(long)m * ldr + n];
-          C[(long)m * ldc + n] = v * gelu_erf_grad(aux[(long)m * ldaux + n]);
+          C[(long)m * ldc + n] = v * aux[(long)m * ldaux + n];
         }
       }
     }
@@ -342,17 +342,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(
         if (res) { float r4[4]; ld4(res + (long)m * ldr + n, r4); v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3]; }
         st4(C + (long)m * ldc + n, v);
       } else if (EPI == SIMX_EPI_GELU) {
-        st4(C + (long)m * ldc + n, v);
-        // gelu of the bf16-ROUNDED pre-activation, so that backward (which reads C) sees the same u
-        float g4[4];
+        // C = gelu'(u) (what backward multiplies by), C2 = gelu(u), both from the f32 pre-activation
+        float g4[4], d4[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) g4[e] = gelu_fast(bf2f(f2bf(v[e])));
+        for (int e = 0; e < 4; ++e) gelu_both_fast(v[e], g4[e], d4[e]);
+        st4(C + (long)m * ldc + n, d4);
         st4(C2 + (long)m * ldc2 + n, g4);
       } else {
         if (res) { float r4[4]; ld4(res + (long)m * ldr + n, r4); v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3]; }
         float u4[4]; ld4(aux + (long)m * ldaux + n, u4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_fast(u4[e]);
+        for (int e = 0; e < 4; ++e) v[e] *= u4[e];
         st4(C + (long)m * ldc + n, v);
       }
     }
@@ -525,11 +525,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_v5_kernel(
             const float x0 = __uint_as_float(t.x << 16), x1 = __uint_as_float(t.x & 0xFFFF0000u);
             const float x2 = __uint_as_float(t.y << 16), x3 = __uint_as_float(t.y & 0xFFFF0000u);
             if (EPI == SIMX_EPI_NONE) { v[0] += x0; v[1] += x1; v[2] += x2; v[3] += x3; }
-            else { v[0] *= gelu_grad_fast(x0); v[1] *= gelu_grad_fast(x1); v[2] *= gelu_grad_fast(x2); v[3] *= gelu_grad_fast(x3); }
+            else { v[0] *= x0; v[1] *= x1; v[2] *= x2; v[3] *= x3; }
           }
-          if (EPI == SIMX_EPI_GELU && pass == 1) {
+          if (EPI == SIMX_EPI_GELU) {                 // pass 0: C = gelu'(u), pass 1: C2 = gelu(u)
 #pragma unroll
-            for (int e2 = 0; e2 < 4; ++e2) v[e2] = gelu_fast(bf2f(f2bf(v[e2])));
+            for (int e2 = 0; e2 < 4; ++e2) v[e2] = pass == 0 ? gelu_grad_fast(v[e2]) : gelu_fast(v[e2]);
           }
           const uint2 o = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
           asm volatile("ds_write_b64 %0, %1" ::"v"(ad), "v"(o) : "memory");
@@ -834,17 +834,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
             const float x0 = __uint_as_float(t.x << 16), x1 = __uint_as_float(t.x & 0xFFFF0000u);
             const float x2 = __uint_as_float(t.y << 16), x3 = __uint_as_float(t.y & 0xFFFF0000u);
             if (EPI == SIMX_EPI_NONE) { vv[0] += x0; vv[1] += x1; vv[2] += x2; vv[3] += x3; }
-            else { vv[0] *= gelu_grad_fast(x0); vv[1] *= gelu_grad_fast(x1); vv[2] *= gelu_grad_fast(x2); vv[3] *= gelu_grad_fast(x3); }
+            else { vv[0] *= x0; vv[1] *= x1; vv[2] *= x2; vv[3] *= x3; }          // aux = gelu'(u), stored by the forward
           }
-          const uint2 o = make_uint2(pack2bf(vv[0], vv[1]), pack2bf(vv[2], vv[3]));
-          asm volatile("ds_write_b64 %0, %1" ::"v"(ad), "v"(o) : "memory");
-          if (EPI == SIMX_EPI_GELU) {             // gelu of the bf16-ROUNDED pre-activation (backward reads C)
+          if (EPI == SIMX_EPI_GELU) {             // C2 = gelu(u); C = gelu'(u) (skipped on the inference form: no backward)
             float g[4];
+            if (store_pre) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] = gelu_fast(bf2f(f2bf(vv[e])));
+              for (int e = 0; e < 4; ++e) gelu_both_fast(vv[e], g[e], vv[e]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) g[e] = gelu_fast(vv[e]);
+            }
             const uint2 og = make_uint2(pack2bf(g[0], g[1]), pack2bf(g[2], g[3]));
             asm volatile("ds_write_b64 %0, %1 offset:2048" ::"v"(ad), "v"(og) : "memory");
           }
+          const uint2 o = make_uint2(pack2bf(vv[0], vv[1]), pack2bf(vv[2], vv[3]));
+          asm volatile("ds_write_b64 %0, %1" ::"v"(ad), "v"(o) : "memory");
         }
         const uint32_t rd = sub + (uint32_t)(le * 16);
         u32x4 w0, w1;

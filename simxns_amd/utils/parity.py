@@ -17,7 +17,11 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.pat
 # query tokens, and d(loss)/d(logit) is ill-conditioned at logits of O(30): a logit error of 1.6 moves a softmax weight 5x),
 # median over all tensors 0.98.  The f32 engine on the same fixture: embeddings 8e-6, logits 1.5e-4 (5e-6 rel.), loss 4e-6,
 # gradient norms 1e-5, slices 6e-5 of their maximum.
-BF16_HOT_TOL = dict(emb_abs=0.26, logits_rel=0.18, teacher_logits_abs=0.14, loss_abs=0.02, gnorm_rel_median=0.027, gnorm_rel_max=0.14,
+# The scalar quantities are ONE draw of the rounding noise each: a change of rounding points anywhere in the forward (e.g. gelu
+# of the f32 pre-activation instead of its bf16 rounding) redraws them -- loss 0.0009 ... 0.025 and gradient-norm median
+# 0.8 % ... 1.8 % (a common-mode factor: every gradient scales with the softmax weights the logit errors move) over the builds
+# and boxes measured so far, with the direction measures unchanged or better (slice cosine min 0.92).  Bounds = 3x the largest.
+BF16_HOT_TOL = dict(emb_abs=0.29, logits_rel=0.18, teacher_logits_abs=0.14, loss_abs=0.08, gnorm_rel_median=0.054, gnorm_rel_max=0.19,
                     gslice_cos_min=0.55, gslice_cos_median_all=0.94)
 
 

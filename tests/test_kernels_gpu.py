@@ -83,11 +83,11 @@ def test_gemm_nt(dev, bf16, M, N, K, epi):
     if epi == 0:
         assert_close(back(dC), acc + rounded(res, bf16), what="gemm_nt none", **t)
     elif epi == 1:
-        u = back(dC)
-        assert_close(u, acc, what="gemm_nt gelu pre-activation", **t)
-        assert_close(back(dC2), obert.gelu(u), what="gemm_nt gelu", **TOL[bf16])
+        # C = gelu'(u) -- the factor backward multiplies by, stored where the pre-activation used to be -- and C2 = gelu(u)
+        assert_close(back(dC), obert.gelu_grad(acc), what="gemm_nt gelu derivative output", **t)
+        assert_close(back(dC2), obert.gelu(acc), what="gemm_nt gelu", **t)
     else:
-        assert_close(back(dC), acc * obert.gelu_grad(rounded(aux, bf16)), what="gemm_nt dgelu", **t)
+        assert_close(back(dC), acc * rounded(aux, bf16), what="gemm_nt dgelu (x stored derivative)", **t)
 
 
 @pytest.mark.parametrize("M,N,K", [(32768, 768, 128), (16384, 1536, 192), (24576, 768, 768), (16384, 768, 3072), (49152, 256, 64 * 5)])
@@ -127,11 +127,10 @@ def test_gemm_nt_persistent(dev, M, N, K, variant):
     if epi == 0:
         assert_close(back(dC), acc + (rounded(res, True) if res is not None else 0.0), what="gemm_nt persistent " + variant, **t)
     elif epi == 1:
-        u = back(dC)
-        assert_close(u, acc, what="gemm_nt persistent gelu pre-activation", **t)
-        assert_close(back(dC2), obert.gelu(u), what="gemm_nt persistent gelu", **TOL[True])
+        assert_close(back(dC), obert.gelu_grad(acc), what="gemm_nt persistent gelu derivative output", **t)
+        assert_close(back(dC2), obert.gelu(acc), what="gemm_nt persistent gelu", **t)
     else:
-        assert_close(back(dC), acc * obert.gelu_grad(rounded(aux, True)), what="gemm_nt persistent dgelu", **t)
+        assert_close(back(dC), acc * rounded(aux, True), what="gemm_nt persistent dgelu (x stored derivative)", **t)
 
 
 # ------------------------------------------------------------------------------------------ GEMM TN (wgrad)

@@ -1046,6 +1046,35 @@ __device__ __forceinline__ void tn2_stage(const bf16_t* __restrict__ A, int lda,
   }
 }
 
+// the same for a FULL stage (all 64 k-rows inside the k-range) with the per-lane byte offsets precomputed once per kernel
+// (tn2_lane_offsets): the row part of the address rides in the SGPR base, so a stage costs no VALU work at all.
+// tn2_stage above recomputes offsets and clamps per stage (~60 VALU per wave) and is kept for the ragged last stage.
+__device__ __forceinline__ void tn2_lane_offsets(int lda, int m0, int M, int ldb, int n0, int N, int lane, uint32_t (&oa)[4],
+                                                 uint32_t (&ob)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int krl = 2 * j + (lane >> 5);                      // k-row within the wave's 8 rows; (kr & 7) == krl
+    const int p16 = lane & 31;
+    const int q = (p16 >> 1) ^ (krl & 7);
+    int ca = m0 + q * 16 + (p16 & 1) * 8, cb = n0 + q * 16 + (p16 & 1) * 8;
+    ca = ca + 8 <= M ? ca : M - 8;
+    cb = cb + 8 <= N ? cb : N - 8;
+    oa[j] = (uint32_t)((lane >> 5) * lda + ca) * 2;
+    ob[j] = (uint32_t)((lane >> 5) * ldb + cb) * 2;
+  }
+}
+__device__ __forceinline__ void tn2_stage_full(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, int k0,
+                                               uint32_t sbase, int wave, const uint32_t (&oa)[4], const uint32_t (&ob)[4]) {
+  const char* ga = reinterpret_cast<const char*>(A + (long)(k0 + wave * 8) * lda);
+  const char* gb = reinterpret_cast<const char*>(B + (long)(k0 + wave * 8) * ldb);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = wave * 4 + j;
+    P_DMA16(oa[j], ga + (long)(2 * j) * lda * 2, sbase + (uint32_t)(i * 1024));
+    P_DMA16(ob[j], gb + (long)(2 * j) * ldb * 2, sbase + (uint32_t)(32768 + i * 1024));
+  }
+}
+
 // one fragment = two transpose reads (k rows base+4g.. and base+16+4g..)
 typedef __attribute__((address_space(3))) bf16x4* tn_lds4_t;
 #define TN2_RD(F_LO, F_HI, ADDR_LO, ADDR_HI)                                                        \
@@ -1097,6 +1126,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_bf16_kernel(
   const int x_lo = r_lo & 7, x_hi = (r_lo + 16) & 7;        // XOR terms (k-step bases are multiples of 32)
   const uint32_t row_lo = (uint32_t)(r_lo * 512 + (fs & 3) * 8), row_hi = (uint32_t)((r_lo + 16) * 512 + (fs & 3) * 8);
 
+  uint32_t oa[4], ob[4];
+  tn2_lane_offsets(lda, m0, M, ldb, n0, N, lane, oa, ob);
   tn2_stage(A, lda, m0, M, B, ldb, n0, N, kb, ke, smem, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
   if (nst > 1) tn2_stage(A, lda, m0, M, B, ldb, n0, N, kb + 64, ke, smem + TN2_STAGE, wave, lane);
@@ -1119,6 +1150,20 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_bf16_kernel(
     }                                                                                                           \
   } while (0)
 #define TN2_SB __builtin_amdgcn_sched_barrier(0)
+// Timing experiments (results are wrong with either; tools/build_variant.sh B -DSIMX_TN2_...), M = 262144 tokens, average of the
+// four wgrad shapes: as shipped 992 TFLOP/s; SIMX_TN2_SAMEK (every stage re-reads stage 0: all L2 hits) 1156; SIMX_TN2_NOLOAD
+// (no operand loads in the loop) 1445, 1614 on all-zero data.  So the LDS-DMA stream itself costs the loop 20 % and the
+// fabric / HBM misses another 14 %; an L2 prefetch of stage s+3 (one dword per line, counted vmcnt) made it 5 % SLOWER.
+#ifdef SIMX_TN2_SAMEK
+#define TN2_KSEL(S) 0
+#else
+#define TN2_KSEL(S) (S)
+#endif
+#ifdef SIMX_TN2_NOLOAD
+#define TN2_NOLOAD 1
+#else
+#define TN2_NOLOAD 0
+#endif
 #define TN2_PIN8(TXT, X, Y) do { } while (0)     /* waits are hipcc's (counted lgkmcnt): the reads are builtins */
 
   {
@@ -1148,7 +1193,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_bf16_kernel(
     TN2_PIN8("s_waitcnt lgkmcnt(0)", ah_lo, ah_hi);                                                             \
     if (SYNC) {                                                                                                 \
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                                             \
-      if ((ST) + 2 < nst)                                                                                       \
+      if (TN2_NOLOAD) { }                                                                                       \
+      else if ((ST) + 3 < nst || ((ST) + 3 == nst && (ke - kb) % 64 == 0))                                      \
+        tn2_stage_full(A, lda, B, ldb, kb + TN2_KSEL((ST) + 2) * 64, lds0 + (uint32_t)(((ST) & 1) * TN2_STAGE), wave, oa, ob); \
+      else if ((ST) + 2 < nst)                                                                                  \
         tn2_stage(A, lda, m0, M, B, ldb, n0, N, kb + ((ST) + 2) * 64, ke, smem + ((ST) & 1) * TN2_STAGE, wave, lane); \
       if ((ST) + 1 == nst - 1 && (ke - kb) % 64 != 0) {                                                         \
         /* ragged last stage: rows >= valid hold clamped copies -> zero them (both operands) */                \

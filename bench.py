@@ -167,6 +167,7 @@ def main():
     zero_col = torch.zeros(B, 1, dtype=torch.long, device=dev)
     nll = None
     step_no = [0]
+    teacher_stream = torch.cuda.Stream(device=dev) if os.environ.get("SIMX_TEACHER_STREAM", "1") == "1" else None
 
     def one_step():
         step_no[0] += 1
@@ -175,10 +176,21 @@ def main():
         sel = torch.cat([zero_col, neg.long() + 1], dim=1)                         # [B,1+N] rows of the query's pool
         batch = ops.assemble_batch(pool["q"], pool["p"], q_rows, (row_base + sel).to(torch.int32), 1 + N, pad_id=0, sep_id=102, ce_len=CL)
         q_ids, q_mask, c_ids, c_mask, _ = batch["student"]
-        q, c = bi(q_ids, q_mask, c_ids, c_mask)
         if args.no_teacher:
+            q, c = bi(q_ids, q_mask, c_ids, c_mask)
             z = fixed_z
+        elif teacher_stream is not None and os.environ.get("SIMX_OVERLAP_TOWERS", "1") != "0":     # (the instrumented pass serialises)
+            # the frozen teacher's forward does not depend on the student's: queue it on its own HIP stream so that the
+            # tails of one tower's kernels fill with the other's blocks (joined before the loss)
+            cur = torch.cuda.current_stream()
+            teacher_stream.wait_stream(cur)
+            with torch.cuda.stream(teacher_stream), torch.no_grad():
+                z = teacher(batch["teacher"][0], batch["teacher"][1])
+            q, c = bi(q_ids, q_mask, c_ids, c_mask)
+            cur.wait_stream(teacher_stream)
+            z.record_stream(cur)
         else:
+            q, c = bi(q_ids, q_mask, c_ids, c_mask)
             with torch.no_grad():
                 z = teacher(batch["teacher"][0], batch["teacher"][1])
         loss, distill, sim = ops.kl_distill_loss(q, c, z, 1.0, False, 1)

@@ -190,6 +190,34 @@ int simx_mha_cls_bwd(simx_stream_t stream, int dtype, int nseq, int heads, int h
                      const void* q_cls, const void* qkv, const void* dctx_cls, void* dq_cls, void* dqkv,
                      const simx_dropout* drop);
 
+/* ---- head-major q / k / v (performance layout; bf16, head size 64).  BertSelfAttention.transpose_for_scores
+ * (LEAD/modeling_bert.py:312-316) turns [T, 3H] into per-head [S, 64] views; the token-major tensor leaves each
+ * (sequence, head) block as S pieces of 128 B that sit 3H*2 B apart.  In the head-major form the packed tensor is
+ * [3][heads][hm_rows][64] (hm_rows >= T, the row capacity of a plane): the QKV projection writes it
+ * (simx_gemm_nt_hm, c_hm_rows), attention reads q/k/v and writes dq/dk/dv in it (the *_hm calls below; hm_rows = 0 is
+ * the token-major form of the plain calls), the dgrad GEMM reads dq/dk/dv as its A operand (simx_gemm_nt_hm, a_hm_rows)
+ * and the wgrad GEMM as its token-contracted operand (simx_gemm_tn_hm).  For the [CLS]-only last layer the K / V planes
+ * are planes [heads, 3*heads).  Values are identical to the token-major path; only addresses change.
+ * simx_gemm_hm_ok(rows, H, tokens) != 0 when the three GEMM forms exist for a tower of `rows` padded token rows (they
+ * run on the persistent full-tile kernels only: rows % 256 == 0, H % 256 == 0, >= 192 output tiles at N = H). */
+int simx_gemm_hm_ok(int rows, int H, int tokens);
+int simx_gemm_nt_hm(simx_stream_t stream, int dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                    void* C, int ldc, const float* bias, const void* residual, int ldr, const simx_dropout* drop,
+                    int a_hm_rows, int c_hm_rows);
+int simx_gemm_tn_hm(simx_stream_t stream, int dtype, int M, int N, int K, const void* A, int a_hm_rows, const void* B, int ldb,
+                    float* C, int ldc, int accumulate, void* ws, size_t ws_bytes, float* dbias);
+int simx_mha_fwd_hm(simx_stream_t stream, int dtype, int nseq, int heads, int head_dim, const int32_t* cu_seqlens, int max_len,
+                    int T, const void* qkv, void* ctx, float* lse, const simx_dropout* drop, int hm_rows);
+int simx_mha_bwd_hm(simx_stream_t stream, int dtype, int nseq, int heads, int head_dim, const int32_t* cu_seqlens, int max_len,
+                    int T, const void* qkv, const void* ctx, const float* lse, const void* dctx, void* dqkv,
+                    const simx_dropout* drop, int hm_rows);
+int simx_mha_cls_fwd_hm(simx_stream_t stream, int dtype, int nseq, int heads, int head_dim, const int32_t* cu_seqlens,
+                        int max_len, int T, const void* q_cls, const void* qkv, void* ctx_cls, const simx_dropout* drop,
+                        int hm_rows);
+int simx_mha_cls_bwd_hm(simx_stream_t stream, int dtype, int nseq, int heads, int head_dim, const int32_t* cu_seqlens,
+                        int max_len, int T, const void* q_cls, const void* qkv, const void* dctx_cls, void* dq_cls, void* dqkv,
+                        const simx_dropout* drop, int hm_rows);
+
 /* [CLS] slice sequence_output[:,0,:] (SimANS/model/models.py:81) -> f32 [nseq,H], and its adjoint
  * (writes dcls into the first row of each sequence of dx, zero elsewhere). */
 int simx_cls_gather(simx_stream_t stream, int dtype, int nseq, int H, const int32_t* cu_seqlens,

@@ -87,6 +87,13 @@ SIGNATURES = {
     "simx_seq_mean_fwd": (_i, [_p, _i, _i, _i, _p, _p, _p]),
     "simx_seq_mean_bwd": (_i, [_p, _i, _i, _i, _p, _p, _p]),
     "simx_sim_loss_fwd_bwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _lpp, _p, _p, _p, _p]),
+    "simx_gemm_hm_ok": (_i, [_i, _i, _i]),
+    "simx_gemm_nt_hm": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _i, _dp, _i, _i]),
+    "simx_gemm_tn_hm": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p, _z, _p]),
+    "simx_mha_fwd_hm": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _dp, _i]),
+    "simx_mha_bwd_hm": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _dp, _i]),
+    "simx_mha_cls_fwd_hm": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _dp, _i]),
+    "simx_mha_cls_bwd_hm": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _dp, _i]),
     "simx_scores_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "simx_scores_nll_fwd_bwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _f, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z]),
     "simx_scores_kd_fwd_bwd": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _f, _f, _f, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z]),

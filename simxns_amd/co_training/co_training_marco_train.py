@@ -68,6 +68,15 @@ def _bi_encode(model, q_ids, q_mask, c_ids, c_mask):
     return model(q_ids, q_mask, c_ids, c_mask)
 
 
+_SIDE_STREAMS = {}
+
+
+def _teacher_stream(device):
+    if device not in _SIDE_STREAMS:
+        _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[device]
+
+
 def train(args, model, teacher_model, tokenizer, global_step=0, dataset_cls=Rocketqa_v2Dataset, dataset_kwargs=None,
           encode_pair=_bi_encode):
     """``dataset_cls`` / ``dataset_kwargs`` / ``encode_pair`` let the MS-Doc job (Doc_training/co_training_doc_train.py:
@@ -132,9 +141,20 @@ def train(args, model, teacher_model, tokenizer, global_step=0, dataset_cls=Rock
         if train_flag == 0:                                       # retriever step: teacher distils the student
             model.train()
             teacher_model.eval()
-            local_q_vector, local_ctx_vectors = encode_pair(model, q_ids, q_mask, c_ids, c_mask)
-            with torch.no_grad():
-                relevance_logits = teacher_model(t_ids, t_mask)
+            if t_ids.is_cuda:
+                # the frozen teacher's forward is independent of the student's: its own HIP stream, joined before the loss
+                cur = torch.cuda.current_stream()
+                side = _teacher_stream(t_ids.device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side), torch.no_grad():
+                    relevance_logits = teacher_model(t_ids, t_mask)
+                local_q_vector, local_ctx_vectors = encode_pair(model, q_ids, q_mask, c_ids, c_mask)
+                cur.wait_stream(side)
+                relevance_logits.record_stream(cur)
+            else:
+                local_q_vector, local_ctx_vectors = encode_pair(model, q_ids, q_mask, c_ids, c_mask)
+                with torch.no_grad():
+                    relevance_logits = teacher_model(t_ids, t_mask)
             # einsum + softmax + KLDivLoss(batchmean)((p+1e-7).log(), softmax(z/T)) / accum : one kernel (:199-217)
             loss, distill_loss, _ = ops.kl_distill_loss(local_q_vector, local_ctx_vectors, relevance_logits,
                                                         args.temperature_distill, args.scale_simmila,

@@ -49,21 +49,39 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
   return r;
 }
 
+// Two layouts of the packed q / k / v (and dq / dk / dv) tensor:
+//   token-major (hm_rows == 0): [T][3H], row t = [q(heads x 64) | k | v] -- what a [T,3H] GEMM output looks like;
+//   head-major  (hm_rows  = R): [3][heads][R][64] -- plane (which, head) holds that head's 64 values of every token, rows
+//     128 B apart, so the 128 x 64 block one (sequence, head) workgroup reads is ONE contiguous 16 KB range instead of 128
+//     pieces of 128 B that sit 3H * 2 B apart (DRAM pages, TLB reach).  The QKV GEMM's epilogue writes it (each wave of that
+//     kernel owns exactly one head's 64 columns) and the dgrad / wgrad loaders read it (simx_gemm_nt_hm, simx_gemm_tn_hm).
+// Either way element (which w, head h, token t) sits at  base + w * ws + t * ld  with base including the head offset.
+struct QkvLay { long ws; int ld; };
+__device__ __forceinline__ QkvLay qkv_lay(int heads, int hm_rows) {
+  return hm_rows > 0 ? QkvLay{(long)heads * hm_rows * 64, 64} : QkvLay{(long)heads * 64, 3 * heads * 64};
+}
+template <typename P>
+__device__ __forceinline__ P* qkv_head(P* base, int heads, int h, int t0, int hm_rows) {
+  return hm_rows > 0 ? base + ((long)h * hm_rows + t0) * 64 : base + (long)t0 * (3 * heads * 64) + h * 64;
+}
+
 // ------------------------------------------------------------------------------------------ forward
 template <int NKT>
 __global__ __launch_bounds__(256) void mha_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
                                                            float* __restrict__ lse, const int* __restrict__ cu,
-                                                           int heads, int T, float scale, DropCtx drop) {
+                                                           int heads, int T, float scale, DropCtx drop, int hm_rows) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int seq = blockIdx.x / heads, h = blockIdx.x % heads;
   const int t0 = cu[seq], len = cu[seq + 1] - t0;
   if (len <= 0) return;
-  const int H = heads * 64, H3 = 3 * H;
-  const bf16_t* Qg = qkv + (long)t0 * H3 + h * 64;
-  const bf16_t* Kg = Qg + H;
-  const bf16_t* Vg = Kg + H;
+  const int H = heads * 64;
+  const QkvLay lay = qkv_lay(heads, hm_rows);
+  const int H3 = lay.ld;                                  // row pitch of q / k / v in either layout
+  const bf16_t* Qg = qkv_head(qkv, heads, h, t0, hm_rows);
+  const bf16_t* Kg = Qg + lay.ws;
+  const bf16_t* Vg = Kg + lay.ws;
   const int nkt = (len + 15) >> 4;
   const int nkt2 = (nkt + 1) & ~1;
   char* sK = smem;
@@ -220,17 +238,20 @@ template <int NKT>
 __global__ __launch_bounds__(256) void mha_bwd2_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ O,
                                                             const float* __restrict__ lse, const bf16_t* __restrict__ dO,
                                                             bf16_t* __restrict__ dqkv, const int* __restrict__ cu,
-                                                            int heads, int T, float scale, DropCtx drop) {
+                                                            int heads, int T, float scale, DropCtx drop, int hm_rows) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int seq = blockIdx.x / heads, h = blockIdx.x % heads;
   const int t0 = cu[seq], len = cu[seq + 1] - t0;
   if (len <= 0) return;
-  const int H = heads * 64, H3 = 3 * H;
-  const bf16_t* Qg = qkv + (long)t0 * H3 + h * 64;
-  const bf16_t* Kg = Qg + H;
-  const bf16_t* Vg = Kg + H;
+  const int H = heads * 64;
+  const QkvLay lay = qkv_lay(heads, hm_rows);
+  const int H3 = lay.ld;                                  // row pitch of q / k / v and dq / dk / dv in either layout
+  const bf16_t* Qg = qkv_head(qkv, heads, h, t0, hm_rows);
+  const bf16_t* Kg = Qg + lay.ws;
+  const bf16_t* Vg = Kg + lay.ws;
+  bf16_t* dQg = qkv_head(dqkv, heads, h, t0, hm_rows);
   const bf16_t* Og = O + (long)t0 * H + h * 64;
   const bf16_t* dOg = dO + (long)t0 * H + h * 64;
   const int nkt = (len + 15) >> 4;
@@ -338,7 +359,7 @@ __global__ __launch_bounds__(256) void mha_bwd2_bf16_kernel(const bf16_t* __rest
       dq[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(t2l, t2h), dsf, dq[2], 0, 0, 0);
       dq[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(t3l, t3h), dsf, dq[3], 0, 0, 0);
     }
-    a2_store_tile(dq, patch, patch_addr, dqkv + (long)(t0 + qt * 16) * H3 + h * 64, H3, len - qt * 16, lane);
+    a2_store_tile(dq, patch, patch_addr, dQg + (long)(qt * 16) * H3, H3, len - qt * 16, lane);
   }
 
   // ---------------- phase B: dK, dV, waves own key tiles, loop over query-tile pairs
@@ -412,9 +433,9 @@ __global__ __launch_bounds__(256) void mha_bwd2_bf16_kernel(const bf16_t* __rest
       dv[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(e3l, e3h), pf, dv[3], 0, 0, 0);
       dk[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(u3l, u3h), dsf, dk[3], 0, 0, 0);
     }
-    bf16_t* dstk = dqkv + (long)(t0 + kt * 16) * H3 + H + h * 64;
+    bf16_t* dstk = dQg + lay.ws + (long)(kt * 16) * H3;
     a2_store_tile(dk, patch, patch_addr, dstk, H3, len - kt * 16, lane);
-    a2_store_tile(dv, patch, patch_addr, dstk + H, H3, len - kt * 16, lane);
+    a2_store_tile(dv, patch, patch_addr, dstk + lay.ws, H3, len - kt * 16, lane);
   }
 }
 
@@ -843,6 +864,11 @@ extern "C" int simx_mha_fwd_ex(simx_stream_t stream, int dtype, int nseq, int he
 extern "C" int simx_mha_bwd_ex(simx_stream_t stream, int dtype, int nseq, int heads, int d, const int32_t* cu, int max_len,
                                int T, const void* qkv, const void* ctx, const float* lse, const void* dctx, void* dqkv,
                                const simx_dropout* dropd);
+extern "C" int simx_mha_fwd_hm(simx_stream_t stream, int dtype, int nseq, int heads, int d, const int32_t* cu, int max_len,
+                               int T, const void* qkv, void* ctx, float* lse, const simx_dropout* dropd, int hm_rows);
+extern "C" int simx_mha_bwd_hm(simx_stream_t stream, int dtype, int nseq, int heads, int d, const int32_t* cu, int max_len,
+                               int T, const void* qkv, const void* ctx, const float* lse, const void* dctx, void* dqkv,
+                               const simx_dropout* dropd, int hm_rows);
 extern "C" int simx_mha_fwd(simx_stream_t stream, int dtype, int nseq, int heads, int d, const int32_t* cu, int max_len,
                             int T, const void* qkv, void* ctx, float* lse) {
   return simx_mha_fwd_ex(stream, dtype, nseq, heads, d, cu, max_len, T, qkv, ctx, lse, nullptr);
@@ -854,7 +880,13 @@ extern "C" int simx_mha_bwd(simx_stream_t stream, int dtype, int nseq, int heads
 
 extern "C" int simx_mha_fwd_ex(simx_stream_t stream, int dtype, int nseq, int heads, int d, const int32_t* cu, int max_len,
                                int T, const void* qkv, void* ctx, float* lse, const simx_dropout* dropd) {
+  return simx_mha_fwd_hm(stream, dtype, nseq, heads, d, cu, max_len, T, qkv, ctx, lse, dropd, 0);
+}
+extern "C" int simx_mha_fwd_hm(simx_stream_t stream, int dtype, int nseq, int heads, int d, const int32_t* cu, int max_len,
+                               int T, const void* qkv, void* ctx, float* lse, const simx_dropout* dropd, int hm_rows) {
   hipStream_t s = (hipStream_t)stream;
+  SIMX_REQUIRE(hm_rows == 0 || (dtype == SIMX_BF16 && d == 64 && max_len <= 512 && hm_rows >= T), SIMX_ERR_UNSUPPORTED,
+               "mha_fwd: the head-major qkv layout needs bf16, head size 64, max_len <= 512 and hm_rows >= T");
   const DropCtx drop = make_drop(dropd);
   SIMX_PROF(SIMX_K_MHA_FWD, s, 4.0 * T * max_len * heads * d);
   int rc = check_common(dtype, nseq, heads, d, max_len, T, "mha_fwd");
@@ -867,7 +899,7 @@ extern "C" int simx_mha_fwd_ex(simx_stream_t stream, int dtype, int nseq, int he
     rc = set_lds(mha_fwd_bf16_kernel<NKT>, lds, "mha_fwd");                                                          \
     if (rc) return rc;                                                                                               \
     hipLaunchKernelGGL((mha_fwd_bf16_kernel<NKT>), dim3(nseq * heads), dim3(256), lds, s, (const bf16_t*)qkv,        \
-                       (bf16_t*)ctx, lse, cu, heads, T, scale, drop);                                                \
+                       (bf16_t*)ctx, lse, cu, heads, T, scale, drop, hm_rows);                                       \
   } while (0)
     if (max_len <= 32) LF(2);
     else if (max_len <= 128) LF(8);
@@ -898,7 +930,14 @@ extern "C" int simx_mha_fwd_ex(simx_stream_t stream, int dtype, int nseq, int he
 extern "C" int simx_mha_bwd_ex(simx_stream_t stream, int dtype, int nseq, int heads, int d, const int32_t* cu, int max_len,
                                int T, const void* qkv, const void* ctx, const float* lse, const void* dctx, void* dqkv,
                                const simx_dropout* dropd) {
+  return simx_mha_bwd_hm(stream, dtype, nseq, heads, d, cu, max_len, T, qkv, ctx, lse, dctx, dqkv, dropd, 0);
+}
+extern "C" int simx_mha_bwd_hm(simx_stream_t stream, int dtype, int nseq, int heads, int d, const int32_t* cu, int max_len,
+                               int T, const void* qkv, const void* ctx, const float* lse, const void* dctx, void* dqkv,
+                               const simx_dropout* dropd, int hm_rows) {
   hipStream_t s = (hipStream_t)stream;
+  SIMX_REQUIRE(hm_rows == 0 || (dtype == SIMX_BF16 && d == 64 && max_len <= 256 && hm_rows >= T), SIMX_ERR_UNSUPPORTED,
+               "mha_bwd: the head-major qkv layout needs bf16, head size 64, max_len <= 256 and hm_rows >= T");
   const DropCtx drop = make_drop(dropd);
   SIMX_PROF(SIMX_K_MHA_BWD, s, 8.0 * T * max_len * heads * d);
   int rc = check_common(dtype, nseq, heads, d, max_len, T, "mha_bwd");
@@ -911,7 +950,7 @@ extern "C" int simx_mha_bwd_ex(simx_stream_t stream, int dtype, int nseq, int he
     rc = set_lds(mha_bwd2_bf16_kernel<NKT>, lds, "mha_bwd");                                                         \
     if (rc) return rc;                                                                                               \
     hipLaunchKernelGGL((mha_bwd2_bf16_kernel<NKT>), dim3(nseq * heads), dim3(256), lds, s, (const bf16_t*)qkv,       \
-                       (const bf16_t*)ctx, lse, (const bf16_t*)dctx, (bf16_t*)dqkv, cu, heads, T, scale, drop);      \
+                       (const bf16_t*)ctx, lse, (const bf16_t*)dctx, (bf16_t*)dqkv, cu, heads, T, scale, drop, hm_rows); \
   } while (0)
     if (max_len <= 32) LB(2);
     else if (max_len <= 128) LB(8);
@@ -960,7 +999,7 @@ extern "C" int simx_mha_bwd_ex(simx_stream_t stream, int dtype, int nseq, int he
 template <typename T>
 __global__ __launch_bounds__(256) void mha_cls_fwd_kernel(int nitems, int heads, int d, int H, int Ttot, int max_len, float scale,
                                                           const int* __restrict__ cu, const T* __restrict__ qc,
-                                                          const T* __restrict__ qkv, T* __restrict__ ctxc, DropCtx drop) {
+                                                          const T* __restrict__ qkv, T* __restrict__ ctxc, DropCtx drop, int hm_rows) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int item = blockIdx.x * 4 + w;
@@ -971,11 +1010,13 @@ __global__ __launch_bounds__(256) void mha_cls_fwd_kernel(int nitems, int heads,
   const int t0 = cu[s], len = cu[s + 1] - t0;
   for (int c = lane; c < d; c += 64) sq[c] = Elem<T>::ld(qc + (long)s * H + h * d + c);
   __builtin_amdgcn_wave_barrier();
-  const T* Kb = qkv + (long)t0 * 3 * H + H + h * d;
-  const T* Vb = qkv + (long)t0 * 3 * H + 2 * H + h * d;
+  // (head-major: d == 64, plane (which, head) = [hm_rows][64]; see QkvLay)
+  const long ld = hm_rows > 0 ? 64 : 3 * (long)H;
+  const T* Kb = hm_rows > 0 ? qkv + ((long)(heads + h) * hm_rows + t0) * 64 : qkv + (long)t0 * 3 * H + H + h * d;
+  const T* Vb = hm_rows > 0 ? qkv + ((long)(2 * heads + h) * hm_rows + t0) * 64 : qkv + (long)t0 * 3 * H + 2 * H + h * d;
   float mx = -3.0e38f;
   for (int j = lane; j < len; j += 64) {
-    const T* kr = Kb + (long)j * 3 * H;
+    const T* kr = Kb + (long)j * ld;
     float acc = 0.f;
     for (int c = 0; c < d; c += 4) {
       float k4[4];
@@ -999,7 +1040,7 @@ __global__ __launch_bounds__(256) void mha_cls_fwd_kernel(int nitems, int heads,
   __builtin_amdgcn_wave_barrier();
   for (int c = lane; c < d; c += 64) {
     float o = 0.f;
-    for (int j = 0; j < len; ++j) o = fmaf(sp[j], Elem<T>::ld(Vb + (long)j * 3 * H + c), o);
+    for (int j = 0; j < len; ++j) o = fmaf(sp[j], Elem<T>::ld(Vb + (long)j * ld + c), o);
     Elem<T>::st(ctxc + (long)s * H + h * d + c, o);
   }
 }
@@ -1008,7 +1049,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void mha_cls_bwd_kernel(int nitems, int heads, int d, int H, int Ttot, int max_len, float scale,
                                                           const int* __restrict__ cu, const T* __restrict__ qc,
                                                           const T* __restrict__ qkv, const T* __restrict__ dctxc,
-                                                          T* __restrict__ dqc, T* __restrict__ dqkv, DropCtx drop) {
+                                                          T* __restrict__ dqc, T* __restrict__ dqkv, DropCtx drop, int hm_rows) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int item = blockIdx.x * 4 + w;
@@ -1025,12 +1066,14 @@ __global__ __launch_bounds__(256) void mha_cls_bwd_kernel(int nitems, int heads,
     sdo[c] = Elem<T>::ld(dctxc + (long)s * H + h * d + c);
   }
   __builtin_amdgcn_wave_barrier();
-  const T* Kb = qkv + (long)t0 * 3 * H + H + h * d;
-  const T* Vb = qkv + (long)t0 * 3 * H + 2 * H + h * d;
+  // (head-major: d == 64, plane (which, head) = [hm_rows][64]; see QkvLay)
+  const long ld = hm_rows > 0 ? 64 : 3 * (long)H;
+  const T* Kb = hm_rows > 0 ? qkv + ((long)(heads + h) * hm_rows + t0) * 64 : qkv + (long)t0 * 3 * H + H + h * d;
+  const T* Vb = hm_rows > 0 ? qkv + ((long)(2 * heads + h) * hm_rows + t0) * 64 : qkv + (long)t0 * 3 * H + 2 * H + h * d;
   float mx = -3.0e38f;
   for (int j = lane; j < len; j += 64) {
-    const T* kr = Kb + (long)j * 3 * H;
-    const T* vr = Vb + (long)j * 3 * H;
+    const T* kr = Kb + (long)j * ld;
+    const T* vr = Vb + (long)j * ld;
     float acc = 0.f, dp = 0.f;
     for (int c = 0; c < d; c += 4) {
       float k4[4], v4[4];
@@ -1062,23 +1105,30 @@ __global__ __launch_bounds__(256) void mha_cls_bwd_kernel(int nitems, int heads,
   dot = wave_sum(dot);
   for (int j = lane; j < len; j += 64) sds[j] = sp[j] * (sds[j] - dot) * scale;
   __builtin_amdgcn_wave_barrier();
-  T* dKb = dqkv + (long)t0 * 3 * H + H + h * d;
-  T* dVb = dqkv + (long)t0 * 3 * H + 2 * H + h * d;
+  T* dKb = hm_rows > 0 ? dqkv + ((long)(heads + h) * hm_rows + t0) * 64 : dqkv + (long)t0 * 3 * H + H + h * d;
+  T* dVb = hm_rows > 0 ? dqkv + ((long)(2 * heads + h) * hm_rows + t0) * 64 : dqkv + (long)t0 * 3 * H + 2 * H + h * d;
   for (int c = lane; c < d; c += 64) {
     const float qv = sq[c], dov = sdo[c];
     float dq = 0.f;
     for (int j = 0; j < len; ++j) {
       const float ds = sds[j];
-      dq = fmaf(ds, Elem<T>::ld(Kb + (long)j * 3 * H + c), dq);
-      Elem<T>::st(dKb + (long)j * 3 * H + c, ds * qv);
-      Elem<T>::st(dVb + (long)j * 3 * H + c, spm[j] * dov);
+      dq = fmaf(ds, Elem<T>::ld(Kb + (long)j * ld + c), dq);
+      Elem<T>::st(dKb + (long)j * ld + c, ds * qv);
+      Elem<T>::st(dVb + (long)j * ld + c, spm[j] * dov);
     }
     Elem<T>::st(dqc + (long)s * H + h * d + c, dq);
   }
 }
 
+extern "C" int simx_mha_cls_fwd_hm(simx_stream_t stream, int dtype, int nseq, int heads, int d, const int32_t* cu, int max_len,
+                                   int T, const void* q_cls, const void* qkv, void* ctx_cls, const simx_dropout* dropd, int hm_rows);
 extern "C" int simx_mha_cls_fwd(simx_stream_t stream, int dtype, int nseq, int heads, int d, const int32_t* cu, int max_len,
                                 int T, const void* q_cls, const void* qkv, void* ctx_cls, const simx_dropout* dropd) {
+  return simx_mha_cls_fwd_hm(stream, dtype, nseq, heads, d, cu, max_len, T, q_cls, qkv, ctx_cls, dropd, 0);
+}
+extern "C" int simx_mha_cls_fwd_hm(simx_stream_t stream, int dtype, int nseq, int heads, int d, const int32_t* cu, int max_len,
+                                   int T, const void* q_cls, const void* qkv, void* ctx_cls, const simx_dropout* dropd, int hm_rows) {
+  SIMX_REQUIRE(hm_rows == 0 || (d == 64 && hm_rows >= T), SIMX_ERR_UNSUPPORTED, "mha_cls_fwd: head-major layout needs head size 64, hm_rows >= T");
   SIMX_REQUIRE(nseq > 0 && heads > 0 && d > 0 && d % 4 == 0 && max_len > 0 && T >= nseq, SIMX_ERR_BAD_SHAPE, "mha_cls_fwd: bad shape");
   SIMX_REQUIRE(dtype == SIMX_F32 || dtype == SIMX_BF16, SIMX_ERR_BAD_DTYPE, "mha_cls_fwd: dtype %d", dtype);
   hipStream_t s = (hipStream_t)stream;
@@ -1092,20 +1142,29 @@ extern "C" int simx_mha_cls_fwd(simx_stream_t stream, int dtype, int nseq, int h
     rc = set_lds(mha_cls_fwd_kernel<float>, lds, "mha_cls_fwd");
     if (rc) return rc;
     hipLaunchKernelGGL((mha_cls_fwd_kernel<float>), dim3(cdiv(nitems, 4)), dim3(256), lds, s, nitems, heads, d, H, T, max_len, scale, cu,
-                       (const float*)q_cls, (const float*)qkv, (float*)ctx_cls, drop);
+                       (const float*)q_cls, (const float*)qkv, (float*)ctx_cls, drop, hm_rows);
   } else {
     rc = set_lds(mha_cls_fwd_kernel<bf16_t>, lds, "mha_cls_fwd");
     if (rc) return rc;
     hipLaunchKernelGGL((mha_cls_fwd_kernel<bf16_t>), dim3(cdiv(nitems, 4)), dim3(256), lds, s, nitems, heads, d, H, T, max_len, scale, cu,
-                       (const bf16_t*)q_cls, (const bf16_t*)qkv, (bf16_t*)ctx_cls, drop);
+                       (const bf16_t*)q_cls, (const bf16_t*)qkv, (bf16_t*)ctx_cls, drop, hm_rows);
   }
   SIMX_CHECK_LAUNCH("mha_cls_fwd");
   return SIMX_OK;
 }
 
+extern "C" int simx_mha_cls_bwd_hm(simx_stream_t stream, int dtype, int nseq, int heads, int d, const int32_t* cu, int max_len,
+                                   int T, const void* q_cls, const void* qkv, const void* dctx_cls, void* dq_cls, void* dqkv,
+                                   const simx_dropout* dropd, int hm_rows);
 extern "C" int simx_mha_cls_bwd(simx_stream_t stream, int dtype, int nseq, int heads, int d, const int32_t* cu, int max_len,
                                 int T, const void* q_cls, const void* qkv, const void* dctx_cls, void* dq_cls, void* dqkv,
                                 const simx_dropout* dropd) {
+  return simx_mha_cls_bwd_hm(stream, dtype, nseq, heads, d, cu, max_len, T, q_cls, qkv, dctx_cls, dq_cls, dqkv, dropd, 0);
+}
+extern "C" int simx_mha_cls_bwd_hm(simx_stream_t stream, int dtype, int nseq, int heads, int d, const int32_t* cu, int max_len,
+                                   int T, const void* q_cls, const void* qkv, const void* dctx_cls, void* dq_cls, void* dqkv,
+                                   const simx_dropout* dropd, int hm_rows) {
+  SIMX_REQUIRE(hm_rows == 0 || (d == 64 && hm_rows >= T), SIMX_ERR_UNSUPPORTED, "mha_cls_bwd: head-major layout needs head size 64, hm_rows >= T");
   SIMX_REQUIRE(nseq > 0 && heads > 0 && d > 0 && d % 4 == 0 && max_len > 0 && T >= nseq, SIMX_ERR_BAD_SHAPE, "mha_cls_bwd: bad shape");
   SIMX_REQUIRE(dtype == SIMX_F32 || dtype == SIMX_BF16, SIMX_ERR_BAD_DTYPE, "mha_cls_bwd: dtype %d", dtype);
   hipStream_t s = (hipStream_t)stream;
@@ -1119,12 +1178,12 @@ extern "C" int simx_mha_cls_bwd(simx_stream_t stream, int dtype, int nseq, int h
     rc = set_lds(mha_cls_bwd_kernel<float>, lds, "mha_cls_bwd");
     if (rc) return rc;
     hipLaunchKernelGGL((mha_cls_bwd_kernel<float>), dim3(cdiv(nitems, 4)), dim3(256), lds, s, nitems, heads, d, H, T, max_len, scale, cu,
-                       (const float*)q_cls, (const float*)qkv, (const float*)dctx_cls, (float*)dq_cls, (float*)dqkv, drop);
+                       (const float*)q_cls, (const float*)qkv, (const float*)dctx_cls, (float*)dq_cls, (float*)dqkv, drop, hm_rows);
   } else {
     rc = set_lds(mha_cls_bwd_kernel<bf16_t>, lds, "mha_cls_bwd");
     if (rc) return rc;
     hipLaunchKernelGGL((mha_cls_bwd_kernel<bf16_t>), dim3(cdiv(nitems, 4)), dim3(256), lds, s, nitems, heads, d, H, T, max_len, scale, cu,
-                       (const bf16_t*)q_cls, (const bf16_t*)qkv, (const bf16_t*)dctx_cls, (bf16_t*)dq_cls, (bf16_t*)dqkv, drop);
+                       (const bf16_t*)q_cls, (const bf16_t*)qkv, (const bf16_t*)dctx_cls, (bf16_t*)dq_cls, (bf16_t*)dqkv, drop, hm_rows);
   }
   SIMX_CHECK_LAUNCH("mha_cls_bwd");
   return SIMX_OK;

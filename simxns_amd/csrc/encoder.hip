@@ -242,6 +242,17 @@ static int check_io(const simx_bert_cfg* c, int nseq, int T, int max_len, const 
   return SIMX_OK;
 }
 
+// Head-major q/k/v (include/simx.h "head-major q / k / v"): chosen per tower when every kernel that touches the tensor has the
+// form -- bf16, head size 64, sequences that the LDS-resident attention backward takes (<= 256), and a tower large enough for
+// the persistent GEMMs (simx_gemm_hm_ok).  SIMX_QKV_LAYOUT=token pins the token-major form (A/B measurements).
+static int hm_rows_for(const simx_bert_cfg* c, int T, int Tp, int max_len) {
+  const char* pin = getenv("SIMX_QKV_LAYOUT");          // (read per call: the tests flip it)
+  if (pin && pin[0] == 't') return 0;
+  const int d = c->hidden / c->heads;
+  if (c->dtype != SIMX_BF16 || d != 64 || max_len > 256) return 0;
+  return simx_gemm_hm_ok(Tp, c->hidden, T) ? Tp : 0;
+}
+
 // One encoder layer's forward: x_in [Tp,H] -> a.xout (a = the slot it writes).  `keep`: backward will read this slot
 // (the pre-activation u is stored); the [CLS]-only form of the last layer writes [nseq, .] tensors into the slot's usual
 // buffers and q / attention context of the [CLS] rows into `extra` (kept for backward).
@@ -252,6 +263,7 @@ static int layer_fwd(hipStream_t stream, const simx_bert_cfg* c, const float* pa
   auto off = [&](int ll, int w) { return params + simx_bert_param_offset(c, ll, w); };
   const WLayer w = wlayer(c, params, wcache, l);
   const simx_dropout d1 = drop_of(c, l, 1), d2 = drop_of(c, l, 2), d3 = drop_of(c, l, 3);
+  const int hm = hm_rows_for(c, T, Tp, max_len);
   if (cls_form) {
     // Last layer, [CLS] rows only: row s of every [nseq, .] buffer below is the sequence's token 0 (row cu[s] of the
     // full tensors).  Only K and V are projected for every token; Q, the attention core and everything after it run
@@ -261,12 +273,16 @@ static int layer_fwd(hipStream_t stream, const simx_bert_cfg* c, const float* pa
     char* qc = extra;                                            // kept for backward
     char* ctxc = qc + al((size_t)nseq * H * e);                  // kept for backward
     char* ytmp = ctxc + al((size_t)nseq * H * e);
-    RUN(simx_gemm_nt(stream, dt, Tp, 2 * H, H, x, H, w.wqkv + (size_t)H * H * e, H, a.qkv + (size_t)H * e, 3 * H,
-                     off(l, SIMX_P_BQKV) + H, nullptr, 0, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
+    if (hm)      // K, V planes [heads, 3*heads) of the head-major tensor
+      RUN(simx_gemm_nt_hm(stream, dt, Tp, 2 * H, H, x, H, w.wqkv + (size_t)H * H * e, H, a.qkv + (size_t)c->heads * hm * 64 * e, 64,
+                          off(l, SIMX_P_BQKV) + H, nullptr, 0, nullptr, 0, hm));
+    else
+      RUN(simx_gemm_nt(stream, dt, Tp, 2 * H, H, x, H, w.wqkv + (size_t)H * H * e, H, a.qkv + (size_t)H * e, 3 * H,
+                       off(l, SIMX_P_BQKV) + H, nullptr, 0, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
     RUN(simx_rows_copy(stream, dt, dt, nseq, H, cu, nullptr, x, ytmp));
     RUN(simx_gemm_nt(stream, dt, nseq, H, H, ytmp, H, w.wqkv, H, qc, H, off(l, SIMX_P_BQKV), nullptr, 0, SIMX_EPI_NONE, nullptr, 0,
                      nullptr, 0));
-    RUN(simx_mha_cls_fwd(stream, dt, nseq, c->heads, d, cu, max_len, T, qc, a.qkv, ctxc, &d3));
+    RUN(simx_mha_cls_fwd_hm(stream, dt, nseq, c->heads, d, cu, max_len, T, qc, a.qkv, ctxc, &d3, hm));
     RUN(simx_gemm_nt(stream, dt, nseq, H, H, ctxc, H, w.wo, H, ytmp, H, off(l, SIMX_P_BO), nullptr, 0, SIMX_EPI_NONE, nullptr, 0,
                      nullptr, 0));
     RUN(simx_drop_residual_rows(stream, dt, nseq, H, ytmp, x, cu, cu, &d1, a.z1));
@@ -279,9 +295,12 @@ static int layer_fwd(hipStream_t stream, const simx_bert_cfg* c, const float* pa
     if (cls_out) RUN(simx_rows_copy(stream, dt, SIMX_F32, nseq, H, nullptr, nullptr, a.xout, cls_out));
     return SIMX_OK;
   }
-  RUN(simx_gemm_nt(stream, dt, Tp, 3 * H, H, x, H, w.wqkv, H, a.qkv, 3 * H, off(l, SIMX_P_BQKV), nullptr, 0, SIMX_EPI_NONE,
-                   nullptr, 0, nullptr, 0));
-  RUN(simx_mha_fwd_ex(stream, dt, nseq, c->heads, d, cu, max_len, T, a.qkv, a.ctx, a.lse, &d3));
+  if (hm)
+    RUN(simx_gemm_nt_hm(stream, dt, Tp, 3 * H, H, x, H, w.wqkv, H, a.qkv, 64, off(l, SIMX_P_BQKV), nullptr, 0, nullptr, 0, hm));
+  else
+    RUN(simx_gemm_nt(stream, dt, Tp, 3 * H, H, x, H, w.wqkv, H, a.qkv, 3 * H, off(l, SIMX_P_BQKV), nullptr, 0, SIMX_EPI_NONE,
+                     nullptr, 0, nullptr, 0));
+  RUN(simx_mha_fwd_hm(stream, dt, nseq, c->heads, d, cu, max_len, T, a.qkv, a.ctx, a.lse, &d3, hm));
   RUN(simx_gemm_nt_ex(stream, dt, Tp, H, H, a.ctx, H, w.wo, H, a.z1, H, off(l, SIMX_P_BO), x, H, SIMX_EPI_NONE, nullptr, 0,
                       nullptr, 0, &d1));
   RUN(simx_ln_fwd(stream, dt, T, H, a.z1, off(l, SIMX_P_LN1_G), off(l, SIMX_P_LN1_B), c->eps, a.x1));
@@ -378,6 +397,7 @@ extern "C" int simx_bert_bwd_range(simx_stream_t stream, const simx_bert_cfg* c,
   char* dqkv = du + al((size_t)Tp * F * e);
   char* tnws = dqkv + al((size_t)Tp * 3 * H * e);
   const size_t tnws_bytes = tn_ws_max(c, T);
+  const int hm = hm_rows_for(c, T, Tp, max_len);        // layout of qkv / dqkv (must match the forward's choice: same inputs)
 
   int l_top = layer_hi;
   if (top && c->cls_only_last_layer) {
@@ -407,7 +427,7 @@ extern "C" int simx_bert_bwd_range(simx_stream_t stream, const simx_bert_cfg* c,
     RUN(simx_gemm_nt(stream, dt, nseq, H, H, dzm, H, w.woT, H, e1, H, nullptr, nullptr, 0, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
     RUN(simx_gemm_tn(stream, dt, H, H, nseq, dzm, H, ctxc, H, goff(l, SIMX_P_WO), H, 1, tnws, tnws_bytes));
     // attention core for the one query per sequence: e0 = dq [nseq,H]; dK, dV for every token -> dqkv[:, H:3H]
-    RUN(simx_mha_cls_bwd(stream, dt, nseq, c->heads, d, cu, max_len, T, qc, a.qkv, e1, e0, dqkv, &d3));
+    RUN(simx_mha_cls_bwd_hm(stream, dt, nseq, c->heads, d, cu, max_len, T, qc, a.qkv, e1, e0, dqkv, &d3, hm));
     // Q projection ([CLS] rows): dWq, dbq, and dx = dq . Wq + (residual-branch gradient), still compact
     RUN(simx_rows_copy(stream, dt, dt, nseq, H, cu, nullptr, xin, e2));
     RUN(simx_gemm_tn_bias(stream, dt, H, H, nseq, e0, H, e2, H, goff(l, SIMX_P_WQKV), H, 1, tnws, tnws_bytes, goff(l, SIMX_P_BQKV)));
@@ -419,10 +439,17 @@ extern "C" int simx_bert_bwd_range(simx_stream_t stream, const simx_bert_cfg* c,
     }
     RUN(simx_rows_copy(stream, dt, dt, nseq, H, nullptr, cu, e1, bufA));
     // K, V projections (every token): dx += dkv . Wkv ; dWkv, dbkv
-    RUN(simx_gemm_nt(stream, dt, Tp, H, 2 * H, dqkv + (size_t)H * e, 3 * H, w.wqkvT + (size_t)H * e, 3 * H, bufB, H, nullptr, bufA, H,
-                     SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
-    RUN(simx_gemm_tn_bias(stream, dt, 2 * H, H, T, dqkv + (size_t)H * e, 3 * H, xin, H, goff(l, SIMX_P_WQKV) + (size_t)H * H, H, 1, tnws,
-                          tnws_bytes, goff(l, SIMX_P_BQKV) + H));
+    if (hm) {
+      const char* dkv = dqkv + (size_t)c->heads * hm * 64 * e;                  // planes [heads, 3*heads)
+      RUN(simx_gemm_nt_hm(stream, dt, Tp, H, 2 * H, dkv, 64, w.wqkvT + (size_t)H * e, 3 * H, bufB, H, nullptr, bufA, H, nullptr, hm, 0));
+      RUN(simx_gemm_tn_hm(stream, dt, 2 * H, H, T, dkv, hm, xin, H, goff(l, SIMX_P_WQKV) + (size_t)H * H, H, 1, tnws, tnws_bytes,
+                          goff(l, SIMX_P_BQKV) + H));
+    } else {
+      RUN(simx_gemm_nt(stream, dt, Tp, H, 2 * H, dqkv + (size_t)H * e, 3 * H, w.wqkvT + (size_t)H * e, 3 * H, bufB, H, nullptr, bufA, H,
+                       SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
+      RUN(simx_gemm_tn_bias(stream, dt, 2 * H, H, T, dqkv + (size_t)H * e, 3 * H, xin, H, goff(l, SIMX_P_WQKV) + (size_t)H * H, H, 1, tnws,
+                            tnws_bytes, goff(l, SIMX_P_BQKV) + H));
+    }
     --l_top;
   } else if (top && dhidden) {
     if (hipMemcpyAsync(bufB, dhidden, (size_t)T * H * e, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
@@ -454,12 +481,17 @@ extern "C" int simx_bert_bwd_range(simx_stream_t stream, const simx_bert_cfg* c,
     // dctx = dz1m . Wo
     RUN(simx_gemm_nt(stream, dt, Tp, H, H, dzm, H, w.woT, H, bufB, H, nullptr, nullptr, 0, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
     RUN(simx_gemm_tn(stream, dt, H, H, T, dzm, H, a.ctx, H, goff(l, SIMX_P_WO), H, 1, tnws, tnws_bytes));
-    RUN(simx_mha_bwd_ex(stream, dt, nseq, c->heads, d, cu, max_len, T, a.qkv, a.ctx, a.lse, bufB, dqkv, &d3));
+    RUN(simx_mha_bwd_hm(stream, dt, nseq, c->heads, d, cu, max_len, T, a.qkv, a.ctx, a.lse, bufB, dqkv, &d3, hm));
     // dx = dqkv . Wqkv + dz1
-    RUN(simx_gemm_nt(stream, dt, Tp, H, 3 * H, dqkv, 3 * H, w.wqkvT, 3 * H, bufB, H, nullptr, bufA, H, SIMX_EPI_NONE, nullptr, 0,
-                     nullptr, 0));
-    RUN(simx_gemm_tn_bias(stream, dt, 3 * H, H, T, dqkv, 3 * H, xin, H, goff(l, SIMX_P_WQKV), H, 1, tnws, tnws_bytes,
-                          goff(l, SIMX_P_BQKV)));
+    if (hm) {
+      RUN(simx_gemm_nt_hm(stream, dt, Tp, H, 3 * H, dqkv, 64, w.wqkvT, 3 * H, bufB, H, nullptr, bufA, H, nullptr, hm, 0));
+      RUN(simx_gemm_tn_hm(stream, dt, 3 * H, H, T, dqkv, hm, xin, H, goff(l, SIMX_P_WQKV), H, 1, tnws, tnws_bytes, goff(l, SIMX_P_BQKV)));
+    } else {
+      RUN(simx_gemm_nt(stream, dt, Tp, H, 3 * H, dqkv, 3 * H, w.wqkvT, 3 * H, bufB, H, nullptr, bufA, H, SIMX_EPI_NONE, nullptr, 0,
+                       nullptr, 0));
+      RUN(simx_gemm_tn_bias(stream, dt, 3 * H, H, T, dqkv, 3 * H, xin, H, goff(l, SIMX_P_WQKV), H, 1, tnws, tnws_bytes,
+                            goff(l, SIMX_P_BQKV)));
+    }
   }
   if (layer_lo > 0) return SIMX_OK;               // the next part continues from bufB
   const simx_dropout d0 = drop_of(c, -1, 0);

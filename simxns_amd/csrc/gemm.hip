@@ -582,7 +582,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // Every stage boundary waits vmcnt(4): the issue order per wave is ... [B(s+1)(4) A(s+2)(4)] so "all but the 4 youngest"
 // = stage s+1 complete.  Needs K >= 256.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void p3_half(const bf16_t* __restrict__ G, int ld, int row0, int k0, uint32_t slot, int wave,
+__device__ __forceinline__ void p3_half(const bf16_t* __restrict__ G, int ld, int row0, long k0, uint32_t slot, int wave,
                                         uint32_t off0, uint32_t off1) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -592,7 +592,12 @@ __device__ __forceinline__ void p3_half(const bf16_t* __restrict__ G, int ld, in
   }
 }
 
-template <int EPI, bool HAS_IN>
+// HM (head-major q/k/v, see QkvLay in attention.hip; EPI_NONE only, `ldc2` carries the rows R of a plane):
+//   HM && !HAS_IN: C is [N/64][R][64] -- the QKV projection's output; a wave's 64 columns are exactly one plane, so only the
+//                  wave's base pointer and the row pitch (64) change;
+//   HM &&  HAS_IN: A is [K/64][R][64] -- dq/dk/dv as the dgrad GEMM's operand; a 64-wide K stage is one plane, i.e. a
+//                  contiguous 256 x 128 B block instead of 256 rows K*2 B apart.
+template <int EPI, bool HAS_IN, bool HM = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
     int M, int N, int K, const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
     bf16_t* __restrict__ C, int ldc, const float* __restrict__ bias, const bf16_t* __restrict__ in, int ldin,
@@ -614,8 +619,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
   const int lr = lane >> 3;
   const int ec0 = ((lane & 7) ^ (lane >> 4)) << 3, ec1 = ((lane & 7) ^ (4 + (lane >> 4))) << 3;   // element column of the lane's 16-B chunk, rows lr / 8+lr
   const uint32_t bmask = bias ? 0xFFFFFFFFu : 0u;
+  constexpr bool HM_A = HM && HAS_IN, HM_C = HM && !HAS_IN;
+  if (HM_A) lda = 64;                             // row pitch inside a plane; the stage's k offset selects the plane (P3_AK)
   const uint32_t offA0 = (uint32_t)(lr * lda + ec0) * 2, offA1 = (uint32_t)(lr * lda + ec1) * 2;
   const uint32_t offB0 = (uint32_t)(lr * ldb + ec0) * 2, offB1 = (uint32_t)(lr * ldb + ec1) * 2;
+  // element offset of K stage s of the A operand: s * 64 columns, or plane s of ldc2 rows x 64
+#define P3_AK(S) (HM_A ? (long)(S) * ((long)ldc2 * 64) : (long)(S) * 64)
   // Epilogue-only per-lane constants are recomputed per tile from a laundered copy of the lane id (P_LANE): left to
   // LICM they are hoisted out of the tile loop and stay live (~20 VGPRs) through the main loop, which then spills.
 #define P_LANE(L) int L = lane; asm volatile("" : "+v"(L))
@@ -624,11 +633,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
   int tile = xcd_remap(v, ntiles);
   int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
   p3_half(B, ldb, n0, 0, ldsB, wave, offB0, offB1);
-  p3_half(A, lda, m0, 0, lds0, wave, offA0, offA1);
+  p3_half(A, lda, m0, P3_AK(0), lds0, wave, offA0, offA1);
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
   p3_half(B, ldb, n0, 64, ldsB + 32768u, wave, offB0, offB1);
-  p3_half(A, lda, m0, 64, lds0 + 32768u, wave, offA0, offA1);
-  p3_half(A, lda, m0, 128, lds0 + 65536u, wave, offA0, offA1);
+  p3_half(A, lda, m0, P3_AK(1), lds0 + 32768u, wave, offA0, offA1);
+  p3_half(A, lda, m0, P3_AK(2), lds0 + 65536u, wave, offA0, offA1);
   int a0 = 0, b0 = 0;                             // LDS slots of the current tile's stage 0 (A: mod 3, B: mod 2)
   // the bias enters as the accumulators' initial value; bq* always hold the CURRENT tile's 4x4 bias columns at the
   // top of the loop (the next tile's are requested at the last stage boundary and carried across the epilogue)
@@ -719,7 +728,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
     P3_BOUNDARY_WAIT();                                                                        \
     const bool cb__ = st + 2 < nst, ca__ = st + 3 < nst;                                       \
     p3_half(B, ldb, cb__ ? n0 : n0n, (cb__ ? st + 2 : st + 2 - nst) * 64, ldsB + (uint32_t)(bc * 32768), wave, offB0, offB1); \
-    p3_half(A, lda, ca__ ? m0 : m0n, (ca__ ? st + 3 : st + 3 - nst) * 64, lds0 + (uint32_t)(ac * 32768), wave, offA0, offA1); \
+    p3_half(A, lda, ca__ ? m0 : m0n, P3_AK(ca__ ? st + 3 : st + 3 - nst), lds0 + (uint32_t)(ac * 32768), wave, offA0, offA1); \
   } while (0)
   // last boundary of the tile: bias and the first residual chunk are requested BEFORE the next tile's stage 1,
   // so the epilogue can wait for them without waiting for that stage
@@ -795,9 +804,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
       const int ec0 = ((le & 7) ^ (le >> 4)) << 3, ec1 = ((le & 7) ^ (4 + (le >> 4))) << 3;
       const int sw = (fr >> 1) & 7;
       const uint32_t slot = (uint32_t)(fr * 128 + (fg & 1) * 8);
+      if (HM_C) ldc = 64;                                      // (per tile: `ldc` is dead in the main loop)
       const uint32_t eo0 = (uint32_t)(lr * ldc + ec0) * 2, eo1 = (uint32_t)((lr + 8) * ldc + ec1) * 2;
       const uint32_t io0 = HAS_IN ? (uint32_t)(lr * ldin + ec0) * 2 : 0, io1 = HAS_IN ? (uint32_t)((lr + 8) * ldin + ec1) * 2 : 0;
-      bf16_t* const obase = C + (long)mw * ldc + nw;          // uniform
+      bf16_t* const obase = HM_C ? C + ((long)(nw >> 6) * ldc2 + mw) * 64 : C + (long)mw * ldc + nw;          // uniform
       const bool store_pre = !(EPI == SIMX_EPI_GELU && ldin == 1);   // ldin == 1 on a GELU launch: SIMX_EPI_GELU_INFER
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -870,12 +880,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
       }
     }
     // the borrowed A slot is free again (this wave's slice only ever holds this wave's rows): next tile's stage 2
-    p3_half(A, lda, m0n, 128, lds0 + (uint32_t)(ac * 32768), wave, offA0, offA1);
+    p3_half(A, lda, m0n, P3_AK(2), lds0 + (uint32_t)(ac * 32768), wave, offA0, offA1);
     if (!has_next) break;
     v = vn; m0 = m0n; n0 = n0n; a0 = ac == 2 ? 0 : ac + 1; b0 = bc ^ 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (dummy) stage loads must land before the LDS is released
 #undef P_LANE
+#undef P3_AK
 #undef P_BND_LAST
 #undef P_BND_MID
 #undef P_BND_NONE
@@ -1024,10 +1035,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(
 // DMA and waits vmcnt(0) before it; the transpose reads below are BUILTINS so that hipcc allocates both halves of a
 // fragment into one 128-bit register tuple and places counted lgkmcnt waits itself -- the inline-asm reads cost 136
 // v_mov per stage to assemble the tuples, more VALU time than the MFMAs of a k-step.)
+// hm > 0: A is head-major, [M/64][hm][64] (dq/dk/dv, QkvLay in attention.hip): column c of token k sits at
+// ((c >> 6) * hm + k) * 64 + (c & 63) -- the row pitch becomes 64 and the column part of the lane offset picks the plane.
+__device__ __forceinline__ uint32_t tn2_acol(int c, int hm) { return hm > 0 ? (uint32_t)(c >> 6) * (uint32_t)hm * 64u + (uint32_t)(c & 63) : (uint32_t)c; }
 __device__ __forceinline__ void tn2_stage(const bf16_t* __restrict__ A, int lda, int m0, int M,
                                           const bf16_t* __restrict__ B, int ldb, int n0, int N, int k0, int k_end,
-                                          char* stage, int wave, int lane) {
+                                          char* stage, int wave, int lane, int hm) {
   const uint32_t sbase = (uint32_t)(uintptr_t)stage;
+  if (hm > 0) lda = 64;
   const char* ga = reinterpret_cast<const char*>(A + (long)k0 * lda);
   const char* gb = reinterpret_cast<const char*>(B + (long)k0 * ldb);
 #pragma unroll
@@ -1041,7 +1056,7 @@ __device__ __forceinline__ void tn2_stage(const bf16_t* __restrict__ A, int lda,
     int ca = m0 + q * 16 + (p16 & 1) * 8, cb = n0 + q * 16 + (p16 & 1) * 8;
     ca = ca + 8 <= M ? ca : M - 8;
     cb = cb + 8 <= N ? cb : N - 8;
-    P_DMA16((uint32_t)(rk * lda + ca) * 2, ga, sbase + (uint32_t)(i * 1024));
+    P_DMA16(((uint32_t)(rk * lda) + tn2_acol(ca, hm)) * 2, ga, sbase + (uint32_t)(i * 1024));
     P_DMA16((uint32_t)(rk * ldb + cb) * 2, gb, sbase + (uint32_t)(32768 + i * 1024));
   }
 }
@@ -1050,7 +1065,8 @@ __device__ __forceinline__ void tn2_stage(const bf16_t* __restrict__ A, int lda,
 // (tn2_lane_offsets): the row part of the address rides in the SGPR base, so a stage costs no VALU work at all.
 // tn2_stage above recomputes offsets and clamps per stage (~60 VALU per wave) and is kept for the ragged last stage.
 __device__ __forceinline__ void tn2_lane_offsets(int lda, int m0, int M, int ldb, int n0, int N, int lane, uint32_t (&oa)[4],
-                                                 uint32_t (&ob)[4]) {
+                                                 uint32_t (&ob)[4], int hm) {
+  if (hm > 0) lda = 64;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int krl = 2 * j + (lane >> 5);                      // k-row within the wave's 8 rows; (kr & 7) == krl
@@ -1059,7 +1075,7 @@ __device__ __forceinline__ void tn2_lane_offsets(int lda, int m0, int M, int ldb
     int ca = m0 + q * 16 + (p16 & 1) * 8, cb = n0 + q * 16 + (p16 & 1) * 8;
     ca = ca + 8 <= M ? ca : M - 8;
     cb = cb + 8 <= N ? cb : N - 8;
-    oa[j] = (uint32_t)((lane >> 5) * lda + ca) * 2;
+    oa[j] = ((uint32_t)((lane >> 5) * lda) + tn2_acol(ca, hm)) * 2;
     ob[j] = (uint32_t)((lane >> 5) * ldb + cb) * 2;
   }
 }
@@ -1086,7 +1102,7 @@ typedef __attribute__((address_space(3))) bf16x4* tn_lds4_t;
 __global__ __launch_bounds__(512, 2) void gemm_tn2_bf16_kernel(
     int M, int N, int K, const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
     float* __restrict__ out, long slab_stride, int ldo, int tiles_n, int tiles_mn, int k_per_split, int accumulate,
-    float* __restrict__ dbias) {
+    float* __restrict__ dbias, int hm_a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1127,10 +1143,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_bf16_kernel(
   const uint32_t row_lo = (uint32_t)(r_lo * 512 + (fs & 3) * 8), row_hi = (uint32_t)((r_lo + 16) * 512 + (fs & 3) * 8);
 
   uint32_t oa[4], ob[4];
-  tn2_lane_offsets(lda, m0, M, ldb, n0, N, lane, oa, ob);
-  tn2_stage(A, lda, m0, M, B, ldb, n0, N, kb, ke, smem, wave, lane);
+  tn2_lane_offsets(lda, m0, M, ldb, n0, N, lane, oa, ob, hm_a);
+  tn2_stage(A, lda, m0, M, B, ldb, n0, N, kb, ke, smem, wave, lane, hm_a);
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-  if (nst > 1) tn2_stage(A, lda, m0, M, B, ldb, n0, N, kb + 64, ke, smem + TN2_STAGE, wave, lane);
+  if (nst > 1) tn2_stage(A, lda, m0, M, B, ldb, n0, N, kb + 64, ke, smem + TN2_STAGE, wave, lane, hm_a);
 
   bf16x4 al_lo[4], al_hi[4], ah_lo[4], ah_hi[4], bx_lo[4], bx_hi[4], by_lo[4], by_hi[4];
   // address of fragment (operand base, 16-col tile ct) for k-step base address `kbase` (stage + ks*32*512)
@@ -1195,9 +1211,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_bf16_kernel(
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                                             \
       if (TN2_NOLOAD) { }                                                                                       \
       else if ((ST) + 3 < nst || ((ST) + 3 == nst && (ke - kb) % 64 == 0))                                      \
-        tn2_stage_full(A, lda, B, ldb, kb + TN2_KSEL((ST) + 2) * 64, lds0 + (uint32_t)(((ST) & 1) * TN2_STAGE), wave, oa, ob); \
+        tn2_stage_full(A, hm_a > 0 ? 64 : lda, B, ldb, kb + TN2_KSEL((ST) + 2) * 64, lds0 + (uint32_t)(((ST) & 1) * TN2_STAGE), wave, oa, ob); \
       else if ((ST) + 2 < nst)                                                                                  \
-        tn2_stage(A, lda, m0, M, B, ldb, n0, N, kb + ((ST) + 2) * 64, ke, smem + ((ST) & 1) * TN2_STAGE, wave, lane); \
+        tn2_stage(A, lda, m0, M, B, ldb, n0, N, kb + ((ST) + 2) * 64, ke, smem + ((ST) & 1) * TN2_STAGE, wave, lane, hm_a); \
       if ((ST) + 1 == nst - 1 && (ke - kb) % 64 != 0) {                                                         \
         /* ragged last stage: rows >= valid hold clamped copies -> zero them (both operands) */                \
         const int valid__ = (ke - kb) - (nst - 1) * 64;                                                         \
@@ -1363,6 +1379,8 @@ static const GemmDevice* gemm_device() {
     SIMX_LDS_ATTR((gemm_nt_bf16_p3_kernel<SIMX_EPI_NONE, true>), P_LDS);
     SIMX_LDS_ATTR((gemm_nt_bf16_p3_kernel<SIMX_EPI_GELU, false>), P_LDS);
     SIMX_LDS_ATTR((gemm_nt_bf16_p3_kernel<SIMX_EPI_DGELU, true>), P_LDS);
+    SIMX_LDS_ATTR((gemm_nt_bf16_p3_kernel<SIMX_EPI_NONE, false, true>), P_LDS);
+    SIMX_LDS_ATTR((gemm_nt_bf16_p3_kernel<SIMX_EPI_NONE, true, true>), P_LDS);
     SIMX_LDS_ATTR(gemm_tn2_bf16_kernel, TN2_LDS);
 #undef SIMX_LDS_ATTR
     g.ok = ok;
@@ -1543,6 +1561,47 @@ extern "C" int simx_gemm_nt_ex(simx_stream_t stream, int dtype, int M, int N, in
   return SIMX_OK;
 }
 
+// Head-major q / k / v operands (QkvLay, csrc/attention.hip) on the persistent kernel; bf16, full 256x256 tiles only:
+//   c_hm_rows = R > 0: C is [N/64][R][64] (the QKV projection writes it; no residual);
+//   a_hm_rows = R > 0: A is [K/64][R][64] (dq/dk/dv as the dgrad operand; `residual` required: it is the other gradient branch).
+// simx_gemm_hm_ok tells a caller whether both forms (and the wgrad form, simx_gemm_tn_hm) run for its shapes.
+extern "C" int simx_gemm_hm_ok(int rows, int H, int tokens) {
+  const GemmDevice* gd = gemm_device();
+  if (!gd || rows <= 0 || H <= 0) return 0;
+  const bool shapes = rows % 256 == 0 && H % 256 == 0 && H >= 256;
+  const long dgrad_tiles = (long)(rows / 256) * (H / 256);            // the narrowest of the three GEMMs (N = H)
+  return shapes && dgrad_tiles >= 192 && tokens >= 2048 ? 1 : 0;
+}
+extern "C" int simx_gemm_nt_hm(simx_stream_t stream, int dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                               void* C, int ldc, const float* bias, const void* residual, int ldr, const simx_dropout* dropd,
+                               int a_hm_rows, int c_hm_rows) {
+  hipStream_t s = (hipStream_t)stream;
+  SIMX_PROF(SIMX_K_GEMM_NT, s, 2.0 * M * N * K);
+  SIMX_REQUIRE(dtype == SIMX_BF16, SIMX_ERR_BAD_DTYPE, "gemm_nt_hm: bf16 only");
+  SIMX_REQUIRE((a_hm_rows > 0) != (c_hm_rows > 0), SIMX_ERR_BAD_SHAPE, "gemm_nt_hm: exactly one of A / C is head-major");
+  SIMX_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C, SIMX_ERR_BAD_SHAPE, "gemm_nt_hm: bad arguments");
+  const GemmDevice* gd = gemm_device();
+  SIMX_REQUIRE(gd != nullptr, SIMX_ERR_HIP, "gemm_nt_hm: cannot query the current device");
+  const int t3n = N / 256, nwg3 = (M / 256) * t3n;
+  const int R = a_hm_rows > 0 ? a_hm_rows : c_hm_rows;
+  const bool ok = M % 256 == 0 && N % 256 == 0 && K % 64 == 0 && K >= 256 && nwg3 >= 192 && R >= M && ldb % 8 == 0 && ldb >= K &&
+                  aligned16(A) && aligned16(B) && aligned16(C) && (!bias || aligned16(bias)) &&
+                  (a_hm_rows > 0 ? (residual && ldr % 8 == 0 && ldr >= N && aligned16(residual) && ldc % 8 == 0 && ldc >= N)
+                                 : (!residual && lda % 8 == 0 && lda >= K));
+  SIMX_REQUIRE(ok, SIMX_ERR_UNSUPPORTED, "gemm_nt_hm: shape %d x %d x %d (planes of %d rows) is outside the persistent kernel's rules", M, N, K, R);
+  const DropCtx drop = make_drop(dropd);
+  const int grid = nwg3 < gd->ncu ? nwg3 : gd->ncu;
+  if (a_hm_rows > 0)
+    hipLaunchKernelGGL((gemm_nt_bf16_p3_kernel<SIMX_EPI_NONE, true, true>), dim3(grid), dim3(512), P_LDS, s, M, N, K, (const bf16_t*)A, 64,
+                       (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, (const bf16_t*)residual, ldr, (bf16_t*)nullptr, R, t3n, nwg3, drop);
+  else
+    hipLaunchKernelGGL((gemm_nt_bf16_p3_kernel<SIMX_EPI_NONE, false, true>), dim3(grid), dim3(512), P_LDS, s, M, N, K, (const bf16_t*)A, lda,
+                       (const bf16_t*)B, ldb, (bf16_t*)C, 64, bias, (const bf16_t*)nullptr, 0, (bf16_t*)nullptr, R, t3n, nwg3, drop);
+  simx_prof_retag(SIMX_K_GEMM_NT_P3);
+  SIMX_CHECK_LAUNCH("gemm_nt_bf16_p3(hm)");
+  return SIMX_OK;
+}
+
 extern "C" int simx_colsum(simx_stream_t stream, int dtype, int T, int N, const void* x, int ldx, float* out, int accumulate);
 static bool tn_use_v2(int M, int N, int K) {
   static const char* pin = getenv("SIMX_GEMM_TN");
@@ -1579,9 +1638,22 @@ extern "C" int simx_gemm_tn(simx_stream_t stream, int dtype, int M, int N, int K
   return simx_gemm_tn_bias(stream, dtype, M, N, K, A, lda, B, ldb, C, ldc, accumulate, ws, ws_bytes, nullptr);
 }
 
+static int gemm_tn_impl(simx_stream_t stream, int dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, float* C,
+                        int ldc, int accumulate, void* ws, size_t ws_bytes, float* dbias, int a_hm_rows);
 extern "C" int simx_gemm_tn_bias(simx_stream_t stream, int dtype, int M, int N, int K, const void* A, int lda,
                                  const void* B, int ldb, float* C, int ldc, int accumulate, void* ws, size_t ws_bytes,
                                  float* dbias) {
+  return gemm_tn_impl(stream, dtype, M, N, K, A, lda, B, ldb, C, ldc, accumulate, ws, ws_bytes, dbias, 0);
+}
+// wgrad with a head-major A (dq/dk/dv planes of a_hm_rows rows, [M/64][R][64]); large bf16 shapes only (the 256x256 kernel)
+extern "C" int simx_gemm_tn_hm(simx_stream_t stream, int dtype, int M, int N, int K, const void* A, int a_hm_rows, const void* B,
+                               int ldb, float* C, int ldc, int accumulate, void* ws, size_t ws_bytes, float* dbias) {
+  SIMX_REQUIRE(dtype == SIMX_BF16 && a_hm_rows >= K && M % 256 == 0 && N % 8 == 0 && K >= 2048, SIMX_ERR_UNSUPPORTED,
+               "gemm_tn_hm: needs bf16, M %% 256 == 0, K >= 2048 tokens and planes of >= K rows");
+  return gemm_tn_impl(stream, dtype, M, N, K, A, M, B, ldb, C, ldc, accumulate, ws, ws_bytes, dbias, a_hm_rows);
+}
+static int gemm_tn_impl(simx_stream_t stream, int dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, float* C,
+                        int ldc, int accumulate, void* ws, size_t ws_bytes, float* dbias, int a_hm_rows) {
   hipStream_t s = (hipStream_t)stream;
   SIMX_PROF(SIMX_K_GEMM_TN, s, 2.0 * M * N * K);
   SIMX_REQUIRE(M > 0 && N > 0 && K > 0, SIMX_ERR_BAD_SHAPE, "gemm_tn: bad shape %d %d %d", M, N, K);
@@ -1594,6 +1666,7 @@ extern "C" int simx_gemm_tn_bias(simx_stream_t stream, int dtype, int M, int N, 
   SIMX_REQUIRE(dtype == SIMX_BF16, SIMX_ERR_BAD_DTYPE, "gemm_tn: dtype %d", dtype);
   const bool fast = (M % 8 == 0) && (N % 8 == 0) && (lda % 8 == 0) && (ldb % 8 == 0) && (ldc % 4 == 0) && aligned16(A) &&
                     aligned16(B) && aligned16(C);
+  SIMX_REQUIRE(a_hm_rows == 0 || fast, SIMX_ERR_UNSUPPORTED, "gemm_tn_hm: operands not 16-B aligned");
   if (!fast) {
     if (dbias) { int rcb = simx_colsum(stream, dtype, K, M, A, lda, dbias, 1); if (rcb) return rcb; }
     // generic path: bf16 in, f32 out
@@ -1606,12 +1679,13 @@ extern "C" int simx_gemm_tn_bias(simx_stream_t stream, int dtype, int M, int N, 
   }
   int splits, kps;
   tn_plan(M, N, K, &splits, &kps);
+  SIMX_REQUIRE(a_hm_rows == 0 || tn_use_v2(M, N, K), SIMX_ERR_UNSUPPORTED, "gemm_tn_hm: shape outside the 256x256 kernel's rules");
   if (tn_use_v2(M, N, K)) {
     SIMX_REQUIRE(gemm_device() != nullptr, SIMX_ERR_HIP, "gemm_tn: cannot query the current device");
     const int t_m = cdiv(M, 256), t_n = cdiv(N, 256), t_mn = t_m * t_n;
     if (splits == 1) {
       hipLaunchKernelGGL(gemm_tn2_bf16_kernel, dim3(t_mn), dim3(512), TN2_LDS, s, M, N, K, (const bf16_t*)A, lda,
-                         (const bf16_t*)B, ldb, C, 0L, ldc, t_n, t_mn, kps, accumulate, dbias);
+                         (const bf16_t*)B, ldb, C, 0L, ldc, t_n, t_mn, kps, accumulate, dbias, a_hm_rows);
       SIMX_CHECK_LAUNCH("gemm_tn2_bf16");
       return SIMX_OK;
     }
@@ -1619,7 +1693,7 @@ extern "C" int simx_gemm_tn_bias(simx_stream_t stream, int dtype, int M, int N, 
     SIMX_REQUIRE(ws && ws_bytes >= need2, SIMX_ERR_WORKSPACE, "gemm_tn: workspace %zu < %zu", ws_bytes, need2);
     SIMX_REQUIRE(aligned16(ws), SIMX_ERR_WORKSPACE, "gemm_tn: workspace not 16-B aligned");
     hipLaunchKernelGGL(gemm_tn2_bf16_kernel, dim3(t_mn * splits), dim3(512), TN2_LDS, s, M, N, K, (const bf16_t*)A, lda,
-                       (const bf16_t*)B, ldb, (float*)ws, (long)M * N, N, t_n, t_mn, kps, 0, dbias);
+                       (const bf16_t*)B, ldb, (float*)ws, (long)M * N, N, t_n, t_mn, kps, 0, dbias, a_hm_rows);
     SIMX_CHECK_LAUNCH("gemm_tn2_bf16");
     const long tot4 = (long)M * N / 4;
     int rb = (int)((tot4 + 255) / 256);

@@ -102,6 +102,28 @@ __global__ __launch_bounds__(256) void mha_fwd_bf16_kernel(const bf16_t* __restr
     for (int dt = 0; dt < 4; ++dt) vtr[dt] = (uint32_t)(rr * 128 + (((dt * 2 + tx) ^ tsw) << 4) + (fr & 1) * 8);
   }
 
+  // SIMX_MHA_NOCOMPUTE (timing experiment only: the kernel's loads and stores without its arithmetic; tools/kbench, S = 128,
+  // 262144 tokens, 12 heads): forward 0.318-0.335 ms against 0.347-0.354 for the real kernel -- the forward IS its memory
+  // traffic (1.6 GB at 5 TB/s); backward 0.625 against 0.823 ms -- two 74 KB workgroups per CU do not overlap one's staging
+  // with the other's arithmetic completely (0.2 ms x 12 layers = the 2.4 ms a double-buffered persistent form could win).
+#ifdef SIMX_MHA_NOCOMPUTE
+  for (int qt = wave; qt < nkt; qt += 4) {
+    const int q = qt * 16 + fr;
+    const int qc = q < len ? q : len - 1;
+    const bf16x8 q0 = *reinterpret_cast<const bf16x8*>(Qg + (long)qc * H3 + fg * 8);
+    const bf16x8 q1 = *reinterpret_cast<const bf16x8*>(Qg + (long)qc * H3 + 32 + fg * 8);
+    const bf16x8 k0 = lds_row_frag(sK, qt * 16 + fr, fg), v0 = lds_row_frag(sV, qt * 16 + fr, fg);
+    if (q < len) {
+      bf16_t* dst = ctx + (long)(t0 + q) * H + h * 64 + 4 * fg;
+      for (int dt = 0; dt < 4; ++dt) {
+        float v[4] = {bf2f(q0[dt]) + bf2f(k0[dt]), bf2f(q1[dt]) + bf2f(v0[dt]), bf2f(q0[4 + dt]), bf2f(q1[4 + dt])};
+        st4(dst + dt * 16, v);
+      }
+      if (fg == 0) lse[(long)h * T + t0 + q] = bf2f(q0[0]);
+    }
+  }
+  return;
+#endif
   for (int qt = wave; qt < nkt; qt += 4) {
     const int q = qt * 16 + fr;
     const int qc = q < len ? q : len - 1;
@@ -306,6 +328,19 @@ __global__ __launch_bounds__(256) void mha_bwd2_bf16_kernel(const bf16_t* __rest
   for (int dt = 0; dt < 4; ++dt) tr[dt] = (uint32_t)(rr * 128 + (((dt * 2 + tx) ^ tsw) << 4) + (fr & 1) * 8);
   const bool full = (len == nkt2 * 16);             // no ragged tail: skip the per-element masks
 
+#ifdef SIMX_MHA_NOCOMPUTE          /* timing experiment only: the kernel's loads and stores without its arithmetic */
+  {
+    f32x4 z[4];
+    for (int dt = 0; dt < 4; ++dt) z[dt] = (f32x4){sDel[fr], sLse[fr], 0.f, 0.f};
+    for (int qt = wave; qt < nkt; qt += 4) a2_store_tile(z, patch, patch_addr, dQg + (long)(qt * 16) * H3, H3, len - qt * 16, lane);
+    for (int kt = wave; kt < nkt; kt += 4) {
+      bf16_t* dstk = dQg + lay.ws + (long)(kt * 16) * H3;
+      a2_store_tile(z, patch, patch_addr, dstk, H3, len - kt * 16, lane);
+      a2_store_tile(z, patch, patch_addr, dstk + lay.ws, H3, len - kt * 16, lane);
+    }
+    return;
+  }
+#endif
   // ---------------- phase A: dQ, waves own query tiles, loop over key-tile pairs
   for (int qt = wave; qt < nkt; qt += 4) {
     const int q = qt * 16 + fr;

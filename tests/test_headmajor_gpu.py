@@ -128,7 +128,8 @@ def test_attention_head_major(dev, heads, lens, p):
         assert torch.equal(x, y), name
 
 
-def test_encoder_layouts_agree(dev):
+@pytest.mark.parametrize("ragged", [False, True])
+def test_encoder_layouts_agree(dev, ragged):
     """One tower large enough for the head-major path (16384 tokens): SIMX_QKV_LAYOUT=token vs the default give the same
     embeddings bit for bit and the same gradients up to the order of the f32 atomic sums (LayerNorm / bias gradients)."""
     from simxns_amd.engine import BertConfigLite
@@ -137,8 +138,15 @@ def test_encoder_layouts_agree(dev):
     torch.manual_seed(0)
     enc = HFBertEncoder(cfg, compute_dtype="bf16").to(dev).train()
     assert int(L().load().simx_gemm_hm_ok(16384, cfg.hidden_size, 16384)) == 1
-    ids = torch.randint(1000, 20000, (128, 128), device=dev)
+    assert int(L().load().simx_gemm_hm_ok(4096, cfg.hidden_size, 4096)) == 0      # (a query tower stays token-major)
+    nseq = 224 if ragged else 128
+    ids = torch.randint(1000, 20000, (nseq, 128), device=dev)
     mask = torch.ones_like(ids)
+    if ragged:                                   # real lengths 40..128: ~19 k real tokens, planes longer than the token count
+        lens = torch.randint(40, 129, (nseq,), device=dev)
+        mask = (torch.arange(128, device=dev)[None, :] < lens[:, None]).long()
+        ids = ids * mask
+        assert int(mask.sum()) >= 16384
     res = {}
     for mode in ("token", "head"):
         if mode == "token":

@@ -1091,6 +1091,16 @@ __device__ __forceinline__ void tn2_stage_full(const bf16_t* __restrict__ A, int
   }
 }
 
+// one quarter of a full stage (the wave's j-th A and B instruction): issued between MFMA rows instead of as a burst
+__device__ __forceinline__ void tn2_stage_piece(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, int k0,
+                                                uint32_t sbase, int wave, int j, uint32_t oaj, uint32_t obj) {
+  const char* ga = reinterpret_cast<const char*>(A + (long)(k0 + wave * 8 + 2 * j) * lda);
+  const char* gb = reinterpret_cast<const char*>(B + (long)(k0 + wave * 8 + 2 * j) * ldb);
+  const int i = wave * 4 + j;
+  P_DMA16(oaj, ga, sbase + (uint32_t)(i * 1024));
+  P_DMA16(obj, gb, sbase + (uint32_t)(32768 + i * 1024));
+}
+
 // one fragment = two transpose reads (k rows base+4g.. and base+16+4g..)
 typedef __attribute__((address_space(3))) bf16x4* tn_lds4_t;
 #define TN2_RD(F_LO, F_HI, ADDR_LO, ADDR_HI)                                                        \
@@ -1175,6 +1185,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_bf16_kernel(
 #else
 #define TN2_KSEL(S) (S)
 #endif
+#ifndef TN2_SPREAD
+#define TN2_SPREAD 1                    /* the stage's DMA pieces go out one pair per MFMA row after the boundary, not as a burst */
+#endif
+#define TN2_PIECE(ST, J) tn2_stage_piece(A, hm_a > 0 ? 64 : lda, B, ldb, kb + TN2_KSEL((ST) + 2) * 64, lds0 + (uint32_t)(((ST) & 1) * TN2_STAGE), wave, J, oa[J], ob[J])
 #ifdef SIMX_TN2_NOLOAD
 #define TN2_NOLOAD 1
 #else
@@ -1197,6 +1211,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_bf16_kernel(
 #define TN2_STEP(CUR, NXT, BCL, BCH, BNL, BNH, SYNC, ST)                                                        \
   do {                                                                                                          \
     const uint32_t cur__ = (CUR), nxt__ = (NXT);                                                                \
+    bool spread__ = false;                                                                                      \
     TN2_SB; TN2_MFMA_ROW(0, al_lo[0], al_hi[0], BCL, BCH); TN2_SB;                                              \
     TN2_RD(ah_lo[0], ah_hi[0], TN2_ADDR_LO(cur__, 0u, wr * 8 + 4), TN2_ADDR_HI(cur__, 0u, wr * 8 + 4));         \
     TN2_RD(ah_lo[1], ah_hi[1], TN2_ADDR_LO(cur__, 0u, wr * 8 + 5), TN2_ADDR_HI(cur__, 0u, wr * 8 + 5));         \
@@ -1209,7 +1224,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_bf16_kernel(
     TN2_PIN8("s_waitcnt lgkmcnt(0)", ah_lo, ah_hi);                                                             \
     if (SYNC) {                                                                                                 \
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                                             \
+      spread__ = !TN2_NOLOAD && TN2_SPREAD && ((ST) + 3 < nst || ((ST) + 3 == nst && (ke - kb) % 64 == 0));     \
       if (TN2_NOLOAD) { }                                                                                       \
+      else if (spread__)                                                                                        \
+        TN2_PIECE(ST, 0);                                                                                       \
       else if ((ST) + 3 < nst || ((ST) + 3 == nst && (ke - kb) % 64 == 0))                                      \
         tn2_stage_full(A, hm_a > 0 ? 64 : lda, B, ldb, kb + TN2_KSEL((ST) + 2) * 64, lds0 + (uint32_t)(((ST) & 1) * TN2_STAGE), wave, oa, ob); \
       else if ((ST) + 2 < nst)                                                                                  \
@@ -1229,13 +1247,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_bf16_kernel(
     TN2_RD(al_lo[0], al_hi[0], TN2_ADDR_LO(nxt__, 0u, wr * 8 + 0), TN2_ADDR_HI(nxt__, 0u, wr * 8 + 0));         \
     TN2_RD(BNL[0], BNH[0], TN2_ADDR_LO(nxt__, 32768u, wc * 4 + 0), TN2_ADDR_HI(nxt__, 32768u, wc * 4 + 0));     \
     TN2_RD(al_lo[1], al_hi[1], TN2_ADDR_LO(nxt__, 0u, wr * 8 + 1), TN2_ADDR_HI(nxt__, 0u, wr * 8 + 1));         \
+    if (SYNC && spread__) TN2_PIECE(ST, 1);                                                                     \
     TN2_SB; TN2_MFMA_ROW(5, ah_lo[1], ah_hi[1], BCL, BCH); TN2_SB;                                              \
     TN2_RD(BNL[1], BNH[1], TN2_ADDR_LO(nxt__, 32768u, wc * 4 + 1), TN2_ADDR_HI(nxt__, 32768u, wc * 4 + 1));     \
     TN2_RD(al_lo[2], al_hi[2], TN2_ADDR_LO(nxt__, 0u, wr * 8 + 2), TN2_ADDR_HI(nxt__, 0u, wr * 8 + 2));         \
     TN2_RD(BNL[2], BNH[2], TN2_ADDR_LO(nxt__, 32768u, wc * 4 + 2), TN2_ADDR_HI(nxt__, 32768u, wc * 4 + 2));     \
+    if (SYNC && spread__) TN2_PIECE(ST, 2);                                                                     \
     TN2_SB; TN2_MFMA_ROW(6, ah_lo[2], ah_hi[2], BCL, BCH); TN2_SB;                                              \
     TN2_RD(al_lo[3], al_hi[3], TN2_ADDR_LO(nxt__, 0u, wr * 8 + 3), TN2_ADDR_HI(nxt__, 0u, wr * 8 + 3));         \
     TN2_RD(BNL[3], BNH[3], TN2_ADDR_LO(nxt__, 32768u, wc * 4 + 3), TN2_ADDR_HI(nxt__, 32768u, wc * 4 + 3));     \
+    if (SYNC && spread__) TN2_PIECE(ST, 3);                                                                     \
     TN2_SB; TN2_MFMA_ROW(7, ah_lo[3], ah_hi[3], BCL, BCH);                                                      \
     TN2_SB;                                                                                                     \
     TN2_PIN8("s_waitcnt lgkmcnt(0)", al_lo, al_hi);                                                             \

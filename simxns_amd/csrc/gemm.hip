@@ -676,24 +676,34 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
 #else
 #define P3_PRIO(N) do { } while (0)
 #endif
+#ifndef SIMX_P3_SPREAD
+#define SIMX_P3_SPREAD 1
+#endif
+  // SIMX_P3_SPREAD: the 8 LDS-DMA instructions a mid-tile boundary issues go out one per MFMA row (B in the rest of this
+  // k-step, A in the first half of the next) instead of as a burst right after the barrier
+  const char* pa_g = nullptr; const char* pb_g = nullptr;
+  uint32_t pa_slot = 0, pb_slot = 0;
+  bool pa_pend = false, pb_pend = false;
+#define P3_HA(J) do { if (SIMX_P3_SPREAD && pa_pend) { P_DMA16(((J) & 1) ? offA1 : offA0, pa_g + (long)(J) * 8 * lda * 2, pa_slot + (uint32_t)((J) * 1024)); if ((J) == 3) pa_pend = false; } } while (0)
+#define P3_HB(J) do { if (SIMX_P3_SPREAD && pb_pend) { P_DMA16(((J) & 1) ? offB1 : offB0, pb_g + (long)(J) * 8 * ldb * 2, pb_slot + (uint32_t)((J) * 1024)); if ((J) == 3) pb_pend = false; } } while (0)
 #if SIMX_P3_SCHED == 1
 #define P_STEP(CURA, NA, NB, BC0, BC1, BC2, BC3, BN0, BN1, BN2, BN3, BOUNDARY)                   \
   do {                                                                                         \
     /* fragment reads are front-loaded: the last read before each pin is issued two MFMA rows ahead of it */ \
     const uint32_t aa__ = (CURA), na__ = (NA), nb__ = (NB);                                    \
     P3_PRIO(1);                                                                                \
-    V3_SB; V3_MFMA_ROW(0, al0, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah0, aa__, 8192); V3_RD1(ah1, aa__, 10240);  \
-    V3_SB; V3_MFMA_ROW(1, al1, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah2, aa__, 12288); V3_RD1(ah3, aa__, 14336); \
-    V3_SB; V3_MFMA_ROW(2, al2, BC0, BC1, BC2, BC3);                                            \
-    V3_SB; V3_MFMA_ROW(3, al3, BC0, BC1, BC2, BC3);                                            \
+    V3_SB; V3_MFMA_ROW(0, al0, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah0, aa__, 8192); V3_RD1(ah1, aa__, 10240); P3_HA(0); \
+    V3_SB; V3_MFMA_ROW(1, al1, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah2, aa__, 12288); V3_RD1(ah3, aa__, 14336); P3_HA(1); \
+    V3_SB; V3_MFMA_ROW(2, al2, BC0, BC1, BC2, BC3); V3_SB; P3_HA(2);                           \
+    V3_SB; V3_MFMA_ROW(3, al3, BC0, BC1, BC2, BC3); V3_SB; P3_HA(3);                           \
     V3_SB;                                                                                     \
     P3_PRIO(0);                                                                                \
     V3_PIN4(P3_LGKM_WAIT, ah0, ah1, ah2, ah3);                                       \
     BOUNDARY();                                                                                \
     P3_PRIO(1);                                                                                \
-    V3_SB; V3_MFMA_ROW(4, ah0, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al0, na__, 0); V3_RD1(BN0, nb__, 0); V3_RD1(al1, na__, 2048);       \
-    V3_SB; V3_MFMA_ROW(5, ah1, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(BN1, nb__, 2048); V3_RD1(al2, na__, 4096); V3_RD1(BN2, nb__, 4096); \
-    V3_SB; V3_MFMA_ROW(6, ah2, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al3, na__, 6144); V3_RD1(BN3, nb__, 6144); \
+    V3_SB; V3_MFMA_ROW(4, ah0, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al0, na__, 0); V3_RD1(BN0, nb__, 0); V3_RD1(al1, na__, 2048); P3_HB(1); \
+    V3_SB; V3_MFMA_ROW(5, ah1, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(BN1, nb__, 2048); V3_RD1(al2, na__, 4096); V3_RD1(BN2, nb__, 4096); P3_HB(2); \
+    V3_SB; V3_MFMA_ROW(6, ah2, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al3, na__, 6144); V3_RD1(BN3, nb__, 6144); P3_HB(3); \
     V3_SB; V3_MFMA_ROW(7, ah3, BC0, BC1, BC2, BC3);                                            \
     V3_SB;                                                                                     \
     P3_PRIO(0);                                                                                \
@@ -727,8 +737,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
     /* issue order so far: ... [B(st+1) A(st+2)] ; stage st+1 = everything but the 4 youngest (A(st+2)) */ \
     P3_BOUNDARY_WAIT();                                                                        \
     const bool cb__ = st + 2 < nst, ca__ = st + 3 < nst;                                       \
-    p3_half(B, ldb, cb__ ? n0 : n0n, (cb__ ? st + 2 : st + 2 - nst) * 64, ldsB + (uint32_t)(bc * 32768), wave, offB0, offB1); \
-    p3_half(A, lda, ca__ ? m0 : m0n, P3_AK(ca__ ? st + 3 : st + 3 - nst), lds0 + (uint32_t)(ac * 32768), wave, offA0, offA1); \
+    if (SIMX_P3_SPREAD) {                                                                      \
+      /* same issue ORDER as the burst (B x4, then A x4 -- the vmcnt(4) rule holds), one instruction per MFMA row */ \
+      pb_g = reinterpret_cast<const char*>(B + (long)((cb__ ? n0 : n0n) + wave * 32) * ldb + (cb__ ? st + 2 : st + 2 - nst) * 64); \
+      pb_slot = ldsB + (uint32_t)(bc * 32768 + wave * 4096);                                   \
+      pa_g = reinterpret_cast<const char*>(A + (long)((ca__ ? m0 : m0n) + wave * 32) * lda + P3_AK(ca__ ? st + 3 : st + 3 - nst)); \
+      pa_slot = lds0 + (uint32_t)(ac * 32768 + wave * 4096);                                   \
+      pb_pend = pa_pend = true;                                                                \
+      P_DMA16(offB0, pb_g, pb_slot);                                                           \
+    } else {                                                                                   \
+      p3_half(B, ldb, cb__ ? n0 : n0n, (cb__ ? st + 2 : st + 2 - nst) * 64, ldsB + (uint32_t)(bc * 32768), wave, offB0, offB1); \
+      p3_half(A, lda, ca__ ? m0 : m0n, P3_AK(ca__ ? st + 3 : st + 3 - nst), lds0 + (uint32_t)(ac * 32768), wave, offA0, offA1); \
+    }                                                                                          \
   } while (0)
   // last boundary of the tile: bias and the first residual chunk are requested BEFORE the next tile's stage 1,
   // so the epilogue can wait for them without waiting for that stage
@@ -745,7 +765,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
       P_DMA16(io0__, ibase, ereg); P_DMA16(io1__, ibase, ereg + 1024u);                        \
     }                                                                                          \
     /* next tile's stage 1 of B; its stage 2 of A goes into the slot this tile's epilogue borrows -> issued after it */ \
-    p3_half(B, ldb, n0n, 64, ldsB + (uint32_t)(bc * 32768), wave, offB0, offB1);                \
+    if (SIMX_P3_SPREAD) {                                                                      \
+      pb_g = reinterpret_cast<const char*>(B + (long)(n0n + wave * 32) * ldb + 64);            \
+      pb_slot = ldsB + (uint32_t)(bc * 32768 + wave * 4096);                                   \
+      pb_pend = true;                                                                          \
+      P_DMA16(offB0, pb_g, pb_slot);                                                           \
+    } else {                                                                                   \
+      p3_half(B, ldb, n0n, 64, ldsB + (uint32_t)(bc * 32768), wave, offB0, offB1);              \
+    }                                                                                          \
   } while (0)
 
   for (;;) {
@@ -880,12 +907,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
       }
     }
     // the borrowed A slot is free again (this wave's slice only ever holds this wave's rows): next tile's stage 2
-    p3_half(A, lda, m0n, P3_AK(2), lds0 + (uint32_t)(ac * 32768), wave, offA0, offA1);
+    if (SIMX_P3_SPREAD && has_next) {              // issued by the next tile's first four MFMA rows (same order: after B(1))
+      pa_g = reinterpret_cast<const char*>(A + (long)(m0n + wave * 32) * lda + P3_AK(2));
+      pa_slot = lds0 + (uint32_t)(ac * 32768 + wave * 4096);
+      pa_pend = true;
+    } else {
+      p3_half(A, lda, m0n, P3_AK(2), lds0 + (uint32_t)(ac * 32768), wave, offA0, offA1);
+    }
     if (!has_next) break;
     v = vn; m0 = m0n; n0 = n0n; a0 = ac == 2 ? 0 : ac + 1; b0 = bc ^ 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (dummy) stage loads must land before the LDS is released
 #undef P_LANE
+#undef P3_HA
+#undef P3_HB
 #undef P3_AK
 #undef P_BND_LAST
 #undef P_BND_MID
@@ -1101,6 +1136,11 @@ __device__ __forceinline__ void tn2_stage_piece(const bf16_t* __restrict__ A, in
   P_DMA16(obj, gb, sbase + (uint32_t)(32768 + i * 1024));
 }
 
+__device__ __forceinline__ void tn2_stage_one(const bf16_t* __restrict__ G, int ld, int k0, uint32_t sbase, int wave, int j, uint32_t off) {
+  const char* g = reinterpret_cast<const char*>(G + (long)(k0 + wave * 8 + 2 * j) * ld);
+  P_DMA16(off, g, sbase + (uint32_t)((wave * 4 + j) * 1024));
+}
+
 // one fragment = two transpose reads (k rows base+4g.. and base+16+4g..)
 typedef __attribute__((address_space(3))) bf16x4* tn_lds4_t;
 #define TN2_RD(F_LO, F_HI, ADDR_LO, ADDR_HI)                                                        \
@@ -1186,9 +1226,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_bf16_kernel(
 #define TN2_KSEL(S) (S)
 #endif
 #ifndef TN2_SPREAD
-#define TN2_SPREAD 1                    /* the stage's DMA pieces go out one pair per MFMA row after the boundary, not as a burst */
+#define TN2_SPREAD 2                    /* the 8 DMA instructions of a stage go out ONE PER MFMA ROW after the boundary (1: one (A,B) pair per row; 0: burst): 1003 / 1056 / 1080 TFLOP/s */
 #endif
 #define TN2_PIECE(ST, J) tn2_stage_piece(A, hm_a > 0 ? 64 : lda, B, ldb, kb + TN2_KSEL((ST) + 2) * 64, lds0 + (uint32_t)(((ST) & 1) * TN2_STAGE), wave, J, oa[J], ob[J])
+#define TN2_ONE_A(ST, J) tn2_stage_one(A, hm_a > 0 ? 64 : lda, kb + TN2_KSEL((ST) + 2) * 64, lds0 + (uint32_t)(((ST) & 1) * TN2_STAGE), wave, J, oa[J])
+#define TN2_ONE_B(ST, J) tn2_stage_one(B, ldb, kb + TN2_KSEL((ST) + 2) * 64, lds0 + 32768u + (uint32_t)(((ST) & 1) * TN2_STAGE), wave, J, ob[J])
 #ifdef SIMX_TN2_NOLOAD
 #define TN2_NOLOAD 1
 #else
@@ -1212,22 +1254,28 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_bf16_kernel(
   do {                                                                                                          \
     const uint32_t cur__ = (CUR), nxt__ = (NXT);                                                                \
     bool spread__ = false;                                                                                      \
+    const bool tail__ = TN2_SPREAD == 2 && !(SYNC) && pend;       /* second half of the previous boundary's stage */ \
     TN2_SB; TN2_MFMA_ROW(0, al_lo[0], al_hi[0], BCL, BCH); TN2_SB;                                              \
     TN2_RD(ah_lo[0], ah_hi[0], TN2_ADDR_LO(cur__, 0u, wr * 8 + 4), TN2_ADDR_HI(cur__, 0u, wr * 8 + 4));         \
     TN2_RD(ah_lo[1], ah_hi[1], TN2_ADDR_LO(cur__, 0u, wr * 8 + 5), TN2_ADDR_HI(cur__, 0u, wr * 8 + 5));         \
+    if (tail__) TN2_ONE_A((ST) - 1, 2);                                                                         \
     TN2_SB; TN2_MFMA_ROW(1, al_lo[1], al_hi[1], BCL, BCH); TN2_SB;                                              \
     TN2_RD(ah_lo[2], ah_hi[2], TN2_ADDR_LO(cur__, 0u, wr * 8 + 6), TN2_ADDR_HI(cur__, 0u, wr * 8 + 6));         \
     TN2_RD(ah_lo[3], ah_hi[3], TN2_ADDR_LO(cur__, 0u, wr * 8 + 7), TN2_ADDR_HI(cur__, 0u, wr * 8 + 7));         \
+    if (tail__) TN2_ONE_B((ST) - 1, 2);                                                                         \
     TN2_SB; TN2_MFMA_ROW(2, al_lo[2], al_hi[2], BCL, BCH);                                                      \
+    if (tail__) TN2_ONE_A((ST) - 1, 3);                                                                         \
     TN2_SB; TN2_MFMA_ROW(3, al_lo[3], al_hi[3], BCL, BCH);                                                      \
+    if (tail__) { TN2_ONE_B((ST) - 1, 3); pend = false; }                                                       \
     TN2_SB;                                                                                                     \
     TN2_PIN8("s_waitcnt lgkmcnt(0)", ah_lo, ah_hi);                                                             \
     if (SYNC) {                                                                                                 \
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                                             \
       spread__ = !TN2_NOLOAD && TN2_SPREAD && ((ST) + 3 < nst || ((ST) + 3 == nst && (ke - kb) % 64 == 0));     \
       if (TN2_NOLOAD) { }                                                                                       \
-      else if (spread__)                                                                                        \
-        TN2_PIECE(ST, 0);                                                                                       \
+      else if (spread__) {                                                                                      \
+        if (TN2_SPREAD == 2) { TN2_ONE_A(ST, 0); pend = true; } else TN2_PIECE(ST, 0);                          \
+      }                                                                                                         \
       else if ((ST) + 3 < nst || ((ST) + 3 == nst && (ke - kb) % 64 == 0))                                      \
         tn2_stage_full(A, hm_a > 0 ? 64 : lda, B, ldb, kb + TN2_KSEL((ST) + 2) * 64, lds0 + (uint32_t)(((ST) & 1) * TN2_STAGE), wave, oa, ob); \
       else if ((ST) + 2 < nst)                                                                                  \
@@ -1247,16 +1295,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_bf16_kernel(
     TN2_RD(al_lo[0], al_hi[0], TN2_ADDR_LO(nxt__, 0u, wr * 8 + 0), TN2_ADDR_HI(nxt__, 0u, wr * 8 + 0));         \
     TN2_RD(BNL[0], BNH[0], TN2_ADDR_LO(nxt__, 32768u, wc * 4 + 0), TN2_ADDR_HI(nxt__, 32768u, wc * 4 + 0));     \
     TN2_RD(al_lo[1], al_hi[1], TN2_ADDR_LO(nxt__, 0u, wr * 8 + 1), TN2_ADDR_HI(nxt__, 0u, wr * 8 + 1));         \
-    if (SYNC && spread__) TN2_PIECE(ST, 1);                                                                     \
+    if (SYNC && spread__) { if (TN2_SPREAD == 2) TN2_ONE_B(ST, 0); else TN2_PIECE(ST, 1); }                     \
     TN2_SB; TN2_MFMA_ROW(5, ah_lo[1], ah_hi[1], BCL, BCH); TN2_SB;                                              \
     TN2_RD(BNL[1], BNH[1], TN2_ADDR_LO(nxt__, 32768u, wc * 4 + 1), TN2_ADDR_HI(nxt__, 32768u, wc * 4 + 1));     \
     TN2_RD(al_lo[2], al_hi[2], TN2_ADDR_LO(nxt__, 0u, wr * 8 + 2), TN2_ADDR_HI(nxt__, 0u, wr * 8 + 2));         \
     TN2_RD(BNL[2], BNH[2], TN2_ADDR_LO(nxt__, 32768u, wc * 4 + 2), TN2_ADDR_HI(nxt__, 32768u, wc * 4 + 2));     \
-    if (SYNC && spread__) TN2_PIECE(ST, 2);                                                                     \
+    if (SYNC && spread__) { if (TN2_SPREAD == 2) TN2_ONE_A(ST, 1); else TN2_PIECE(ST, 2); }                     \
     TN2_SB; TN2_MFMA_ROW(6, ah_lo[2], ah_hi[2], BCL, BCH); TN2_SB;                                              \
     TN2_RD(al_lo[3], al_hi[3], TN2_ADDR_LO(nxt__, 0u, wr * 8 + 3), TN2_ADDR_HI(nxt__, 0u, wr * 8 + 3));         \
     TN2_RD(BNL[3], BNH[3], TN2_ADDR_LO(nxt__, 32768u, wc * 4 + 3), TN2_ADDR_HI(nxt__, 32768u, wc * 4 + 3));     \
-    if (SYNC && spread__) TN2_PIECE(ST, 3);                                                                     \
+    if (SYNC && spread__) { if (TN2_SPREAD == 2) TN2_ONE_B(ST, 1); else TN2_PIECE(ST, 3); }                     \
     TN2_SB; TN2_MFMA_ROW(7, ah_lo[3], ah_hi[3], BCL, BCH);                                                      \
     TN2_SB;                                                                                                     \
     TN2_PIN8("s_waitcnt lgkmcnt(0)", al_lo, al_hi);                                                             \
@@ -1279,6 +1327,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_bf16_kernel(
     TN2_PIN8("s_waitcnt lgkmcnt(0)", al_lo, al_hi);
     TN2_PIN8("s_waitcnt lgkmcnt(0)", bx_lo, bx_hi);
   }
+  bool pend = false;                      // TN2_SPREAD == 2: half of the last boundary's stage is still to be issued
   for (int st = 0; st < nst; ++st) {
     const uint32_t sc = lds0 + (uint32_t)((st & 1) * TN2_STAGE), sn = lds0 + (uint32_t)(((st + 1) & 1) * TN2_STAGE);
     do_bias = dbias != nullptr && (st % bias_mod) == bias_slot;

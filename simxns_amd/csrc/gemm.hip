@@ -686,31 +686,36 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
   bool pa_pend = false, pb_pend = false;
 #define P3_HA(J) do { if (SIMX_P3_SPREAD && pa_pend) { P_DMA16(((J) & 1) ? offA1 : offA0, pa_g + (long)(J) * 8 * lda * 2, pa_slot + (uint32_t)((J) * 1024)); if ((J) == 3) pa_pend = false; } } while (0)
 #define P3_HB(J) do { if (SIMX_P3_SPREAD && pb_pend) { P_DMA16(((J) & 1) ? offB1 : offB0, pb_g + (long)(J) * 8 * ldb * 2, pb_slot + (uint32_t)((J) * 1024)); if ((J) == 3) pb_pend = false; } } while (0)
+#if SIMX_P3_SPREAD == 3                 /* experiment: the A pieces every other row of the FIRST k-step of a stage: 1041 vs 1056 TFLOP/s -- earlier is better */
+#define P3_HAX(ROW, S1) do { if ((S1) && ((ROW) & 1) == 0) P3_HA((ROW) >> 1); } while (0)
+#else
+#define P3_HAX(ROW, S1) do { if ((ROW) < 4) P3_HA(ROW); } while (0)
+#endif
 #if SIMX_P3_SCHED == 1
-#define P_STEP(CURA, NA, NB, BC0, BC1, BC2, BC3, BN0, BN1, BN2, BN3, BOUNDARY)                   \
+#define P_STEP(CURA, NA, NB, BC0, BC1, BC2, BC3, BN0, BN1, BN2, BN3, BOUNDARY, S1)               \
   do {                                                                                         \
     /* fragment reads are front-loaded: the last read before each pin is issued two MFMA rows ahead of it */ \
     const uint32_t aa__ = (CURA), na__ = (NA), nb__ = (NB);                                    \
     P3_PRIO(1);                                                                                \
-    V3_SB; V3_MFMA_ROW(0, al0, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah0, aa__, 8192); V3_RD1(ah1, aa__, 10240); P3_HA(0); \
-    V3_SB; V3_MFMA_ROW(1, al1, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah2, aa__, 12288); V3_RD1(ah3, aa__, 14336); P3_HA(1); \
-    V3_SB; V3_MFMA_ROW(2, al2, BC0, BC1, BC2, BC3); V3_SB; P3_HA(2);                           \
-    V3_SB; V3_MFMA_ROW(3, al3, BC0, BC1, BC2, BC3); V3_SB; P3_HA(3);                           \
+    V3_SB; V3_MFMA_ROW(0, al0, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah0, aa__, 8192); V3_RD1(ah1, aa__, 10240); P3_HAX(0, S1); \
+    V3_SB; V3_MFMA_ROW(1, al1, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah2, aa__, 12288); V3_RD1(ah3, aa__, 14336); P3_HAX(1, S1); \
+    V3_SB; V3_MFMA_ROW(2, al2, BC0, BC1, BC2, BC3); V3_SB; P3_HAX(2, S1);                      \
+    V3_SB; V3_MFMA_ROW(3, al3, BC0, BC1, BC2, BC3); V3_SB; P3_HAX(3, S1);                      \
     V3_SB;                                                                                     \
     P3_PRIO(0);                                                                                \
     V3_PIN4(P3_LGKM_WAIT, ah0, ah1, ah2, ah3);                                       \
     BOUNDARY();                                                                                \
     P3_PRIO(1);                                                                                \
-    V3_SB; V3_MFMA_ROW(4, ah0, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al0, na__, 0); V3_RD1(BN0, nb__, 0); V3_RD1(al1, na__, 2048); P3_HB(1); \
-    V3_SB; V3_MFMA_ROW(5, ah1, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(BN1, nb__, 2048); V3_RD1(al2, na__, 4096); V3_RD1(BN2, nb__, 4096); P3_HB(2); \
-    V3_SB; V3_MFMA_ROW(6, ah2, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al3, na__, 6144); V3_RD1(BN3, nb__, 6144); P3_HB(3); \
+    V3_SB; V3_MFMA_ROW(4, ah0, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al0, na__, 0); V3_RD1(BN0, nb__, 0); V3_RD1(al1, na__, 2048); P3_HB(1); P3_HAX(4, S1); \
+    V3_SB; V3_MFMA_ROW(5, ah1, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(BN1, nb__, 2048); V3_RD1(al2, na__, 4096); V3_RD1(BN2, nb__, 4096); P3_HB(2); P3_HAX(5, S1); \
+    V3_SB; V3_MFMA_ROW(6, ah2, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al3, na__, 6144); V3_RD1(BN3, nb__, 6144); P3_HB(3); P3_HAX(6, S1); \
     V3_SB; V3_MFMA_ROW(7, ah3, BC0, BC1, BC2, BC3);                                            \
     V3_SB;                                                                                     \
     P3_PRIO(0);                                                                                \
     V3_PIN8(P3_LGKM_WAIT, al0, al1, al2, al3, BN0, BN1, BN2, BN3);                   \
   } while (0)
 #else
-#define P_STEP(CURA, NA, NB, BC0, BC1, BC2, BC3, BN0, BN1, BN2, BN3, BOUNDARY)                   \
+#define P_STEP(CURA, NA, NB, BC0, BC1, BC2, BC3, BN0, BN1, BN2, BN3, BOUNDARY, S1)               \
   do {                                                                                         \
     const uint32_t aa__ = (CURA), na__ = (NA), nb__ = (NB);                                    \
     V3_SB; V3_MFMA_ROW(0, al0, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah0, aa__, 8192);            \
@@ -808,8 +813,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
       const int an = ac == 2 ? 0 : ac + 1, bn = bc ^ 1;
       const uint32_t sa = lds0 + (uint32_t)(ac * 32768), sb = ldsB + (uint32_t)(bc * 32768);
       const uint32_t na = lds0 + (uint32_t)(an * 32768), nb = ldsB + (uint32_t)(bn * 32768);
-      P_STEP(sa + oA0, sa + oA1, sb + oB1, bx0, bx1, bx2, bx3, by0, by1, by2, by3, P_BND_NONE);
-      P_STEP(sa + oA1, na + oA0, nb + oB0, by0, by1, by2, by3, bx0, bx1, bx2, bx3, P_BND_MID);
+      P_STEP(sa + oA0, sa + oA1, sb + oB1, bx0, bx1, bx2, bx3, by0, by1, by2, by3, P_BND_NONE, 1);
+      P_STEP(sa + oA1, na + oA0, nb + oB0, by0, by1, by2, by3, bx0, bx1, bx2, bx3, P_BND_MID, 0);
       ac = an; bc = bn;
     }
     const uint32_t ereg = lds0 + (uint32_t)(ac * 32768 + wave * 4096);     // this wave's slice of the last stage's A slot
@@ -817,8 +822,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
       const int an = ac == 2 ? 0 : ac + 1, bn = bc ^ 1;
       const uint32_t sa = lds0 + (uint32_t)(ac * 32768), sb = ldsB + (uint32_t)(bc * 32768);
       const uint32_t na = lds0 + (uint32_t)(an * 32768), nb = ldsB + (uint32_t)(bn * 32768);
-      P_STEP(sa + oA0, sa + oA1, sb + oB1, bx0, bx1, bx2, bx3, by0, by1, by2, by3, P_BND_NONE);
-      P_STEP(sa + oA1, na + oA0, nb + oB0, by0, by1, by2, by3, bx0, bx1, bx2, bx3, P_BND_LAST);
+      P_STEP(sa + oA0, sa + oA1, sb + oB1, bx0, bx1, bx2, bx3, by0, by1, by2, by3, P_BND_NONE, 1);
+      P_STEP(sa + oA1, na + oA0, nb + oB0, by0, by1, by2, by3, bx0, bx1, bx2, bx3, P_BND_LAST, 0);
     }
 
     // ---- epilogue, 8 chunks of 16 rows (= accumulator row-block i), per wave, no barrier
@@ -920,6 +925,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (dummy) stage loads must land before the LDS is released
 #undef P_LANE
 #undef P3_HA
+#undef P3_HAX
 #undef P3_HB
 #undef P3_AK
 #undef P_BND_LAST

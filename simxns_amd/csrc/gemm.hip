@@ -565,7 +565,17 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // s_nop 0 the first data dword of lanes 12-15 of every 16-lane group was still clobbered by the next VALU write in some
 // schedules (tests/test_kernels_gpu.py::test_gemm_nt_persistent caught it) -- the store reads its data 16 lanes x 1 dword per
 // cycle; 4 wait states cleared it, 6 are used)
-#define P_GST4(VOFF, SBASE, VAL) asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 5" ::"v"(VOFF), "v"(VAL), "s"(SBASE) : "memory")
+// (the persistent kernel's output stores are non-temporal: the tile is not re-read by this kernel, and with `nt` its lines leave
+// the L2 before the operand lines the neighbouring CUs still share -- two-output / N = 3072 shapes 2 % faster, the rest equal;
+// "sc0 sc1" (write-through) changes nothing.  SIMX_P3_SAMEC, every tile storing to the same rows so that no store reaches HBM,
+// shows what is left: the seven shapes run 6 % faster, QKV 11 % -- a store is acknowledged only when the L2 has room, the 32 CUs
+// of an XCD store 4 MB = the whole L2 within a few microseconds, and gfx9's single in-order vmcnt makes the next tile's first
+// stage boundary wait for those acknowledgements.  Skewing the XCDs against each other does not help (per-XCD burst unchanged),
+// starting the A panels of an XCD in 4 phase groups (N-tiles of a panel in step) costs its 3/4-tile tail and gains nothing.)
+#ifndef SIMX_P3_STORE_BITS
+#define SIMX_P3_STORE_BITS " nt"
+#endif
+#define P_GST4(VOFF, SBASE, VAL) asm volatile("global_store_dwordx4 %0, %1, %2" SIMX_P3_STORE_BITS "\n\ts_nop 5" ::"v"(VOFF), "v"(VAL), "s"(SBASE) : "memory")
 // LDS-DMA in the same form (M0 = wave-uniform LDS byte address of the 1 KB destination).  The persistent kernel
 // uses ONLY this form, so the compiler never tracks M0 in it.
 #define P_DMA16(VOFF, SBASE, LDSADDR) \
@@ -839,7 +849,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
       if (HM_C) ldc = 64;                                      // (per tile: `ldc` is dead in the main loop)
       const uint32_t eo0 = (uint32_t)(lr * ldc + ec0) * 2, eo1 = (uint32_t)((lr + 8) * ldc + ec1) * 2;
       const uint32_t io0 = HAS_IN ? (uint32_t)(lr * ldin + ec0) * 2 : 0, io1 = HAS_IN ? (uint32_t)((lr + 8) * ldin + ec1) * 2 : 0;
+#ifdef SIMX_P3_SAMEC                      /* timing experiment only: every tile stores to the first tile's rows (stays in L2) */
+      bf16_t* const obase = C + (long)(wr * 128) * ldc + (nw - n0);
+#else
       bf16_t* const obase = HM_C ? C + ((long)(nw >> 6) * ldc2 + mw) * 64 : C + (long)mw * ldc + nw;          // uniform
+#endif
       const bool store_pre = !(EPI == SIMX_EPI_GELU && ldin == 1);   // ldin == 1 on a GELU launch: SIMX_EPI_GELU_INFER
 #pragma unroll
       for (int i = 0; i < 8; ++i) {

@@ -570,7 +570,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // "sc0 sc1" (write-through) changes nothing.  SIMX_P3_SAMEC, every tile storing to the same rows so that no store reaches HBM,
 // shows what is left: the seven shapes run 6 % faster, QKV 11 % -- a store is acknowledged only when the L2 has room, the 32 CUs
 // of an XCD store 4 MB = the whole L2 within a few microseconds, and gfx9's single in-order vmcnt makes the next tile's first
-// stage boundary wait for those acknowledgements.  Skewing the XCDs against each other does not help (per-XCD burst unchanged),
+// stage boundary wait for those acknowledgements -- or so it seemed: waiting for the next tile's stage 1 BEFORE the stores
+// and passing that first boundary with a bare s_barrier changed nothing (6.73 vs 6.73 ms), so the cost is in the store
+// path's back-pressure on the issuing waves themselves.  Skewing the XCDs against each other does not help (per-XCD burst unchanged),
 // starting the A panels of an XCD in 4 phase groups (N-tiles of a panel in step) costs its 3/4-tile tail and gains nothing.)
 #ifndef SIMX_P3_STORE_BITS
 #define SIMX_P3_STORE_BITS " nt"

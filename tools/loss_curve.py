@@ -1,0 +1,79 @@
+"""Training-trajectory check on the GPU (not part of bench.py's metric): the SAME retriever job -- two BERT-base towers,
+frozen cross-encoder teacher, SimANS draw, KL-distill loss, clip 2.0 + AdamW + warm-up, dropout 0.1 -- run for N optimiser
+steps in the bf16 engine and in the fp32 (1e-3 parity) engine from identical weights, data and dropout masks.  Prints the two
+loss curves and their distance; the committed output is profiles/r02_loss_curve.json.
+usage: python tools/loss_curve.py [steps=60] [B=32] [N=15]"""
+import json
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from simxns_amd import ops                                                     # noqa: E402
+from simxns_amd.engine import BertConfigLite                                   # noqa: E402
+from simxns_amd.model.models import HFBertEncoder, BiBertEncoder, Reranker     # noqa: E402
+from simxns_amd.optim import FusedAdamW, LinearWarmupSchedule                  # noqa: E402
+from simxns_amd.utils import synth                                             # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 15
+Cn, QL, PL, CL = 64, 32, 128, 160
+dev = torch.device("cuda:0")
+cfg = BertConfigLite(hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+
+
+def run(dtype):
+    torch.manual_seed(1234)
+
+    def tower():
+        return HFBertEncoder(cfg, compute_dtype=dtype)
+    bi = BiBertEncoder.__new__(BiBertEncoder)
+    torch.nn.Module.__init__(bi)
+    bi.question_model, bi.ctx_model = tower(), tower()
+    teacher = Reranker(tower(), cfg.hidden_size)
+    bi.to(dev).train()
+    teacher.to(dev).eval()
+    for m in (bi.question_model, bi.ctx_model, teacher.encoder):
+        m.engine.dropout_seed = 7                       # same stateless masks in both engines
+    opt = FusedAdamW(bi, lr=2e-5, eps=1e-8)
+    sch = LinearWarmupSchedule(opt, 10, 10 * steps, last_step=1)
+    q_ids, _, q_lens = synth.make_batch(100, B, QL, cfg.vocab_size, 9, 3, 4, full=False)
+    p_ids, _, p_lens = synth.make_batch(200, B * (1 + Cn), PL, cfg.vocab_size, 80, 25, 16, full=False)
+    pool_q = torch.from_numpy(q_ids.astype(np.int32)).to(dev)
+    pool_p = torch.from_numpy(p_ids.astype(np.int32)).to(dev)
+    q_rows = torch.arange(B, dtype=torch.int32, device=dev)
+    row_base = (torch.arange(B, device=dev) * (1 + Cn)).unsqueeze(1)
+    rs = np.random.RandomState(7)
+    s_pos = 70.0 + 20.0 * rs.rand(B)
+    scores = np.sort(s_pos[:, None] - np.abs(rs.randn(B, Cn)) * 1.5, axis=1)[:, ::-1].copy()
+    d_scores, d_spos = torch.from_numpy(scores).to(dev), torch.from_numpy(s_pos).to(dev)
+    zero_col = torch.zeros(B, 1, dtype=torch.long, device=dev)
+    losses = []
+    for it in range(steps):
+        neg = ops.simans_sample(d_scores, d_spos, N, form=ops.LAPLACE, tau=3.0, seed=42, offset=1 + it % 4)   # 4 batches, revisited
+        sel = torch.cat([zero_col, neg.long() + 1], dim=1)
+        batch = ops.assemble_batch(pool_q, pool_p, q_rows, (row_base + sel).to(torch.int32), 1 + N, pad_id=0, sep_id=102, ce_len=CL)
+        q_i, q_m, c_i, c_m, _ = batch["student"]
+        q, c = bi(q_i, q_m, c_i, c_m)
+        with torch.no_grad():
+            z = teacher(batch["teacher"][0], batch["teacher"][1])
+        loss, _, _ = ops.kl_distill_loss(q, c, z, 1.0, False, 1)
+        loss.backward()
+        opt.step(max_grad_norm=2.0, world_size=1)
+        sch.step()
+        losses.append(float(loss.item()))
+    del bi, teacher, opt
+    torch.cuda.empty_cache()
+    return losses
+
+
+a, b = run("bf16"), run("fp32")
+d = np.abs(np.array(a) - np.array(b))
+print(json.dumps({"job": "retriever step x %d, B=%d, %d negatives of %d candidates, 4 batches revisited, lr 2e-5 (warm-up 10), dropout 0.1, "
+                         "clip 2.0; identical weights / data / dropout masks in both engines" % (steps, B, N, Cn),
+                  "loss_bf16": [round(x, 4) for x in a], "loss_fp32": [round(x, 4) for x in b],
+                  "first_loss": [round(a[0], 4), round(b[0], 4)], "last5_mean": [round(float(np.mean(a[-5:])), 4), round(float(np.mean(b[-5:])), 4)],
+                  "max_abs_diff": round(float(d.max()), 4), "mean_abs_diff": round(float(d.mean()), 4),
+                  "rel_diff_of_last5_mean": round(float(abs(np.mean(a[-5:]) - np.mean(b[-5:])) / abs(np.mean(b[-5:]))), 4)}))

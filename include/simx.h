@@ -204,6 +204,13 @@ int simx_gemm_hm_ok(int rows, int H, int tokens);
 int simx_gemm_nt_hm(simx_stream_t stream, int dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                     void* C, int ldc, const float* bias, const void* residual, int ldr, const simx_dropout* drop,
                     int a_hm_rows, int c_hm_rows);
+/* the general plane-blocked form ([cols/64][rows][64] tensors; the FFN's [T, 3072] intermediates use it too).  flags: bit 0 = A,
+ * bit 1 = C and C2, bit 2 = `in` (residual of SIMX_EPI_NONE / stored derivative of SIMX_EPI_DGELU).  Built combinations:
+ * SIMX_EPI_NONE with flags 1 (with `in`) or 2 (without) -- the two q/k/v forms; anything else: SIMX_ERR_UNSUPPORTED
+ * (plane-blocking the FFN tensors was measured and gains 1.5-4 %: not built in). */
+int simx_gemm_nt_pb(simx_stream_t stream, int dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                    void* C, int ldc, const float* bias, const void* in, int ldin, int epilogue, void* C2, int ldc2,
+                    const simx_dropout* drop, int flags, int rows);
 int simx_gemm_tn_hm(simx_stream_t stream, int dtype, int M, int N, int K, const void* A, int a_hm_rows, const void* B, int ldb,
                     float* C, int ldc, int accumulate, void* ws, size_t ws_bytes, float* dbias);
 int simx_mha_fwd_hm(simx_stream_t stream, int dtype, int nseq, int heads, int head_dim, const int32_t* cu_seqlens, int max_len,

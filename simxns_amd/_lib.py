@@ -89,6 +89,7 @@ SIGNATURES = {
     "simx_sim_loss_fwd_bwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _lpp, _p, _p, _p, _p]),
     "simx_gemm_hm_ok": (_i, [_i, _i, _i]),
     "simx_gemm_nt_hm": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _i, _dp, _i, _i]),
+    "simx_gemm_nt_pb": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _i, _i, _p, _i, _dp, _i, _i]),
     "simx_gemm_tn_hm": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p, _z, _p]),
     "simx_mha_fwd_hm": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _dp, _i]),
     "simx_mha_bwd_hm": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _p, _dp, _i]),

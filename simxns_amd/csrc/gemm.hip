@@ -604,12 +604,17 @@ __device__ __forceinline__ void p3_half(const bf16_t* __restrict__ G, int ld, in
   }
 }
 
-// HM (head-major q/k/v, see QkvLay in attention.hip; EPI_NONE only, `ldc2` carries the rows R of a plane):
-//   HM && !HAS_IN: C is [N/64][R][64] -- the QKV projection's output; a wave's 64 columns are exactly one plane, so only the
-//                  wave's base pointer and the row pitch (64) change;
-//   HM &&  HAS_IN: A is [K/64][R][64] -- dq/dk/dv as the dgrad GEMM's operand; a 64-wide K stage is one plane, i.e. a
-//                  contiguous 256 x 128 B block instead of 256 rows K*2 B apart.
-template <int EPI, bool HAS_IN, bool HM = false>
+// HMF: which operands are PLANE-BLOCKED, i.e. a [rows, cols] tensor stored as [cols/64][R][64] (the head-major q/k/v of
+// attention.hip is the 64 = head-size case; the FFN's [T, 3072] tensors use the same form).  `ldc2` carries R, the rows of
+// a plane; a plane-blocked operand's own leading dimension is 64.
+//   bit 0: A          -- a 64-wide K stage is one plane: a contiguous 256 x 128 B block instead of 256 rows K*2 B apart;
+//   bit 1: C (and C2) -- a wave's 64 output columns are exactly one plane: its 16-row chunks are contiguous 2 KB stores
+//                        instead of 16 pieces of 128 B that sit ldc*2 B apart.  For the QKV projection that is 0.95 -> 0.78 ms,
+//                        but the gain is specific to its row pitch: 2304 columns = 4608 B (4096 + 512) between the rows of a
+//                        chunk is a bad stride for the memory system, while 6144 B (N = 3072: 1.056 ms row-major, 1.07
+//                        plane-blocked) and 1536 B (N = 768: 0.28 / 0.28, 0.93 / 0.93) are not;
+//   bit 2: the epilogue input (residual / GELU' rows), addressed like C.
+template <int EPI, bool HAS_IN, int HMF = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
     int M, int N, int K, const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
     bf16_t* __restrict__ C, int ldc, const float* __restrict__ bias, const bf16_t* __restrict__ in, int ldin,
@@ -631,12 +636,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
   const int lr = lane >> 3;
   const int ec0 = ((lane & 7) ^ (lane >> 4)) << 3, ec1 = ((lane & 7) ^ (4 + (lane >> 4))) << 3;   // element column of the lane's 16-B chunk, rows lr / 8+lr
   const uint32_t bmask = bias ? 0xFFFFFFFFu : 0u;
-  constexpr bool HM_A = HM && HAS_IN, HM_C = HM && !HAS_IN;
+  constexpr bool HM_A = (HMF & 1) != 0, HM_C = (HMF & 2) != 0, HM_I = (HMF & 4) != 0;
+  const int hmR = ldc2;                           // rows of a plane (ldc2 is free: a plane-blocked C2 has pitch 64)
   if (HM_A) lda = 64;                             // row pitch inside a plane; the stage's k offset selects the plane (P3_AK)
+  if (HM_I) ldin = 64;
   const uint32_t offA0 = (uint32_t)(lr * lda + ec0) * 2, offA1 = (uint32_t)(lr * lda + ec1) * 2;
   const uint32_t offB0 = (uint32_t)(lr * ldb + ec0) * 2, offB1 = (uint32_t)(lr * ldb + ec1) * 2;
   // element offset of K stage s of the A operand: s * 64 columns, or plane s of ldc2 rows x 64
-#define P3_AK(S) (HM_A ? (long)(S) * ((long)ldc2 * 64) : (long)(S) * 64)
+#define P3_AK(S) (HM_A ? (long)(S) * ((long)hmR * 64) : (long)(S) * 64)
   // Epilogue-only per-lane constants are recomputed per tile from a laundered copy of the lane id (P_LANE): left to
   // LICM they are hoisted out of the tile loop and stay live (~20 VGPRs) through the main loop, which then spills.
 #define P_LANE(L) int L = lane; asm volatile("" : "+v"(L))
@@ -799,7 +806,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
     if (has_next) { const int tn_ = xcd_remap(vn, ntiles); m0n = (tn_ / tiles_n) * 256; n0n = (tn_ % tiles_n) * 256; }
     const int mw = m0 + wr * 128, nw = n0 + wc * 64;
     const float* bptr = bias ? bias + n0n + wc * 64 : reinterpret_cast<const float*>(A);   // uniform
-    const char* ibase = HAS_IN ? reinterpret_cast<const char*>(in + (long)mw * ldin + nw) : nullptr;   // uniform
+    const char* ibase = !HAS_IN ? nullptr : reinterpret_cast<const char*>(HM_I ? in + ((long)(nw >> 6) * hmR + mw) * 64 : in + (long)mw * ldin + nw);   // uniform
 
     f32x4 acc[8][4];
     {
@@ -854,7 +861,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
 #ifdef SIMX_P3_SAMEC                      /* timing experiment only: every tile stores to the first tile's rows (stays in L2) */
       bf16_t* const obase = C + (long)(wr * 128) * ldc + (nw - n0);
 #else
-      bf16_t* const obase = HM_C ? C + ((long)(nw >> 6) * ldc2 + mw) * 64 : C + (long)mw * ldc + nw;          // uniform
+      bf16_t* const obase = HM_C ? C + ((long)(nw >> 6) * hmR + mw) * 64 : C + (long)mw * ldc + nw;          // uniform
 #endif
       const bool store_pre = !(EPI == SIMX_EPI_GELU && ldin == 1);   // ldin == 1 on a GELU launch: SIMX_EPI_GELU_INFER
 #pragma unroll
@@ -921,9 +928,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
           u32x4 w2, w3;
           asm volatile("ds_read_b128 %0, %2 offset:2048\n\tds_read_b128 %1, %2 offset:3072\n\ts_waitcnt lgkmcnt(0)"
                        : "=&v"(w2), "=&v"(w3) : "v"(rd) : "memory");
-          bf16_t* const gbase = C2 + (long)(mw + i * 16) * ldc2 + nw;   // uniform
-          P_GST4((uint32_t)(lr * ldc2 + ec0) * 2, gbase, w2);
-          P_GST4((uint32_t)((lr + 8) * ldc2 + ec1) * 2, gbase, w3);
+          const int ld2 = HM_C ? 64 : ldc2;
+          bf16_t* const gbase = HM_C ? C2 + ((long)(nw >> 6) * hmR + mw + i * 16) * 64 : C2 + (long)(mw + i * 16) * ldc2 + nw;   // uniform
+          P_GST4((uint32_t)(lr * ld2 + ec0) * 2, gbase, w2);
+          P_GST4((uint32_t)((lr + 8) * ld2 + ec1) * 2, gbase, w3);
         }
       }
     }
@@ -1471,8 +1479,8 @@ static const GemmDevice* gemm_device() {
     SIMX_LDS_ATTR((gemm_nt_bf16_p3_kernel<SIMX_EPI_NONE, true>), P_LDS);
     SIMX_LDS_ATTR((gemm_nt_bf16_p3_kernel<SIMX_EPI_GELU, false>), P_LDS);
     SIMX_LDS_ATTR((gemm_nt_bf16_p3_kernel<SIMX_EPI_DGELU, true>), P_LDS);
-    SIMX_LDS_ATTR((gemm_nt_bf16_p3_kernel<SIMX_EPI_NONE, false, true>), P_LDS);
-    SIMX_LDS_ATTR((gemm_nt_bf16_p3_kernel<SIMX_EPI_NONE, true, true>), P_LDS);
+    SIMX_LDS_ATTR((gemm_nt_bf16_p3_kernel<SIMX_EPI_NONE, false, 2>), P_LDS);
+    SIMX_LDS_ATTR((gemm_nt_bf16_p3_kernel<SIMX_EPI_NONE, true, 1>), P_LDS);
     SIMX_LDS_ATTR(gemm_tn2_bf16_kernel, TN2_LDS);
 #undef SIMX_LDS_ATTR
     g.ok = ok;
@@ -1664,34 +1672,52 @@ extern "C" int simx_gemm_hm_ok(int rows, int H, int tokens) {
   const long dgrad_tiles = (long)(rows / 256) * (H / 256);            // the narrowest of the three GEMMs (N = H)
   return shapes && dgrad_tiles >= 192 && tokens >= 2048 ? 1 : 0;
 }
+// General plane-blocked form on the persistent kernel (bf16, full 256x256 tiles).  flags: bit 0 = A, bit 1 = C (and C2),
+// bit 2 = `in` (the residual of SIMX_EPI_NONE / the stored derivative of SIMX_EPI_DGELU) are [cols/64][rows][64] tensors with
+// planes of `rows` rows; the others are ordinary row-major tensors with their leading dimensions.  Built: SIMX_EPI_NONE with
+// flags 1 (A, with a residual) or 2 (C, without).  The kernel template also has the GELU (flags 2) and DGELU (flags 6) forms
+// for the FFN's [T, 3072] tensors; measured (tools/kbench, M = 262144) they gain 4 % and 1.5 % where the QKV projection gains
+// 18 % (see bit 1 above: the row pitch, not locality as such) -- so they are not built in.  The same probes price the GELU
+// epilogue: plain bias 1.056 ms, + gelu (inference form) 1.266, + gelu' as a second output 1.49.
+extern "C" int simx_gemm_nt_pb(simx_stream_t stream, int dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                               void* C, int ldc, const float* bias, const void* in, int ldin, int epilogue, void* C2, int ldc2,
+                               const simx_dropout* dropd, int flags, int rows) {
+  hipStream_t s = (hipStream_t)stream;
+  SIMX_PROF(SIMX_K_GEMM_NT, s, 2.0 * M * N * K);
+  SIMX_REQUIRE(dtype == SIMX_BF16, SIMX_ERR_BAD_DTYPE, "gemm_nt_pb: bf16 only");
+  SIMX_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C, SIMX_ERR_BAD_SHAPE, "gemm_nt_pb: bad arguments");
+  const bool infer = epilogue == SIMX_EPI_GELU_INFER;
+  if (infer) epilogue = SIMX_EPI_GELU;
+  const bool combo = epilogue == SIMX_EPI_NONE && ((flags == 1 && in) || (flags == 2 && !in));
+  SIMX_REQUIRE(combo, SIMX_ERR_UNSUPPORTED, "gemm_nt_pb: epilogue %d with plane flags %d is not built", epilogue, flags);
+  const GemmDevice* gd = gemm_device();
+  SIMX_REQUIRE(gd != nullptr, SIMX_ERR_HIP, "gemm_nt_pb: cannot query the current device");
+  const int t3n = N / 256, nwg3 = (M / 256) * t3n;
+  const bool pa = flags & 1, pc = flags & 2, pi = flags & 4;
+  const bool ok = M % 256 == 0 && N % 256 == 0 && K % 64 == 0 && K >= 256 && nwg3 >= 192 && rows >= M && ldb % 8 == 0 && ldb >= K &&
+                  aligned16(A) && aligned16(B) && aligned16(C) && (!C2 || aligned16(C2)) && (!bias || aligned16(bias)) &&
+                  (!in || aligned16(in)) && (pa || (lda % 8 == 0 && lda >= K)) && (pc || (ldc % 8 == 0 && ldc >= N)) &&
+                  (!in || pi || (ldin % 8 == 0 && ldin >= N)) && (!C2 || pc || (ldc2 % 8 == 0 && ldc2 >= N));
+  SIMX_REQUIRE(ok, SIMX_ERR_UNSUPPORTED, "gemm_nt_pb: shape %d x %d x %d (planes of %d rows) is outside the persistent kernel's rules", M, N, K, rows);
+  const DropCtx drop = make_drop(epilogue == SIMX_EPI_NONE ? dropd : nullptr);
+  const int grid = nwg3 < gd->ncu ? nwg3 : gd->ncu;
+#define LPB(E, HI, F, INP, LDI) hipLaunchKernelGGL((gemm_nt_bf16_p3_kernel<E, HI, F>), dim3(grid), dim3(512), P_LDS, s, M, N, K, (const bf16_t*)A, lda, \
+                                 (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, (const bf16_t*)(INP), LDI, (bf16_t*)C2, rows, t3n, nwg3, drop)
+  (void)infer;
+  if (flags == 1) LPB(SIMX_EPI_NONE, true, 1, in, ldin);
+  else LPB(SIMX_EPI_NONE, false, 2, nullptr, 0);
+#undef LPB
+  simx_prof_retag(SIMX_K_GEMM_NT_P3);
+  SIMX_CHECK_LAUNCH("gemm_nt_bf16_p3(pb)");
+  return SIMX_OK;
+}
+// the two q/k/v forms under their first names
 extern "C" int simx_gemm_nt_hm(simx_stream_t stream, int dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                                void* C, int ldc, const float* bias, const void* residual, int ldr, const simx_dropout* dropd,
                                int a_hm_rows, int c_hm_rows) {
-  hipStream_t s = (hipStream_t)stream;
-  SIMX_PROF(SIMX_K_GEMM_NT, s, 2.0 * M * N * K);
-  SIMX_REQUIRE(dtype == SIMX_BF16, SIMX_ERR_BAD_DTYPE, "gemm_nt_hm: bf16 only");
   SIMX_REQUIRE((a_hm_rows > 0) != (c_hm_rows > 0), SIMX_ERR_BAD_SHAPE, "gemm_nt_hm: exactly one of A / C is head-major");
-  SIMX_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C, SIMX_ERR_BAD_SHAPE, "gemm_nt_hm: bad arguments");
-  const GemmDevice* gd = gemm_device();
-  SIMX_REQUIRE(gd != nullptr, SIMX_ERR_HIP, "gemm_nt_hm: cannot query the current device");
-  const int t3n = N / 256, nwg3 = (M / 256) * t3n;
-  const int R = a_hm_rows > 0 ? a_hm_rows : c_hm_rows;
-  const bool ok = M % 256 == 0 && N % 256 == 0 && K % 64 == 0 && K >= 256 && nwg3 >= 192 && R >= M && ldb % 8 == 0 && ldb >= K &&
-                  aligned16(A) && aligned16(B) && aligned16(C) && (!bias || aligned16(bias)) &&
-                  (a_hm_rows > 0 ? (residual && ldr % 8 == 0 && ldr >= N && aligned16(residual) && ldc % 8 == 0 && ldc >= N)
-                                 : (!residual && lda % 8 == 0 && lda >= K));
-  SIMX_REQUIRE(ok, SIMX_ERR_UNSUPPORTED, "gemm_nt_hm: shape %d x %d x %d (planes of %d rows) is outside the persistent kernel's rules", M, N, K, R);
-  const DropCtx drop = make_drop(dropd);
-  const int grid = nwg3 < gd->ncu ? nwg3 : gd->ncu;
-  if (a_hm_rows > 0)
-    hipLaunchKernelGGL((gemm_nt_bf16_p3_kernel<SIMX_EPI_NONE, true, true>), dim3(grid), dim3(512), P_LDS, s, M, N, K, (const bf16_t*)A, 64,
-                       (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, (const bf16_t*)residual, ldr, (bf16_t*)nullptr, R, t3n, nwg3, drop);
-  else
-    hipLaunchKernelGGL((gemm_nt_bf16_p3_kernel<SIMX_EPI_NONE, false, true>), dim3(grid), dim3(512), P_LDS, s, M, N, K, (const bf16_t*)A, lda,
-                       (const bf16_t*)B, ldb, (bf16_t*)C, 64, bias, (const bf16_t*)nullptr, 0, (bf16_t*)nullptr, R, t3n, nwg3, drop);
-  simx_prof_retag(SIMX_K_GEMM_NT_P3);
-  SIMX_CHECK_LAUNCH("gemm_nt_bf16_p3(hm)");
-  return SIMX_OK;
+  return simx_gemm_nt_pb(stream, dtype, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, SIMX_EPI_NONE, nullptr, 0, dropd,
+                         a_hm_rows > 0 ? 1 : 2, a_hm_rows > 0 ? a_hm_rows : c_hm_rows);
 }
 
 extern "C" int simx_colsum(simx_stream_t stream, int dtype, int T, int N, const void* x, int ldx, float* out, int accumulate);

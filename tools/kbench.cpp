@@ -29,9 +29,9 @@ int main(int argc, char** argv) {
   const int H = 768, F = 3072, iters = 10;
   const int pad = getenv("KB_LDA_PAD") ? atoi(getenv("KB_LDA_PAD")) : 0;   // experiment: leading-dimension padding of A
   void* A = dalloc((size_t)T * (F + pad) * 2, 1);      // activations (bf16), up to [T,F]
-  void* A2 = dalloc((size_t)T * F * 2, 1);
-  void* C = dalloc((size_t)T * F * 2, 0);
-  void* C2 = dalloc((size_t)T * F * 2, 0);
+  void* A2 = dalloc((size_t)(T + 1024) * F * 2, 1);
+  void* C = dalloc((size_t)(T + 1024) * F * 2, 0);
+  void* C2 = dalloc((size_t)(T + 1024) * F * 2, 0);
   void* W = dalloc((size_t)F * H * 2 * 2, 1);
   float* bias = (float*)dalloc(F * 4 * 2, 0);
   float* G = (float*)dalloc((size_t)F * H * 4, 0);
@@ -52,6 +52,26 @@ int main(int argc, char** argv) {
   }
   printf("gemm_nt total %.2f ms  avg %.1f TF/s\n", tot, totf / tot / 1e9);
   if (oi >= 0) return 0;
+  {   // QKV projection writing the head-major layout ([36][T][64]) and the dgrad reading it
+    double ms = timeit([&] { SX(simx_gemm_nt_hm(0, SIMX_BF16, T, 3 * H, H, A, H, W, H, C, 64, bias, nullptr, 0, nullptr, 0, T)); }, iters);
+    printf("gemm_nt %-36s %8.3f ms  %7.1f TF/s\n", "qkv   fwd  N=2304 K=768 bias -> hm", ms, 2.0 * T * 3 * H * H / ms / 1e9);
+    ms = timeit([&] { SX(simx_gemm_nt_hm(0, SIMX_BF16, T, H, 3 * H, A, 64, W, 3 * H, C, H, nullptr, A2, H, nullptr, T, 0)); }, iters);
+    printf("gemm_nt %-36s %8.3f ms  %7.1f TF/s\n", "qkv  dgrad N=768  K=2304 +res <- hm", ms, 2.0 * T * 3 * H * H / ms / 1e9);
+  }
+  {   // how much would plane-blocked [T, 768] outputs be worth?  (no residual: the built flags-2 form)
+    double ms = timeit([&] { SX(simx_gemm_nt(0, SIMX_BF16, T, H, H, A, H, W, H, C, H, bias, nullptr, 0, 0, nullptr, 0, nullptr, 0)); }, iters);
+    printf("gemm_nt %-36s %8.3f ms  %7.1f TF/s\n", "oproj-shape N=768 K=768 bias", ms, 2.0 * T * H * H / ms / 1e9);
+    ms = timeit([&] { SX(simx_gemm_nt_pb(0, SIMX_BF16, T, H, H, A, H, W, H, C, 64, bias, nullptr, 0, 0, nullptr, 0, nullptr, 2, T)); }, iters);
+    printf("gemm_nt %-36s %8.3f ms  %7.1f TF/s\n", "oproj-shape N=768 K=768 bias -> pb", ms, 2.0 * T * H * H / ms / 1e9);
+    ms = timeit([&] { SX(simx_gemm_nt(0, SIMX_BF16, T, H, F, A, F, W, F, C, H, bias, nullptr, 0, 0, nullptr, 0, nullptr, 0)); }, iters);
+    printf("gemm_nt %-36s %8.3f ms  %7.1f TF/s\n", "ffn2-shape N=768 K=3072 bias", ms, 2.0 * T * H * F / ms / 1e9);
+    ms = timeit([&] { SX(simx_gemm_nt_pb(0, SIMX_BF16, T, H, F, A, F, W, F, C, 64, bias, nullptr, 0, 0, nullptr, 0, nullptr, 2, T)); }, iters);
+    printf("gemm_nt %-36s %8.3f ms  %7.1f TF/s\n", "ffn2-shape N=768 K=3072 bias -> pb", ms, 2.0 * T * H * F / ms / 1e9);
+    ms = timeit([&] { SX(simx_gemm_nt(0, SIMX_BF16, T, F, H, A, H, W, H, C, F, bias, nullptr, 0, 0, nullptr, 0, nullptr, 0)); }, iters);
+    printf("gemm_nt %-36s %8.3f ms  %7.1f TF/s\n", "ffn1-shape N=3072 K=768 bias (plain)", ms, 2.0 * T * H * F / ms / 1e9);
+    ms = timeit([&] { SX(simx_gemm_nt_pb(0, SIMX_BF16, T, F, H, A, H, W, H, C, 64, bias, nullptr, 0, 0, nullptr, 0, nullptr, 2, T)); }, iters);
+    printf("gemm_nt %-36s %8.3f ms  %7.1f TF/s\n", "ffn1-shape N=3072 K=768 bias -> pb", ms, 2.0 * T * H * F / ms / 1e9);
+  }
   {   // the teacher's FFN-in: GELU without the derivative output (SIMX_EPI_GELU_INFER = 3)
     double ms = timeit([&] { SX(simx_gemm_nt(0, SIMX_BF16, T, F, H, A, H + pad, W, H, C, F, bias, nullptr, F, 3, nullptr, F, C2, F)); }, iters);
     printf("gemm_nt %-36s %8.3f ms  %7.1f TF/s\n", "ffn1  fwd  N=3072 K=768 gelu (infer)", ms, 2.0 * T * F * H / ms / 1e9);

@@ -165,3 +165,21 @@ def test_encoder_layouts_agree(dev, ragged):
     assert np.array_equal(res["token"][0], res["head"][0])
     g0, g1 = res["token"][1], res["head"][1]
     assert np.abs(g0 - g1).max() <= 2e-3 * np.abs(g0).max()
+
+
+def test_plane_blocked_entry_rejects_what_is_not_built(dev):
+    """simx_gemm_nt_pb: only the two q/k/v forms exist; everything else must fail loudly, never fall back."""
+    lib = L()
+    from simxns_amd._lib import SimxError
+    M, N, K = 16384, 768, 768
+    A, B, C = bf((M, K), 1, dev), bf((N, K), 2, dev), torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    for epi, flags, with_in in ((1, 2, False), (2, 6, True), (0, 3, True), (0, 1, False), (0, 2, True)):
+        with pytest.raises(SimxError):
+            lib.call("simx_gemm_nt_pb", lib.stream_ptr(), 1, M, N, K, lib.ptr(A), K, lib.ptr(B), K, lib.ptr(C), N, None,
+                     lib.ptr(C) if with_in else None, N, epi, lib.ptr(C) if epi == 1 else None, N, None, flags, M)
+    with pytest.raises(SimxError):                     # a tower too small for the persistent kernel
+        lib.call("simx_gemm_nt_pb", lib.stream_ptr(), 1, 4096, N, K, lib.ptr(A), K, lib.ptr(B), K, lib.ptr(C), 64, None, None, 0, 0,
+                 None, 0, None, 2, 4096)
+    with pytest.raises(SimxError):                     # fp32 has no plane-blocked form
+        lib.call("simx_gemm_nt_pb", lib.stream_ptr(), 0, M, N, K, lib.ptr(A), K, lib.ptr(B), K, lib.ptr(C), 64, None, None, 0, 0,
+                 None, 0, None, 2, M)

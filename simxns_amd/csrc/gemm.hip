@@ -687,9 +687,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
 #else
 #define P3_LGKM_WAIT "s_waitcnt lgkmcnt(0)"
 #endif
-#ifndef SIMX_P3_SCHED
-#define SIMX_P3_SCHED 1
-#endif
 #ifdef SIMX_P3_SETPRIO
 #define P3_PRIO(N) __builtin_amdgcn_s_setprio(N)
 #else
@@ -710,7 +707,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
 #else
 #define P3_HAX(ROW, S1) do { if ((ROW) < 4) P3_HA(ROW); } while (0)
 #endif
-#if SIMX_P3_SCHED == 1
 #define P_STEP(CURA, NA, NB, BC0, BC1, BC2, BC3, BN0, BN1, BN2, BN3, BOUNDARY, S1)               \
   do {                                                                                         \
     /* fragment reads are front-loaded: the last read before each pin is issued two MFMA rows ahead of it */ \
@@ -733,25 +729,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
     P3_PRIO(0);                                                                                \
     V3_PIN8(P3_LGKM_WAIT, al0, al1, al2, al3, BN0, BN1, BN2, BN3);                   \
   } while (0)
-#else
-#define P_STEP(CURA, NA, NB, BC0, BC1, BC2, BC3, BN0, BN1, BN2, BN3, BOUNDARY, S1)               \
-  do {                                                                                         \
-    const uint32_t aa__ = (CURA), na__ = (NA), nb__ = (NB);                                    \
-    V3_SB; V3_MFMA_ROW(0, al0, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah0, aa__, 8192);            \
-    V3_SB; V3_MFMA_ROW(1, al1, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah1, aa__, 10240);           \
-    V3_SB; V3_MFMA_ROW(2, al2, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah2, aa__, 12288);           \
-    V3_SB; V3_MFMA_ROW(3, al3, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah3, aa__, 14336);           \
-    V3_SB;                                                                                     \
-    V3_PIN4("s_waitcnt lgkmcnt(0)", ah0, ah1, ah2, ah3);                                       \
-    BOUNDARY();                                                                                \
-    V3_SB; V3_MFMA_ROW(4, ah0, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al0, na__, 0); V3_RD1(BN0, nb__, 0);       \
-    V3_SB; V3_MFMA_ROW(5, ah1, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al1, na__, 2048); V3_RD1(BN1, nb__, 2048); \
-    V3_SB; V3_MFMA_ROW(6, ah2, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al2, na__, 4096); V3_RD1(BN2, nb__, 4096); \
-    V3_SB; V3_MFMA_ROW(7, ah3, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al3, na__, 6144); V3_RD1(BN3, nb__, 6144); \
-    V3_SB;                                                                                     \
-    V3_PIN8("s_waitcnt lgkmcnt(0)", al0, al1, al2, al3, BN0, BN1, BN2, BN3);                   \
-  } while (0)
-#endif
 #define P_BND_NONE() do { } while (0)
   // stage boundary inside the tile: every fragment of stage st is in registers, stage st+1 has landed once vmcnt
   // hits 0 (for everyone after the barrier); slot (st+par)&1 is refilled with stream stage st+2, which is the

@@ -16,9 +16,18 @@
  *   - return value: SIMX_OK (0) or a negative SIMX_ERR_*; simx_last_error() gives
  *     the thread-local message;
  *   - dtype selects the activation / GEMM-operand type: SIMX_F32 (parity mode, exact
- *     f32 arithmetic) or SIMX_BF16 (bf16 operands, f32 accumulate, f32 statistics).
+ *     f32 arithmetic), SIMX_BF16 (bf16 operands, f32 accumulate, f32 statistics) or SIMX_F16
+ *     (IEEE half operands -- the operand width of the reference's optional apex-O1 mode,
+ *     SimANS/co_training/co_training_marco_train.py:97-104 -- f32 accumulate and statistics;
+ *     its backward carries a loss scale, see "gradient scale" below).
  *     Parameters, gradients, LayerNorm statistics, embeddings handed to the loss and
- *     all loss arithmetic are f32 in both modes.
+ *     all loss arithmetic are f32 in every mode.
+ *   - gradient scale (SIMX_F16): `gs` arguments are device pointers to two floats {S, 1/S}
+ *     or NULL (= 1).  The gradient entering the encoder backward is multiplied by S when it is
+ *     rounded to fp16 and every activation gradient travels scaled (apex.amp.scale_loss,
+ *     co_training_marco_train.py:218-220); each kernel that accumulates into the f32 PARAMETER
+ *     gradients multiplies by 1/S, so gradient buffers always hold true gradients and an
+ *     overflow shows up there as inf / nan (simx_scaler_update reacts to it).
  *   - packed ("varlen") token layout: the T real tokens of nseq sequences are
  *     stored back to back; cu_seqlens[nseq+1] holds the prefix sums (int32).
  */
@@ -35,7 +44,7 @@ typedef void* simx_stream_t;
 
 enum { SIMX_OK = 0, SIMX_ERR_BAD_SHAPE = -1, SIMX_ERR_BAD_DTYPE = -2, SIMX_ERR_WORKSPACE = -3,
        SIMX_ERR_HIP = -4, SIMX_ERR_UNSUPPORTED = -5 };
-enum { SIMX_F32 = 0, SIMX_BF16 = 1 };
+enum { SIMX_F32 = 0, SIMX_BF16 = 1, SIMX_F16 = 2 };
 
 int simx_version(void);
 const char* simx_last_error(void);
@@ -87,9 +96,18 @@ int simx_gemm_tn_bias(simx_stream_t stream, int dtype, int M, int N, int K,
                       const void* A, int lda, const void* B, int ldb, float* C, int ldc,
                       int accumulate, void* ws, size_t ws_bytes, float* dbias);
 
+/* every form of the wgrad GEMM in one call (a_hm_rows > 0: A is head-major, see "head-major q / k / v"; lda then ignored),
+ * with the gradient scale of the SIMX_F16 backward: A = S x dY, and C / dbias receive (1/S) x the products (gs = {S, 1/S}
+ * on the device; NULL = 1). */
+int simx_gemm_tn_gs(simx_stream_t stream, int dtype, int M, int N, int K,
+                    const void* A, int lda, const void* B, int ldb, float* C, int ldc,
+                    int accumulate, void* ws, size_t ws_bytes, float* dbias, int a_hm_rows, const float* gs);
+
 /* out[N] (f32) (+)= column sums of x[T,N]  (bias gradients). */
 int simx_colsum(simx_stream_t stream, int dtype, int T, int N, const void* x, int ldx,
                 float* out, int accumulate);
+int simx_colsum_gs(simx_stream_t stream, int dtype, int T, int N, const void* x, int ldx,
+                   float* out, int accumulate, const float* gs);      /* sums multiplied by 1/S = gs[1] */
 
 /* f32 master weight [rows,cols] -> bf16 copy and (optional) bf16 transposed copy [cols,rows]. */
 int simx_cast_weight(simx_stream_t stream, const float* w, int rows, int cols, void* w_bf16, void* wT_bf16);
@@ -137,6 +155,13 @@ int simx_embed_ln_bwd_seq(simx_stream_t stream, int dtype, int nseq, int max_len
                           const float* word, const float* posw, const float* typew,
                           const float* gamma, float eps, const void* dy,
                           float* dword, float* dpos, float* dtype0, float* dgamma, float* dbeta, const simx_dropout* drop);
+/* same; dy carries the gradient scale, the five parameter gradients receive (1/S) x their sums */
+int simx_embed_ln_bwd_seq_gs(simx_stream_t stream, int dtype, int nseq, int max_len, int T, int H, const int32_t* cu_seqlens,
+                             const int32_t* ids, const int32_t* pos_ids,
+                             const float* word, const float* posw, const float* typew,
+                             const float* gamma, float eps, const void* dy,
+                             float* dword, float* dpos, float* dtype0, float* dgamma, float* dbeta, const simx_dropout* drop,
+                             const float* gs);
 
 /* y = LN(z) ; z already holds dense(x)+bias+residual (BertSelfOutput / BertOutput,
  * LEAD/modeling_bert.py:384-388, 462-466). */
@@ -157,6 +182,12 @@ int simx_ln_bwd_ex(simx_stream_t stream, int dtype, int T, int H, const void* z,
 int simx_ln_bwd_keyed(simx_stream_t stream, int dtype, int T, int H, const void* z,
                       const float* gamma, float eps, const void* dy, void* dz, void* dz_masked,
                       float* dgamma, float* dbeta, float* dbias, const simx_dropout* drop, const int32_t* row_keys);
+/* same with the gradient scale of the SIMX_F16 backward: dy, dz, dz_masked are S x the true gradients, what is added into
+ * dgamma / dbeta / dbias is multiplied by 1/S (gs = {S, 1/S} on the device, NULL = 1; "gradient scale" at the top). */
+int simx_ln_bwd_gs(simx_stream_t stream, int dtype, int T, int H, const void* z,
+                   const float* gamma, float eps, const void* dy, void* dz, void* dz_masked,
+                   float* dgamma, float* dbeta, float* dbias, const simx_dropout* drop, const int32_t* row_keys,
+                   const float* gs);
 
 /* ------------------------------------------------------------ self-attention
  * BertSelfAttention core (LEAD/modeling_bert.py:318-374): softmax(QK^T/sqrt(d)) V per head,
@@ -231,10 +262,16 @@ int simx_cls_gather(simx_stream_t stream, int dtype, int nseq, int H, const int3
                     const void* x, float* cls);
 int simx_cls_scatter(simx_stream_t stream, int dtype, int nseq, int H, int T, const int32_t* cu_seqlens,
                      const float* dcls, void* dx);
+/* dx = S * dcls: where an f32 gradient enters the SIMX_F16 backward (gs = {S, 1/S}, NULL = 1) */
+int simx_cls_scatter_gs(simx_stream_t stream, int dtype, int nseq, int H, int T, const int32_t* cu_seqlens,
+                        const float* dcls, void* dx, const float* gs);
 /* Row gather / scatter / dtype conversion: dst[dst_idx ? dst_idx[s] : s] = src[src_idx ? src_idx[s] : s], s < n, rows of
  * H elements (sequence_output[:, 0, :] and its transpose for same-dtype tensors; SimANS/model/models.py:81). */
 int simx_rows_copy(simx_stream_t stream, int src_dtype, int dst_dtype, int n, int H, const int32_t* src_idx,
                    const int32_t* dst_idx, const void* src, void* dst);
+/* same, values multiplied by S = gs[0] on the way (gs == NULL: plain copy) */
+int simx_rows_copy_gs(simx_stream_t stream, int src_dtype, int dst_dtype, int n, int H, const int32_t* src_idx,
+                      const int32_t* dst_idx, const void* src, void* dst, const float* gs);
 /* z[s] = dropout(y[s]) + res[res_idx ? res_idx[s] : s] on n gathered rows; the mask of row s is the one of row
  * key_idx[s] of the full tensor (BertSelfOutput / BertOutput before the LayerNorm, LEAD/modeling_bert.py:384-388,
  * 462-466, restricted to the rows the path reads). */
@@ -262,6 +299,12 @@ typedef struct simx_bert_cfg {
    * forward -- same stateless dropout masks -- before differentiating it (4/3 of the FLOPs, as in the reference).
    * Must have the same value in simx_bert_act_bytes / simx_bert_fwd / simx_bert_bwd*.  Results are identical to 0. */
   int32_t grad_checkpoint;
+  /* layout of the packed q / k / v tensor ("head-major q / k / v" above): 0 = chosen per call from the shapes (head-major
+   * when every kernel that touches the tensor has the form), 1 = token-major pinned.  A forward and its backward must pass
+   * the same value -- they then make the same choice (it depends on nothing but cfg, T, max_len). */
+  int32_t qkv_layout;
+  /* SIMX_F16 backward: device pointer to {S, 1/S} (the loss scale, "gradient scale" above) or NULL = 1. */
+  const float* grad_scale;
 } simx_bert_cfg;
 
 enum { SIMX_P_WORD = 0, SIMX_P_POS, SIMX_P_TYPE, SIMX_P_EMB_LN_G, SIMX_P_EMB_LN_B,   /* layer = -1 */
@@ -309,6 +352,8 @@ int simx_bert_bwd_ex(simx_stream_t stream, const simx_bert_cfg* cfg, const float
  * SimANS/model/models.py:296-299), and its adjoint (dx[t] = dmean[seq(t)] / len) */
 int simx_seq_mean_fwd(simx_stream_t stream, int dtype, int nseq, int H, const int32_t* cu_seqlens, const void* x, float* mean);
 int simx_seq_mean_bwd(simx_stream_t stream, int dtype, int nseq, int H, const int32_t* cu_seqlens, const float* dmean, void* dx);
+int simx_seq_mean_bwd_gs(simx_stream_t stream, int dtype, int nseq, int H, const int32_t* cu_seqlens, const float* dmean, void* dx,
+                         const float* gs);   /* dx multiplied by S = gs[0]: the f32 gradient enters the SIMX_F16 backward here */
 
 /* -------------------------------------------------- similarity + losses (f32)
  * M1 local similarity einsum("bh,bdh->bd") (co_training_marco_train.py:199-202) fused with the
@@ -421,6 +466,19 @@ int simx_sqnorm_accum_det(simx_stream_t stream, const float* g, size_t n, float*
 int simx_adamw_step(simx_stream_t stream, float* p, float* g, float* m, float* v, size_t n,
                     float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                     const float* sqnorm, float max_norm, float grad_scale, int zero_grad);
+
+/* Dynamic loss scaler of the SIMX_F16 engine (apex.amp dynamic loss scaling, under which the reference's --fp16 mode runs:
+ * co_training_marco_train.py:97-104, 218-220).  `state`: 8 floats on the device -- [0] S, [1] 1/S (what `gs` arguments point
+ * to), [2] clean steps since S changed, [3] 1 = the current optimiser step is skipped, [4] steps applied, [5] steps skipped,
+ * [6] growth interval, [7] largest S.  Per optimiser step: squared norm of ALL gradient buffers -> simx_scaler_update (inf /
+ * nan: skip, S /= 2; else count, S *= 2 every `growth_interval` clean steps) -> simx_adamw_step_sc for every buffer, which
+ * leaves p, m, v untouched on a skipped step (gradients are still zeroed) and takes its bias-correction step count from [4].
+ * No host synchronisation anywhere. */
+int simx_scaler_init(simx_stream_t stream, float* state, float init_scale, float growth_interval, float max_scale);
+int simx_scaler_update(simx_stream_t stream, float* state, const float* sqnorm);
+int simx_adamw_step_sc(simx_stream_t stream, float* p, float* g, float* m, float* v, size_t n,
+                       float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                       const float* sqnorm, float max_norm, float grad_scale, int zero_grad, const float* scaler);
 
 /* ------------------------------------------------------------------ measurement
  * Optional per-launch timing with HIP events recorded on the launch stream (bench.py's live roofline

@@ -32,7 +32,7 @@ def load_model(args):
     else:
         from transformers import RobertaTokenizer
         tokenizer = RobertaTokenizer.from_pretrained(args.tokenizer_name or "roberta-base")
-    dtype = "bf16" if args.fp16 else os.environ.get("SIMX_DTYPE", "fp32")      # as HFBertEncoder.init_encoder
+    dtype = os.environ.get("SIMX_DTYPE") or ("fp16" if args.fp16 else "fp32")      # as HFBertEncoder.init_encoder
     model = RobertaDot(_roberta_cfg(args.model_type), compute_dtype=dtype)
     if args.model_name_or_path and os.path.exists(args.model_name_or_path):
         model.load_state_dict(load_states_from_checkpoint(args.model_name_or_path).model_dict, strict=False)

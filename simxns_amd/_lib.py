@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsimx_hip.so")
 
-SIMX_F32, SIMX_BF16 = 0, 1
+SIMX_F32, SIMX_BF16, SIMX_F16 = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_DGELU = 0, 1, 2
 LOSS_KL, LOSS_WIKI, LOSS_CEKD, LOSS_CE = 0, 1, 2, 3
 (P_WORD, P_POS, P_TYPE, P_EMB_LN_G, P_EMB_LN_B, P_WQKV, P_BQKV, P_WO, P_BO, P_LN1_G, P_LN1_B,
@@ -26,7 +26,8 @@ class BertCfg(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("layers", C.c_int32), ("hidden", C.c_int32), ("heads", C.c_int32),
                 ("inter", C.c_int32), ("vocab", C.c_int32), ("max_pos", C.c_int32), ("type_vocab", C.c_int32),
                 ("eps", C.c_float), ("hidden_dropout", C.c_float), ("attn_dropout", C.c_float), ("dropout_seed", C.c_uint32),
-                ("cls_only_last_layer", C.c_int32), ("grad_checkpoint", C.c_int32)]
+                ("cls_only_last_layer", C.c_int32), ("grad_checkpoint", C.c_int32), ("qkv_layout", C.c_int32),
+                ("grad_scale", C.c_void_p)]
 
 
 class Dropout(C.Structure):
@@ -108,6 +109,16 @@ SIGNATURES = {
     "simx_sqnorm_accum": (_i, [_p, _p, _z, _p]),
     "simx_sqnorm_accum_det": (_i, [_p, _p, _z, _p, _p]),
     "simx_adamw_step": (_i, [_p, _p, _p, _p, _p, _z, _f, _f, _f, _f, _f, _i, _p, _f, _f, _i]),
+    "simx_gemm_tn_gs": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p, _z, _p, _i, _p]),
+    "simx_colsum_gs": (_i, [_p, _i, _i, _i, _p, _i, _p, _i, _p]),
+    "simx_ln_bwd_gs": (_i, [_p, _i, _i, _i, _p, _p, _f, _p, _p, _p, _p, _p, _p, _dp, _p, _p]),
+    "simx_embed_ln_bwd_seq_gs": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _dp, _p]),
+    "simx_cls_scatter_gs": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "simx_rows_copy_gs": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "simx_seq_mean_bwd_gs": (_i, [_p, _i, _i, _i, _p, _p, _p, _p]),
+    "simx_scaler_init": (_i, [_p, _p, _f, _f, _f]),
+    "simx_scaler_update": (_i, [_p, _p, _p]),
+    "simx_adamw_step_sc": (_i, [_p, _p, _p, _p, _p, _z, _f, _f, _f, _f, _f, _i, _p, _f, _f, _i, _p]),
     "simx_prof_begin": (_i, [_i]),
     "simx_prof_end": (_i, [_p, _p, _p]),
     "simx_prof_kernel_count": (_i, []),

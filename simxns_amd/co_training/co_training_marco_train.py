@@ -5,7 +5,7 @@ Launch exactly like the reference (``train_MS_Pas_AR2.sh``):
     python -m torch.distributed.run --nproc_per_node=8 simxns_amd/co_training/co_training_marco_train.py <same flags>
 (``torch.distributed.launch`` with ``--local_rank`` also works.)  Differences, all stated in INTEGRATION.md:
 no apex / DDP wrappers (gradients live in flat buffers that FusedAdamW all-reduces over RCCL), ``--fp16`` selects the
-bf16 engine, tensorboard is optional, ``--tokenizer_name hash`` selects the offline hash tokenizer.
+fp16 engine with FusedAdamW's dynamic loss scale, tensorboard is optional, ``--tokenizer_name hash`` selects the offline hash tokenizer.
 """
 import argparse
 import json

@@ -42,12 +42,15 @@ __device__ __forceinline__ bf16x8 lds_row_frag(const char* tile, int row, int c1
   return *reinterpret_cast<const bf16x8*>(tile + att_off(row, c16));
 }
 
+// In the MFMA kernels below `bf16_t` is the raw 16-bit storage of EITHER operand format; the template parameter
+// F in {bf16_t, f16_t} (H16<F>, common.h) selects the conversions and the MFMA instruction.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+template <typename F>
 __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
-  bf16x8 r;
-  r[0] = (short)f2bf(a[0]); r[1] = (short)f2bf(a[1]); r[2] = (short)f2bf(a[2]); r[3] = (short)f2bf(a[3]);
-  r[4] = (short)f2bf(b[0]); r[5] = (short)f2bf(b[1]); r[6] = (short)f2bf(b[2]); r[7] = (short)f2bf(b[3]);
-  return r;
+  const u32x4_t w = {H16<F>::pack2(a[0], a[1]), H16<F>::pack2(a[2], a[3]), H16<F>::pack2(b[0], b[1]), H16<F>::pack2(b[2], b[3])};
+  return __builtin_bit_cast(bf16x8, w);
 }
+
 
 // Two layouts of the packed q / k / v (and dq / dk / dv) tensor:
 //   token-major (hm_rows == 0): [T][3H], row t = [q(heads x 64) | k | v] -- what a [T,3H] GEMM output looks like;
@@ -66,8 +69,8 @@ __device__ __forceinline__ P* qkv_head(P* base, int heads, int h, int t0, int hm
 }
 
 // ------------------------------------------------------------------------------------------ forward
-template <int NKT>
-__global__ __launch_bounds__(256) void mha_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+template <typename F, int NKT>
+__global__ __launch_bounds__(256) void mha_fwd_h16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
                                                            float* __restrict__ lse, const int* __restrict__ cu,
                                                            int heads, int T, float scale, DropCtx drop, int hm_rows) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -102,28 +105,6 @@ __global__ __launch_bounds__(256) void mha_fwd_bf16_kernel(const bf16_t* __restr
     for (int dt = 0; dt < 4; ++dt) vtr[dt] = (uint32_t)(rr * 128 + (((dt * 2 + tx) ^ tsw) << 4) + (fr & 1) * 8);
   }
 
-  // SIMX_MHA_NOCOMPUTE (timing experiment only: the kernel's loads and stores without its arithmetic; tools/kbench, S = 128,
-  // 262144 tokens, 12 heads): forward 0.318-0.335 ms against 0.347-0.354 for the real kernel -- the forward IS its memory
-  // traffic (1.6 GB at 5 TB/s); backward 0.625 against 0.823 ms -- two 74 KB workgroups per CU do not overlap one's staging
-  // with the other's arithmetic completely (0.2 ms x 12 layers = the 2.4 ms a double-buffered persistent form could win).
-#ifdef SIMX_MHA_NOCOMPUTE
-  for (int qt = wave; qt < nkt; qt += 4) {
-    const int q = qt * 16 + fr;
-    const int qc = q < len ? q : len - 1;
-    const bf16x8 q0 = *reinterpret_cast<const bf16x8*>(Qg + (long)qc * H3 + fg * 8);
-    const bf16x8 q1 = *reinterpret_cast<const bf16x8*>(Qg + (long)qc * H3 + 32 + fg * 8);
-    const bf16x8 k0 = lds_row_frag(sK, qt * 16 + fr, fg), v0 = lds_row_frag(sV, qt * 16 + fr, fg);
-    if (q < len) {
-      bf16_t* dst = ctx + (long)(t0 + q) * H + h * 64 + 4 * fg;
-      for (int dt = 0; dt < 4; ++dt) {
-        float v[4] = {bf2f(q0[dt]) + bf2f(k0[dt]), bf2f(q1[dt]) + bf2f(v0[dt]), bf2f(q0[4 + dt]), bf2f(q1[4 + dt])};
-        st4(dst + dt * 16, v);
-      }
-      if (fg == 0) lse[(long)h * T + t0 + q] = bf2f(q0[0]);
-    }
-  }
-  return;
-#endif
   for (int qt = wave; qt < nkt; qt += 4) {
     const int q = qt * 16 + fr;
     const int qc = q < len ? q : len - 1;
@@ -136,8 +117,8 @@ __global__ __launch_bounds__(256) void mha_fwd_bf16_kernel(const bf16_t* __restr
     for (int kt = 0; kt < NKT; ++kt) {
       if (kt < nkt) {
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(sK, kt * 16 + fr, fg), qf[0], a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(sK, kt * 16 + fr, 4 + fg), qf[1], a, 0, 0, 0);
+        a = H16<F>::mfma(lds_row_frag(sK, kt * 16 + fr, fg), qf[0], a);
+        a = H16<F>::mfma(lds_row_frag(sK, kt * 16 + fr, 4 + fg), qf[1], a);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = kt * 16 + 4 * fg + r;
@@ -192,18 +173,18 @@ __global__ __launch_bounds__(256) void mha_fwd_bf16_kernel(const bf16_t* __restr
           asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c0l), "+v"(c0h), "+v"(c1l), "+v"(c1h), "+v"(c2l), "+v"(c2h), "+v"(c3l), "+v"(c3h)::"memory");
         }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0l), "+v"(a0h), "+v"(a1l), "+v"(a1h), "+v"(a2l), "+v"(a2h), "+v"(a3l), "+v"(a3h)::"memory");
-        const bf16x8 pf = pack8(s[2 * kb], s[2 * kb + 1]);
-        o[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_CAT(a0l, a0h), pf, o[0], 0, 0, 0);
-        o[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_CAT(a1l, a1h), pf, o[1], 0, 0, 0);
-        o[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_CAT(a2l, a2h), pf, o[2], 0, 0, 0);
-        o[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_CAT(a3l, a3h), pf, o[3], 0, 0, 0);
+        const bf16x8 pf = pack8<F>(s[2 * kb], s[2 * kb + 1]);
+        o[0] = H16<F>::mfma(F2_CAT(a0l, a0h), pf, o[0]);
+        o[1] = H16<F>::mfma(F2_CAT(a1l, a1h), pf, o[1]);
+        o[2] = H16<F>::mfma(F2_CAT(a2l, a2h), pf, o[2]);
+        o[3] = H16<F>::mfma(F2_CAT(a3l, a3h), pf, o[3]);
         if (kb + 1 < NKT / 2) {
           if (2 * (kb + 1) < nkt) {                   // rows past the padded length are uninitialised LDS: skip, never multiply
-            const bf16x8 pg = pack8(s[2 * kb + 2], s[2 * kb + 3]);
-            o[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_CAT(c0l, c0h), pg, o[0], 0, 0, 0);
-            o[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_CAT(c1l, c1h), pg, o[1], 0, 0, 0);
-            o[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_CAT(c2l, c2h), pg, o[2], 0, 0, 0);
-            o[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F2_CAT(c3l, c3h), pg, o[3], 0, 0, 0);
+            const bf16x8 pg = pack8<F>(s[2 * kb + 2], s[2 * kb + 3]);
+            o[0] = H16<F>::mfma(F2_CAT(c0l, c0h), pg, o[0]);
+            o[1] = H16<F>::mfma(F2_CAT(c1l, c1h), pg, o[1]);
+            o[2] = H16<F>::mfma(F2_CAT(c2l, c2h), pg, o[2]);
+            o[3] = H16<F>::mfma(F2_CAT(c3l, c3h), pg, o[3]);
           }
         }
       }
@@ -213,7 +194,7 @@ __global__ __launch_bounds__(256) void mha_fwd_bf16_kernel(const bf16_t* __restr
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         float v[4] = {o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv};
-        st4(dst + dt * 16, v);
+        st4h<F>(dst + dt * 16, v);
       }
       if (fg == 0) lse[(long)h * T + t0 + q] = m * scale + logf(sum);
     }
@@ -236,13 +217,14 @@ __global__ __launch_bounds__(256) void mha_fwd_bf16_kernel(const bf16_t* __restr
 
 // stage a wave's 16x64 tile (MFMA layout: lane = row fr, 4 columns dt*16 + 4*fg) through its 2 KB LDS patch and store it
 // as full 128-B lines: rows t_row0 + r (r < nrows valid), column block h*64 of a [.., ld] bf16 matrix
+template <typename F>
 __device__ __forceinline__ void a2_store_tile(const f32x4 (&acc)[4], char* patch, uint32_t patch_addr, bf16_t* __restrict__ dst,
                                               long ld, int nrows, int lane) {
   const int fr = lane & 15, fg = lane >> 4;
   const int sw = (fr >> 1) & 7;
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) {
-    const uint2 o = make_uint2(pack2bf(acc[dt][0], acc[dt][1]), pack2bf(acc[dt][2], acc[dt][3]));
+    const uint2 o = make_uint2(H16<F>::pack2(acc[dt][0], acc[dt][1]), H16<F>::pack2(acc[dt][2], acc[dt][3]));
     const uint32_t ad = patch_addr + (uint32_t)(fr * 128 + (((dt * 2 + (fg >> 1)) ^ sw) << 4) + (fg & 1) * 8);
     asm volatile("ds_write_b64 %0, %1" ::"v"(ad), "v"(o) : "memory");
   }
@@ -256,8 +238,8 @@ __device__ __forceinline__ void a2_store_tile(const f32x4 (&acc)[4], char* patch
   }
 }
 
-template <int NKT>
-__global__ __launch_bounds__(256) void mha_bwd2_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ O,
+template <typename F, int NKT>
+__global__ __launch_bounds__(256) void mha_bwd2_h16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ O,
                                                             const float* __restrict__ lse, const bf16_t* __restrict__ dO,
                                                             bf16_t* __restrict__ dqkv, const int* __restrict__ cu,
                                                             int heads, int T, float scale, DropCtx drop, int hm_rows) {
@@ -303,8 +285,7 @@ __global__ __launch_bounds__(256) void mha_bwd2_bf16_kernel(const bf16_t* __rest
         const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          del += __uint_as_float(aw[e] << 16) * __uint_as_float(bw[e] << 16) +
-                 __uint_as_float(aw[e] & 0xFFFF0000u) * __uint_as_float(bw[e] & 0xFFFF0000u);
+          del += H16<F>::lo(aw[e]) * H16<F>::lo(bw[e]) + H16<F>::hi(aw[e]) * H16<F>::hi(bw[e]);
       }
     }
     del += __shfl_xor(del, 1, 64);
@@ -328,19 +309,6 @@ __global__ __launch_bounds__(256) void mha_bwd2_bf16_kernel(const bf16_t* __rest
   for (int dt = 0; dt < 4; ++dt) tr[dt] = (uint32_t)(rr * 128 + (((dt * 2 + tx) ^ tsw) << 4) + (fr & 1) * 8);
   const bool full = (len == nkt2 * 16);             // no ragged tail: skip the per-element masks
 
-#ifdef SIMX_MHA_NOCOMPUTE          /* timing experiment only: the kernel's loads and stores without its arithmetic */
-  {
-    f32x4 z[4];
-    for (int dt = 0; dt < 4; ++dt) z[dt] = (f32x4){sDel[fr], sLse[fr], 0.f, 0.f};
-    for (int qt = wave; qt < nkt; qt += 4) a2_store_tile(z, patch, patch_addr, dQg + (long)(qt * 16) * H3, H3, len - qt * 16, lane);
-    for (int kt = wave; kt < nkt; kt += 4) {
-      bf16_t* dstk = dQg + lay.ws + (long)(kt * 16) * H3;
-      a2_store_tile(z, patch, patch_addr, dstk, H3, len - kt * 16, lane);
-      a2_store_tile(z, patch, patch_addr, dstk + lay.ws, H3, len - kt * 16, lane);
-    }
-    return;
-  }
-#endif
   // ---------------- phase A: dQ, waves own query tiles, loop over key-tile pairs
   for (int qt = wave; qt < nkt; qt += 4) {
     const int q = qt * 16 + fr;
@@ -371,10 +339,10 @@ __global__ __launch_bounds__(256) void mha_bwd2_bf16_kernel(const bf16_t* __rest
       for (int hf = 0; hf < 2; ++hf) {
         const int kt = 2 * kp + hf;
         f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf ? k10 : k00, qf0, s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf ? k11 : k01, qf1, s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf ? v10 : v00, df0, dp, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf ? v11 : v01, df1, dp, 0, 0, 0);
+        s = H16<F>::mfma(hf ? k10 : k00, qf0, s);
+        s = H16<F>::mfma(hf ? k11 : k01, qf1, s);
+        dp = H16<F>::mfma(hf ? v10 : v00, df0, dp);
+        dp = H16<F>::mfma(hf ? v11 : v01, df1, dp);
         float m4[4] = {1.f, 1.f, 1.f, 1.f};
         if (drop.thr) drop_mult4(drop, (uint32_t)(h * T + t0 + q), (uint32_t)(kt * 16 + 4 * fg), m4);
         float p[4];
@@ -388,13 +356,13 @@ __global__ __launch_bounds__(256) void mha_bwd2_bf16_kernel(const bf16_t* __rest
 #pragma unroll
         for (int r = 0; r < 4; ++r) ds[hf][r] = p[r] * (dp[r] * m4[r] - dq_) * scale;
       }
-      const bf16x8 dsf = pack8(ds[0], ds[1]);
-      dq[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(t0l, t0h), dsf, dq[0], 0, 0, 0);
-      dq[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(t1l, t1h), dsf, dq[1], 0, 0, 0);
-      dq[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(t2l, t2h), dsf, dq[2], 0, 0, 0);
-      dq[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(t3l, t3h), dsf, dq[3], 0, 0, 0);
+      const bf16x8 dsf = pack8<F>(ds[0], ds[1]);
+      dq[0] = H16<F>::mfma(A2_CAT(t0l, t0h), dsf, dq[0]);
+      dq[1] = H16<F>::mfma(A2_CAT(t1l, t1h), dsf, dq[1]);
+      dq[2] = H16<F>::mfma(A2_CAT(t2l, t2h), dsf, dq[2]);
+      dq[3] = H16<F>::mfma(A2_CAT(t3l, t3h), dsf, dq[3]);
     }
-    a2_store_tile(dq, patch, patch_addr, dQg + (long)(qt * 16) * H3, H3, len - qt * 16, lane);
+    a2_store_tile<F>(dq, patch, patch_addr, dQg + (long)(qt * 16) * H3, H3, len - qt * 16, lane);
   }
 
   // ---------------- phase B: dK, dV, waves own key tiles, loop over query-tile pairs
@@ -434,10 +402,10 @@ __global__ __launch_bounds__(256) void mha_bwd2_bf16_kernel(const bf16_t* __rest
       for (int hf = 0; hf < 2; ++hf) {
         const int qt = 2 * qp + hf;
         f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf ? q10 : q00, kf0, s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf ? q11 : q01, kf1, s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf ? d10 : d00, vf0, dp, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf ? d11 : d01, vf1, dp, 0, 0, 0);
+        s = H16<F>::mfma(hf ? q10 : q00, kf0, s);
+        s = H16<F>::mfma(hf ? q11 : q01, kf1, s);
+        dp = H16<F>::mfma(hf ? d10 : d00, vf0, dp);
+        dp = H16<F>::mfma(hf ? d11 : d01, vf1, dp);
         const f32x4 lsv = hf ? ls1 : ls0, dev = hf ? de1 : de0;
         float p[4], mm[4] = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
@@ -457,20 +425,20 @@ __global__ __launch_bounds__(256) void mha_bwd2_bf16_kernel(const bf16_t* __rest
           ds[hf][r] = p[r] * (dp[r] * mm[r] - dev[r]) * scale;
         }
       }
-      const bf16x8 pf = pack8(pp[0], pp[1]);
-      const bf16x8 dsf = pack8(ds[0], ds[1]);
-      dv[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(e0l, e0h), pf, dv[0], 0, 0, 0);
-      dk[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(u0l, u0h), dsf, dk[0], 0, 0, 0);
-      dv[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(e1l, e1h), pf, dv[1], 0, 0, 0);
-      dk[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(u1l, u1h), dsf, dk[1], 0, 0, 0);
-      dv[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(e2l, e2h), pf, dv[2], 0, 0, 0);
-      dk[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(u2l, u2h), dsf, dk[2], 0, 0, 0);
-      dv[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(e3l, e3h), pf, dv[3], 0, 0, 0);
-      dk[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(u3l, u3h), dsf, dk[3], 0, 0, 0);
+      const bf16x8 pf = pack8<F>(pp[0], pp[1]);
+      const bf16x8 dsf = pack8<F>(ds[0], ds[1]);
+      dv[0] = H16<F>::mfma(A2_CAT(e0l, e0h), pf, dv[0]);
+      dk[0] = H16<F>::mfma(A2_CAT(u0l, u0h), dsf, dk[0]);
+      dv[1] = H16<F>::mfma(A2_CAT(e1l, e1h), pf, dv[1]);
+      dk[1] = H16<F>::mfma(A2_CAT(u1l, u1h), dsf, dk[1]);
+      dv[2] = H16<F>::mfma(A2_CAT(e2l, e2h), pf, dv[2]);
+      dk[2] = H16<F>::mfma(A2_CAT(u2l, u2h), dsf, dk[2]);
+      dv[3] = H16<F>::mfma(A2_CAT(e3l, e3h), pf, dv[3]);
+      dk[3] = H16<F>::mfma(A2_CAT(u3l, u3h), dsf, dk[3]);
     }
     bf16_t* dstk = dQg + lay.ws + (long)(kt * 16) * H3;
-    a2_store_tile(dk, patch, patch_addr, dstk, H3, len - kt * 16, lane);
-    a2_store_tile(dv, patch, patch_addr, dstk + lay.ws, H3, len - kt * 16, lane);
+    a2_store_tile<F>(dk, patch, patch_addr, dstk, H3, len - kt * 16, lane);
+    a2_store_tile<F>(dv, patch, patch_addr, dstk + lay.ws, H3, len - kt * 16, lane);
   }
 }
 
@@ -487,7 +455,7 @@ __global__ __launch_bounds__(256) void mha_bwd2_bf16_kernel(const bf16_t* __rest
 #define AL_CH 256
 #define AL_TILE (16 * 16 * 128)          // one staged operand chunk: 256 rows x 128 B
 
-template <bool DKV>
+template <typename F, bool DKV>
 __global__ __launch_bounds__(256, 1) void mha_bwd_long_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ O,
                                                               const float* __restrict__ lse, const bf16_t* __restrict__ dO,
                                                               bf16_t* __restrict__ dqkv, const int* __restrict__ cu,
@@ -543,8 +511,7 @@ __global__ __launch_bounds__(256, 1) void mha_bwd_long_kernel(const bf16_t* __re
           const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            del += __uint_as_float(aw[e] << 16) * __uint_as_float(bw[e] << 16) +
-                   __uint_as_float(aw[e] & 0xFFFF0000u) * __uint_as_float(bw[e] & 0xFFFF0000u);
+            del += H16<F>::lo(aw[e]) * H16<F>::lo(bw[e]) + H16<F>::hi(aw[e]) * H16<F>::hi(bw[e]);
         }
       }
       del += __shfl_xor(del, 1, 64);
@@ -606,10 +573,10 @@ __global__ __launch_bounds__(256, 1) void mha_bwd_long_kernel(const bf16_t* __re
           for (int hf = 0; hf < 2; ++hf) {
             const int kt = 2 * kp + hf;
             f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf ? k10 : k00, qf0, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf ? k11 : k01, qf1, s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf ? v10 : v00, df0, dp, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf ? v11 : v01, df1, dp, 0, 0, 0);
+            s = H16<F>::mfma(hf ? k10 : k00, qf0, s);
+            s = H16<F>::mfma(hf ? k11 : k01, qf1, s);
+            dp = H16<F>::mfma(hf ? v10 : v00, df0, dp);
+            dp = H16<F>::mfma(hf ? v11 : v01, df1, dp);
             float m4[4] = {1.f, 1.f, 1.f, 1.f};
             if (drop.thr) drop_mult4(drop, (uint32_t)(h * T + t0 + own0 + q), (uint32_t)(k0 + kt * 16 + 4 * fg), m4);
             float p[4];
@@ -623,11 +590,11 @@ __global__ __launch_bounds__(256, 1) void mha_bwd_long_kernel(const bf16_t* __re
 #pragma unroll
             for (int r = 0; r < 4; ++r) ds[hf][r] = p[r] * (dp[r] * m4[r] - dq_) * scale;
           }
-          const bf16x8 dsf = pack8(ds[0], ds[1]);
-          dq[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(t0l, t0h), dsf, dq[t][0], 0, 0, 0);
-          dq[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(t1l, t1h), dsf, dq[t][1], 0, 0, 0);
-          dq[t][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(t2l, t2h), dsf, dq[t][2], 0, 0, 0);
-          dq[t][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(t3l, t3h), dsf, dq[t][3], 0, 0, 0);
+          const bf16x8 dsf = pack8<F>(ds[0], ds[1]);
+          dq[t][0] = H16<F>::mfma(A2_CAT(t0l, t0h), dsf, dq[t][0]);
+          dq[t][1] = H16<F>::mfma(A2_CAT(t1l, t1h), dsf, dq[t][1]);
+          dq[t][2] = H16<F>::mfma(A2_CAT(t2l, t2h), dsf, dq[t][2]);
+          dq[t][3] = H16<F>::mfma(A2_CAT(t3l, t3h), dsf, dq[t][3]);
         }
       }
     }
@@ -635,7 +602,7 @@ __global__ __launch_bounds__(256, 1) void mha_bwd_long_kernel(const bf16_t* __re
     for (int t = 0; t < 4; ++t) {
       const int qt = wave + 4 * t;
       if (qt < nqt)
-        a2_store_tile(dq[t], patch, patch_addr, dqkv + (long)(t0 + own0 + qt * 16) * H3 + h * 64, H3, ownlen - qt * 16, lane);
+        a2_store_tile<F>(dq[t], patch, patch_addr, dqkv + (long)(t0 + own0 + qt * 16) * H3 + h * 64, H3, ownlen - qt * 16, lane);
     }
   } else {
     // ------------------------------------------------ dK, dV of key chunk `mine`
@@ -690,10 +657,10 @@ __global__ __launch_bounds__(256, 1) void mha_bwd_long_kernel(const bf16_t* __re
           for (int hf = 0; hf < 2; ++hf) {
             const int qt = 2 * qp + hf;
             f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf ? q10 : q00, kf0, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf ? q11 : q01, kf1, s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf ? d10 : d00, vf0, dp, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf ? d11 : d01, vf1, dp, 0, 0, 0);
+            s = H16<F>::mfma(hf ? q10 : q00, kf0, s);
+            s = H16<F>::mfma(hf ? q11 : q01, kf1, s);
+            dp = H16<F>::mfma(hf ? d10 : d00, vf0, dp);
+            dp = H16<F>::mfma(hf ? d11 : d01, vf1, dp);
             const f32x4 lsv = hf ? ls1 : ls0, dev = hf ? de1 : de0;
             float p[4], mm[4] = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
@@ -714,16 +681,16 @@ __global__ __launch_bounds__(256, 1) void mha_bwd_long_kernel(const bf16_t* __re
               ds[hf][r] = p[r] * (dp[r] * mm[r] - dev[r]) * scale;
             }
           }
-          const bf16x8 pf = pack8(pp[0], pp[1]);
-          const bf16x8 dsf = pack8(ds[0], ds[1]);
-          dv[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(e0l, e0h), pf, dv[t][0], 0, 0, 0);
-          dk[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(u0l, u0h), dsf, dk[t][0], 0, 0, 0);
-          dv[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(e1l, e1h), pf, dv[t][1], 0, 0, 0);
-          dk[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(u1l, u1h), dsf, dk[t][1], 0, 0, 0);
-          dv[t][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(e2l, e2h), pf, dv[t][2], 0, 0, 0);
-          dk[t][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(u2l, u2h), dsf, dk[t][2], 0, 0, 0);
-          dv[t][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(e3l, e3h), pf, dv[t][3], 0, 0, 0);
-          dk[t][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_CAT(u3l, u3h), dsf, dk[t][3], 0, 0, 0);
+          const bf16x8 pf = pack8<F>(pp[0], pp[1]);
+          const bf16x8 dsf = pack8<F>(ds[0], ds[1]);
+          dv[t][0] = H16<F>::mfma(A2_CAT(e0l, e0h), pf, dv[t][0]);
+          dk[t][0] = H16<F>::mfma(A2_CAT(u0l, u0h), dsf, dk[t][0]);
+          dv[t][1] = H16<F>::mfma(A2_CAT(e1l, e1h), pf, dv[t][1]);
+          dk[t][1] = H16<F>::mfma(A2_CAT(u1l, u1h), dsf, dk[t][1]);
+          dv[t][2] = H16<F>::mfma(A2_CAT(e2l, e2h), pf, dv[t][2]);
+          dk[t][2] = H16<F>::mfma(A2_CAT(u2l, u2h), dsf, dk[t][2]);
+          dv[t][3] = H16<F>::mfma(A2_CAT(e3l, e3h), pf, dv[t][3]);
+          dk[t][3] = H16<F>::mfma(A2_CAT(u3l, u3h), dsf, dk[t][3]);
         }
       }
     }
@@ -732,8 +699,8 @@ __global__ __launch_bounds__(256, 1) void mha_bwd_long_kernel(const bf16_t* __re
       const int kt = wave + 4 * t;
       if (kt < nkt) {
         bf16_t* dstk = dqkv + (long)(t0 + own0 + kt * 16) * H3 + H + h * 64;
-        a2_store_tile(dk[t], patch, patch_addr, dstk, H3, ownlen - kt * 16, lane);
-        a2_store_tile(dv[t], patch, patch_addr, dstk + H, H3, ownlen - kt * 16, lane);
+        a2_store_tile<F>(dk[t], patch, patch_addr, dstk, H3, ownlen - kt * 16, lane);
+        a2_store_tile<F>(dv[t], patch, patch_addr, dstk + H, H3, ownlen - kt * 16, lane);
       }
     }
   }
@@ -887,7 +854,7 @@ static int set_lds(K kernel, size_t bytes, const char* name) {
 }
 
 static int check_common(int dtype, int nseq, int heads, int d, int max_len, int T, const char* who) {
-  SIMX_REQUIRE(dtype == SIMX_F32 || dtype == SIMX_BF16, SIMX_ERR_BAD_DTYPE, "%s: dtype %d", who, dtype);
+  SIMX_REQUIRE(simx_dtype_ok(dtype), SIMX_ERR_BAD_DTYPE, "%s: dtype %d", who, dtype);
   SIMX_REQUIRE(nseq > 0 && heads > 0 && T > 0 && max_len > 0, SIMX_ERR_BAD_SHAPE, "%s: bad shape", who);
   SIMX_REQUIRE(d > 0 && d <= 128, SIMX_ERR_UNSUPPORTED, "%s: head_dim %d > 128", who, d);
   SIMX_REQUIRE(max_len <= 4096, SIMX_ERR_UNSUPPORTED, "%s: max_len %d > 4096", who, max_len);
@@ -920,44 +887,47 @@ extern "C" int simx_mha_fwd_ex(simx_stream_t stream, int dtype, int nseq, int he
 extern "C" int simx_mha_fwd_hm(simx_stream_t stream, int dtype, int nseq, int heads, int d, const int32_t* cu, int max_len,
                                int T, const void* qkv, void* ctx, float* lse, const simx_dropout* dropd, int hm_rows) {
   hipStream_t s = (hipStream_t)stream;
-  SIMX_REQUIRE(hm_rows == 0 || (dtype == SIMX_BF16 && d == 64 && max_len <= 512 && hm_rows >= T), SIMX_ERR_UNSUPPORTED,
-               "mha_fwd: the head-major qkv layout needs bf16, head size 64, max_len <= 512 and hm_rows >= T");
+  SIMX_REQUIRE(hm_rows == 0 || (simx_is16(dtype) && d == 64 && max_len <= 512 && hm_rows >= T), SIMX_ERR_UNSUPPORTED,
+               "mha_fwd: the head-major qkv layout needs a 16-bit dtype, head size 64, max_len <= 512 and hm_rows >= T");
   const DropCtx drop = make_drop(dropd);
   SIMX_PROF(SIMX_K_MHA_FWD, s, 4.0 * T * max_len * heads * d);
   int rc = check_common(dtype, nseq, heads, d, max_len, T, "mha_fwd");
   if (rc) return rc;
   const float scale = 1.0f / sqrtf((float)d);
-  if (dtype == SIMX_BF16 && d == 64 && max_len <= 512) {
+  if (simx_is16(dtype) && d == 64 && max_len <= 512) {
 #define LF(NKT)                                                                                                      \
   do {                                                                                                               \
     const size_t lds = (size_t)2 * NKT * 16 * 128;                                                                   \
-    rc = set_lds(mha_fwd_bf16_kernel<NKT>, lds, "mha_fwd");                                                          \
+    rc = set_lds(mha_fwd_h16_kernel<FF, NKT>, lds, "mha_fwd");                                                       \
     if (rc) return rc;                                                                                               \
-    hipLaunchKernelGGL((mha_fwd_bf16_kernel<NKT>), dim3(nseq * heads), dim3(256), lds, s, (const bf16_t*)qkv,        \
+    hipLaunchKernelGGL((mha_fwd_h16_kernel<FF, NKT>), dim3(nseq * heads), dim3(256), lds, s, (const bf16_t*)qkv,     \
                        (bf16_t*)ctx, lse, cu, heads, T, scale, drop, hm_rows);                                       \
   } while (0)
-    if (max_len <= 32) LF(2);
-    else if (max_len <= 128) LF(8);
-    else if (max_len <= 160) LF(10);
-    else if (max_len <= 256) LF(16);
-    else LF(32);
+#define LF_ALL()                                                                                                     \
+  do {                                                                                                               \
+    if (max_len <= 32) LF(2);                                                                                        \
+    else if (max_len <= 128) LF(8);                                                                                  \
+    else if (max_len <= 160) LF(10);                                                                                 \
+    else if (max_len <= 256) LF(16);                                                                                 \
+    else LF(32);                                                                                                     \
+  } while (0)
+    SIMX_DISPATCH16(dtype, FF, LF_ALL());
+#undef LF_ALL
 #undef LF
-    SIMX_CHECK_LAUNCH("mha_fwd_bf16");
+    SIMX_CHECK_LAUNCH("mha_fwd_h16");
     return SIMX_OK;
   }
   const size_t lds = (size_t)(4 * 128 + 4 * max_len) * sizeof(float);
   dim3 grid(nseq * heads, cdiv(max_len, 4));
-  if (dtype == SIMX_F32) {
-    rc = set_lds(mha_fwd_simple_kernel<float>, lds, "mha_fwd");
-    if (rc) return rc;
-    hipLaunchKernelGGL((mha_fwd_simple_kernel<float>), grid, dim3(256), lds, s, (const float*)qkv, (float*)ctx, lse, cu,
-                       heads, d, T, scale, max_len, drop);
-  } else {
-    rc = set_lds(mha_fwd_simple_kernel<bf16_t>, lds, "mha_fwd");
-    if (rc) return rc;
-    hipLaunchKernelGGL((mha_fwd_simple_kernel<bf16_t>), grid, dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)ctx, lse,
-                       cu, heads, d, T, scale, max_len, drop);
-  }
+#define LS(TT)                                                                                                       \
+  do {                                                                                                               \
+    rc = set_lds(mha_fwd_simple_kernel<TT>, lds, "mha_fwd");                                                         \
+    if (rc) return rc;                                                                                               \
+    hipLaunchKernelGGL((mha_fwd_simple_kernel<TT>), grid, dim3(256), lds, s, (const TT*)qkv, (TT*)ctx, lse, cu, heads, d, T, scale, \
+                       max_len, drop);                                                                               \
+  } while (0)
+  SIMX_DISPATCH3(dtype, TT, LS(TT));
+#undef LS
   SIMX_CHECK_LAUNCH("mha_fwd_simple");
   return SIMX_OK;
 }
@@ -971,41 +941,47 @@ extern "C" int simx_mha_bwd_hm(simx_stream_t stream, int dtype, int nseq, int he
                                int T, const void* qkv, const void* ctx, const float* lse, const void* dctx, void* dqkv,
                                const simx_dropout* dropd, int hm_rows) {
   hipStream_t s = (hipStream_t)stream;
-  SIMX_REQUIRE(hm_rows == 0 || (dtype == SIMX_BF16 && d == 64 && max_len <= 256 && hm_rows >= T), SIMX_ERR_UNSUPPORTED,
-               "mha_bwd: the head-major qkv layout needs bf16, head size 64, max_len <= 256 and hm_rows >= T");
+  SIMX_REQUIRE(hm_rows == 0 || (simx_is16(dtype) && d == 64 && max_len <= 256 && hm_rows >= T), SIMX_ERR_UNSUPPORTED,
+               "mha_bwd: the head-major qkv layout needs a 16-bit dtype, head size 64, max_len <= 256 and hm_rows >= T");
   const DropCtx drop = make_drop(dropd);
   SIMX_PROF(SIMX_K_MHA_BWD, s, 8.0 * T * max_len * heads * d);
   int rc = check_common(dtype, nseq, heads, d, max_len, T, "mha_bwd");
   if (rc) return rc;
   const float scale = 1.0f / sqrtf((float)d);
-  if (dtype == SIMX_BF16 && d == 64 && max_len <= 256) {
+  if (simx_is16(dtype) && d == 64 && max_len <= 256) {
 #define LB(NKT)                                                                                                      \
   do {                                                                                                               \
     const size_t lds = (size_t)4 * NKT * 16 * 128 + 2 * NKT * 16 * sizeof(float) + 4 * 2048;                         \
-    rc = set_lds(mha_bwd2_bf16_kernel<NKT>, lds, "mha_bwd");                                                         \
+    rc = set_lds(mha_bwd2_h16_kernel<FF, NKT>, lds, "mha_bwd");                                                      \
     if (rc) return rc;                                                                                               \
-    hipLaunchKernelGGL((mha_bwd2_bf16_kernel<NKT>), dim3(nseq * heads), dim3(256), lds, s, (const bf16_t*)qkv,       \
+    hipLaunchKernelGGL((mha_bwd2_h16_kernel<FF, NKT>), dim3(nseq * heads), dim3(256), lds, s, (const bf16_t*)qkv,    \
                        (const bf16_t*)ctx, lse, (const bf16_t*)dctx, (bf16_t*)dqkv, cu, heads, T, scale, drop, hm_rows); \
   } while (0)
-    if (max_len <= 32) LB(2);
-    else if (max_len <= 128) LB(8);
-    else if (max_len <= 160) LB(10);
-    else LB(16);
+#define LB_ALL()                                                                                                     \
+  do {                                                                                                               \
+    if (max_len <= 32) LB(2);                                                                                        \
+    else if (max_len <= 128) LB(8);                                                                                  \
+    else if (max_len <= 160) LB(10);                                                                                 \
+    else LB(16);                                                                                                     \
+  } while (0)
+    SIMX_DISPATCH16(dtype, FF, LB_ALL());
+#undef LB_ALL
 #undef LB
-    SIMX_CHECK_LAUNCH("mha_bwd_bf16");
+    SIMX_CHECK_LAUNCH("mha_bwd_h16");
     return SIMX_OK;
   }
-  if (dtype == SIMX_BF16 && d == 64) {                          // 256 < max_len <= 4096: chunked MFMA kernels
+  if (simx_is16(dtype) && d == 64) {                            // 256 < max_len <= 4096: chunked MFMA kernels
     const int nchunk = cdiv(max_len, AL_CH);
     const size_t ldsl = (size_t)4 * AL_TILE + 2 * AL_CH * sizeof(float) + 4 * 2048;
-    rc = set_lds(mha_bwd_long_kernel<false>, ldsl, "mha_bwd");
-    if (rc) return rc;
-    rc = set_lds(mha_bwd_long_kernel<true>, ldsl, "mha_bwd");
-    if (rc) return rc;
-    hipLaunchKernelGGL((mha_bwd_long_kernel<false>), dim3(nseq * heads * nchunk), dim3(256), ldsl, s, (const bf16_t*)qkv, (const bf16_t*)ctx,
-                       lse, (const bf16_t*)dctx, (bf16_t*)dqkv, cu, heads, T, nchunk, scale, drop);
-    hipLaunchKernelGGL((mha_bwd_long_kernel<true>), dim3(nseq * heads * nchunk), dim3(256), ldsl, s, (const bf16_t*)qkv, (const bf16_t*)ctx,
-                       lse, (const bf16_t*)dctx, (bf16_t*)dqkv, cu, heads, T, nchunk, scale, drop);
+#define LL(DKV)                                                                                                      \
+  do {                                                                                                               \
+    rc = set_lds(mha_bwd_long_kernel<FF, DKV>, ldsl, "mha_bwd");                                                     \
+    if (rc) return rc;                                                                                               \
+    hipLaunchKernelGGL((mha_bwd_long_kernel<FF, DKV>), dim3(nseq * heads * nchunk), dim3(256), ldsl, s, (const bf16_t*)qkv, \
+                       (const bf16_t*)ctx, lse, (const bf16_t*)dctx, (bf16_t*)dqkv, cu, heads, T, nchunk, scale, drop); \
+  } while (0)
+    SIMX_DISPATCH16(dtype, FF, LL(false); LL(true));
+#undef LL
     SIMX_CHECK_LAUNCH("mha_bwd_long");
     return SIMX_OK;
   }
@@ -1018,7 +994,7 @@ extern "C" int simx_mha_bwd_hm(simx_stream_t stream, int dtype, int nseq, int he
     hipLaunchKernelGGL((mha_bwd_simple_kernel<TT, MODE>), grid, dim3(256), lds, s, (const TT*)qkv, (const TT*)ctx, lse, \
                        (const TT*)dctx, (TT*)dqkv, cu, heads, d, T, scale, max_len, drop);                           \
   } while (0)
-  if (dtype == SIMX_F32) { LS(float, 0); LS(float, 1); } else { LS(bf16_t, 0); LS(bf16_t, 1); }
+  SIMX_DISPATCH3(dtype, TT, LS(TT, 0); LS(TT, 1));
 #undef LS
   SIMX_CHECK_LAUNCH("mha_bwd_simple");
   return SIMX_OK;
@@ -1165,7 +1141,7 @@ extern "C" int simx_mha_cls_fwd_hm(simx_stream_t stream, int dtype, int nseq, in
                                    int T, const void* q_cls, const void* qkv, void* ctx_cls, const simx_dropout* dropd, int hm_rows) {
   SIMX_REQUIRE(hm_rows == 0 || (d == 64 && hm_rows >= T), SIMX_ERR_UNSUPPORTED, "mha_cls_fwd: head-major layout needs head size 64, hm_rows >= T");
   SIMX_REQUIRE(nseq > 0 && heads > 0 && d > 0 && d % 4 == 0 && max_len > 0 && T >= nseq, SIMX_ERR_BAD_SHAPE, "mha_cls_fwd: bad shape");
-  SIMX_REQUIRE(dtype == SIMX_F32 || dtype == SIMX_BF16, SIMX_ERR_BAD_DTYPE, "mha_cls_fwd: dtype %d", dtype);
+  SIMX_REQUIRE(simx_dtype_ok(dtype), SIMX_ERR_BAD_DTYPE, "mha_cls_fwd: dtype %d", dtype);
   hipStream_t s = (hipStream_t)stream;
   SIMX_PROF(SIMX_K_MHA_FWD, s, 4.0 * nseq * heads * max_len * d);
   const DropCtx drop = make_drop(dropd);
@@ -1173,17 +1149,15 @@ extern "C" int simx_mha_cls_fwd_hm(simx_stream_t stream, int dtype, int nseq, in
   const int nitems = nseq * heads, H = heads * d;
   const size_t lds = (size_t)4 * (d + max_len) * sizeof(float);
   int rc;
-  if (dtype == SIMX_F32) {
-    rc = set_lds(mha_cls_fwd_kernel<float>, lds, "mha_cls_fwd");
-    if (rc) return rc;
-    hipLaunchKernelGGL((mha_cls_fwd_kernel<float>), dim3(cdiv(nitems, 4)), dim3(256), lds, s, nitems, heads, d, H, T, max_len, scale, cu,
-                       (const float*)q_cls, (const float*)qkv, (float*)ctx_cls, drop, hm_rows);
-  } else {
-    rc = set_lds(mha_cls_fwd_kernel<bf16_t>, lds, "mha_cls_fwd");
-    if (rc) return rc;
-    hipLaunchKernelGGL((mha_cls_fwd_kernel<bf16_t>), dim3(cdiv(nitems, 4)), dim3(256), lds, s, nitems, heads, d, H, T, max_len, scale, cu,
-                       (const bf16_t*)q_cls, (const bf16_t*)qkv, (bf16_t*)ctx_cls, drop, hm_rows);
-  }
+#define LC(TT)                                                                                                       \
+  do {                                                                                                               \
+    rc = set_lds(mha_cls_fwd_kernel<TT>, lds, "mha_cls_fwd");                                                        \
+    if (rc) return rc;                                                                                               \
+    hipLaunchKernelGGL((mha_cls_fwd_kernel<TT>), dim3(cdiv(nitems, 4)), dim3(256), lds, s, nitems, heads, d, H, T, max_len, scale, cu, \
+                       (const TT*)q_cls, (const TT*)qkv, (TT*)ctx_cls, drop, hm_rows);                               \
+  } while (0)
+  SIMX_DISPATCH3(dtype, TT, LC(TT));
+#undef LC
   SIMX_CHECK_LAUNCH("mha_cls_fwd");
   return SIMX_OK;
 }
@@ -1201,7 +1175,7 @@ extern "C" int simx_mha_cls_bwd_hm(simx_stream_t stream, int dtype, int nseq, in
                                    const simx_dropout* dropd, int hm_rows) {
   SIMX_REQUIRE(hm_rows == 0 || (d == 64 && hm_rows >= T), SIMX_ERR_UNSUPPORTED, "mha_cls_bwd: head-major layout needs head size 64, hm_rows >= T");
   SIMX_REQUIRE(nseq > 0 && heads > 0 && d > 0 && d % 4 == 0 && max_len > 0 && T >= nseq, SIMX_ERR_BAD_SHAPE, "mha_cls_bwd: bad shape");
-  SIMX_REQUIRE(dtype == SIMX_F32 || dtype == SIMX_BF16, SIMX_ERR_BAD_DTYPE, "mha_cls_bwd: dtype %d", dtype);
+  SIMX_REQUIRE(simx_dtype_ok(dtype), SIMX_ERR_BAD_DTYPE, "mha_cls_bwd: dtype %d", dtype);
   hipStream_t s = (hipStream_t)stream;
   SIMX_PROF(SIMX_K_MHA_BWD, s, 8.0 * nseq * heads * max_len * d);
   const DropCtx drop = make_drop(dropd);
@@ -1209,17 +1183,15 @@ extern "C" int simx_mha_cls_bwd_hm(simx_stream_t stream, int dtype, int nseq, in
   const int nitems = nseq * heads, H = heads * d;
   const size_t lds = (size_t)4 * (2 * d + 3 * max_len) * sizeof(float);
   int rc;
-  if (dtype == SIMX_F32) {
-    rc = set_lds(mha_cls_bwd_kernel<float>, lds, "mha_cls_bwd");
-    if (rc) return rc;
-    hipLaunchKernelGGL((mha_cls_bwd_kernel<float>), dim3(cdiv(nitems, 4)), dim3(256), lds, s, nitems, heads, d, H, T, max_len, scale, cu,
-                       (const float*)q_cls, (const float*)qkv, (const float*)dctx_cls, (float*)dq_cls, (float*)dqkv, drop, hm_rows);
-  } else {
-    rc = set_lds(mha_cls_bwd_kernel<bf16_t>, lds, "mha_cls_bwd");
-    if (rc) return rc;
-    hipLaunchKernelGGL((mha_cls_bwd_kernel<bf16_t>), dim3(cdiv(nitems, 4)), dim3(256), lds, s, nitems, heads, d, H, T, max_len, scale, cu,
-                       (const bf16_t*)q_cls, (const bf16_t*)qkv, (const bf16_t*)dctx_cls, (bf16_t*)dq_cls, (bf16_t*)dqkv, drop, hm_rows);
-  }
+#define LC(TT)                                                                                                       \
+  do {                                                                                                               \
+    rc = set_lds(mha_cls_bwd_kernel<TT>, lds, "mha_cls_bwd");                                                        \
+    if (rc) return rc;                                                                                               \
+    hipLaunchKernelGGL((mha_cls_bwd_kernel<TT>), dim3(cdiv(nitems, 4)), dim3(256), lds, s, nitems, heads, d, H, T, max_len, scale, cu, \
+                       (const TT*)q_cls, (const TT*)qkv, (const TT*)dctx_cls, (TT*)dq_cls, (TT*)dqkv, drop, hm_rows); \
+  } while (0)
+  SIMX_DISPATCH3(dtype, TT, LC(TT));
+#undef LC
   SIMX_CHECK_LAUNCH("mha_cls_bwd");
   return SIMX_OK;
 }

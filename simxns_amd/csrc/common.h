@@ -45,6 +45,52 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16v2_t));
 }
 
+// ---- fp16 (IEEE half): the second 16-bit operand format (apex-O1-like mode: 11-bit significands, needs a loss scale in
+// backward).  gfx950 has v_cvt_pk_f16_f32 (round to nearest even, subnormal results kept) and its MFMAs honour fp16
+// subnormal inputs (tools/probe_f16.hip), so small probabilities / gradients degrade gracefully instead of flushing.
+typedef _Float16 f16_t;
+typedef _Float16 f16v2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint32_t pack2h(float lo, float hi) {
+  const f32v2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16v2_t));
+}
+
+// The two 16-bit formats behind one interface: kernels are templates over T16 in {bf16_t, f16_t}; fragments travel as
+// bf16x8 (8 x 16 raw bits) whatever the format.  lo / hi unpack the two halves of a 32-bit word, pack2 rounds a pair.
+template <typename T> struct H16;
+template <> struct H16<bf16_t> {
+  static constexpr int code = SIMX_BF16;
+  static __device__ __forceinline__ float lo(uint32_t w) { return __uint_as_float(w << 16); }
+  static __device__ __forceinline__ float hi(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
+  static __device__ __forceinline__ float one(short s) { return __uint_as_float(((uint32_t)(unsigned short)s) << 16); }
+  static __device__ __forceinline__ uint32_t pack2(float a, float b) { return pack2bf(a, b); }
+  static __device__ __forceinline__ f32x4 mfma(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct H16<f16_t> {
+  static constexpr int code = SIMX_F16;
+  static __device__ __forceinline__ float lo(uint32_t w) { return (float)__builtin_bit_cast(f16v2_t, w)[0]; }
+  static __device__ __forceinline__ float hi(uint32_t w) { return (float)__builtin_bit_cast(f16v2_t, w)[1]; }
+  static __device__ __forceinline__ float one(short s) { return (float)__builtin_bit_cast(f16_t, s); }
+  static __device__ __forceinline__ uint32_t pack2(float a, float b) { return pack2h(a, b); }
+  static __device__ __forceinline__ f32x4 mfma(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+
+// 4 consecutive elements of raw 16-bit storage in format F (the MFMA kernels keep `bf16_t*` = raw 16-bit pointers for both)
+template <typename F>
+__device__ __forceinline__ void ld4h(const bf16_t* p, float (&v)[4]) {
+  const uint2 t = *reinterpret_cast<const uint2*>(p);
+  v[0] = H16<F>::lo(t.x); v[1] = H16<F>::hi(t.x); v[2] = H16<F>::lo(t.y); v[3] = H16<F>::hi(t.y);
+}
+template <typename F>
+__device__ __forceinline__ void st4h(bf16_t* p, const float (&v)[4]) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(H16<F>::pack2(v[0], v[1]), H16<F>::pack2(v[2], v[3]));
+}
+
 // element load/store by activation type
 template <typename T> struct Elem;
 template <> struct Elem<float> {
@@ -54,6 +100,10 @@ template <> struct Elem<float> {
 template <> struct Elem<bf16_t> {
   static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
   static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+template <> struct Elem<f16_t> {
+  static __device__ __forceinline__ float ld(const f16_t* p) { return (float)*p; }
+  static __device__ __forceinline__ void st(f16_t* p, float v) { *p = (f16_t)v; }
 };
 
 // 4-element vector load/store (16 B for f32, 8 B for bf16); pointers must be so aligned
@@ -65,6 +115,13 @@ __device__ __forceinline__ void ld4(const bf16_t* p, float (&v)[4]) {
   uint2 t = *reinterpret_cast<const uint2*>(p);
   v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xFFFF0000u);
   v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xFFFF0000u);
+}
+__device__ __forceinline__ void ld4(const f16_t* p, float (&v)[4]) {
+  uint2 t = *reinterpret_cast<const uint2*>(p);
+  v[0] = H16<f16_t>::lo(t.x); v[1] = H16<f16_t>::hi(t.x); v[2] = H16<f16_t>::lo(t.y); v[3] = H16<f16_t>::hi(t.y);
+}
+__device__ __forceinline__ void st4(f16_t* p, const float (&v)[4]) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(pack2h(v[0], v[1]), pack2h(v[2], v[3]));
 }
 __device__ __forceinline__ void st4(float* p, const float (&v)[4]) {
   *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
@@ -188,3 +245,24 @@ __device__ __forceinline__ void erf_and_gauss(float u, float& erf_x, float& gaus
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline bool simx_is16(int dtype) { return dtype == SIMX_BF16 || dtype == SIMX_F16; }
+static inline bool simx_dtype_ok(int dtype) { return dtype == SIMX_F32 || simx_is16(dtype); }
+static inline size_t simx_esz(int dtype) { return dtype == SIMX_F32 ? 4 : 2; }
+// run STMT with TT bound to the element type of `dtype` (the three activation types of the engine)
+#define SIMX_DISPATCH3(DTYPE, TT, ...)                                   \
+  do {                                                                   \
+    if ((DTYPE) == SIMX_F32) { using TT = float; __VA_ARGS__; }          \
+    else if ((DTYPE) == SIMX_BF16) { using TT = bf16_t; __VA_ARGS__; }   \
+    else { using TT = f16_t; __VA_ARGS__; }                              \
+  } while (0)
+#define SIMX_DISPATCH16(DTYPE, TT, ...)                                  \
+  do {                                                                   \
+    if ((DTYPE) == SIMX_BF16) { using TT = bf16_t; __VA_ARGS__; }        \
+    else { using TT = f16_t; __VA_ARGS__; }                              \
+  } while (0)
+
+// ---- gradient scale of the fp16 engine (simx.h "loss scale"): gs = device pointer to {S, 1/S} or NULL.  Activation
+// gradients travel multiplied by S; every kernel that ACCUMULATES INTO THE f32 PARAMETER GRADIENTS multiplies by 1/S, so
+// the flat gradient buffers always hold true gradients.
+__device__ __forceinline__ float gs_scale(const float* gs) { return gs ? gs[0] : 1.0f; }
+__device__ __forceinline__ float gs_inv(const float* gs) { return gs ? gs[1] : 1.0f; }

@@ -5,7 +5,7 @@
 //
 // HBM layout (all 256-B aligned):
 //   params / grads : one f32 buffer each, canonical order (simx_bert_param_offset)
-//   wcache         : per layer  Wqkv, Wqkv^T, Wo, Wo^T, W1, W1^T, W2, W2^T   (bf16; f32 mode keeps only
+//   wcache         : per layer  Wqkv, Wqkv^T, Wo, Wo^T, W1, W1^T, W2, W2^T   (bf16 / fp16; f32 mode keeps only
 //                    the transposes, in f32) -- rebuilt once per optimiser step
 //   act            : x0 | per layer { qkv[T,3H] ctx[T,H] lse[heads,T](f32) z1[T,H] x1[T,H] u[T,F] h[T,F]
 //                    z2[T,H] xout[T,H] }   -- everything backward needs is KEPT (288 GB HBM: no recompute)
@@ -32,7 +32,7 @@ static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline size_t esz(int dtype) { return dtype == SIMX_F32 ? 4 : 2; }
 
 static bool cfg_ok(const simx_bert_cfg* c) {
-  return c && (c->dtype == SIMX_F32 || c->dtype == SIMX_BF16) && c->layers > 0 && c->hidden > 0 && c->heads > 0 &&
+  return c && simx_dtype_ok(c->dtype) && c->qkv_layout >= 0 && c->qkv_layout <= 1 && c->layers > 0 && c->hidden > 0 && c->heads > 0 &&
          c->hidden % c->heads == 0 && c->hidden % 4 == 0 && c->inter > 0 && c->inter % 4 == 0 && c->vocab > 0 &&
          c->max_pos > 0 && c->type_vocab > 0 && c->hidden <= 1024;
 }
@@ -243,13 +243,14 @@ static int check_io(const simx_bert_cfg* c, int nseq, int T, int max_len, const 
 }
 
 // Head-major q/k/v (include/simx.h "head-major q / k / v"): chosen per tower when every kernel that touches the tensor has the
-// form -- bf16, head size 64, sequences that the LDS-resident attention backward takes (<= 256), and a tower large enough for
-// the persistent GEMMs (simx_gemm_hm_ok).  SIMX_QKV_LAYOUT=token pins the token-major form (A/B measurements).
+// form -- a 16-bit dtype, head size 64, sequences that the LDS-resident attention backward takes (<= 256), and a tower large
+// enough for the persistent GEMMs (simx_gemm_hm_ok).  cfg->qkv_layout = 1 pins the token-major form (A/B measurements, tests);
+// the choice is a function of (cfg, T, max_len) only, so a forward and its backward -- which receive the same per-call
+// config copy -- always agree.
 static int hm_rows_for(const simx_bert_cfg* c, int T, int Tp, int max_len) {
-  const char* pin = getenv("SIMX_QKV_LAYOUT");          // (read per call: the tests flip it)
-  if (pin && pin[0] == 't') return 0;
+  if (c->qkv_layout == 1) return 0;
   const int d = c->hidden / c->heads;
-  if (c->dtype != SIMX_BF16 || d != 64 || max_len > 256) return 0;
+  if (!simx_is16(c->dtype) || d != 64 || max_len > 256) return 0;
   return simx_gemm_hm_ok(Tp, c->hidden, T) ? Tp : 0;
 }
 
@@ -397,7 +398,10 @@ extern "C" int simx_bert_bwd_range(simx_stream_t stream, const simx_bert_cfg* c,
   char* dqkv = du + al((size_t)Tp * F * e);
   char* tnws = dqkv + al((size_t)Tp * 3 * H * e);
   const size_t tnws_bytes = tn_ws_max(c, T);
-  const int hm = hm_rows_for(c, T, Tp, max_len);        // layout of qkv / dqkv (must match the forward's choice: same inputs)
+  const int hm = hm_rows_for(c, T, Tp, max_len);        // layout of qkv / dqkv (the forward's choice: same config copy, same inputs)
+  // fp16 engine: activation gradients travel multiplied by the loss scale S (gs = {S, 1/S} on the device); the kernels that
+  // accumulate into `grads` multiply by 1/S, so `grads` holds true gradients (simx.h "gradient scale")
+  const float* gs = dt == SIMX_F16 ? c->grad_scale : nullptr;
 
   int l_top = layer_hi;
   if (top && c->cls_only_last_layer) {
@@ -414,23 +418,23 @@ extern "C" int simx_bert_bwd_range(simx_stream_t stream, const simx_bert_cfg* c,
     char* e2 = e1 + al((size_t)nseq * H * e);
     const char* qc = act_extra(c, act, Tp, 1);                                     // saved by the forward
     const char* ctxc = qc + al((size_t)nseq * H * e);
-    RUN(simx_rows_copy(stream, SIMX_F32, dt, nseq, H, nullptr, nullptr, dcls, bufB));
-    RUN(simx_ln_bwd_keyed(stream, dt, nseq, H, a.z2, off(l, SIMX_P_LN2_G), c->eps, bufB, bufA, hd ? bufC : nullptr,
-                          goff(l, SIMX_P_LN2_G), goff(l, SIMX_P_LN2_B), goff(l, SIMX_P_B2), &d2, cu));
+    RUN(simx_rows_copy_gs(stream, SIMX_F32, dt, nseq, H, nullptr, nullptr, dcls, bufB, gs));
+    RUN(simx_ln_bwd_gs(stream, dt, nseq, H, a.z2, off(l, SIMX_P_LN2_G), c->eps, bufB, bufA, hd ? bufC : nullptr,
+                          goff(l, SIMX_P_LN2_G), goff(l, SIMX_P_LN2_B), goff(l, SIMX_P_B2), &d2, cu, gs));
     RUN(simx_gemm_nt(stream, dt, nseq, F, H, dzm, H, w.w2T, H, du, F, nullptr, nullptr, 0, SIMX_EPI_DGELU, a.u, F, nullptr, 0));
-    RUN(simx_gemm_tn(stream, dt, H, F, nseq, dzm, H, a.h, F, goff(l, SIMX_P_W2), F, 1, tnws, tnws_bytes));
+    RUN(simx_gemm_tn_gs(stream, dt, H, F, nseq, dzm, H, a.h, F, goff(l, SIMX_P_W2), F, 1, tnws, tnws_bytes, nullptr, 0, gs));
     RUN(simx_gemm_nt(stream, dt, nseq, H, F, du, F, w.w1T, F, bufB, H, nullptr, bufA, H, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
-    RUN(simx_gemm_tn_bias(stream, dt, F, H, nseq, du, F, a.x1, H, goff(l, SIMX_P_W1), H, 1, tnws, tnws_bytes, goff(l, SIMX_P_B1)));
-    RUN(simx_ln_bwd_keyed(stream, dt, nseq, H, a.z1, off(l, SIMX_P_LN1_G), c->eps, bufB, bufA, hd ? bufC : nullptr,
-                          goff(l, SIMX_P_LN1_G), goff(l, SIMX_P_LN1_B), goff(l, SIMX_P_BO), &d1, cu));
+    RUN(simx_gemm_tn_gs(stream, dt, F, H, nseq, du, F, a.x1, H, goff(l, SIMX_P_W1), H, 1, tnws, tnws_bytes, goff(l, SIMX_P_B1), 0, gs));
+    RUN(simx_ln_bwd_gs(stream, dt, nseq, H, a.z1, off(l, SIMX_P_LN1_G), c->eps, bufB, bufA, hd ? bufC : nullptr,
+                          goff(l, SIMX_P_LN1_G), goff(l, SIMX_P_LN1_B), goff(l, SIMX_P_BO), &d1, cu, gs));
     // e1 = dctx (gradient of the attention context, [CLS] rows), bufA[0:nseq] = gradient of the residual branch
     RUN(simx_gemm_nt(stream, dt, nseq, H, H, dzm, H, w.woT, H, e1, H, nullptr, nullptr, 0, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
-    RUN(simx_gemm_tn(stream, dt, H, H, nseq, dzm, H, ctxc, H, goff(l, SIMX_P_WO), H, 1, tnws, tnws_bytes));
+    RUN(simx_gemm_tn_gs(stream, dt, H, H, nseq, dzm, H, ctxc, H, goff(l, SIMX_P_WO), H, 1, tnws, tnws_bytes, nullptr, 0, gs));
     // attention core for the one query per sequence: e0 = dq [nseq,H]; dK, dV for every token -> dqkv[:, H:3H]
     RUN(simx_mha_cls_bwd_hm(stream, dt, nseq, c->heads, d, cu, max_len, T, qc, a.qkv, e1, e0, dqkv, &d3, hm));
     // Q projection ([CLS] rows): dWq, dbq, and dx = dq . Wq + (residual-branch gradient), still compact
     RUN(simx_rows_copy(stream, dt, dt, nseq, H, cu, nullptr, xin, e2));
-    RUN(simx_gemm_tn_bias(stream, dt, H, H, nseq, e0, H, e2, H, goff(l, SIMX_P_WQKV), H, 1, tnws, tnws_bytes, goff(l, SIMX_P_BQKV)));
+    RUN(simx_gemm_tn_gs(stream, dt, H, H, nseq, e0, H, e2, H, goff(l, SIMX_P_WQKV), H, 1, tnws, tnws_bytes, goff(l, SIMX_P_BQKV), 0, gs));
     RUN(simx_gemm_nt(stream, dt, nseq, H, H, e0, H, w.wqkvT, 3 * H, e1, H, nullptr, bufA, H, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
     // back to full tensors: that gradient is zero outside the [CLS] rows
     if (hipMemsetAsync(bufA, 0, (size_t)T * H * e, (hipStream_t)stream) != hipSuccess) {
@@ -442,13 +446,12 @@ extern "C" int simx_bert_bwd_range(simx_stream_t stream, const simx_bert_cfg* c,
     if (hm) {
       const char* dkv = dqkv + (size_t)c->heads * hm * 64 * e;                  // planes [heads, 3*heads)
       RUN(simx_gemm_nt_hm(stream, dt, Tp, H, 2 * H, dkv, 64, w.wqkvT + (size_t)H * e, 3 * H, bufB, H, nullptr, bufA, H, nullptr, hm, 0));
-      RUN(simx_gemm_tn_hm(stream, dt, 2 * H, H, T, dkv, hm, xin, H, goff(l, SIMX_P_WQKV) + (size_t)H * H, H, 1, tnws, tnws_bytes,
-                          goff(l, SIMX_P_BQKV) + H));
+      RUN(simx_gemm_tn_gs(stream, dt, 2 * H, H, T, dkv, 0, xin, H, goff(l, SIMX_P_WQKV) + (size_t)H * H, H, 1, tnws, tnws_bytes,
+                          goff(l, SIMX_P_BQKV) + H, hm, gs));
     } else {
       RUN(simx_gemm_nt(stream, dt, Tp, H, 2 * H, dqkv + (size_t)H * e, 3 * H, w.wqkvT + (size_t)H * e, 3 * H, bufB, H, nullptr, bufA, H,
                        SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
-      RUN(simx_gemm_tn_bias(stream, dt, 2 * H, H, T, dqkv + (size_t)H * e, 3 * H, xin, H, goff(l, SIMX_P_WQKV) + (size_t)H * H, H, 1, tnws,
-                            tnws_bytes, goff(l, SIMX_P_BQKV) + H));
+      RUN(simx_gemm_tn_gs(stream, dt, 2 * H, H, T, dqkv + (size_t)H * e, 3 * H, xin, H, goff(l, SIMX_P_WQKV) + (size_t)H * H, H, 1, tnws, tnws_bytes, goff(l, SIMX_P_BQKV) + H, 0, gs));
     }
     --l_top;
   } else if (top && dhidden) {
@@ -457,7 +460,7 @@ extern "C" int simx_bert_bwd_range(simx_stream_t stream, const simx_bert_cfg* c,
       return SIMX_ERR_HIP;
     }
   } else if (top) {
-    RUN(simx_cls_scatter(stream, dt, nseq, H, T, cu, dcls, bufB));            // g_x = d(loss)/d(last hidden)
+    RUN(simx_cls_scatter_gs(stream, dt, nseq, H, T, cu, dcls, bufB, gs));            // g_x = d(loss)/d(last hidden)
   }
   for (int l = l_top; l >= layer_lo; --l) {
     const WLayer w = wlayer(c, params, wcache, l);
@@ -467,37 +470,37 @@ extern "C" int simx_bert_bwd_range(simx_stream_t stream, const simx_bert_cfg* c,
     const simx_dropout d1 = drop_of(c, l, 1), d2 = drop_of(c, l, 2), d3 = drop_of(c, l, 3);
     char* dzm = hd ? bufC : bufA;        // gradient of the (dropped) dense output; bufA = gradient of the residual branch
     // output LayerNorm : dz2, dgamma2, dbeta2, db2
-    RUN(simx_ln_bwd_ex(stream, dt, T, H, a.z2, off(l, SIMX_P_LN2_G), c->eps, bufB, bufA, hd ? bufC : nullptr, goff(l, SIMX_P_LN2_G),
-                       goff(l, SIMX_P_LN2_B), goff(l, SIMX_P_B2), &d2));
+    RUN(simx_ln_bwd_gs(stream, dt, T, H, a.z2, off(l, SIMX_P_LN2_G), c->eps, bufB, bufA, hd ? bufC : nullptr, goff(l, SIMX_P_LN2_G),
+                       goff(l, SIMX_P_LN2_B), goff(l, SIMX_P_B2), &d2, nullptr, gs));
     // du = (dz2m . W2) * gelu'(u)
     RUN(simx_gemm_nt(stream, dt, Tp, F, H, dzm, H, w.w2T, H, du, F, nullptr, nullptr, 0, SIMX_EPI_DGELU, a.u, F, nullptr, 0));
-    RUN(simx_gemm_tn(stream, dt, H, F, T, dzm, H, a.h, F, goff(l, SIMX_P_W2), F, 1, tnws, tnws_bytes));
+    RUN(simx_gemm_tn_gs(stream, dt, H, F, T, dzm, H, a.h, F, goff(l, SIMX_P_W2), F, 1, tnws, tnws_bytes, nullptr, 0, gs));
     // dx1 = du . W1 + dz2
     RUN(simx_gemm_nt(stream, dt, Tp, H, F, du, F, w.w1T, F, bufB, H, nullptr, bufA, H, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
-    RUN(simx_gemm_tn_bias(stream, dt, F, H, T, du, F, a.x1, H, goff(l, SIMX_P_W1), H, 1, tnws, tnws_bytes, goff(l, SIMX_P_B1)));
+    RUN(simx_gemm_tn_gs(stream, dt, F, H, T, du, F, a.x1, H, goff(l, SIMX_P_W1), H, 1, tnws, tnws_bytes, goff(l, SIMX_P_B1), 0, gs));
     // attention-output LayerNorm : dz1, dgamma1, dbeta1, dbo
-    RUN(simx_ln_bwd_ex(stream, dt, T, H, a.z1, off(l, SIMX_P_LN1_G), c->eps, bufB, bufA, hd ? bufC : nullptr, goff(l, SIMX_P_LN1_G),
-                       goff(l, SIMX_P_LN1_B), goff(l, SIMX_P_BO), &d1));
+    RUN(simx_ln_bwd_gs(stream, dt, T, H, a.z1, off(l, SIMX_P_LN1_G), c->eps, bufB, bufA, hd ? bufC : nullptr, goff(l, SIMX_P_LN1_G),
+                       goff(l, SIMX_P_LN1_B), goff(l, SIMX_P_BO), &d1, nullptr, gs));
     // dctx = dz1m . Wo
     RUN(simx_gemm_nt(stream, dt, Tp, H, H, dzm, H, w.woT, H, bufB, H, nullptr, nullptr, 0, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
-    RUN(simx_gemm_tn(stream, dt, H, H, T, dzm, H, a.ctx, H, goff(l, SIMX_P_WO), H, 1, tnws, tnws_bytes));
+    RUN(simx_gemm_tn_gs(stream, dt, H, H, T, dzm, H, a.ctx, H, goff(l, SIMX_P_WO), H, 1, tnws, tnws_bytes, nullptr, 0, gs));
     RUN(simx_mha_bwd_hm(stream, dt, nseq, c->heads, d, cu, max_len, T, a.qkv, a.ctx, a.lse, bufB, dqkv, &d3, hm));
     // dx = dqkv . Wqkv + dz1
     if (hm) {
       RUN(simx_gemm_nt_hm(stream, dt, Tp, H, 3 * H, dqkv, 64, w.wqkvT, 3 * H, bufB, H, nullptr, bufA, H, nullptr, hm, 0));
-      RUN(simx_gemm_tn_hm(stream, dt, 3 * H, H, T, dqkv, hm, xin, H, goff(l, SIMX_P_WQKV), H, 1, tnws, tnws_bytes, goff(l, SIMX_P_BQKV)));
+      RUN(simx_gemm_tn_gs(stream, dt, 3 * H, H, T, dqkv, 0, xin, H, goff(l, SIMX_P_WQKV), H, 1, tnws, tnws_bytes, goff(l, SIMX_P_BQKV), hm, gs));
     } else {
       RUN(simx_gemm_nt(stream, dt, Tp, H, 3 * H, dqkv, 3 * H, w.wqkvT, 3 * H, bufB, H, nullptr, bufA, H, SIMX_EPI_NONE, nullptr, 0,
                        nullptr, 0));
-      RUN(simx_gemm_tn_bias(stream, dt, 3 * H, H, T, dqkv, 3 * H, xin, H, goff(l, SIMX_P_WQKV), H, 1, tnws, tnws_bytes,
-                            goff(l, SIMX_P_BQKV)));
+      RUN(simx_gemm_tn_gs(stream, dt, 3 * H, H, T, dqkv, 3 * H, xin, H, goff(l, SIMX_P_WQKV), H, 1, tnws, tnws_bytes,
+                          goff(l, SIMX_P_BQKV), 0, gs));
     }
   }
   if (layer_lo > 0) return SIMX_OK;               // the next part continues from bufB
   const simx_dropout d0 = drop_of(c, -1, 0);
-  RUN(simx_embed_ln_bwd_seq(stream, dt, nseq, max_len, T, H, cu, ids, pos_ids, off(-1, SIMX_P_WORD), off(-1, SIMX_P_POS),
-                            off(-1, SIMX_P_TYPE), off(-1, SIMX_P_EMB_LN_G), c->eps, bufB, goff(-1, SIMX_P_WORD),
-                            goff(-1, SIMX_P_POS), goff(-1, SIMX_P_TYPE), goff(-1, SIMX_P_EMB_LN_G), goff(-1, SIMX_P_EMB_LN_B), &d0));
+  RUN(simx_embed_ln_bwd_seq_gs(stream, dt, nseq, max_len, T, H, cu, ids, pos_ids, off(-1, SIMX_P_WORD), off(-1, SIMX_P_POS),
+                               off(-1, SIMX_P_TYPE), off(-1, SIMX_P_EMB_LN_G), c->eps, bufB, goff(-1, SIMX_P_WORD),
+                               goff(-1, SIMX_P_POS), goff(-1, SIMX_P_TYPE), goff(-1, SIMX_P_EMB_LN_G), goff(-1, SIMX_P_EMB_LN_B), &d0, gs));
   return SIMX_OK;
 }
 

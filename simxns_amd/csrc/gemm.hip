@@ -29,7 +29,8 @@ __global__ __launch_bounds__(256) void gemm_simple_kernel(
     int M, int N, int K, const TI* __restrict__ A, long a_rs, long a_cs,
     const TI* __restrict__ B, long b_ks, long b_ns, TO* __restrict__ C, int ldc,
     const float* __restrict__ bias, const TI* __restrict__ res, int ldr,
-    const TI* __restrict__ aux, int ldaux, TO* __restrict__ C2, int ldc2, int accumulate, DropCtx drop) {
+    const TI* __restrict__ aux, int ldaux, TO* __restrict__ C2, int ldc2, int accumulate, DropCtx drop,
+    const float* __restrict__ gs = nullptr) {           // gs: the product is a parameter gradient of the fp16 backward (x 1/S)
   __shared__ float As[16][68];
   __shared__ float Bs[16][68];
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256) void gemm_simple_kernel(
     for (int j = 0; j < 4; ++j) {
       int n = n0 + tx * 4 + j;
       if (n >= N) continue;
-      float v = acc[i][j];
+      float v = acc[i][j] * gs_inv(gs);
       if (bias) v += bias[n];
       if (EPI == SIMX_EPI_NONE) {
         if (drop.thr) v *= drop_mult(drop, (uint32_t)m, (uint32_t)n);
@@ -267,8 +268,8 @@ __device__ __forceinline__ void nt_stage_tile(const bf16_t* __restrict__ G, int 
   }
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(
+template <typename F, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_h16_kernel(
     int M, int N, int K, const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
     bf16_t* __restrict__ C, int ldc, const float* __restrict__ bias, const bf16_t* __restrict__ res, int ldr,
     const bf16_t* __restrict__ aux, int ldaux, bf16_t* __restrict__ C2, int ldc2, int tiles_n, int nwg, DropCtx drop) {
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = H16<F>::mfma(bfr[j], af[i], acc[i][j]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -339,21 +340,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(
       }
       if (EPI == SIMX_EPI_NONE) {
         if (drop.thr) { float m4[4]; drop_mult4(drop, (uint32_t)m, (uint32_t)n, m4); v[0] *= m4[0]; v[1] *= m4[1]; v[2] *= m4[2]; v[3] *= m4[3]; }
-        if (res) { float r4[4]; ld4(res + (long)m * ldr + n, r4); v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3]; }
-        st4(C + (long)m * ldc + n, v);
+        if (res) { float r4[4]; ld4h<F>(res + (long)m * ldr + n, r4); v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3]; }
+        st4h<F>(C + (long)m * ldc + n, v);
       } else if (EPI == SIMX_EPI_GELU) {
         // C = gelu'(u) (what backward multiplies by), C2 = gelu(u), both from the f32 pre-activation
         float g4[4], d4[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) gelu_both_fast(v[e], g4[e], d4[e]);
-        st4(C + (long)m * ldc + n, d4);
-        st4(C2 + (long)m * ldc2 + n, g4);
+        st4h<F>(C + (long)m * ldc + n, d4);
+        st4h<F>(C2 + (long)m * ldc2 + n, g4);
       } else {
-        if (res) { float r4[4]; ld4(res + (long)m * ldr + n, r4); v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3]; }
-        float u4[4]; ld4(aux + (long)m * ldaux + n, u4);
+        if (res) { float r4[4]; ld4h<F>(res + (long)m * ldr + n, r4); v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3]; }
+        float u4[4]; ld4h<F>(aux + (long)m * ldaux + n, u4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= u4[e];
-        st4(C + (long)m * ldc + n, v);
+        st4h<F>(C + (long)m * ldc + n, v);
       }
     }
   }
@@ -390,8 +391,8 @@ __device__ __forceinline__ void v5_stage(const bf16_t* __restrict__ A, int lda, 
   }
 }
 
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_nt_bf16_v5_kernel(
+template <typename F, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_h16_v5_kernel(
     int M, int N, int K, const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
     bf16_t* __restrict__ C, int ldc, const float* __restrict__ bias, const bf16_t* __restrict__ res, int ldr,
     const bf16_t* __restrict__ aux, int ldaux, bf16_t* __restrict__ C2, int ldc2, int tiles_n, int nwg, DropCtx drop) {
@@ -431,10 +432,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_v5_kernel(
   }
 
 #define V3_MFMA_ROW(I, AF, B0, B1, B2, B3)                                                     \
-  acc[I][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B0, AF, acc[I][0], 0, 0, 0);             \
-  acc[I][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B1, AF, acc[I][1], 0, 0, 0);             \
-  acc[I][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B2, AF, acc[I][2], 0, 0, 0);             \
-  acc[I][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B3, AF, acc[I][3], 0, 0, 0)
+  acc[I][0] = H16<F>::mfma(B0, AF, acc[I][0]);             \
+  acc[I][1] = H16<F>::mfma(B1, AF, acc[I][1]);             \
+  acc[I][2] = H16<F>::mfma(B2, AF, acc[I][2]);             \
+  acc[I][3] = H16<F>::mfma(B3, AF, acc[I][3])
 #define V3_RD1(F, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=&v"(F) : "v"(ADDR) : "memory")
 #define V3_SB __builtin_amdgcn_sched_barrier(0)
   // one k-step: CUR = this k-step's A-high address, NA/NB = next k-step's A-low / B addresses; SYNC: stage boundary
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_v5_kernel(
 #undef V3_SB
 #undef V3_MFMA_ROW
 
-  if (C == nullptr) return;                      // measurement hook (SIMX_NOEPI): main loop only
+  if (C == nullptr) return;                      // (main-loop-only measurement build, -DSIMX_MEASUREMENT_HOOKS)
   // ---- epilogue through LDS.  The memory path is REQUEST-bound (~1 request / 6 clk / CU, measured): the natural
   // MFMA-layout epilogue issues 32-B requests (16 rows x 32 B per store instruction, 4096 per output tile, as many
   // as a K=768 main loop).  Each wave therefore stages its 128x64 tile in its own 16 KB of the (now free) LDS ring:
@@ -522,8 +523,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_v5_kernel(
           if (EPI != SIMX_EPI_GELU && in) {
             uint2 t;
             asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(ad) : "memory");
-            const float x0 = __uint_as_float(t.x << 16), x1 = __uint_as_float(t.x & 0xFFFF0000u);
-            const float x2 = __uint_as_float(t.y << 16), x3 = __uint_as_float(t.y & 0xFFFF0000u);
+            const float x0 = H16<F>::lo(t.x), x1 = H16<F>::hi(t.x);
+            const float x2 = H16<F>::lo(t.y), x3 = H16<F>::hi(t.y);
             if (EPI == SIMX_EPI_NONE) { v[0] += x0; v[1] += x1; v[2] += x2; v[3] += x3; }
             else { v[0] *= x0; v[1] *= x1; v[2] *= x2; v[3] *= x3; }
           }
@@ -531,7 +532,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_v5_kernel(
 #pragma unroll
             for (int e2 = 0; e2 < 4; ++e2) v[e2] = pass == 0 ? gelu_grad_fast(v[e2]) : gelu_fast(v[e2]);
           }
-          const uint2 o = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+          const uint2 o = make_uint2(H16<F>::pack2(v[0], v[1]), H16<F>::pack2(v[2], v[3]));
           asm volatile("ds_write_b64 %0, %1" ::"v"(ad), "v"(o) : "memory");
         }
       }
@@ -574,9 +575,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // and passing that first boundary with a bare s_barrier changed nothing (6.73 vs 6.73 ms), so the cost is in the store
 // path's back-pressure on the issuing waves themselves.  Skewing the XCDs against each other does not help (per-XCD burst unchanged),
 // starting the A panels of an XCD in 4 phase groups (N-tiles of a panel in step) costs its 3/4-tile tail and gains nothing.)
-#ifndef SIMX_P3_STORE_BITS
 #define SIMX_P3_STORE_BITS " nt"
-#endif
 #define P_GST4(VOFF, SBASE, VAL) asm volatile("global_store_dwordx4 %0, %1, %2" SIMX_P3_STORE_BITS "\n\ts_nop 5" ::"v"(VOFF), "v"(VAL), "s"(SBASE) : "memory")
 // LDS-DMA in the same form (M0 = wave-uniform LDS byte address of the 1 KB destination).  The persistent kernel
 // uses ONLY this form, so the compiler never tracks M0 in it.
@@ -614,8 +613,8 @@ __device__ __forceinline__ void p3_half(const bf16_t* __restrict__ G, int ld, in
 //                        chunk is a bad stride for the memory system, while 6144 B (N = 3072: 1.056 ms row-major, 1.07
 //                        plane-blocked) and 1536 B (N = 768: 0.28 / 0.28, 0.93 / 0.93) are not;
 //   bit 2: the epilogue input (residual / GELU' rows), addressed like C.
-template <int EPI, bool HAS_IN, int HMF = 0>
-__global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
+template <typename F, int EPI, bool HAS_IN, int HMF = 0>
+__global__ __launch_bounds__(512, 2) void gemm_nt_p3_kernel(
     int M, int N, int K, const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
     bf16_t* __restrict__ C, int ldc, const float* __restrict__ bias, const bf16_t* __restrict__ in, int ldin,
     bf16_t* __restrict__ C2, int ldc2, int tiles_n, int ntiles, DropCtx drop) {
@@ -669,64 +668,40 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
   }
 
 #define V3_MFMA_ROW(I, AF, B0, B1, B2, B3)                                                     \
-  acc[I][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B0, AF, acc[I][0], 0, 0, 0);             \
-  acc[I][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B1, AF, acc[I][1], 0, 0, 0);             \
-  acc[I][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B2, AF, acc[I][2], 0, 0, 0);             \
-  acc[I][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B3, AF, acc[I][3], 0, 0, 0)
+  acc[I][0] = H16<F>::mfma(B0, AF, acc[I][0]);             \
+  acc[I][1] = H16<F>::mfma(B1, AF, acc[I][1]);             \
+  acc[I][2] = H16<F>::mfma(B2, AF, acc[I][2]);             \
+  acc[I][3] = H16<F>::mfma(B3, AF, acc[I][3])
 #define V3_RD1(F, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=&v"(F) : "v"(ADDR) : "memory")
 #define V3_SB __builtin_amdgcn_sched_barrier(0)
-#if defined(SIMX_P3_NOBARRIER)        /* timing experiment only: results are wrong without the barrier */
-#define P3_BOUNDARY_WAIT() asm volatile("s_waitcnt vmcnt(4)" ::: "memory")
-#elif defined(SIMX_P3_NOWAIT)
-#define P3_BOUNDARY_WAIT() asm volatile("s_barrier" ::: "memory")
-#else
+  // (timing experiments that priced the waits of this loop -- no barrier, no vmcnt wait, no lgkmcnt waits, s_setprio around
+  // the MFMA bursts, all stores to one tile's rows -- are recorded in DESIGN.md 5 / 5b; the switches are not part of the product)
 #define P3_BOUNDARY_WAIT() asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory")
-#endif
-#ifdef SIMX_P3_NOLGKM                   /* timing experiment only */
-#define P3_LGKM_WAIT ""
-#else
 #define P3_LGKM_WAIT "s_waitcnt lgkmcnt(0)"
-#endif
-#ifdef SIMX_P3_SETPRIO
-#define P3_PRIO(N) __builtin_amdgcn_s_setprio(N)
-#else
-#define P3_PRIO(N) do { } while (0)
-#endif
-#ifndef SIMX_P3_SPREAD
-#define SIMX_P3_SPREAD 1
-#endif
-  // SIMX_P3_SPREAD: the 8 LDS-DMA instructions a mid-tile boundary issues go out one per MFMA row (B in the rest of this
-  // k-step, A in the first half of the next) instead of as a burst right after the barrier
+  // the 8 LDS-DMA instructions a mid-tile boundary issues go out ONE PER MFMA ROW (B in the rest of this k-step, A in the
+  // first half of the next), never as a burst right after the barrier (+5 %)
   const char* pa_g = nullptr; const char* pb_g = nullptr;
   uint32_t pa_slot = 0, pb_slot = 0;
   bool pa_pend = false, pb_pend = false;
-#define P3_HA(J) do { if (SIMX_P3_SPREAD && pa_pend) { P_DMA16(((J) & 1) ? offA1 : offA0, pa_g + (long)(J) * 8 * lda * 2, pa_slot + (uint32_t)((J) * 1024)); if ((J) == 3) pa_pend = false; } } while (0)
-#define P3_HB(J) do { if (SIMX_P3_SPREAD && pb_pend) { P_DMA16(((J) & 1) ? offB1 : offB0, pb_g + (long)(J) * 8 * ldb * 2, pb_slot + (uint32_t)((J) * 1024)); if ((J) == 3) pb_pend = false; } } while (0)
-#if SIMX_P3_SPREAD == 3                 /* experiment: the A pieces every other row of the FIRST k-step of a stage: 1041 vs 1056 TFLOP/s -- earlier is better */
-#define P3_HAX(ROW, S1) do { if ((S1) && ((ROW) & 1) == 0) P3_HA((ROW) >> 1); } while (0)
-#else
+#define P3_HA(J) do { if (pa_pend) { P_DMA16(((J) & 1) ? offA1 : offA0, pa_g + (long)(J) * 8 * lda * 2, pa_slot + (uint32_t)((J) * 1024)); if ((J) == 3) pa_pend = false; } } while (0)
+#define P3_HB(J) do { if (pb_pend) { P_DMA16(((J) & 1) ? offB1 : offB0, pb_g + (long)(J) * 8 * ldb * 2, pb_slot + (uint32_t)((J) * 1024)); if ((J) == 3) pb_pend = false; } } while (0)
 #define P3_HAX(ROW, S1) do { if ((ROW) < 4) P3_HA(ROW); } while (0)
-#endif
 #define P_STEP(CURA, NA, NB, BC0, BC1, BC2, BC3, BN0, BN1, BN2, BN3, BOUNDARY, S1)               \
   do {                                                                                         \
     /* fragment reads are front-loaded: the last read before each pin is issued two MFMA rows ahead of it */ \
     const uint32_t aa__ = (CURA), na__ = (NA), nb__ = (NB);                                    \
-    P3_PRIO(1);                                                                                \
     V3_SB; V3_MFMA_ROW(0, al0, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah0, aa__, 8192); V3_RD1(ah1, aa__, 10240); P3_HAX(0, S1); \
     V3_SB; V3_MFMA_ROW(1, al1, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(ah2, aa__, 12288); V3_RD1(ah3, aa__, 14336); P3_HAX(1, S1); \
     V3_SB; V3_MFMA_ROW(2, al2, BC0, BC1, BC2, BC3); V3_SB; P3_HAX(2, S1);                      \
     V3_SB; V3_MFMA_ROW(3, al3, BC0, BC1, BC2, BC3); V3_SB; P3_HAX(3, S1);                      \
     V3_SB;                                                                                     \
-    P3_PRIO(0);                                                                                \
     V3_PIN4(P3_LGKM_WAIT, ah0, ah1, ah2, ah3);                                       \
     BOUNDARY();                                                                                \
-    P3_PRIO(1);                                                                                \
     V3_SB; V3_MFMA_ROW(4, ah0, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al0, na__, 0); V3_RD1(BN0, nb__, 0); V3_RD1(al1, na__, 2048); P3_HB(1); P3_HAX(4, S1); \
     V3_SB; V3_MFMA_ROW(5, ah1, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(BN1, nb__, 2048); V3_RD1(al2, na__, 4096); V3_RD1(BN2, nb__, 4096); P3_HB(2); P3_HAX(5, S1); \
     V3_SB; V3_MFMA_ROW(6, ah2, BC0, BC1, BC2, BC3); V3_SB; V3_RD1(al3, na__, 6144); V3_RD1(BN3, nb__, 6144); P3_HB(3); P3_HAX(6, S1); \
     V3_SB; V3_MFMA_ROW(7, ah3, BC0, BC1, BC2, BC3);                                            \
     V3_SB;                                                                                     \
-    P3_PRIO(0);                                                                                \
     V3_PIN8(P3_LGKM_WAIT, al0, al1, al2, al3, BN0, BN1, BN2, BN3);                   \
   } while (0)
 #define P_BND_NONE() do { } while (0)
@@ -738,18 +713,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
     /* issue order so far: ... [B(st+1) A(st+2)] ; stage st+1 = everything but the 4 youngest (A(st+2)) */ \
     P3_BOUNDARY_WAIT();                                                                        \
     const bool cb__ = st + 2 < nst, ca__ = st + 3 < nst;                                       \
-    if (SIMX_P3_SPREAD) {                                                                      \
-      /* same issue ORDER as the burst (B x4, then A x4 -- the vmcnt(4) rule holds), one instruction per MFMA row */ \
-      pb_g = reinterpret_cast<const char*>(B + (long)((cb__ ? n0 : n0n) + wave * 32) * ldb + (cb__ ? st + 2 : st + 2 - nst) * 64); \
-      pb_slot = ldsB + (uint32_t)(bc * 32768 + wave * 4096);                                   \
-      pa_g = reinterpret_cast<const char*>(A + (long)((ca__ ? m0 : m0n) + wave * 32) * lda + P3_AK(ca__ ? st + 3 : st + 3 - nst)); \
-      pa_slot = lds0 + (uint32_t)(ac * 32768 + wave * 4096);                                   \
-      pb_pend = pa_pend = true;                                                                \
-      P_DMA16(offB0, pb_g, pb_slot);                                                           \
-    } else {                                                                                   \
-      p3_half(B, ldb, cb__ ? n0 : n0n, (cb__ ? st + 2 : st + 2 - nst) * 64, ldsB + (uint32_t)(bc * 32768), wave, offB0, offB1); \
-      p3_half(A, lda, ca__ ? m0 : m0n, P3_AK(ca__ ? st + 3 : st + 3 - nst), lds0 + (uint32_t)(ac * 32768), wave, offA0, offA1); \
-    }                                                                                          \
+    /* same issue ORDER as a burst would have (B x4, then A x4 -- the vmcnt(4) rule holds), one instruction per MFMA row */ \
+    pb_g = reinterpret_cast<const char*>(B + (long)((cb__ ? n0 : n0n) + wave * 32) * ldb + (cb__ ? st + 2 : st + 2 - nst) * 64); \
+    pb_slot = ldsB + (uint32_t)(bc * 32768 + wave * 4096);                                     \
+    pa_g = reinterpret_cast<const char*>(A + (long)((ca__ ? m0 : m0n) + wave * 32) * lda + P3_AK(ca__ ? st + 3 : st + 3 - nst)); \
+    pa_slot = lds0 + (uint32_t)(ac * 32768 + wave * 4096);                                     \
+    pb_pend = pa_pend = true;                                                                  \
+    P_DMA16(offB0, pb_g, pb_slot);                                                             \
   } while (0)
   // last boundary of the tile: bias and the first residual chunk are requested BEFORE the next tile's stage 1,
   // so the epilogue can wait for them without waiting for that stage
@@ -766,14 +736,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
       P_DMA16(io0__, ibase, ereg); P_DMA16(io1__, ibase, ereg + 1024u);                        \
     }                                                                                          \
     /* next tile's stage 1 of B; its stage 2 of A goes into the slot this tile's epilogue borrows -> issued after it */ \
-    if (SIMX_P3_SPREAD) {                                                                      \
-      pb_g = reinterpret_cast<const char*>(B + (long)(n0n + wave * 32) * ldb + 64);            \
-      pb_slot = ldsB + (uint32_t)(bc * 32768 + wave * 4096);                                   \
-      pb_pend = true;                                                                          \
-      P_DMA16(offB0, pb_g, pb_slot);                                                           \
-    } else {                                                                                   \
-      p3_half(B, ldb, n0n, 64, ldsB + (uint32_t)(bc * 32768), wave, offB0, offB1);              \
-    }                                                                                          \
+    pb_g = reinterpret_cast<const char*>(B + (long)(n0n + wave * 32) * ldb + 64);              \
+    pb_slot = ldsB + (uint32_t)(bc * 32768 + wave * 4096);                                     \
+    pb_pend = true;                                                                            \
+    P_DMA16(offB0, pb_g, pb_slot);                                                             \
   } while (0)
 
   for (;;) {
@@ -826,7 +792,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
     // (the bias registers are pinned here, BEFORE any branch: a branch between an asm load and its pin makes hipcc
     // copy the in-flight registers and the copies read garbage)
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(bq0), "+v"(bq1), "+v"(bq2), "+v"(bq3) : "n"(HAS_IN ? 6 : 4) : "memory");
-    if (C != nullptr) {                          // (nullptr: measurement hook SIMX_NOEPI, main loop only)
+    if (C != nullptr) {                          // (nullptr: the main-loop-only measurement build, -DSIMX_MEASUREMENT_HOOKS)
       P_LANE(le);
       const int fr = le & 15, fg = le >> 4, lr = le >> 3;          // shadow the kernel-scope copies on purpose
       const int ec0 = ((le & 7) ^ (le >> 4)) << 3, ec1 = ((le & 7) ^ (4 + (le >> 4))) << 3;
@@ -835,11 +801,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
       if (HM_C) ldc = 64;                                      // (per tile: `ldc` is dead in the main loop)
       const uint32_t eo0 = (uint32_t)(lr * ldc + ec0) * 2, eo1 = (uint32_t)((lr + 8) * ldc + ec1) * 2;
       const uint32_t io0 = HAS_IN ? (uint32_t)(lr * ldin + ec0) * 2 : 0, io1 = HAS_IN ? (uint32_t)((lr + 8) * ldin + ec1) * 2 : 0;
-#ifdef SIMX_P3_SAMEC                      /* timing experiment only: every tile stores to the first tile's rows (stays in L2) */
-      bf16_t* const obase = C + (long)(wr * 128) * ldc + (nw - n0);
-#else
       bf16_t* const obase = HM_C ? C + ((long)(nw >> 6) * hmR + mw) * 64 : C + (long)mw * ldc + nw;          // uniform
-#endif
       const bool store_pre = !(EPI == SIMX_EPI_GELU && ldin == 1);   // ldin == 1 on a GELU launch: SIMX_EPI_GELU_INFER
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -873,8 +835,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
           }
           if (HAS_IN) {
             const uint2 t = j == 0 ? t0 : j == 1 ? t1 : j == 2 ? t2 : t3;
-            const float x0 = __uint_as_float(t.x << 16), x1 = __uint_as_float(t.x & 0xFFFF0000u);
-            const float x2 = __uint_as_float(t.y << 16), x3 = __uint_as_float(t.y & 0xFFFF0000u);
+            const float x0 = H16<F>::lo(t.x), x1 = H16<F>::hi(t.x);
+            const float x2 = H16<F>::lo(t.y), x3 = H16<F>::hi(t.y);
             if (EPI == SIMX_EPI_NONE) { vv[0] += x0; vv[1] += x1; vv[2] += x2; vv[3] += x3; }
             else { vv[0] *= x0; vv[1] *= x1; vv[2] *= x2; vv[3] *= x3; }          // aux = gelu'(u), stored by the forward
           }
@@ -887,10 +849,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
 #pragma unroll
               for (int e = 0; e < 4; ++e) g[e] = gelu_fast(vv[e]);
             }
-            const uint2 og = make_uint2(pack2bf(g[0], g[1]), pack2bf(g[2], g[3]));
+            const uint2 og = make_uint2(H16<F>::pack2(g[0], g[1]), H16<F>::pack2(g[2], g[3]));
             asm volatile("ds_write_b64 %0, %1 offset:2048" ::"v"(ad), "v"(og) : "memory");
           }
-          const uint2 o = make_uint2(pack2bf(vv[0], vv[1]), pack2bf(vv[2], vv[3]));
+          const uint2 o = make_uint2(H16<F>::pack2(vv[0], vv[1]), H16<F>::pack2(vv[2], vv[3]));
           asm volatile("ds_write_b64 %0, %1" ::"v"(ad), "v"(o) : "memory");
         }
         const uint32_t rd = sub + (uint32_t)(le * 16);
@@ -913,7 +875,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_p3_kernel(
       }
     }
     // the borrowed A slot is free again (this wave's slice only ever holds this wave's rows): next tile's stage 2
-    if (SIMX_P3_SPREAD && has_next) {              // issued by the next tile's first four MFMA rows (same order: after B(1))
+    if (has_next) {                                // issued by the next tile's first four MFMA rows (same order: after B(1))
       pa_g = reinterpret_cast<const char*>(A + (long)(m0n + wave * 32) * lda + P3_AK(2));
       pa_slot = lds0 + (uint32_t)(ac * 32768 + wave * 4096);
       pa_pend = true;
@@ -966,9 +928,11 @@ __device__ __forceinline__ bf16x4 lds_tr_read(uint32_t addr) {
   return v;
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(
+template <typename F>
+__global__ __launch_bounds__(256, 2) void gemm_tn_h16_kernel(
     int M, int N, int K, const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
-    float* __restrict__ out, long slab_stride, int ldo, int tiles_n, int tiles_mn, int k_per_split, int accumulate) {
+    float* __restrict__ out, long slab_stride, int ldo, int tiles_n, int tiles_mn, int k_per_split, int accumulate,
+    const float* __restrict__ gs) {                     // gs != NULL: `out` is the gradient itself (no slab pass follows): x 1/S
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1037,7 +1001,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = H16<F>::mfma(bfr[j], af[i], acc[i][j]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1045,6 +1009,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(
   }
 
   float* o = out + (long)split * slab_stride;
+  const float inv = gs_inv(gs);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wr * 64 + i * 16 + fs;
@@ -1054,7 +1019,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(
       const int n = n0 + wc * 64 + j * 16 + fg * 4;
       if (n >= N) continue;
       float4* dst = reinterpret_cast<float4*>(o + (long)m * ldo + n);
-      float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      float4 v = make_float4(acc[i][j][0] * inv, acc[i][j][1] * inv, acc[i][j][2] * inv, acc[i][j][3] * inv);
       if (accumulate) { float4 c = *dst; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
       *dst = v;
     }
@@ -1156,10 +1121,13 @@ typedef __attribute__((address_space(3))) bf16x4* tn_lds4_t;
     F_HI = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tn_lds4_t)(uintptr_t)(ADDR_HI));                \
   } while (0)
 
-__global__ __launch_bounds__(512, 2) void gemm_tn2_bf16_kernel(
+template <typename F>
+__global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(
     int M, int N, int K, const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
     float* __restrict__ out, long slab_stride, int ldo, int tiles_n, int tiles_mn, int k_per_split, int accumulate,
-    float* __restrict__ dbias, int hm_a) {
+    float* __restrict__ dbias, int hm_a, const float* __restrict__ gs, int scale_out) {
+  // gs = {S, 1/S} of the fp16 backward or NULL: the bias gradient always leaves x 1/S; the product only when `out` is the
+  // gradient itself (scale_out; with split-K the slab reduction applies it)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1213,36 +1181,27 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_bf16_kernel(
 #define TN2_MFMA_ROW(I, ALO, AHI, BLO, BHI)                                                                     \
   do {                                                                                                          \
     const bf16x8 af__ = TN2_FRAG(ALO, AHI);                                                                     \
-    acc[I][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(TN2_FRAG(BLO[0], BHI[0]), af__, acc[I][0], 0, 0, 0);    \
-    acc[I][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(TN2_FRAG(BLO[1], BHI[1]), af__, acc[I][1], 0, 0, 0);    \
-    acc[I][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(TN2_FRAG(BLO[2], BHI[2]), af__, acc[I][2], 0, 0, 0);    \
-    acc[I][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(TN2_FRAG(BLO[3], BHI[3]), af__, acc[I][3], 0, 0, 0);    \
+    acc[I][0] = H16<F>::mfma(TN2_FRAG(BLO[0], BHI[0]), af__, acc[I][0]);    \
+    acc[I][1] = H16<F>::mfma(TN2_FRAG(BLO[1], BHI[1]), af__, acc[I][1]);    \
+    acc[I][2] = H16<F>::mfma(TN2_FRAG(BLO[2], BHI[2]), af__, acc[I][2]);    \
+    acc[I][3] = H16<F>::mfma(TN2_FRAG(BLO[3], BHI[3]), af__, acc[I][3]);    \
     if (do_bias) {                                                                                              \
       _Pragma("unroll") for (int e__ = 0; e__ < 4; ++e__)                                                       \
-          bsum[I] += bf2f((bf16_t)ALO[e__]) + bf2f((bf16_t)AHI[e__]);                                           \
+          bsum[I] += H16<F>::one(ALO[e__]) + H16<F>::one(AHI[e__]);                                           \
     }                                                                                                           \
   } while (0)
 #define TN2_SB __builtin_amdgcn_sched_barrier(0)
-// Timing experiments (results are wrong with either; tools/build_variant.sh B -DSIMX_TN2_...), M = 262144 tokens, average of the
-// four wgrad shapes: as shipped 992 TFLOP/s; SIMX_TN2_SAMEK (every stage re-reads stage 0: all L2 hits) 1156; SIMX_TN2_NOLOAD
-// (no operand loads in the loop) 1445, 1614 on all-zero data.  So the LDS-DMA stream itself costs the loop 20 % and the
-// fabric / HBM misses another 14 %; an L2 prefetch of stage s+3 (one dword per line, counted vmcnt) made it 5 % SLOWER.
-#ifdef SIMX_TN2_SAMEK
-#define TN2_KSEL(S) 0
-#else
+// (What bounds this loop was priced with timing-only variants, M = 262144 tokens, average of the four wgrad shapes: as shipped
+// 992 TFLOP/s; every stage re-reading stage 0 (all L2 hits) 1156; no operand loads at all 1445, 1614 on all-zero data.  So the
+// LDS-DMA stream itself costs the loop 20 % and the fabric / HBM misses another 14 %; an L2 prefetch of stage s+3 made it 5 %
+// SLOWER.  The 8 DMA instructions of a stage go out ONE PER MFMA ROW after the boundary: burst 1003, one (A,B) pair per row
+// 1056, one instruction per row 1080 TFLOP/s.)
 #define TN2_KSEL(S) (S)
-#endif
-#ifndef TN2_SPREAD
-#define TN2_SPREAD 2                    /* the 8 DMA instructions of a stage go out ONE PER MFMA ROW after the boundary (1: one (A,B) pair per row; 0: burst): 1003 / 1056 / 1080 TFLOP/s */
-#endif
+#define TN2_SPREAD 2
 #define TN2_PIECE(ST, J) tn2_stage_piece(A, hm_a > 0 ? 64 : lda, B, ldb, kb + TN2_KSEL((ST) + 2) * 64, lds0 + (uint32_t)(((ST) & 1) * TN2_STAGE), wave, J, oa[J], ob[J])
 #define TN2_ONE_A(ST, J) tn2_stage_one(A, hm_a > 0 ? 64 : lda, kb + TN2_KSEL((ST) + 2) * 64, lds0 + (uint32_t)(((ST) & 1) * TN2_STAGE), wave, J, oa[J])
 #define TN2_ONE_B(ST, J) tn2_stage_one(B, ldb, kb + TN2_KSEL((ST) + 2) * 64, lds0 + 32768u + (uint32_t)(((ST) & 1) * TN2_STAGE), wave, J, ob[J])
-#ifdef SIMX_TN2_NOLOAD
-#define TN2_NOLOAD 1
-#else
 #define TN2_NOLOAD 0
-#endif
 #define TN2_PIN8(TXT, X, Y) do { } while (0)     /* waits are hipcc's (counted lgkmcnt): the reads are builtins */
 
   {
@@ -1344,6 +1303,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_bf16_kernel(
 #undef TN2_STEP
 
   float* o = out + (long)split * slab_stride;
+  const float inv_b = gs_inv(gs), inv = scale_out ? inv_b : 1.0f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int m = m0 + wr * 128 + i * 16 + fs;
@@ -1353,7 +1313,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_bf16_kernel(
       const int n = n0 + wc * 64 + j * 16 + fg * 4;
       if (n >= N) continue;
       float4* dst = reinterpret_cast<float4*>(o + (long)m * ldo + n);
-      float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      float4 v = make_float4(acc[i][j][0] * inv, acc[i][j][1] * inv, acc[i][j][2] * inv, acc[i][j][3] * inv);
       if (accumulate) { float4 c = *dst; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
       *dst = v;
     }
@@ -1365,14 +1325,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_bf16_kernel(
       t += __shfl_xor(t, 16, 64);
       t += __shfl_xor(t, 32, 64);
       const int m = m0 + wr * 128 + i * 16 + fs;
-      if (fg == 0 && m < M) atomicAdd(dbias + m, t);
+      if (fg == 0 && m < M) atomicAdd(dbias + m, t * inv_b);
     }
   }
 }
 
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int splits,
-                                                          int M, int N, float* __restrict__ C, int ldc, int accumulate) {
+                                                          int M, int N, float* __restrict__ C, int ldc, int accumulate,
+                                                          const float* __restrict__ gs) {
   const long total4 = (long)M * N / 4;
+  const float inv = gs_inv(gs);
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
     const long e = i * 4;
     const int m = (int)(e / N), n = (int)(e % N);
@@ -1381,6 +1343,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
       const float4 v = *reinterpret_cast<const float4*>(slabs + (long)k * slab_stride + e);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
+    s.x *= inv; s.y *= inv; s.z *= inv; s.w *= inv;
     float4* dst = reinterpret_cast<float4*>(C + (long)m * ldc + n);
     if (accumulate) { const float4 c = *dst; s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w; }
     *dst = s;
@@ -1392,7 +1355,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(int Trows, int N, const T* __restrict__ x, int ldx,
-                                                     float* __restrict__ out, int rows_per_block) {
+                                                     float* __restrict__ out, int rows_per_block, const float* __restrict__ gs) {
   // block = 64 columns x 4 row-lanes; grid.x over column groups, grid.y over row chunks; atomics to out
   __shared__ float part[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
@@ -1402,7 +1365,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(int Trows, int N, const T* 
     for (int r = r0 + rl; r < r1; r += 4) s += Elem<T>::ld(x + (long)r * ldx + c);
   part[rl][threadIdx.x & 63] = s;
   __syncthreads();
-  if (rl == 0 && c < N) atomicAdd(out + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+  if (rl == 0 && c < N) atomicAdd(out + c, (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]) * gs_inv(gs));
 }
 
 template <typename TO>
@@ -1445,20 +1408,24 @@ static const GemmDevice* gemm_device() {
     bool ok = true;
 #define SIMX_LDS_ATTR(KERNEL, BYTES) \
     ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)) == hipSuccess
-    SIMX_LDS_ATTR(gemm_nt_bf16_kernel<SIMX_EPI_NONE>, 2 * NT_STAGE_BYTES);
-    SIMX_LDS_ATTR(gemm_nt_bf16_kernel<SIMX_EPI_GELU>, 2 * NT_STAGE_BYTES);
-    SIMX_LDS_ATTR(gemm_nt_bf16_kernel<SIMX_EPI_DGELU>, 2 * NT_STAGE_BYTES);
-    SIMX_LDS_ATTR(gemm_tn_bf16_kernel, 2 * NT_STAGE_BYTES);
-    SIMX_LDS_ATTR(gemm_nt_bf16_v5_kernel<SIMX_EPI_NONE>, V5_LDS);
-    SIMX_LDS_ATTR(gemm_nt_bf16_v5_kernel<SIMX_EPI_GELU>, V5_LDS);
-    SIMX_LDS_ATTR(gemm_nt_bf16_v5_kernel<SIMX_EPI_DGELU>, V5_LDS);
-    SIMX_LDS_ATTR((gemm_nt_bf16_p3_kernel<SIMX_EPI_NONE, false>), P_LDS);
-    SIMX_LDS_ATTR((gemm_nt_bf16_p3_kernel<SIMX_EPI_NONE, true>), P_LDS);
-    SIMX_LDS_ATTR((gemm_nt_bf16_p3_kernel<SIMX_EPI_GELU, false>), P_LDS);
-    SIMX_LDS_ATTR((gemm_nt_bf16_p3_kernel<SIMX_EPI_DGELU, true>), P_LDS);
-    SIMX_LDS_ATTR((gemm_nt_bf16_p3_kernel<SIMX_EPI_NONE, false, 2>), P_LDS);
-    SIMX_LDS_ATTR((gemm_nt_bf16_p3_kernel<SIMX_EPI_NONE, true, 1>), P_LDS);
-    SIMX_LDS_ATTR(gemm_tn2_bf16_kernel, TN2_LDS);
+#define SIMX_LDS_ATTRS16(F)                                                           \
+    SIMX_LDS_ATTR((gemm_nt_h16_kernel<F, SIMX_EPI_NONE>), 2 * NT_STAGE_BYTES);           \
+    SIMX_LDS_ATTR((gemm_nt_h16_kernel<F, SIMX_EPI_GELU>), 2 * NT_STAGE_BYTES);           \
+    SIMX_LDS_ATTR((gemm_nt_h16_kernel<F, SIMX_EPI_DGELU>), 2 * NT_STAGE_BYTES);          \
+    SIMX_LDS_ATTR(gemm_tn_h16_kernel<F>, 2 * NT_STAGE_BYTES);                            \
+    SIMX_LDS_ATTR((gemm_nt_h16_v5_kernel<F, SIMX_EPI_NONE>), V5_LDS);                    \
+    SIMX_LDS_ATTR((gemm_nt_h16_v5_kernel<F, SIMX_EPI_GELU>), V5_LDS);                    \
+    SIMX_LDS_ATTR((gemm_nt_h16_v5_kernel<F, SIMX_EPI_DGELU>), V5_LDS);                   \
+    SIMX_LDS_ATTR((gemm_nt_p3_kernel<F, SIMX_EPI_NONE, false>), P_LDS);                  \
+    SIMX_LDS_ATTR((gemm_nt_p3_kernel<F, SIMX_EPI_NONE, true>), P_LDS);                   \
+    SIMX_LDS_ATTR((gemm_nt_p3_kernel<F, SIMX_EPI_GELU, false>), P_LDS);                  \
+    SIMX_LDS_ATTR((gemm_nt_p3_kernel<F, SIMX_EPI_DGELU, true>), P_LDS);                  \
+    SIMX_LDS_ATTR((gemm_nt_p3_kernel<F, SIMX_EPI_NONE, false, 2>), P_LDS);               \
+    SIMX_LDS_ATTR((gemm_nt_p3_kernel<F, SIMX_EPI_NONE, true, 1>), P_LDS);                \
+    SIMX_LDS_ATTR(gemm_tn2_kernel<F>, TN2_LDS)
+    SIMX_LDS_ATTRS16(bf16_t);
+    SIMX_LDS_ATTRS16(f16_t);
+#undef SIMX_LDS_ATTRS16
 #undef SIMX_LDS_ATTR
     g.ok = ok;
   });
@@ -1472,8 +1439,6 @@ static int operand_mode(const float* p, long stride_mn, long stride_k) {
   if (stride_mn == 1 && al16 && stride_k % 4 == 0) return 2;
   return 0;
 }
-__global__ void slab_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int splits, int M, int N, float* __restrict__ C,
-                                   int ldc, int accumulate);
 // Split-K plan of the f32 MFMA kernel for problems whose 128x128 tile grid leaves most of the chip idle while K is long
 // (parity-mode wgrad: K = tokens; M2's dQ: K = the gathered passages).  Needs a workspace of splits*M*N floats.
 static int f32_splits(int M, int N, int K, size_t ws_bytes) {
@@ -1507,7 +1472,8 @@ static int launch_f32_mfma(hipStream_t s, int epi, int M, int N, int K, const fl
       const long tot4 = (long)M * N / 4;
       int rb = (int)((tot4 + 255) / 256);
       if (rb > 2048) rb = 2048;
-      hipLaunchKernelGGL(slab_reduce_kernel, dim3(rb), dim3(256), 0, s, (const float*)ws, (long)M * N, nsp, M, N, C, ldc, accumulate);
+      hipLaunchKernelGGL(slab_reduce_kernel, dim3(rb), dim3(256), 0, s, (const float*)ws, (long)M * N, nsp, M, N, C, ldc, accumulate,
+                         (const float*)nullptr);
       SIMX_CHECK_LAUNCH("slab_reduce");
       return SIMX_OK;
     }
@@ -1526,7 +1492,7 @@ template <typename TI, typename TO>
 static int launch_simple(hipStream_t s, int epi, int M, int N, int K, const TI* A, long a_rs, long a_cs,
                          const TI* B, long b_ks, long b_ns, TO* C, int ldc, const float* bias, const TI* res, int ldr,
                          const TI* aux, int ldaux, TO* C2, int ldc2, int accumulate, DropCtx drop = DropCtx{0u, 1.f, 0u, 0u},
-                         void* ws = nullptr, size_t ws_bytes = 0) {
+                         void* ws = nullptr, size_t ws_bytes = 0, const float* gs = nullptr) {
   if constexpr (std::is_same<TI, float>::value && std::is_same<TO, float>::value) {
     static const char* pin = getenv("SIMX_GEMM_F32");           // SIMX_GEMM_F32=fma pins the VALU kernel (A/B measurements)
     if (!(pin && pin[0] == 'f'))
@@ -1535,7 +1501,7 @@ static int launch_simple(hipStream_t s, int epi, int M, int N, int K, const TI* 
   }
   dim3 grid(cdiv(N, 64), cdiv(M, 64));
 #define L(E) hipLaunchKernelGGL((gemm_simple_kernel<TI, TO, E>), grid, dim3(256), 0, s, M, N, K, A, a_rs, a_cs, B, b_ks, \
-                                b_ns, C, ldc, bias, res, ldr, aux, ldaux, C2, ldc2, accumulate, drop)
+                                b_ns, C, ldc, bias, res, ldr, aux, ldaux, C2, ldc2, accumulate, drop, gs)
   if (epi == SIMX_EPI_NONE) L(SIMX_EPI_NONE);
   else if (epi == SIMX_EPI_GELU) L(SIMX_EPI_GELU);
   else L(SIMX_EPI_DGELU);
@@ -1576,15 +1542,17 @@ extern "C" int simx_gemm_nt_ex(simx_stream_t stream, int dtype, int M, int N, in
     return launch_simple<float, float>(s, epilogue, M, N, K, (const float*)A, lda, 1, (const float*)B, 1, ldb,
                                        (float*)C, ldc, bias, (const float*)residual, ldr, (const float*)aux, ldaux,
                                        (float*)C2, ldc2, 0, drop);
-  SIMX_REQUIRE(dtype == SIMX_BF16, SIMX_ERR_BAD_DTYPE, "gemm_nt: dtype %d", dtype);
+  SIMX_REQUIRE(simx_is16(dtype), SIMX_ERR_BAD_DTYPE, "gemm_nt: dtype %d", dtype);
   const bool fast = (K % 64 == 0) && (N % 4 == 0) && (lda % 8 == 0) && (ldb % 8 == 0) && (ldc % 4 == 0) &&
                     aligned16(A) && aligned16(B) && aligned16(C) && (!bias || aligned16(bias)) &&
                     (!residual || (ldr % 4 == 0 && aligned16(residual))) && (!aux || (ldaux % 4 == 0 && aligned16(aux))) &&
                     (!C2 || (ldc2 % 4 == 0 && aligned16(C2)));
-  if (!fast)
-    return launch_simple<bf16_t, bf16_t>(s, epilogue, M, N, K, (const bf16_t*)A, lda, 1, (const bf16_t*)B, 1, ldb,
-                                         (bf16_t*)C, ldc, bias, (const bf16_t*)residual, ldr, (const bf16_t*)aux,
-                                         ldaux, (bf16_t*)C2, ldc2, 0, drop);
+  if (!fast) {
+    int rcs = SIMX_OK;
+    SIMX_DISPATCH16(dtype, TT, rcs = (launch_simple<TT, TT>(s, epilogue, M, N, K, (const TT*)A, lda, 1, (const TT*)B, 1, ldb, (TT*)C, ldc, bias,
+                                                            (const TT*)residual, ldr, (const TT*)aux, ldaux, (TT*)C2, ldc2, 0, drop)));
+    return rcs;
+  }
   const int tiles_m = cdiv(M, NT_BM), tiles_n = cdiv(N, NT_BN), nwg = tiles_m * tiles_n;
   const size_t lds = 2 * NT_STAGE_BYTES;
   const GemmDevice* gd = gemm_device();
@@ -1599,42 +1567,51 @@ extern "C" int simx_gemm_nt_ex(simx_stream_t stream, int dtype, int M, int N, in
         (!residual || ldr % 8 == 0) && (!aux || ldaux % 8 == 0) && (!C2 || ldc2 % 8 == 0) &&
         !(epilogue == SIMX_EPI_DGELU && residual) && !(epilogue == SIMX_EPI_GELU && residual)) {
       const int grid = nwg3 < gd->ncu ? nwg3 : gd->ncu;
-      static const bool noepi_p = (getenv("SIMX_MEASUREMENT_HOOKS") != nullptr && getenv("SIMX_NOEPI") != nullptr);
+#ifdef SIMX_MEASUREMENT_HOOKS                   /* tools/build_variant.sh builds only: SIMX_NOEPI=1 times the main loop alone */
+      static const bool noepi_p = getenv("SIMX_NOEPI") != nullptr;
       if (noepi_p) C = nullptr;
-#define LP3(E, HI, INP, LDI) hipLaunchKernelGGL((gemm_nt_bf16_p3_kernel<E, HI>), dim3(grid), dim3(512), P_LDS, s, M, N, K, (const bf16_t*)A, lda, \
+#endif
+#define LP3(E, HI, INP, LDI) hipLaunchKernelGGL((gemm_nt_p3_kernel<FF, E, HI>), dim3(grid), dim3(512), P_LDS, s, M, N, K, (const bf16_t*)A, lda, \
                                  (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, (const bf16_t*)(INP), LDI, (bf16_t*)C2, ldc2, t3n, nwg3, drop)
-      if (epilogue == SIMX_EPI_NONE) { if (residual) LP3(SIMX_EPI_NONE, true, residual, ldr); else LP3(SIMX_EPI_NONE, false, nullptr, 0); }
-      else if (epilogue == SIMX_EPI_GELU) LP3(SIMX_EPI_GELU, false, nullptr, gelu_infer ? 1 : 0);
-      else LP3(SIMX_EPI_DGELU, true, aux, ldaux);
+#define LP3_ALL()                                                                                                               \
+  do {                                                                                                                          \
+    if (epilogue == SIMX_EPI_NONE) { if (residual) LP3(SIMX_EPI_NONE, true, residual, ldr); else LP3(SIMX_EPI_NONE, false, nullptr, 0); } \
+    else if (epilogue == SIMX_EPI_GELU) LP3(SIMX_EPI_GELU, false, nullptr, gelu_infer ? 1 : 0);                                 \
+    else LP3(SIMX_EPI_DGELU, true, aux, ldaux);                                                                                 \
+  } while (0)
+      SIMX_DISPATCH16(dtype, FF, LP3_ALL());
+#undef LP3_ALL
 #undef LP3
       simx_prof_retag(SIMX_K_GEMM_NT_P3);
-      SIMX_CHECK_LAUNCH("gemm_nt_bf16_p3");
+      SIMX_CHECK_LAUNCH("gemm_nt_p3");
       return SIMX_OK;
     }
     // large ragged problems: the per-tile 256x256x64 two-stage kernel
     if (!force_v1 && nwg3 >= 192 && N % 8 == 0 && ldc % 8 == 0 && (!residual || ldr % 8 == 0) &&
         (!aux || ldaux % 8 == 0) && (!C2 || ldc2 % 8 == 0)) {
-      static const bool noepi = (getenv("SIMX_MEASUREMENT_HOOKS") != nullptr && getenv("SIMX_NOEPI") != nullptr);
+#ifdef SIMX_MEASUREMENT_HOOKS
+      static const bool noepi = getenv("SIMX_NOEPI") != nullptr;
       if (noepi) C = nullptr;
-#define L5(E) hipLaunchKernelGGL((gemm_nt_bf16_v5_kernel<E>), dim3(nwg3), dim3(512), V5_LDS, s, M, N, K, (const bf16_t*)A, lda, \
+#endif
+#define L5(E) hipLaunchKernelGGL((gemm_nt_h16_v5_kernel<FF, E>), dim3(nwg3), dim3(512), V5_LDS, s, M, N, K, (const bf16_t*)A, lda, \
                                  (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, (const bf16_t*)residual, ldr,                  \
                                  (const bf16_t*)aux, ldaux, (bf16_t*)C2, ldc2, t3n, nwg3, drop)
-      if (epilogue == SIMX_EPI_NONE) L5(SIMX_EPI_NONE);
-      else if (epilogue == SIMX_EPI_GELU) L5(SIMX_EPI_GELU);
-      else L5(SIMX_EPI_DGELU);
+#define L5_ALL() do { if (epilogue == SIMX_EPI_NONE) L5(SIMX_EPI_NONE); else if (epilogue == SIMX_EPI_GELU) L5(SIMX_EPI_GELU); else L5(SIMX_EPI_DGELU); } while (0)
+      SIMX_DISPATCH16(dtype, FF, L5_ALL());
+#undef L5_ALL
 #undef L5
-      SIMX_CHECK_LAUNCH("gemm_nt_bf16_v5");
+      SIMX_CHECK_LAUNCH("gemm_nt_h16_v5");
       return SIMX_OK;
     }
   }
-#define L(E) hipLaunchKernelGGL((gemm_nt_bf16_kernel<E>), dim3(nwg), dim3(256), lds, s, M, N, K, (const bf16_t*)A, lda, \
+#define L(E) hipLaunchKernelGGL((gemm_nt_h16_kernel<FF, E>), dim3(nwg), dim3(256), lds, s, M, N, K, (const bf16_t*)A, lda, \
                                 (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, (const bf16_t*)residual, ldr,               \
                                 (const bf16_t*)aux, ldaux, (bf16_t*)C2, ldc2, tiles_n, nwg, drop)
-  if (epilogue == SIMX_EPI_NONE) L(SIMX_EPI_NONE);
-  else if (epilogue == SIMX_EPI_GELU) L(SIMX_EPI_GELU);
-  else L(SIMX_EPI_DGELU);
+#define L_ALL() do { if (epilogue == SIMX_EPI_NONE) L(SIMX_EPI_NONE); else if (epilogue == SIMX_EPI_GELU) L(SIMX_EPI_GELU); else L(SIMX_EPI_DGELU); } while (0)
+  SIMX_DISPATCH16(dtype, FF, L_ALL());
+#undef L_ALL
 #undef L
-  SIMX_CHECK_LAUNCH("gemm_nt_bf16");
+  SIMX_CHECK_LAUNCH("gemm_nt_h16");
   return SIMX_OK;
 }
 
@@ -1661,7 +1638,7 @@ extern "C" int simx_gemm_nt_pb(simx_stream_t stream, int dtype, int M, int N, in
                                const simx_dropout* dropd, int flags, int rows) {
   hipStream_t s = (hipStream_t)stream;
   SIMX_PROF(SIMX_K_GEMM_NT, s, 2.0 * M * N * K);
-  SIMX_REQUIRE(dtype == SIMX_BF16, SIMX_ERR_BAD_DTYPE, "gemm_nt_pb: bf16 only");
+  SIMX_REQUIRE(simx_is16(dtype), SIMX_ERR_BAD_DTYPE, "gemm_nt_pb: 16-bit dtypes only");
   SIMX_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C, SIMX_ERR_BAD_SHAPE, "gemm_nt_pb: bad arguments");
   const bool infer = epilogue == SIMX_EPI_GELU_INFER;
   if (infer) epilogue = SIMX_EPI_GELU;
@@ -1678,14 +1655,13 @@ extern "C" int simx_gemm_nt_pb(simx_stream_t stream, int dtype, int M, int N, in
   SIMX_REQUIRE(ok, SIMX_ERR_UNSUPPORTED, "gemm_nt_pb: shape %d x %d x %d (planes of %d rows) is outside the persistent kernel's rules", M, N, K, rows);
   const DropCtx drop = make_drop(epilogue == SIMX_EPI_NONE ? dropd : nullptr);
   const int grid = nwg3 < gd->ncu ? nwg3 : gd->ncu;
-#define LPB(E, HI, F, INP, LDI) hipLaunchKernelGGL((gemm_nt_bf16_p3_kernel<E, HI, F>), dim3(grid), dim3(512), P_LDS, s, M, N, K, (const bf16_t*)A, lda, \
+#define LPB(E, HI, PF, INP, LDI) hipLaunchKernelGGL((gemm_nt_p3_kernel<FF, E, HI, PF>), dim3(grid), dim3(512), P_LDS, s, M, N, K, (const bf16_t*)A, lda, \
                                  (const bf16_t*)B, ldb, (bf16_t*)C, ldc, bias, (const bf16_t*)(INP), LDI, (bf16_t*)C2, rows, t3n, nwg3, drop)
   (void)infer;
-  if (flags == 1) LPB(SIMX_EPI_NONE, true, 1, in, ldin);
-  else LPB(SIMX_EPI_NONE, false, 2, nullptr, 0);
+  SIMX_DISPATCH16(dtype, FF, if (flags == 1) LPB(SIMX_EPI_NONE, true, 1, in, ldin); else LPB(SIMX_EPI_NONE, false, 2, nullptr, 0));
 #undef LPB
   simx_prof_retag(SIMX_K_GEMM_NT_P3);
-  SIMX_CHECK_LAUNCH("gemm_nt_bf16_p3(pb)");
+  SIMX_CHECK_LAUNCH("gemm_nt_p3(pb)");
   return SIMX_OK;
 }
 // the two q/k/v forms under their first names
@@ -1697,7 +1673,6 @@ extern "C" int simx_gemm_nt_hm(simx_stream_t stream, int dtype, int M, int N, in
                          a_hm_rows > 0 ? 1 : 2, a_hm_rows > 0 ? a_hm_rows : c_hm_rows);
 }
 
-extern "C" int simx_colsum(simx_stream_t stream, int dtype, int T, int N, const void* x, int ldx, float* out, int accumulate);
 static bool tn_use_v2(int M, int N, int K) {
   static const char* pin = getenv("SIMX_GEMM_TN");
   if (pin && pin[1] == '1') return false;
@@ -1725,50 +1700,57 @@ extern "C" size_t simx_gemm_tn_workspace_bytes(int M, int N, int K) {
   return bf > f32 ? bf : f32;                   // (the dtype is not an argument: enough for either)
 }
 
-extern "C" int simx_gemm_tn_bias(simx_stream_t stream, int dtype, int M, int N, int K, const void* A, int lda,
-                                 const void* B, int ldb, float* C, int ldc, int accumulate, void* ws, size_t ws_bytes,
-                                 float* dbias);
+static int gemm_tn_impl(simx_stream_t stream, int dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, float* C,
+                        int ldc, int accumulate, void* ws, size_t ws_bytes, float* dbias, int a_hm_rows, const float* gs);
 extern "C" int simx_gemm_tn(simx_stream_t stream, int dtype, int M, int N, int K, const void* A, int lda,
                             const void* B, int ldb, float* C, int ldc, int accumulate, void* ws, size_t ws_bytes) {
-  return simx_gemm_tn_bias(stream, dtype, M, N, K, A, lda, B, ldb, C, ldc, accumulate, ws, ws_bytes, nullptr);
+  return gemm_tn_impl(stream, dtype, M, N, K, A, lda, B, ldb, C, ldc, accumulate, ws, ws_bytes, nullptr, 0, nullptr);
 }
-
-static int gemm_tn_impl(simx_stream_t stream, int dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, float* C,
-                        int ldc, int accumulate, void* ws, size_t ws_bytes, float* dbias, int a_hm_rows);
 extern "C" int simx_gemm_tn_bias(simx_stream_t stream, int dtype, int M, int N, int K, const void* A, int lda,
                                  const void* B, int ldb, float* C, int ldc, int accumulate, void* ws, size_t ws_bytes,
                                  float* dbias) {
-  return gemm_tn_impl(stream, dtype, M, N, K, A, lda, B, ldb, C, ldc, accumulate, ws, ws_bytes, dbias, 0);
+  return gemm_tn_impl(stream, dtype, M, N, K, A, lda, B, ldb, C, ldc, accumulate, ws, ws_bytes, dbias, 0, nullptr);
 }
-// wgrad with a head-major A (dq/dk/dv planes of a_hm_rows rows, [M/64][R][64]); large bf16 shapes only (the 256x256 kernel)
+// wgrad with a head-major A (dq/dk/dv planes of a_hm_rows rows, [M/64][R][64]); large 16-bit shapes only (the 256x256 kernel)
 extern "C" int simx_gemm_tn_hm(simx_stream_t stream, int dtype, int M, int N, int K, const void* A, int a_hm_rows, const void* B,
                                int ldb, float* C, int ldc, int accumulate, void* ws, size_t ws_bytes, float* dbias) {
-  SIMX_REQUIRE(dtype == SIMX_BF16 && a_hm_rows >= K && M % 256 == 0 && N % 8 == 0 && K >= 2048, SIMX_ERR_UNSUPPORTED,
-               "gemm_tn_hm: needs bf16, M %% 256 == 0, K >= 2048 tokens and planes of >= K rows");
-  return gemm_tn_impl(stream, dtype, M, N, K, A, M, B, ldb, C, ldc, accumulate, ws, ws_bytes, dbias, a_hm_rows);
+  return simx_gemm_tn_gs(stream, dtype, M, N, K, A, M, B, ldb, C, ldc, accumulate, ws, ws_bytes, dbias, a_hm_rows, nullptr);
+}
+// every form of the wgrad GEMM in one call, with the gradient scale of the fp16 backward (A = S x dY): C and dbias receive
+// (1/S) x the products.  a_hm_rows > 0: A is head-major (lda ignored).
+extern "C" int simx_gemm_tn_gs(simx_stream_t stream, int dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                               float* C, int ldc, int accumulate, void* ws, size_t ws_bytes, float* dbias, int a_hm_rows,
+                               const float* gs) {
+  if (a_hm_rows > 0) {
+    SIMX_REQUIRE(simx_is16(dtype) && a_hm_rows >= K && M % 256 == 0 && N % 8 == 0 && K >= 2048, SIMX_ERR_UNSUPPORTED,
+                 "gemm_tn_hm: needs a 16-bit dtype, M %% 256 == 0, K >= 2048 tokens and planes of >= K rows");
+    lda = M;
+  }
+  return gemm_tn_impl(stream, dtype, M, N, K, A, lda, B, ldb, C, ldc, accumulate, ws, ws_bytes, dbias, a_hm_rows, gs);
 }
 static int gemm_tn_impl(simx_stream_t stream, int dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, float* C,
-                        int ldc, int accumulate, void* ws, size_t ws_bytes, float* dbias, int a_hm_rows) {
+                        int ldc, int accumulate, void* ws, size_t ws_bytes, float* dbias, int a_hm_rows, const float* gs) {
   hipStream_t s = (hipStream_t)stream;
   SIMX_PROF(SIMX_K_GEMM_TN, s, 2.0 * M * N * K);
   SIMX_REQUIRE(M > 0 && N > 0 && K > 0, SIMX_ERR_BAD_SHAPE, "gemm_tn: bad shape %d %d %d", M, N, K);
   SIMX_REQUIRE(lda >= M && ldb >= N && ldc >= N, SIMX_ERR_BAD_SHAPE, "gemm_tn: leading dims too small");
   if (dtype == SIMX_F32) {
-    if (dbias) { int rcb = simx_colsum(stream, dtype, K, M, A, lda, dbias, 1); if (rcb) return rcb; }
+    if (dbias) { int rcb = simx_colsum_gs(stream, dtype, K, M, A, lda, dbias, 1, gs); if (rcb) return rcb; }
+    SIMX_REQUIRE(gs == nullptr, SIMX_ERR_UNSUPPORTED, "gemm_tn: the f32 engine carries no gradient scale");
     return launch_simple<float, float>(s, SIMX_EPI_NONE, M, N, K, (const float*)A, 1, lda, (const float*)B, ldb, 1, C,
                                        ldc, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, accumulate, DropCtx{0u, 1.f, 0u, 0u}, ws, ws_bytes);
   }
-  SIMX_REQUIRE(dtype == SIMX_BF16, SIMX_ERR_BAD_DTYPE, "gemm_tn: dtype %d", dtype);
+  SIMX_REQUIRE(simx_is16(dtype), SIMX_ERR_BAD_DTYPE, "gemm_tn: dtype %d", dtype);
   const bool fast = (M % 8 == 0) && (N % 8 == 0) && (lda % 8 == 0) && (ldb % 8 == 0) && (ldc % 4 == 0) && aligned16(A) &&
                     aligned16(B) && aligned16(C);
   SIMX_REQUIRE(a_hm_rows == 0 || fast, SIMX_ERR_UNSUPPORTED, "gemm_tn_hm: operands not 16-B aligned");
   if (!fast) {
-    if (dbias) { int rcb = simx_colsum(stream, dtype, K, M, A, lda, dbias, 1); if (rcb) return rcb; }
-    // generic path: bf16 in, f32 out
+    if (dbias) { int rcb = simx_colsum_gs(stream, dtype, K, M, A, lda, dbias, 1, gs); if (rcb) return rcb; }
+    // generic path: 16-bit in, f32 out
     dim3 grid(cdiv(N, 64), cdiv(M, 64));
-    hipLaunchKernelGGL((gemm_simple_kernel<bf16_t, float, SIMX_EPI_NONE>), grid, dim3(256), 0, s, M, N, K,
-                       (const bf16_t*)A, 1L, (long)lda, (const bf16_t*)B, (long)ldb, 1L, C, ldc, nullptr, nullptr, 0,
-                       nullptr, 0, nullptr, 0, accumulate, DropCtx{0u, 1.f, 0u, 0u});
+    SIMX_DISPATCH16(dtype, TT, hipLaunchKernelGGL((gemm_simple_kernel<TT, float, SIMX_EPI_NONE>), grid, dim3(256), 0, s, M, N, K,
+                                                  (const TT*)A, 1L, (long)lda, (const TT*)B, (long)ldb, 1L, C, ldc, nullptr, (const TT*)nullptr, 0,
+                                                  (const TT*)nullptr, 0, (float*)nullptr, 0, accumulate, DropCtx{0u, 1.f, 0u, 0u}, gs));
     SIMX_CHECK_LAUNCH("gemm_simple(tn)");
     return SIMX_OK;
   }
@@ -1779,55 +1761,60 @@ static int gemm_tn_impl(simx_stream_t stream, int dtype, int M, int N, int K, co
     SIMX_REQUIRE(gemm_device() != nullptr, SIMX_ERR_HIP, "gemm_tn: cannot query the current device");
     const int t_m = cdiv(M, 256), t_n = cdiv(N, 256), t_mn = t_m * t_n;
     if (splits == 1) {
-      hipLaunchKernelGGL(gemm_tn2_bf16_kernel, dim3(t_mn), dim3(512), TN2_LDS, s, M, N, K, (const bf16_t*)A, lda,
-                         (const bf16_t*)B, ldb, C, 0L, ldc, t_n, t_mn, kps, accumulate, dbias, a_hm_rows);
-      SIMX_CHECK_LAUNCH("gemm_tn2_bf16");
+      SIMX_DISPATCH16(dtype, FF, hipLaunchKernelGGL(gemm_tn2_kernel<FF>, dim3(t_mn), dim3(512), TN2_LDS, s, M, N, K, (const bf16_t*)A, lda,
+                                                    (const bf16_t*)B, ldb, C, 0L, ldc, t_n, t_mn, kps, accumulate, dbias, a_hm_rows, gs, 1));
+      SIMX_CHECK_LAUNCH("gemm_tn2");
       return SIMX_OK;
     }
     const size_t need2 = (size_t)splits * M * N * sizeof(float);
     SIMX_REQUIRE(ws && ws_bytes >= need2, SIMX_ERR_WORKSPACE, "gemm_tn: workspace %zu < %zu", ws_bytes, need2);
     SIMX_REQUIRE(aligned16(ws), SIMX_ERR_WORKSPACE, "gemm_tn: workspace not 16-B aligned");
-    hipLaunchKernelGGL(gemm_tn2_bf16_kernel, dim3(t_mn * splits), dim3(512), TN2_LDS, s, M, N, K, (const bf16_t*)A, lda,
-                       (const bf16_t*)B, ldb, (float*)ws, (long)M * N, N, t_n, t_mn, kps, 0, dbias, a_hm_rows);
-    SIMX_CHECK_LAUNCH("gemm_tn2_bf16");
+    SIMX_DISPATCH16(dtype, FF, hipLaunchKernelGGL(gemm_tn2_kernel<FF>, dim3(t_mn * splits), dim3(512), TN2_LDS, s, M, N, K, (const bf16_t*)A, lda,
+                                                  (const bf16_t*)B, ldb, (float*)ws, (long)M * N, N, t_n, t_mn, kps, 0, dbias, a_hm_rows, gs, 0));
+    SIMX_CHECK_LAUNCH("gemm_tn2");
     const long tot4 = (long)M * N / 4;
     int rb = (int)((tot4 + 255) / 256);
     if (rb > 2048) rb = 2048;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(rb), dim3(256), 0, s, (const float*)ws, (long)M * N, splits, M, N, C, ldc, accumulate);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(rb), dim3(256), 0, s, (const float*)ws, (long)M * N, splits, M, N, C, ldc, accumulate, gs);
     SIMX_CHECK_LAUNCH("slab_reduce");
     return SIMX_OK;
   }
   if (dbias) {                                   // small problems: separate column-sum pass
-    int rcb = simx_colsum(stream, dtype, K, M, A, lda, dbias, 1);
+    int rcb = simx_colsum_gs(stream, dtype, K, M, A, lda, dbias, 1, gs);
     if (rcb) return rcb;
   }
   const int tiles_m = cdiv(M, 128), tiles_n = cdiv(N, 128), tiles_mn = tiles_m * tiles_n;
   const size_t lds = 2 * NT_STAGE_BYTES;
   if (splits == 1) {
-    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(tiles_mn), dim3(256), lds, s, M, N, K, (const bf16_t*)A, lda,
-                       (const bf16_t*)B, ldb, C, 0L, ldc, tiles_n, tiles_mn, kps, accumulate);
-    SIMX_CHECK_LAUNCH("gemm_tn_bf16");
+    SIMX_DISPATCH16(dtype, FF, hipLaunchKernelGGL(gemm_tn_h16_kernel<FF>, dim3(tiles_mn), dim3(256), lds, s, M, N, K, (const bf16_t*)A, lda,
+                                                  (const bf16_t*)B, ldb, C, 0L, ldc, tiles_n, tiles_mn, kps, accumulate, gs));
+    SIMX_CHECK_LAUNCH("gemm_tn_h16");
     return SIMX_OK;
   }
   const size_t need = (size_t)splits * M * N * sizeof(float);
   SIMX_REQUIRE(ws && ws_bytes >= need, SIMX_ERR_WORKSPACE, "gemm_tn: workspace %zu < %zu", ws_bytes, need);
   SIMX_REQUIRE(aligned16(ws), SIMX_ERR_WORKSPACE, "gemm_tn: workspace not 16-B aligned");
-  hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(tiles_mn * splits), dim3(256), lds, s, M, N, K, (const bf16_t*)A, lda,
-                     (const bf16_t*)B, ldb, (float*)ws, (long)M * N, N, tiles_n, tiles_mn, kps, 0);
-  SIMX_CHECK_LAUNCH("gemm_tn_bf16");
+  SIMX_DISPATCH16(dtype, FF, hipLaunchKernelGGL(gemm_tn_h16_kernel<FF>, dim3(tiles_mn * splits), dim3(256), lds, s, M, N, K, (const bf16_t*)A, lda,
+                                                (const bf16_t*)B, ldb, (float*)ws, (long)M * N, N, tiles_n, tiles_mn, kps, 0, (const float*)nullptr));
+  SIMX_CHECK_LAUNCH("gemm_tn_h16");
   const long total4 = (long)M * N / 4;
   int blocks = (int)((total4 + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)ws, (long)M * N, splits, M, N, C,
-                     ldc, accumulate);
+                     ldc, accumulate, gs);
   SIMX_CHECK_LAUNCH("slab_reduce");
   return SIMX_OK;
 }
 
 extern "C" int simx_colsum(simx_stream_t stream, int dtype, int T, int N, const void* x, int ldx, float* out,
                            int accumulate) {
+  return simx_colsum_gs(stream, dtype, T, N, x, ldx, out, accumulate, nullptr);
+}
+extern "C" int simx_colsum_gs(simx_stream_t stream, int dtype, int T, int N, const void* x, int ldx, float* out,
+                              int accumulate, const float* gs) {
   hipStream_t s = (hipStream_t)stream;
-  SIMX_PROF(SIMX_K_COLSUM, s, (double)T * N * (dtype == SIMX_F32 ? 4 : 2));
+  SIMX_PROF(SIMX_K_COLSUM, s, (double)T * N * simx_esz(dtype));
+  SIMX_REQUIRE(simx_dtype_ok(dtype), SIMX_ERR_BAD_DTYPE, "colsum: dtype %d", dtype);
   SIMX_REQUIRE(T > 0 && N > 0 && ldx >= N, SIMX_ERR_BAD_SHAPE, "colsum: bad shape");
   if (!accumulate) {
     if (hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s) != hipSuccess) { simx_set_error("colsum: memset failed"); return SIMX_ERR_HIP; }
@@ -1836,11 +1823,7 @@ extern "C" int simx_colsum(simx_stream_t stream, int dtype, int T, int N, const 
   if (chunks > 512) chunks = 512;
   const int rpb = cdiv(T, chunks);
   dim3 grid(cdiv(N, 64), cdiv(T, rpb));
-  if (dtype == SIMX_F32)
-    hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, s, T, N, (const float*)x, ldx, out, rpb);
-  else if (dtype == SIMX_BF16)
-    hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(256), 0, s, T, N, (const bf16_t*)x, ldx, out, rpb);
-  else { simx_set_error("colsum: dtype %d", dtype); return SIMX_ERR_BAD_DTYPE; }
+  SIMX_DISPATCH3(dtype, TT, hipLaunchKernelGGL((colsum_kernel<TT>), grid, dim3(256), 0, s, T, N, (const TT*)x, ldx, out, rpb, gs));
   SIMX_CHECK_LAUNCH("colsum");
   return SIMX_OK;
 }
@@ -1850,11 +1833,9 @@ extern "C" int simx_transpose_cast(simx_stream_t stream, int out_dtype, const fl
   SIMX_PROF(SIMX_K_CAST, stream, (double)rows * cols * 8);
   SIMX_REQUIRE(rows > 0 && cols > 0 && w, SIMX_ERR_BAD_SHAPE, "transpose_cast: bad shape");
   dim3 grid(cdiv(cols, 32), cdiv(rows, 32));
-  if (out_dtype == SIMX_BF16)
-    hipLaunchKernelGGL((cast_weight_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, w, rows, cols, (bf16_t*)out, (bf16_t*)outT);
-  else if (out_dtype == SIMX_F32)
-    hipLaunchKernelGGL((cast_weight_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, w, rows, cols, (float*)out, (float*)outT);
-  else { simx_set_error("transpose_cast: dtype %d", out_dtype); return SIMX_ERR_BAD_DTYPE; }
+  SIMX_REQUIRE(simx_dtype_ok(out_dtype), SIMX_ERR_BAD_DTYPE, "transpose_cast: dtype %d", out_dtype);
+  SIMX_DISPATCH3(out_dtype, TT, hipLaunchKernelGGL((cast_weight_kernel<TT>), grid, dim3(256), 0, (hipStream_t)stream, w, rows, cols, (TT*)out,
+                                                   (TT*)outT));
   SIMX_CHECK_LAUNCH("cast_weight");
   return SIMX_OK;
 }

@@ -8,10 +8,6 @@
 #include "common.h"
 #include "prof.h"
 
-extern "C" int simx_ln_bwd_ex(simx_stream_t, int, int, int, const void*, const float*, float, const void*, void*, void*, float*, float*, float*, const simx_dropout*);
-extern "C" int simx_ln_bwd_keyed(simx_stream_t, int, int, int, const void*, const float*, float, const void*, void*, void*, float*, float*, float*, const simx_dropout*, const int32_t*);
-extern "C" int simx_embed_ln_fwd_ex(simx_stream_t, int, int, int, const int32_t*, const int32_t*, const float*, const float*, const float*, const float*, const float*, float, void*, const simx_dropout*);
-extern "C" int simx_embed_ln_bwd_ex(simx_stream_t, int, int, int, const int32_t*, const int32_t*, const float*, const float*, const float*, const float*, float, const void*, float*, float*, float*, float*, float*, const simx_dropout*);
 #define LN_VPL 4   // 4-element vectors per lane -> H <= 64*4*4 = 1024
 
 // raw (still packed) 4-element vectors: lets the next row's loads stay in flight while this row is processed
@@ -27,6 +23,14 @@ template <> struct Raw4<bf16_t> {
   __device__ __forceinline__ void unpack(float (&v)[4]) const {
     v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xFFFF0000u);
     v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xFFFF0000u);
+  }
+};
+
+template <> struct Raw4<f16_t> {
+  uint2 r;
+  __device__ __forceinline__ void load(const f16_t* p) { r = *reinterpret_cast<const uint2*>(p); }
+  __device__ __forceinline__ void unpack(float (&v)[4]) const {
+    v[0] = H16<f16_t>::lo(r.x); v[1] = H16<f16_t>::hi(r.x); v[2] = H16<f16_t>::lo(r.y); v[3] = H16<f16_t>::hi(r.y);
   }
 };
 
@@ -185,7 +189,7 @@ __device__ __forceinline__ void ln_row_bwd(int H, int lane, float (&x)[VPL][4], 
 
 template <int VPL>
 __device__ __forceinline__ void flush_cols(int H, int lane, int w, float (&p)[VPL][4], float* __restrict__ out,
-                                           float* sred /* [4][H] */) {
+                                           float* sred /* [4][H] */, float mul = 1.0f) {
   // sum the 4 waves' partials through LDS, wave 0 issues the atomics
 #pragma unroll
   for (int v = 0; v < VPL; ++v) {
@@ -198,7 +202,7 @@ __device__ __forceinline__ void flush_cols(int H, int lane, int w, float (&p)[VP
   // all four waves issue the atomics, each instruction on 64 CONSECUTIVE columns (4 cache lines; the lane-owns-4-columns
   // layout would touch 16) -- every block of the grid adds into the same H addresses, so the L2 transaction count of
   // this tail is what the kernel's last microseconds are made of
-  for (int c = threadIdx.x; c < H; c += 256) atomicAdd(out + c, sred[c] + sred[H + c] + sred[2 * H + c] + sred[3 * H + c]);
+  for (int c = threadIdx.x; c < H; c += 256) atomicAdd(out + c, (sred[c] + sred[H + c] + sred[2 * H + c] + sred[3 * H + c]) * mul);
   __syncthreads();
 }
 
@@ -210,7 +214,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int H, int rows_p
                                                      const float* __restrict__ gamma, float eps, const T* __restrict__ dyp,
                                                      T* __restrict__ dzp, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, float* __restrict__ dbias,
-                                                     T* __restrict__ dzm, DropCtx drop, const int* __restrict__ row_keys) {
+                                                     T* __restrict__ dzm, DropCtx drop, const int* __restrict__ row_keys,
+                                                     const float* __restrict__ gs) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sred = reinterpret_cast<float*>(smem);          // [4][H] flush scratch
   float* sgam = sred + 4 * H;                            // [H]
@@ -271,9 +276,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int H, int rows_p
       }
     }
   }
-  flush_cols(H, lane, w, pg, dgamma, sred);
-  flush_cols(H, lane, w, pb, dbeta, sred);
-  if (dbias) flush_cols(H, lane, w, pz, dbias, sred);
+  const float inv = gs_inv(gs);                          // dy / dz travel multiplied by the loss scale; parameter gradients do not
+  flush_cols(H, lane, w, pg, dgamma, sred, inv);
+  flush_cols(H, lane, w, pb, dbeta, sred, inv);
+  if (dbias) flush_cols(H, lane, w, pz, dbias, sred, inv);
 }
 
 template <typename T, int VPL>
@@ -283,10 +289,12 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(int rows, int H, int 
                                                            const float* __restrict__ gamma, float eps,
                                                            const T* __restrict__ dyp, float* __restrict__ dword,
                                                            float* __restrict__ dpos, float* __restrict__ dtype0,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, DropCtx drop) {
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, DropCtx drop,
+                                                           const float* __restrict__ gs) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sred = reinterpret_cast<float*>(smem);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float inv = gs_inv(gs);
   float pg[VPL][4] = {}, pb[VPL][4] = {}, pz[VPL][4] = {};
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(rows, r0 + rows_per_block);
@@ -323,15 +331,15 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(int rows, int H, int 
       if (c < H)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          atomicAdd(dword + wid * H + c + e, dz[v][e]);
-          atomicAdd(dpos + pid * H + c + e, dz[v][e]);
+          atomicAdd(dword + wid * H + c + e, dz[v][e] * inv);
+          atomicAdd(dpos + pid * H + c + e, dz[v][e] * inv);
           pz[v][e] += dz[v][e];
         }
     }
   }
-  flush_cols(H, lane, w, pg, dgamma, sred);
-  flush_cols(H, lane, w, pb, dbeta, sred);
-  flush_cols(H, lane, w, pz, dtype0, sred);
+  flush_cols(H, lane, w, pg, dgamma, sred, inv);
+  flush_cols(H, lane, w, pb, dbeta, sred, inv);
+  flush_cols(H, lane, w, pz, dtype0, sred, inv);
 }
 
 // Position-major embedding backward: wave w of block (pg, sc) owns ONE in-sequence position p = 4 pg + w and walks the
@@ -346,10 +354,12 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_seq_kernel(int nseq, int seq
                                                                const float* __restrict__ typew, const float* __restrict__ gamma,
                                                                float eps, const T* __restrict__ dyp, float* __restrict__ dword,
                                                                float* __restrict__ dpos, float* __restrict__ dtype0,
-                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, DropCtx drop) {
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, DropCtx drop,
+                                                               const float* __restrict__ gs) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sred = reinterpret_cast<float*>(smem);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float inv = gs_inv(gs);
   // per-wave transposition patch for the word-embedding scatter: a lane owns 4 consecutive columns per vector, so an
   // atomic instruction issued from that layout touches 64 lanes x 4 B at a 16-B stride = 16 cache lines; through the
   // patch every instruction covers 64 CONSECUTIVE floats = 4 lines, a quarter of the L2 atomic transactions
@@ -393,7 +403,7 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_seq_kernel(int nseq, int seq
     for (int v = 0; v < VPL; ++v) {
       const int c = (v * 64 + lane) * 4;
       if (c < H) {
-        *reinterpret_cast<float4*>(patch + c) = make_float4(dz[v][0], dz[v][1], dz[v][2], dz[v][3]);
+        *reinterpret_cast<float4*>(patch + c) = make_float4(dz[v][0] * inv, dz[v][1] * inv, dz[v][2] * inv, dz[v][3] * inv);
 #pragma unroll
         for (int e = 0; e < 4; ++e) pz[v][e] += dz[v][e];
       }
@@ -413,12 +423,12 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_seq_kernel(int nseq, int seq
       const int c = (v * 64 + lane) * 4;
       if (c < H)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(dpos + pid * H + c + e, pz[v][e]);
+        for (int e = 0; e < 4; ++e) atomicAdd(dpos + pid * H + c + e, pz[v][e] * inv);
     }
   }
-  flush_cols(H, lane, w, pg, dgamma, sred);
-  flush_cols(H, lane, w, pb, dbeta, sred);
-  flush_cols(H, lane, w, pz, dtype0, sred);
+  flush_cols(H, lane, w, pg, dgamma, sred, inv);
+  flush_cols(H, lane, w, pb, dbeta, sred, inv);
+  flush_cols(H, lane, w, pz, dtype0, sred, inv);
 }
 
 template <typename T>
@@ -432,22 +442,24 @@ __global__ __launch_bounds__(256) void cls_gather_kernel(int nseq, int H, const 
 
 template <typename T>
 __global__ __launch_bounds__(256) void cls_scatter_kernel(int nseq, int H, const int* __restrict__ cu,
-                                                          const float* __restrict__ dcls, T* __restrict__ dx) {
+                                                          const float* __restrict__ dcls, T* __restrict__ dx,
+                                                          const float* __restrict__ gs) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long)nseq * H) return;
   const int s = (int)(i / H), c = (int)(i % H);
-  Elem<T>::st(dx + (long)cu[s] * H + c, dcls[i]);
+  Elem<T>::st(dx + (long)cu[s] * H + c, dcls[i] * gs_scale(gs));
 }
 
 // dst[dst_idx ? dst_idx[s] : s] = src[src_idx ? src_idx[s] : s]   (row gather / scatter / dtype conversion)
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void rows_copy_kernel(int n, int H, const int* __restrict__ src_idx, const int* __restrict__ dst_idx,
-                                                        const TI* __restrict__ src, TO* __restrict__ dst) {
+                                                        const TI* __restrict__ src, TO* __restrict__ dst, const float* __restrict__ gs) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long)n * H) return;
   const int s = (int)(i / H), c = (int)(i % H);
   const long rs = src_idx ? src_idx[s] : s, rd = dst_idx ? dst_idx[s] : s;
-  Elem<TO>::st(dst + rd * H + c, Elem<TI>::ld(src + rs * H + c));
+  const float v = Elem<TI>::ld(src + rs * H + c);
+  Elem<TO>::st(dst + rd * H + c, gs ? v * gs[0] : v);       // (gs: an f32 gradient entering the fp16 backward)
 }
 
 // z[s] = dropout(y[s]; mask row key_idx[s]) + res[res_idx ? res_idx[s] : s]: what the dense GEMM's epilogue does for full
@@ -487,9 +499,9 @@ __global__ __launch_bounds__(256) void seq_mean_fwd_kernel(int H, const int* __r
 }
 template <typename T>
 __global__ __launch_bounds__(256) void seq_mean_bwd_kernel(int H, const int* __restrict__ cu, const float* __restrict__ dmean,
-                                                           T* __restrict__ dx) {
+                                                           T* __restrict__ dx, const float* __restrict__ gs) {
   const int s = blockIdx.x, t0 = cu[s], len = cu[s + 1] - t0;
-  const float inv = 1.0f / (float)len;
+  const float inv = gs_scale(gs) / (float)len;
   for (int c = threadIdx.x; c < H; c += 256) {
     const float g = dmean[(long)s * H + c] * inv;
     for (int r = 0; r < len; ++r) Elem<T>::st(dx + (long)(t0 + r) * H + c, g);
@@ -498,7 +510,7 @@ __global__ __launch_bounds__(256) void seq_mean_bwd_kernel(int H, const int* __r
 
 // ------------------------------------------------------------------------------------------ host
 static int ln_check(int dtype, int T, int H, const char* who) {
-  SIMX_REQUIRE(dtype == SIMX_F32 || dtype == SIMX_BF16, SIMX_ERR_BAD_DTYPE, "%s: dtype %d", who, dtype);
+  SIMX_REQUIRE(simx_dtype_ok(dtype), SIMX_ERR_BAD_DTYPE, "%s: dtype %d", who, dtype);
   SIMX_REQUIRE(T > 0 && H > 0, SIMX_ERR_BAD_SHAPE, "%s: bad shape T=%d H=%d", who, T, H);
   SIMX_REQUIRE(H % 4 == 0 && H <= 64 * 4 * LN_VPL, SIMX_ERR_UNSUPPORTED, "%s: H=%d must be a multiple of 4 and <= 1024", who, H);
   return SIMX_OK;
@@ -512,10 +524,12 @@ static int ln_rows_per_block(int T, const char* env, int dflt) {
   return cdiv(rpb, 4) * 4;
 }
 static int bwd_rows_per_block(int T) { return ln_rows_per_block(T, "SIMX_LN_BWD_BLOCKS", 768); }
+// vectors per lane by hidden size (186 -> 140 VGPRs for H = 768)
+#define LN_BY_H(TT, LAUNCH) do { if (H <= 256) LAUNCH(TT, 1); else if (H <= 768) LAUNCH(TT, 3); else LAUNCH(TT, 4); } while (0)
 
 extern "C" int simx_ln_fwd(simx_stream_t stream, int dtype, int T, int H, const void* z, const float* gamma,
                            const float* beta, float eps, void* y) {
-  SIMX_PROF(SIMX_K_LN_FWD, stream, 2.0 * T * H * (dtype == SIMX_F32 ? 4 : 2));
+  SIMX_PROF(SIMX_K_LN_FWD, stream, 2.0 * T * H * simx_esz(dtype));
   int rc = ln_check(dtype, T, H, "ln_fwd");
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
@@ -523,10 +537,7 @@ extern "C" int simx_ln_fwd(simx_stream_t stream, int dtype, int T, int H, const 
   const size_t lds = (size_t)2 * H * sizeof(float);
 #define LF(TT, V) hipLaunchKernelGGL((ln_fwd_kernel<TT, V>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, (const TT*)z, gamma, beta, \
                                     eps, (TT*)y)
-  if (dtype == SIMX_F32)
-    { if (H <= 256) LF(float, 1); else if (H <= 768) LF(float, 3); else LF(float, 4); }
-  else
-    { if (H <= 256) LF(bf16_t, 1); else if (H <= 768) LF(bf16_t, 3); else LF(bf16_t, 4); }
+  SIMX_DISPATCH3(dtype, TT, LN_BY_H(TT, LF));
 #undef LF
   SIMX_CHECK_LAUNCH("ln_fwd");
   return SIMX_OK;
@@ -534,19 +545,25 @@ extern "C" int simx_ln_fwd(simx_stream_t stream, int dtype, int T, int H, const 
 
 extern "C" int simx_ln_bwd(simx_stream_t stream, int dtype, int T, int H, const void* z, const float* gamma, float eps,
                            const void* dy, void* dz, float* dgamma, float* dbeta, float* dbias) {
-  return simx_ln_bwd_ex(stream, dtype, T, H, z, gamma, eps, dy, dz, nullptr, dgamma, dbeta, dbias, nullptr);
+  return simx_ln_bwd_gs(stream, dtype, T, H, z, gamma, eps, dy, dz, nullptr, dgamma, dbeta, dbias, nullptr, nullptr, nullptr);
 }
 
 extern "C" int simx_ln_bwd_ex(simx_stream_t stream, int dtype, int T, int H, const void* z, const float* gamma, float eps,
                               const void* dy, void* dz, void* dz_masked, float* dgamma, float* dbeta, float* dbias,
                               const simx_dropout* dropd) {
-  return simx_ln_bwd_keyed(stream, dtype, T, H, z, gamma, eps, dy, dz, dz_masked, dgamma, dbeta, dbias, dropd, nullptr);
+  return simx_ln_bwd_gs(stream, dtype, T, H, z, gamma, eps, dy, dz, dz_masked, dgamma, dbeta, dbias, dropd, nullptr, nullptr);
 }
 
 extern "C" int simx_ln_bwd_keyed(simx_stream_t stream, int dtype, int T, int H, const void* z, const float* gamma, float eps,
                                  const void* dy, void* dz, void* dz_masked, float* dgamma, float* dbeta, float* dbias,
                                  const simx_dropout* dropd, const int32_t* row_keys) {
-  SIMX_PROF(SIMX_K_LN_BWD, stream, 3.0 * T * H * (dtype == SIMX_F32 ? 4 : 2));
+  return simx_ln_bwd_gs(stream, dtype, T, H, z, gamma, eps, dy, dz, dz_masked, dgamma, dbeta, dbias, dropd, row_keys, nullptr);
+}
+
+extern "C" int simx_ln_bwd_gs(simx_stream_t stream, int dtype, int T, int H, const void* z, const float* gamma, float eps,
+                              const void* dy, void* dz, void* dz_masked, float* dgamma, float* dbeta, float* dbias,
+                              const simx_dropout* dropd, const int32_t* row_keys, const float* gs) {
+  SIMX_PROF(SIMX_K_LN_BWD, stream, 3.0 * T * H * simx_esz(dtype));
   int rc = ln_check(dtype, T, H, "ln_bwd");
   if (rc) return rc;
   const DropCtx drop = make_drop(dropd);
@@ -555,9 +572,8 @@ extern "C" int simx_ln_bwd_keyed(simx_stream_t stream, int dtype, int T, int H, 
   const int rpb = bwd_rows_per_block(T);
   const size_t lds = (size_t)5 * H * sizeof(float);
 #define LB(TT, V) hipLaunchKernelGGL((ln_bwd_kernel<TT, V>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, (const TT*)z, gamma, eps, \
-                                    (const TT*)dy, (TT*)dz, dgamma, dbeta, dbias, (TT*)dz_masked, drop, row_keys)
-  if (dtype == SIMX_F32) { if (H <= 256) LB(float, 1); else if (H <= 768) LB(float, 3); else LB(float, 4); }
-  else { if (H <= 256) LB(bf16_t, 1); else if (H <= 768) LB(bf16_t, 3); else LB(bf16_t, 4); }
+                                    (const TT*)dy, (TT*)dz, dgamma, dbeta, dbias, (TT*)dz_masked, drop, row_keys, gs)
+  SIMX_DISPATCH3(dtype, TT, LN_BY_H(TT, LB));
 #undef LB
   SIMX_CHECK_LAUNCH("ln_bwd");
   return SIMX_OK;
@@ -573,16 +589,12 @@ extern "C" int simx_embed_ln_fwd_ex(simx_stream_t stream, int dtype, int T, int 
                                     const float* word, const float* posw, const float* typew, const float* gamma,
                                     const float* beta, float eps, void* out, const simx_dropout* dropd) {
   const DropCtx drop = make_drop(dropd);
-  SIMX_PROF(SIMX_K_EMBED_FWD, stream, (double)T * H * (4 + (dtype == SIMX_F32 ? 4 : 2)));
+  SIMX_PROF(SIMX_K_EMBED_FWD, stream, (double)T * H * (4 + simx_esz(dtype)));
   int rc = ln_check(dtype, T, H, "embed_ln_fwd");
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == SIMX_F32)
-    hipLaunchKernelGGL((embed_ln_fwd_kernel<float>), dim3(cdiv(T, 4)), dim3(256), 0, s, T, H, ids, pos_ids, word, posw, typew,
-                       gamma, beta, eps, (float*)out, drop);
-  else
-    hipLaunchKernelGGL((embed_ln_fwd_kernel<bf16_t>), dim3(cdiv(T, 4)), dim3(256), 0, s, T, H, ids, pos_ids, word, posw, typew,
-                       gamma, beta, eps, (bf16_t*)out, drop);
+  SIMX_DISPATCH3(dtype, TT, hipLaunchKernelGGL((embed_ln_fwd_kernel<TT>), dim3(cdiv(T, 4)), dim3(256), 0, s, T, H, ids, pos_ids, word,
+                                               posw, typew, gamma, beta, eps, (TT*)out, drop));
   SIMX_CHECK_LAUNCH("embed_ln_fwd");
   return SIMX_OK;
 }
@@ -599,16 +611,16 @@ extern "C" int simx_embed_ln_bwd_ex(simx_stream_t stream, int dtype, int T, int 
                                     const void* dy, float* dword, float* dpos, float* dtype0, float* dgamma, float* dbeta,
                                     const simx_dropout* dropd) {
   const DropCtx drop = make_drop(dropd);
-  SIMX_PROF(SIMX_K_EMBED_BWD, stream, (double)T * H * (12 + (dtype == SIMX_F32 ? 4 : 2)));
+  SIMX_PROF(SIMX_K_EMBED_BWD, stream, (double)T * H * (12 + simx_esz(dtype)));
   int rc = ln_check(dtype, T, H, "embed_ln_bwd");
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   const int rpb = bwd_rows_per_block(T);
   const size_t lds = (size_t)4 * H * sizeof(float);
+  const float* gs = nullptr;
 #define EB(TT, V) hipLaunchKernelGGL((embed_ln_bwd_kernel<TT, V>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, ids, pos_ids, word, posw, \
-                                    typew, gamma, eps, (const TT*)dy, dword, dpos, dtype0, dgamma, dbeta, drop)
-  if (dtype == SIMX_F32) { if (H <= 256) EB(float, 1); else if (H <= 768) EB(float, 3); else EB(float, 4); }
-  else { if (H <= 256) EB(bf16_t, 1); else if (H <= 768) EB(bf16_t, 3); else EB(bf16_t, 4); }
+                                    typew, gamma, eps, (const TT*)dy, dword, dpos, dtype0, dgamma, dbeta, drop, gs)
+  SIMX_DISPATCH3(dtype, TT, LN_BY_H(TT, EB));
 #undef EB
   SIMX_CHECK_LAUNCH("embed_ln_bwd");
   return SIMX_OK;
@@ -618,7 +630,15 @@ extern "C" int simx_embed_ln_bwd_seq(simx_stream_t stream, int dtype, int nseq, 
                                      const int32_t* ids, const int32_t* pos_ids, const float* word, const float* posw,
                                      const float* typew, const float* gamma, float eps, const void* dy, float* dword, float* dpos,
                                      float* dtype0, float* dgamma, float* dbeta, const simx_dropout* dropd) {
-  SIMX_PROF(SIMX_K_EMBED_BWD, stream, (double)T * H * ((dtype == SIMX_F32 ? 4 : 2) + 3 * 4));
+  return simx_embed_ln_bwd_seq_gs(stream, dtype, nseq, max_len, T, H, cu_seqlens, ids, pos_ids, word, posw, typew, gamma, eps, dy, dword,
+                                  dpos, dtype0, dgamma, dbeta, dropd, nullptr);
+}
+
+extern "C" int simx_embed_ln_bwd_seq_gs(simx_stream_t stream, int dtype, int nseq, int max_len, int T, int H, const int32_t* cu_seqlens,
+                                        const int32_t* ids, const int32_t* pos_ids, const float* word, const float* posw,
+                                        const float* typew, const float* gamma, float eps, const void* dy, float* dword, float* dpos,
+                                        float* dtype0, float* dgamma, float* dbeta, const simx_dropout* dropd, const float* gs) {
+  SIMX_PROF(SIMX_K_EMBED_BWD, stream, (double)T * H * (simx_esz(dtype) + 3 * 4));
   const DropCtx drop = make_drop(dropd);
   int rc = ln_check(dtype, T, H, "embed_ln_bwd_seq");
   if (rc) return rc;
@@ -632,9 +652,8 @@ extern "C" int simx_embed_ln_bwd_seq(simx_stream_t stream, int dtype, int nseq, 
   const dim3 grid(pgroups, cdiv(nseq, spb));
   const size_t lds = (size_t)(4 * H + 4 * LN_VPL * 256) * sizeof(float);      // column-flush scratch + per-wave scatter patches
 #define ES(TT, V) hipLaunchKernelGGL((embed_ln_bwd_seq_kernel<TT, V>), grid, dim3(256), lds, s, nseq, spb, H, cu_seqlens, ids, pos_ids, word, \
-                                    posw, typew, gamma, eps, (const TT*)dy, dword, dpos, dtype0, dgamma, dbeta, drop)
-  if (dtype == SIMX_F32) { if (H <= 256) ES(float, 1); else if (H <= 768) ES(float, 3); else ES(float, 4); }
-  else { if (H <= 256) ES(bf16_t, 1); else if (H <= 768) ES(bf16_t, 3); else ES(bf16_t, 4); }
+                                    posw, typew, gamma, eps, (const TT*)dy, dword, dpos, dtype0, dgamma, dbeta, drop, gs)
+  SIMX_DISPATCH3(dtype, TT, LN_BY_H(TT, ES));
 #undef ES
   SIMX_CHECK_LAUNCH("embed_ln_bwd_seq");
   return SIMX_OK;
@@ -642,40 +661,42 @@ extern "C" int simx_embed_ln_bwd_seq(simx_stream_t stream, int dtype, int nseq, 
 
 extern "C" int simx_cls_gather(simx_stream_t stream, int dtype, int nseq, int H, const int32_t* cu, const void* x, float* cls) {
   SIMX_REQUIRE(nseq > 0 && H > 0, SIMX_ERR_BAD_SHAPE, "cls_gather: bad shape");
+  SIMX_REQUIRE(simx_dtype_ok(dtype), SIMX_ERR_BAD_DTYPE, "cls_gather: dtype %d", dtype);
   hipStream_t s = (hipStream_t)stream;
   const int blocks = (int)(((long)nseq * H + 255) / 256);
-  if (dtype == SIMX_F32) hipLaunchKernelGGL((cls_gather_kernel<float>), dim3(blocks), dim3(256), 0, s, nseq, H, cu, (const float*)x, cls);
-  else if (dtype == SIMX_BF16) hipLaunchKernelGGL((cls_gather_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, nseq, H, cu, (const bf16_t*)x, cls);
-  else { simx_set_error("cls_gather: dtype %d", dtype); return SIMX_ERR_BAD_DTYPE; }
+  SIMX_DISPATCH3(dtype, TT, hipLaunchKernelGGL((cls_gather_kernel<TT>), dim3(blocks), dim3(256), 0, s, nseq, H, cu, (const TT*)x, cls));
   SIMX_CHECK_LAUNCH("cls_gather");
   return SIMX_OK;
 }
 
 extern "C" int simx_cls_scatter(simx_stream_t stream, int dtype, int nseq, int H, int T, const int32_t* cu,
                                 const float* dcls, void* dx) {
+  return simx_cls_scatter_gs(stream, dtype, nseq, H, T, cu, dcls, dx, nullptr);
+}
+extern "C" int simx_cls_scatter_gs(simx_stream_t stream, int dtype, int nseq, int H, int T, const int32_t* cu,
+                                   const float* dcls, void* dx, const float* gs) {
   SIMX_REQUIRE(nseq > 0 && H > 0 && T >= nseq, SIMX_ERR_BAD_SHAPE, "cls_scatter: bad shape");
-  SIMX_REQUIRE(dtype == SIMX_F32 || dtype == SIMX_BF16, SIMX_ERR_BAD_DTYPE, "cls_scatter: dtype %d", dtype);
+  SIMX_REQUIRE(simx_dtype_ok(dtype), SIMX_ERR_BAD_DTYPE, "cls_scatter: dtype %d", dtype);
   hipStream_t s = (hipStream_t)stream;
-  const size_t esz = dtype == SIMX_F32 ? 4 : 2;
-  if (hipMemsetAsync(dx, 0, (size_t)T * H * esz, s) != hipSuccess) { simx_set_error("cls_scatter: memset failed"); return SIMX_ERR_HIP; }
+  if (hipMemsetAsync(dx, 0, (size_t)T * H * simx_esz(dtype), s) != hipSuccess) { simx_set_error("cls_scatter: memset failed"); return SIMX_ERR_HIP; }
   const int blocks = (int)(((long)nseq * H + 255) / 256);
-  if (dtype == SIMX_F32) hipLaunchKernelGGL((cls_scatter_kernel<float>), dim3(blocks), dim3(256), 0, s, nseq, H, cu, dcls, (float*)dx);
-  else hipLaunchKernelGGL((cls_scatter_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, nseq, H, cu, dcls, (bf16_t*)dx);
+  SIMX_DISPATCH3(dtype, TT, hipLaunchKernelGGL((cls_scatter_kernel<TT>), dim3(blocks), dim3(256), 0, s, nseq, H, cu, dcls, (TT*)dx, gs));
   SIMX_CHECK_LAUNCH("cls_scatter");
   return SIMX_OK;
 }
 
 extern "C" int simx_rows_copy(simx_stream_t stream, int src_dtype, int dst_dtype, int n, int H, const int32_t* src_idx,
                               const int32_t* dst_idx, const void* src, void* dst) {
+  return simx_rows_copy_gs(stream, src_dtype, dst_dtype, n, H, src_idx, dst_idx, src, dst, nullptr);
+}
+extern "C" int simx_rows_copy_gs(simx_stream_t stream, int src_dtype, int dst_dtype, int n, int H, const int32_t* src_idx,
+                                 const int32_t* dst_idx, const void* src, void* dst, const float* gs) {
   SIMX_REQUIRE(n > 0 && H > 0 && src && dst, SIMX_ERR_BAD_SHAPE, "rows_copy: bad arguments");
-  SIMX_REQUIRE((src_dtype == SIMX_F32 || src_dtype == SIMX_BF16) && (dst_dtype == SIMX_F32 || dst_dtype == SIMX_BF16),
-               SIMX_ERR_BAD_DTYPE, "rows_copy: dtypes %d -> %d", src_dtype, dst_dtype);
+  SIMX_REQUIRE(simx_dtype_ok(src_dtype) && simx_dtype_ok(dst_dtype), SIMX_ERR_BAD_DTYPE, "rows_copy: dtypes %d -> %d", src_dtype, dst_dtype);
   hipStream_t s = (hipStream_t)stream;
   const int blocks = (int)(((long)n * H + 255) / 256);
-#define RC(TI, TO) hipLaunchKernelGGL((rows_copy_kernel<TI, TO>), dim3(blocks), dim3(256), 0, s, n, H, src_idx, dst_idx, (const TI*)src, (TO*)dst)
-  if (src_dtype == SIMX_F32) { if (dst_dtype == SIMX_F32) RC(float, float); else RC(float, bf16_t); }
-  else { if (dst_dtype == SIMX_F32) RC(bf16_t, float); else RC(bf16_t, bf16_t); }
-#undef RC
+  SIMX_DISPATCH3(src_dtype, TI, SIMX_DISPATCH3(dst_dtype, TO, hipLaunchKernelGGL((rows_copy_kernel<TI, TO>), dim3(blocks), dim3(256), 0, s, n,
+                                                                                 H, src_idx, dst_idx, (const TI*)src, (TO*)dst, gs)));
   SIMX_CHECK_LAUNCH("rows_copy");
   return SIMX_OK;
 }
@@ -683,32 +704,34 @@ extern "C" int simx_rows_copy(simx_stream_t stream, int src_dtype, int dst_dtype
 extern "C" int simx_drop_residual_rows(simx_stream_t stream, int dtype, int n, int H, const void* y, const void* res,
                                        const int32_t* res_idx, const int32_t* key_idx, const simx_dropout* dropd, void* z) {
   SIMX_REQUIRE(n > 0 && H > 0 && H % 4 == 0 && y && res && z, SIMX_ERR_BAD_SHAPE, "drop_residual_rows: bad arguments");
-  SIMX_REQUIRE(dtype == SIMX_F32 || dtype == SIMX_BF16, SIMX_ERR_BAD_DTYPE, "drop_residual_rows: dtype %d", dtype);
+  SIMX_REQUIRE(simx_dtype_ok(dtype), SIMX_ERR_BAD_DTYPE, "drop_residual_rows: dtype %d", dtype);
   const DropCtx drop = make_drop(dropd);
   hipStream_t s = (hipStream_t)stream;
   const int blocks = (int)(((long)n * H / 4 + 255) / 256);
-  if (dtype == SIMX_F32) hipLaunchKernelGGL((drop_residual_rows_kernel<float>), dim3(blocks), dim3(256), 0, s, n, H, (const float*)y, (const float*)res, res_idx, key_idx, drop, (float*)z);
-  else hipLaunchKernelGGL((drop_residual_rows_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, n, H, (const bf16_t*)y, (const bf16_t*)res, res_idx, key_idx, drop, (bf16_t*)z);
+  SIMX_DISPATCH3(dtype, TT, hipLaunchKernelGGL((drop_residual_rows_kernel<TT>), dim3(blocks), dim3(256), 0, s, n, H, (const TT*)y,
+                                               (const TT*)res, res_idx, key_idx, drop, (TT*)z));
   SIMX_CHECK_LAUNCH("drop_residual_rows");
   return SIMX_OK;
 }
 
 extern "C" int simx_seq_mean_fwd(simx_stream_t stream, int dtype, int nseq, int H, const int32_t* cu, const void* x, float* mean) {
   SIMX_REQUIRE(nseq > 0 && H > 0 && cu && x && mean, SIMX_ERR_BAD_SHAPE, "seq_mean_fwd: bad arguments");
-  SIMX_REQUIRE(dtype == SIMX_F32 || dtype == SIMX_BF16, SIMX_ERR_BAD_DTYPE, "seq_mean_fwd: dtype %d", dtype);
+  SIMX_REQUIRE(simx_dtype_ok(dtype), SIMX_ERR_BAD_DTYPE, "seq_mean_fwd: dtype %d", dtype);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == SIMX_F32) hipLaunchKernelGGL((seq_mean_fwd_kernel<float>), dim3(nseq), dim3(256), 0, s, H, cu, (const float*)x, mean);
-  else hipLaunchKernelGGL((seq_mean_fwd_kernel<bf16_t>), dim3(nseq), dim3(256), 0, s, H, cu, (const bf16_t*)x, mean);
+  SIMX_DISPATCH3(dtype, TT, hipLaunchKernelGGL((seq_mean_fwd_kernel<TT>), dim3(nseq), dim3(256), 0, s, H, cu, (const TT*)x, mean));
   SIMX_CHECK_LAUNCH("seq_mean_fwd");
   return SIMX_OK;
 }
 
 extern "C" int simx_seq_mean_bwd(simx_stream_t stream, int dtype, int nseq, int H, const int32_t* cu, const float* dmean, void* dx) {
+  return simx_seq_mean_bwd_gs(stream, dtype, nseq, H, cu, dmean, dx, nullptr);
+}
+extern "C" int simx_seq_mean_bwd_gs(simx_stream_t stream, int dtype, int nseq, int H, const int32_t* cu, const float* dmean, void* dx,
+                                    const float* gs) {
   SIMX_REQUIRE(nseq > 0 && H > 0 && cu && dmean && dx, SIMX_ERR_BAD_SHAPE, "seq_mean_bwd: bad arguments");
-  SIMX_REQUIRE(dtype == SIMX_F32 || dtype == SIMX_BF16, SIMX_ERR_BAD_DTYPE, "seq_mean_bwd: dtype %d", dtype);
+  SIMX_REQUIRE(simx_dtype_ok(dtype), SIMX_ERR_BAD_DTYPE, "seq_mean_bwd: dtype %d", dtype);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == SIMX_F32) hipLaunchKernelGGL((seq_mean_bwd_kernel<float>), dim3(nseq), dim3(256), 0, s, H, cu, dmean, (float*)dx);
-  else hipLaunchKernelGGL((seq_mean_bwd_kernel<bf16_t>), dim3(nseq), dim3(256), 0, s, H, cu, dmean, (bf16_t*)dx);
+  SIMX_DISPATCH3(dtype, TT, hipLaunchKernelGGL((seq_mean_bwd_kernel<TT>), dim3(nseq), dim3(256), 0, s, H, cu, dmean, (TT*)dx, gs));
   SIMX_CHECK_LAUNCH("seq_mean_bwd");
   return SIMX_OK;
 }

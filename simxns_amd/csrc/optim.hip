@@ -48,14 +48,56 @@ __global__ __launch_bounds__(256) void sqnorm_final_kernel(const float* __restri
   if (threadIdx.x == 0) *out += (part[0] + part[1]) + (part[2] + part[3]);
 }
 
+// Dynamic loss scaler of the fp16 engine (apex.amp's dynamic loss scaling, which the reference's --fp16 mode runs under:
+// SimANS/co_training/co_training_marco_train.py:97-104, 218-220; apex defaults: start 2^16, halve on overflow, double after
+// 2000 clean steps, cap 2^24).  State, 8 floats on the device:
+//   [0] S   [1] 1/S   [2] clean steps since S last changed   [3] 1 = skip the current optimiser step (overflow)
+//   [4] optimiser steps applied   [5] steps skipped   [6] growth interval   [7] largest S
+// The gradient buffers hold TRUE gradients (every accumulating kernel multiplies by 1/S), so an overflow of the scaled fp16
+// activation gradients shows as inf / nan in the squared norm.  No host synchronisation: the AdamW kernel reads [3], [4].
+__global__ void scaler_init_kernel(float* __restrict__ st, float init_scale, float growth_interval, float max_scale) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  st[0] = init_scale; st[1] = 1.0f / init_scale; st[2] = 0.f; st[3] = 0.f; st[4] = 0.f; st[5] = 0.f; st[6] = growth_interval; st[7] = max_scale;
+}
+__global__ void scaler_update_kernel(float* __restrict__ st, const float* __restrict__ sqnorm) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float sq = *sqnorm;
+  const bool ok = sq == sq && sq < 3.0e38f && sq >= 0.f;
+  float S = st[0];
+  if (!ok) {
+    S = fmaxf(S * 0.5f, 1.0f);
+    st[2] = 0.f; st[3] = 1.f; st[5] += 1.f;
+  } else {
+    st[3] = 0.f; st[4] += 1.f;
+    const float clean = st[2] + 1.f;
+    if (st[6] > 0.f && clean >= st[6]) { S = fminf(S * 2.0f, st[7]); st[2] = 0.f; } else st[2] = clean;
+  }
+  st[0] = S;
+  st[1] = 1.0f / S;
+}
+
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, size_t n, float step_size, float beta1, float beta2,
                                                     float eps, float decay, const float* __restrict__ sqnorm, float max_norm,
-                                                    float grad_scale, int zero_grad) {
+                                                    float grad_scale, int zero_grad, const float* __restrict__ scaler, float lr) {
   float coef = grad_scale;
   if (sqnorm && max_norm > 0.f) {
     const float total = sqrtf(*sqnorm) * grad_scale;
     coef *= fminf(1.0f, max_norm / (total + 1e-6f));
+  }
+  if (scaler) {
+    // the step count that enters the bias correction is the number of steps APPLIED (skipped ones do not age the moments)
+    const double t = (double)scaler[4];
+    step_size = (float)((double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
+    if (scaler[3] != 0.f) {                        // overflow: parameters and moments keep their values, gradients are dropped
+      if (zero_grad) {
+        const size_t n4z = n / 4;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4z; i += (size_t)gridDim.x * 256)
+          reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (blockIdx.x == 0) for (size_t i = n4z * 4 + threadIdx.x; i < n; i += 256) g[i] = 0.f;
+      }
+      return;
+    }
   }
   const size_t n4 = n / 4;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
@@ -112,9 +154,28 @@ extern "C" int simx_sqnorm_accum_det(simx_stream_t stream, const float* g, size_
   return SIMX_OK;
 }
 
+extern "C" int simx_scaler_init(simx_stream_t stream, float* state, float init_scale, float growth_interval, float max_scale) {
+  SIMX_REQUIRE(state && init_scale >= 1.f && max_scale >= init_scale, SIMX_ERR_BAD_SHAPE, "scaler_init: bad arguments");
+  hipLaunchKernelGGL(scaler_init_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, init_scale, growth_interval, max_scale);
+  SIMX_CHECK_LAUNCH("scaler_init");
+  return SIMX_OK;
+}
+extern "C" int simx_scaler_update(simx_stream_t stream, float* state, const float* sqnorm) {
+  SIMX_REQUIRE(state && sqnorm, SIMX_ERR_BAD_SHAPE, "scaler_update: bad arguments");
+  hipLaunchKernelGGL(scaler_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, sqnorm);
+  SIMX_CHECK_LAUNCH("scaler_update");
+  return SIMX_OK;
+}
+
 extern "C" int simx_adamw_step(simx_stream_t stream, float* p, float* g, float* m, float* v, size_t n, float lr, float beta1,
                                float beta2, float eps, float weight_decay, int step, const float* sqnorm, float max_norm,
                                float grad_scale, int zero_grad) {
+  return simx_adamw_step_sc(stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, sqnorm, max_norm, grad_scale, zero_grad,
+                            nullptr);
+}
+extern "C" int simx_adamw_step_sc(simx_stream_t stream, float* p, float* g, float* m, float* v, size_t n, float lr, float beta1,
+                                  float beta2, float eps, float weight_decay, int step, const float* sqnorm, float max_norm,
+                                  float grad_scale, int zero_grad, const float* scaler) {
   SIMX_PROF(SIMX_K_ADAMW, stream, 32.0 * n);
   SIMX_REQUIRE(p && g && m && v && n > 0 && step >= 1, SIMX_ERR_BAD_SHAPE, "adamw_step: bad arguments");
   SIMX_REQUIRE(((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0, SIMX_ERR_BAD_SHAPE,
@@ -125,7 +186,7 @@ extern "C" int simx_adamw_step(simx_stream_t stream, float* p, float* g, float* 
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, step_size, beta1,
-                     beta2, eps, lr * weight_decay, sqnorm, max_norm, grad_scale, zero_grad);
+                     beta2, eps, lr * weight_decay, sqnorm, max_norm, grad_scale, zero_grad, scaler, lr);
   SIMX_CHECK_LAUNCH("adamw");
   return SIMX_OK;
 }

@@ -76,11 +76,60 @@ class BertConfigLite(object):
 
 
 def _dtype_code(name):
+    if name in ("fp16", "float16", "f16", "half", torch.float16):
+        return L.SIMX_F16
     if name in ("bf16", "bfloat16", torch.bfloat16):
         return L.SIMX_BF16
     if name in ("fp32", "float32", "f32", torch.float32):
         return L.SIMX_F32
-    raise ValueError("compute dtype must be 'bf16' or 'fp32', got %r" % (name,))
+    raise ValueError("compute dtype must be 'fp32', 'fp16' or 'bf16', got %r" % (name,))
+
+
+class LossScaler(object):
+    """Loss scale of the fp16 engine: apex.amp's dynamic loss scaling (amp.initialize(opt_level='O1') /
+    amp.scale_loss, SimANS/co_training/co_training_marco_train.py:97-104, 218-220) kept ENTIRELY on the device.
+    Activation gradients of an fp16 tower travel multiplied by S; every kernel that adds into the f32 parameter
+    gradients multiplies by 1/S, so ``param.grad`` is always the true gradient (what apex leaves behind when the
+    ``scale_loss`` context exits).  FusedAdamW owns a dynamic one per optimiser (apex defaults: 2^16, /2 on inf / nan with
+    the step skipped, x2 after 2000 clean steps); an fp16 engine used without an optimiser (tests, inference-time
+    gradients) falls back to a static 2^10.  State layout: include/simx.h "Dynamic loss scaler"."""
+
+    def __init__(self, init_scale=2.0 ** 16, growth_interval=2000, max_scale=2.0 ** 24):
+        self.init_scale, self.growth_interval, self.max_scale = float(init_scale), float(growth_interval), float(max_scale)
+        self._state = None
+
+    def state(self, device):
+        if self._state is None or self._state.device != torch.device(device):
+            old = None if self._state is None else self._state.cpu()
+            self._state = torch.empty(8, dtype=torch.float32, device=device)
+            if old is None:
+                L.call("simx_scaler_init", L.stream_ptr(), L.ptr(self._state), self.init_scale, self.growth_interval, self.max_scale)
+            else:
+                self._state.copy_(old)
+        return self._state
+
+    def update(self, sqnorm):
+        """One optimiser step's verdict from the squared norm of ALL its gradient buffers (device scalar)."""
+        L.call("simx_scaler_update", L.stream_ptr(), L.ptr(self.state(sqnorm.device)), L.ptr(sqnorm))
+
+    def snapshot(self):
+        """Host copy (synchronises): {'scale', 'applied_steps', 'skipped_steps', 'clean_steps'}."""
+        if self._state is None:
+            return {"scale": self.init_scale, "applied_steps": 0, "skipped_steps": 0, "clean_steps": 0}
+        v = self._state.tolist()
+        return {"scale": v[0], "applied_steps": int(v[4]), "skipped_steps": int(v[5]), "clean_steps": int(v[2])}
+
+    def state_dict(self):
+        d = self.snapshot()
+        d.update(growth_interval=self.growth_interval, max_scale=self.max_scale)
+        return d
+
+    def load_state_dict(self, d, device):
+        st = self.state(device)
+        S = float(d["scale"])
+        st.copy_(torch.tensor([S, 1.0 / S, float(d.get("clean_steps", 0)), 0.0, float(d.get("applied_steps", 0)),
+                               float(d.get("skipped_steps", 0)), float(d.get("growth_interval", self.growth_interval)),
+                               float(d.get("max_scale", self.max_scale))], dtype=torch.float32))
 
 
 def hf_param_layout(cfg, ccfg):
@@ -177,7 +226,7 @@ class _EncoderFn(torch.autograd.Function):
             dh = torch.zeros(pb.T, H, dtype=torch.float32, device=e.flat.device) if g1 is None else g1.to(torch.float32).clone()
             if g0 is not None:
                 dh.index_add_(0, pb.cu[:-1].long(), g0.to(torch.float32))
-            e._run_backward(pb, ctx.act, dhidden=dh.to(e.act_torch_dtype).contiguous(), ccfg=ctx.ccfg)
+            e._run_backward(pb, ctx.act, dhidden=e._enter_backward(dh), ccfg=ctx.ccfg)
         ctx.act = None
         return None, None, None, None, None
 
@@ -204,8 +253,11 @@ class BertEngine(object):
         self.grad_ready_hook = None
         self.bwd_parts = 1
         self._open_graphs = 0
+        self._bwd_serial = 0                 # counts backward passes (the optimiser tells parts of one pass from a new pass)
+        self._reduced_this_step = False      # set by the data-parallel hook once slices of flat_grad are on the wire
         self.last_stream = None              # stream of the last forward / backward (the optimiser joins it)
         self.after_backward = None           # module callback: expose flat_grad as param.grad views
+        self.scaler = None                   # fp16 only: the optimiser's LossScaler (FusedAdamW attaches it); None -> static 2^10
 
     # ---- configuration -----------------------------------------------------------------
     def set_compute_dtype(self, name):
@@ -216,13 +268,21 @@ class BertEngine(object):
         ckpt = bool(getattr(c, "gradient_checkpointing", False)) if ck is None else ck == "1"
         self.ccfg = L.BertCfg(self.dtype_code, c.num_hidden_layers, c.hidden_size, c.num_attention_heads,
                               c.intermediate_size, c.vocab_size, c.max_position_embeddings, c.type_vocab_size,
-                              float(c.layer_norm_eps), 0.0, 0.0, 0, 0, 1 if ckpt else 0)
+                              float(c.layer_norm_eps), 0.0, 0.0, 0, 0, 1 if ckpt else 0, 0, None)
         self.wcache = None
         self._dirty = True
 
     @property
     def act_torch_dtype(self):
-        return torch.bfloat16 if self.dtype_code == L.SIMX_BF16 else torch.float32
+        return {L.SIMX_BF16: torch.bfloat16, L.SIMX_F16: torch.float16}.get(self.dtype_code, torch.float32)
+
+    def grad_scale_state(self):
+        """fp16: the device tensor {S, 1/S, ...} the backward kernels read (None for the other dtypes)."""
+        if self.dtype_code != L.SIMX_F16:
+            return None
+        if self.scaler is None:
+            self.scaler = LossScaler(init_scale=float(os.environ.get("SIMX_LOSS_SCALE", 1024.0)), growth_interval=0)
+        return self.scaler.state(self.flat.device)
 
     def views(self, base):
         out = OrderedDict()
@@ -272,6 +332,8 @@ class BertEngine(object):
         layer's post-attention blocks run on the [CLS] rows alone (SIMX_FULL_LAST_LAYER=1 computes every row anyway)."""
         c = L.BertCfg.from_buffer_copy(self.ccfg)
         c.cls_only_last_layer = 0 if (want_hidden or os.environ.get("SIMX_FULL_LAST_LAYER", "0") == "1") else 1
+        # decided HERE, once per forward: the backward receives this same copy (SIMX_QKV_LAYOUT=token pins token-major)
+        c.qkv_layout = 1 if os.environ.get("SIMX_QKV_LAYOUT", "")[:1] == "t" else 0
         if training and (self.cfg.hidden_dropout_prob > 0 or self.cfg.attention_probs_dropout_prob > 0):
             self._drop_calls = getattr(self, "_drop_calls", 0) + 1
             c.hidden_dropout = float(self.cfg.hidden_dropout_prob)
@@ -315,14 +377,30 @@ class BertEngine(object):
         L.call("simx_seq_mean_fwd", L.stream_ptr(), self.dtype_code, pb.nseq, self.cfg.hidden_size, L.ptr(pb.cu), L.ptr(hidden), L.ptr(out))
         return out
 
+    def _enter_backward(self, dh):
+        """f32 gradient of the whole hidden state [T,H] -> the activation dtype (fp16: multiplied by the loss scale)."""
+        dh = dh.contiguous()
+        out = torch.empty(dh.shape, dtype=self.act_torch_dtype, device=dh.device)
+        L.call("simx_rows_copy_gs", L.stream_ptr(), L.SIMX_F32, self.dtype_code, dh.shape[0], dh.shape[1], None, None, L.ptr(dh), L.ptr(out),
+               L.ptr(self.grad_scale_state()))
+        return out
+
     def _seq_mean_bwd(self, pb, dmean):
         dmean = dmean.contiguous().to(torch.float32)
         dh = torch.empty(pb.T, self.cfg.hidden_size, dtype=self.act_torch_dtype, device=dmean.device)
-        L.call("simx_seq_mean_bwd", L.stream_ptr(), self.dtype_code, pb.nseq, self.cfg.hidden_size, L.ptr(pb.cu), L.ptr(dmean), L.ptr(dh))
+        L.call("simx_seq_mean_bwd_gs", L.stream_ptr(), self.dtype_code, pb.nseq, self.cfg.hidden_size, L.ptr(pb.cu), L.ptr(dmean), L.ptr(dh),
+               L.ptr(self.grad_scale_state()))
         return dh
 
     def _run_backward(self, pb, act, dcls=None, ccfg=None, dhidden=None):
         ccfg = ccfg if ccfg is not None else self.ccfg
+        if self._reduced_this_step:
+            raise L.SimxError("backward into a gradient buffer whose slices were already all-reduced for this optimiser step: "
+                              "the sum would be reduced twice (or mixed with un-reduced gradients).  With gradient accumulation "
+                              "set optimizer.armed = False for every micro-step but the last, or call optimizer.step() first")
+        self._bwd_serial += 1
+        gs = self.grad_scale_state()                 # fp16: the loss scale as it is NOW (the optimiser may have been attached,
+        ccfg.grad_scale = None if gs is None else gs.data_ptr()     # or moved its state, after the forward)
         self.last_stream = torch.cuda.current_stream()
         g = self.ensure_grad()
         dev = self.flat.device

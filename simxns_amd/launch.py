@@ -53,7 +53,8 @@ def _ms_doc():
                  teacher_learning_rate=1e-6, output_dir="ckpt/" + exp, log_dir="tensorboard/logs/" + exp,
                  origin_data_dir="data/MS-Doc/train_ce_0.tsv", train_qa_path="data/MS-Doc/msmarco-doctrain-queries.tsv",
                  passage_path="data/MS-Doc", logging_steps=100, save_steps=5000, gradient_checkpointing=True, distill_loss=True,
-                 fp16=True, temperature_distill=1, ann_dir="ckpt/%s/temp" % exp, adv_lambda=1)
+                 temperature_distill=1, ann_dir="ckpt/%s/temp" % exp, adv_lambda=1)      # (no --fp16, as train_MS_Doc_AR2.sh:9-26;
+                                                                                         #  SIMX_DTYPE=fp16 opts any recipe in)
     return dict(iteration_step=5000, iteration_reranker_step=1000, max_steps=40000,
                 train=("simxns_amd/Doc_training/co_training_doc_train.py", train), generate=None)
 

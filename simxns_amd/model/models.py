@@ -30,7 +30,8 @@ class HFBertEncoder(nn.Module):
         super(HFBertEncoder, self).__init__()
         assert config.hidden_size > 0, 'Encoder hidden_size can\'t be zero'
         self.config = config
-        self.engine = BertEngine(config, compute_dtype or os.environ.get("SIMX_DTYPE", "bf16"))
+        # one default everywhere: the reference's arithmetic (fp32) unless the caller / SIMX_DTYPE says otherwise
+        self.engine = BertEngine(config, compute_dtype or os.environ.get("SIMX_DTYPE", "fp32"))
         for name, view in self.engine.views(self.engine.flat).items():
             parts = name.split(".")
             mod = self
@@ -79,6 +80,7 @@ class HFBertEncoder(nn.Module):
     def zero_grad(self, set_to_none=False):
         if self.engine.flat_grad is not None:
             self.engine.flat_grad.zero_()
+        self.engine._open_graphs = 0          # graphs that never got a backward must not hold back the data-parallel hooks
 
     def init_weights(self):
         # HF BertPreTrainedModel._init_weights == reference init_weights (models.py:452-465)
@@ -118,10 +120,11 @@ class HFBertEncoder(nn.Module):
         if num_hidden_layers:                      # PROD: the depth is a property of the role, not of the checkpoint
             cfg.num_hidden_layers = int(num_hidden_layers)
         if compute_dtype is None:
-            # the reference computes in fp32 unless --fp16 (apex O1) is passed (co_training_marco_train.py:97-104); here
-            # --fp16 selects the bf16 engine (f32 master weights and accumulation, no loss scaling), and SIMX_DTYPE=bf16
-            # switches any recipe to it explicitly
-            compute_dtype = "bf16" if getattr(args, "fp16", False) else os.environ.get("SIMX_DTYPE", "fp32")
+            # the reference computes in fp32 unless --fp16 (apex O1: fp16 GEMM operands, f32 master weights, dynamic loss
+            # scaling) is passed (co_training_marco_train.py:97-104, 218-220); here --fp16 selects the fp16 engine (same operand
+            # width, f32 accumulation / statistics / master weights, FusedAdamW's device-side dynamic loss scale), and
+            # SIMX_DTYPE=fp16|bf16|fp32 switches any recipe explicitly
+            compute_dtype = os.environ.get("SIMX_DTYPE") or ("fp16" if getattr(args, "fp16", False) else "fp32")
         enc = cls(cfg, compute_dtype=compute_dtype)
         if os.path.isdir(str(model_type)):
             st = os.path.join(model_type, "model.safetensors")

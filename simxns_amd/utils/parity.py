@@ -1,14 +1,23 @@
 """Check of an installation against the committed reference goldens (tests/golden/step_*.npz, written by the imported
 reference in the build container: oracle/make_golden.py).  Product-side: no oracle import -- the fixture is data.
-Used by tests/test_encoder_gpu.py and by bench.py's `parity_bf16` block (the measured distance of the benchmarked bf16
-engine from the reference on the shapes its hot kernels need)."""
+Used by tests/test_encoder_gpu.py and by bench.py's `parity_16bit` block (the measured distance of the benchmarked 16-bit
+engine from the reference on the shapes its hot kernels need).  The fixtures are looked up in $SIMX_GOLDEN_DIR, else in
+<repository>/tests/golden next to an in-tree package."""
 import json
 import os
 
 import numpy as np
 import torch
 
-GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden")
+
+def golden_dir():
+    env = os.environ.get("SIMX_GOLDEN_DIR")
+    if env:
+        return env
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden")
+
+
+GOLDEN_DIR = golden_dir()
 
 # bf16 tolerances = 3x the errors MEASURED on MI355X with this fixture (tests print them; DESIGN.md "bf16 parity").  Measured,
 # [CLS]-only / full last layer: embeddings max |err| 0.070 / 0.085 (values up to 4.4), student logits 1.65 / 1.57 on a scale
@@ -21,8 +30,17 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.pat
 # of the f32 pre-activation instead of its bf16 rounding) redraws them -- loss 0.0009 ... 0.025 and gradient-norm median
 # 0.8 % ... 1.8 % (a common-mode factor: every gradient scales with the softmax weights the logit errors move) over the builds
 # and boxes measured so far, with the direction measures unchanged or better (slice cosine min 0.92).  Bounds = 3x the largest.
-BF16_HOT_TOL = dict(emb_abs=0.29, logits_rel=0.18, teacher_logits_abs=0.14, loss_abs=0.08, gnorm_rel_median=0.054, gnorm_rel_max=0.19,
-                    gslice_cos_min=0.55, gslice_cos_median_all=0.94)
+# Round 3: the direction bound is what would catch a regression (a doubled error roughly halves 1 - cos), so it sits at the
+# worst box's measurement minus a third of its distance to 1, not at 3x: cosine min >= 0.80 (measured 0.845-0.92).
+BF16_HOT_TOL = dict(emb_abs=0.2, logits_rel=0.12, teacher_logits_abs=0.1, loss_abs=0.06, gnorm_rel_median=0.04, gnorm_rel_max=0.13,
+                    gslice_cos_min=0.80, gslice_cos_median_all=0.96)
+# fp16 engine (IEEE half operands = the operand width of the reference's own optional apex-O1 mode; f32 accumulation,
+# statistics, master weights; loss-scaled backward).  11-bit significands instead of 8: every figure above shrinks ~8x.
+# Bounds are the round-2 verdict's targets (logits <= 1 % of scale, loss <= 5e-3, slice cosine >= 0.97) or ~3x the
+# measurement where that is tighter; measured values: DESIGN.md 2.
+FP16_HOT_TOL = dict(emb_abs=0.04, logits_rel=0.01, teacher_logits_abs=0.02, loss_abs=5e-3, gnorm_rel_median=0.01, gnorm_rel_max=0.04,
+                    gslice_cos_min=0.97, gslice_cos_median_all=0.995)
+HOT_TOL = {"bf16": BF16_HOT_TOL, "fp16": FP16_HOT_TOL}
 
 
 def _cfg_from(G):
@@ -112,7 +130,7 @@ def golden_errors(R, G):
 
 def parity_report(dev, dtype="bf16", fixture="step_base_hot.npz"):
     """-> dict of measured errors of `dtype` against the reference golden, or None when the fixture is absent."""
-    path = os.path.join(GOLDEN_DIR, fixture)
+    path = os.path.join(golden_dir(), fixture)
     if not os.path.exists(path):
         return None
     G = np.load(path)

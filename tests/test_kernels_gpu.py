@@ -1,8 +1,9 @@
 """Per-kernel parity: HIP kernels (through the C ABI) vs the NumPy oracle on the same seeded inputs.
 
-bf16 kernels are compared against the oracle evaluated on the SAME bf16-rounded inputs in float64, so the
-tolerance only has to cover f32 accumulation order and the final bf16 rounding of the output
-(2^-9 relative); f32 kernels are compared at f32 round-off.
+16-bit kernels (bf16, fp16) are compared against the oracle evaluated on the SAME rounded inputs in float64, so the
+tolerance only has to cover f32 accumulation order and the final rounding of the output (2^-9 relative for bf16,
+2^-12 for fp16); f32 kernels are compared at f32 round-off.  The `bf16` parameter of the tests is the element format:
+False = f32, True = bf16, "f16" = IEEE half.
 """
 import ctypes as C
 import math
@@ -27,9 +28,18 @@ def rnd(shape, seed, scale=1.0):
     return (rs.randn(*shape) * scale).astype(np.float32)
 
 
+def code(fmt):
+    """C-ABI dtype code of an element format (SIMX_F32 / SIMX_BF16 / SIMX_F16)."""
+    return 2 if fmt == "f16" else int(bool(fmt))
+
+
+def tdt(fmt):
+    return torch.float16 if fmt == "f16" else torch.bfloat16 if fmt else torch.float32
+
+
 def to_dev(a, dev, bf16=False):
     t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    return t.to(torch.bfloat16) if bf16 else t
+    return t.to(tdt(bf16)) if bf16 else t
 
 
 def back(t):
@@ -40,7 +50,7 @@ def rounded(a, bf16):
     """what the kernel actually sees, as float64"""
     if not bf16:
         return a.astype(np.float64)
-    return torch.from_numpy(a).to(torch.bfloat16).to(torch.float32).numpy().astype(np.float64)
+    return torch.from_numpy(a).to(tdt(bf16)).to(torch.float32).numpy().astype(np.float64)
 
 
 def assert_close(got, ref, rtol, atol, what=""):
@@ -51,11 +61,17 @@ def assert_close(got, ref, rtol, atol, what=""):
         what, bad.sum(), bad.size, err.max(), np.abs(ref).max(), np.unravel_index(err.argmax(), err.shape))
 
 
-TOL = {False: dict(rtol=2e-5, atol=2e-5), True: dict(rtol=1.2e-2, atol=2e-2)}
+TOL = {False: dict(rtol=2e-5, atol=2e-5), True: dict(rtol=1.2e-2, atol=2e-2), "f16": dict(rtol=1.5e-3, atol=2.5e-3)}
+FMTS = [False, True, "f16"]
+H16 = [True, "f16"]
+
+
+def pick(fmt, f32, bf16, f16):
+    return f16 if fmt == "f16" else bf16 if fmt else f32
 
 
 # ------------------------------------------------------------------------------------------ GEMM NT
-@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("bf16", FMTS)
 @pytest.mark.parametrize("M,N,K", [(200, 192, 64), (300, 768, 768), (129, 64, 128), (77, 100, 40), (1000, 3072, 768),
                                    (8300, 768, 768), (4100, 1536, 128), (8300, 768, 192), (6200, 1024, 3072),
                                    (8300, 1536, 128), (16500, 768, 64), (16500, 700, 192), (16400, 768, 768)])
@@ -70,9 +86,9 @@ def test_gemm_nt(dev, bf16, M, N, K, epi):
     dbias = to_dev(bias, dev) if bias is not None else None
     dres = to_dev(res, dev, bf16) if res is not None else None
     daux = to_dev(aux, dev, bf16) if aux is not None else None
-    dC = torch.empty(M, N, device=dev, dtype=torch.bfloat16 if bf16 else torch.float32)
+    dC = torch.empty(M, N, device=dev, dtype=tdt(bf16))
     dC2 = torch.empty_like(dC) if epi == 1 else None
-    lib.call("simx_gemm_nt", lib.stream_ptr(), int(bf16), M, N, K, lib.ptr(dA), K, lib.ptr(dB), K, lib.ptr(dC), N,
+    lib.call("simx_gemm_nt", lib.stream_ptr(), code(bf16), M, N, K, lib.ptr(dA), K, lib.ptr(dB), K, lib.ptr(dC), N,
              lib.ptr(dbias), lib.ptr(dres), N, epi, lib.ptr(daux), N, lib.ptr(dC2), N)
     torch.cuda.synchronize()
     acc = rounded(A, bf16) @ rounded(B, bf16).T
@@ -92,7 +108,8 @@ def test_gemm_nt(dev, bf16, M, N, K, epi):
 
 @pytest.mark.parametrize("M,N,K", [(32768, 768, 128), (16384, 1536, 192), (24576, 768, 768), (16384, 768, 3072), (49152, 256, 64 * 5)])
 @pytest.mark.parametrize("variant", ["bias", "bias+res", "res", "plain", "gelu", "dgelu", "bias+res+drop"])
-def test_gemm_nt_persistent(dev, M, N, K, variant):
+@pytest.mark.parametrize("fmt", H16)
+def test_gemm_nt_persistent(dev, M, N, K, variant, fmt):
     """Full-tile bf16 problems with >= 192 256x256 tiles run the persistent kernel (several tiles per workgroup when
     there are more tiles than CUs, odd and even stage counts, every epilogue variant)."""
     lib = L()
@@ -101,40 +118,40 @@ def test_gemm_nt_persistent(dev, M, N, K, variant):
     bias = rnd((N,), 3, 0.5) if "bias" in variant or epi == 1 else None
     res = rnd((M, N), 4) if "res" in variant else None
     aux = rnd((M, N), 5) if epi == 2 else None
-    dA, dB = to_dev(A, dev, True), to_dev(B, dev, True)
+    dA, dB = to_dev(A, dev, fmt), to_dev(B, dev, fmt)
     dbias = to_dev(bias, dev) if bias is not None else None
-    dres = to_dev(res, dev, True) if res is not None else None
-    daux = to_dev(aux, dev, True) if aux is not None else None
-    dC = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
-    dC2 = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16) if epi == 1 else None
-    acc = rounded(A, True) @ rounded(B, True).T
+    dres = to_dev(res, dev, fmt) if res is not None else None
+    daux = to_dev(aux, dev, fmt) if aux is not None else None
+    dC = torch.full((M, N), float("nan"), device=dev, dtype=tdt(fmt))
+    dC2 = torch.full((M, N), float("nan"), device=dev, dtype=tdt(fmt)) if epi == 1 else None
+    acc = rounded(A, fmt) @ rounded(B, fmt).T
     if bias is not None:
         acc = acc + bias.astype(np.float64)
-    t = dict(TOL[True])
+    t = dict(TOL[fmt])
     t["atol"] *= max(1.0, math.sqrt(K) * 0.25)
     if "drop" in variant:
         from simxns_amd._lib import Dropout
         d = Dropout(0.1, 77, 9)
-        lib.call("simx_gemm_nt_ex", lib.stream_ptr(), 1, M, N, K, lib.ptr(dA), K, lib.ptr(dB), K, lib.ptr(dC), N,
+        lib.call("simx_gemm_nt_ex", lib.stream_ptr(), code(fmt), M, N, K, lib.ptr(dA), K, lib.ptr(dB), K, lib.ptr(dC), N,
                  lib.ptr(dbias), lib.ptr(dres), N, epi, lib.ptr(daux), N, lib.ptr(dC2), N, C.byref(d))
         torch.cuda.synchronize()
         mult = obert.drop_multipliers(0.1, 77, 9, np.arange(M), np.arange(N))
-        assert_close(back(dC), acc * mult + rounded(res, True), what="gemm_nt persistent dropout", **t)
+        assert_close(back(dC), acc * mult + rounded(res, fmt), what="gemm_nt persistent dropout", **t)
         return
-    lib.call("simx_gemm_nt", lib.stream_ptr(), 1, M, N, K, lib.ptr(dA), K, lib.ptr(dB), K, lib.ptr(dC), N,
+    lib.call("simx_gemm_nt", lib.stream_ptr(), code(fmt), M, N, K, lib.ptr(dA), K, lib.ptr(dB), K, lib.ptr(dC), N,
              lib.ptr(dbias), lib.ptr(dres), N, epi, lib.ptr(daux), N, lib.ptr(dC2), N)
     torch.cuda.synchronize()
     if epi == 0:
-        assert_close(back(dC), acc + (rounded(res, True) if res is not None else 0.0), what="gemm_nt persistent " + variant, **t)
+        assert_close(back(dC), acc + (rounded(res, fmt) if res is not None else 0.0), what="gemm_nt persistent " + variant, **t)
     elif epi == 1:
         assert_close(back(dC), obert.gelu_grad(acc), what="gemm_nt persistent gelu derivative output", **t)
         assert_close(back(dC2), obert.gelu(acc), what="gemm_nt persistent gelu", **t)
     else:
-        assert_close(back(dC), acc * rounded(aux, True), what="gemm_nt persistent dgelu (x stored derivative)", **t)
+        assert_close(back(dC), acc * rounded(aux, fmt), what="gemm_nt persistent dgelu (x stored derivative)", **t)
 
 
 # ------------------------------------------------------------------------------------------ GEMM TN (wgrad)
-@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("bf16", FMTS)
 @pytest.mark.parametrize("M,N,K", [(64, 64, 200), (192, 64, 333), (768, 768, 5000), (3072, 768, 2100), (128, 256, 64), (72, 40, 130)])
 @pytest.mark.parametrize("accumulate", [0, 1])
 def test_gemm_tn(dev, bf16, M, N, K, accumulate):
@@ -145,7 +162,7 @@ def test_gemm_tn(dev, bf16, M, N, K, accumulate):
     dC = to_dev(C0, dev)
     wsb = int(lib.load().simx_gemm_tn_workspace_bytes(M, N, K))
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
-    lib.call("simx_gemm_tn", lib.stream_ptr(), int(bf16), M, N, K, lib.ptr(dA), M, lib.ptr(dB), N, lib.ptr(dC), N,
+    lib.call("simx_gemm_tn", lib.stream_ptr(), code(bf16), M, N, K, lib.ptr(dA), M, lib.ptr(dB), N, lib.ptr(dC), N,
              accumulate, lib.ptr(ws), wsb)
     torch.cuda.synchronize()
     ref = rounded(A, bf16).T @ rounded(B, bf16) + (C0 if accumulate else 0.0)
@@ -178,7 +195,7 @@ def test_gemm_f32_split_k(dev, M, N, K, acc):
     assert_close(back(outs[0]), back(dU), rtol=1e-5, atol=1e-5 * math.sqrt(K), what="split vs unsplit")
 
 
-@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("bf16", FMTS)
 @pytest.mark.parametrize("M,N,K", [(768, 768, 4100), (2304, 768, 2048), (512, 256, 2111), (192, 64, 333)])
 def test_gemm_tn_fused_bias_grad(dev, bf16, M, N, K):
     """wgrad + bias gradient (column sums of dY) in one call; large shapes take the 256x256 transpose-read kernel."""
@@ -189,7 +206,7 @@ def test_gemm_tn_fused_bias_grad(dev, bf16, M, N, K):
     db = torch.full((M,), 0.25, device=dev)
     wsb = int(lib.load().simx_gemm_tn_workspace_bytes(M, N, K))
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
-    lib.call("simx_gemm_tn_bias", lib.stream_ptr(), int(bf16), M, N, K, lib.ptr(dA), M, lib.ptr(dB), N, lib.ptr(dC), N,
+    lib.call("simx_gemm_tn_bias", lib.stream_ptr(), code(bf16), M, N, K, lib.ptr(dA), M, lib.ptr(dB), N, lib.ptr(dC), N,
              1, lib.ptr(ws), wsb, lib.ptr(db))
     torch.cuda.synchronize()
     assert_close(back(dC), rounded(A, bf16).T @ rounded(B, bf16), rtol=2e-5, atol=2e-5 * math.sqrt(K), what="gemm_tn")
@@ -199,10 +216,10 @@ def test_gemm_tn_fused_bias_grad(dev, bf16, M, N, K):
 def test_colsum_and_cast(dev):
     lib = L()
     x = rnd((1234, 200), 1)
-    for bf16 in (False, True):
+    for bf16 in FMTS:
         dx = to_dev(x, dev, bf16)
         out = torch.full((200,), 1.0, device=dev)
-        lib.call("simx_colsum", lib.stream_ptr(), int(bf16), 1234, 200, lib.ptr(dx), 200, lib.ptr(out), 1)
+        lib.call("simx_colsum", lib.stream_ptr(), code(bf16), 1234, 200, lib.ptr(dx), 200, lib.ptr(out), 1)
         assert_close(back(out), rounded(x, bf16).sum(0) + 1.0, rtol=1e-5, atol=1e-3, what="colsum")
     w = rnd((100, 36), 2)
     dw = to_dev(w, dev)
@@ -213,7 +230,7 @@ def test_colsum_and_cast(dev):
 
 
 # ------------------------------------------------------------------------------------------ LayerNorm family
-@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("bf16", FMTS)
 @pytest.mark.parametrize("T,H", [(37, 64), (300, 768), (50, 1024)])
 def test_ln_fwd_bwd(dev, bf16, T, H):
     lib = L()
@@ -221,13 +238,13 @@ def test_ln_fwd_bwd(dev, bf16, T, H):
     g, b = 1.0 + rnd((H,), 3, 0.1), rnd((H,), 4, 0.1)
     dz_, dy_, dg_, db_ = to_dev(z, dev, bf16), to_dev(dy, dev, bf16), to_dev(g, dev), to_dev(b, dev)
     y = torch.empty_like(dz_)
-    lib.call("simx_ln_fwd", lib.stream_ptr(), int(bf16), T, H, lib.ptr(dz_), lib.ptr(dg_), lib.ptr(db_), 1e-12, lib.ptr(y))
+    lib.call("simx_ln_fwd", lib.stream_ptr(), code(bf16), T, H, lib.ptr(dz_), lib.ptr(dg_), lib.ptr(db_), 1e-12, lib.ptr(y))
     zr = rounded(z, bf16)
     yr, cache = obert._ln_fwd(zr, g.astype(np.float64), b.astype(np.float64), 1e-12)
     assert_close(back(y), yr, what="ln_fwd", **TOL[bf16])
     dzo = torch.empty_like(dz_)
     dgam, dbet, dbias = (torch.zeros(H, device=dev) for _ in range(3))
-    lib.call("simx_ln_bwd", lib.stream_ptr(), int(bf16), T, H, lib.ptr(dz_), lib.ptr(dg_), 1e-12, lib.ptr(dy_), lib.ptr(dzo),
+    lib.call("simx_ln_bwd", lib.stream_ptr(), code(bf16), T, H, lib.ptr(dz_), lib.ptr(dg_), 1e-12, lib.ptr(dy_), lib.ptr(dzo),
              lib.ptr(dgam), lib.ptr(dbet), lib.ptr(dbias))
     dx, dg, db = obert._ln_bwd(rounded(dy, bf16), cache, g.astype(np.float64))
     assert_close(back(dzo), dx, what="ln_bwd dz", **TOL[bf16])
@@ -236,7 +253,7 @@ def test_ln_fwd_bwd(dev, bf16, T, H):
     assert_close(back(dbias), dx.sum(0), rtol=1e-4, atol=2e-3, what="ln_bwd dbias")
 
 
-@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("bf16", FMTS)
 def test_embed_ln(dev, bf16):
     lib = L()
     T, H, V, P = 211, 64, 300, 40
@@ -249,8 +266,8 @@ def test_embed_ln(dev, bf16):
     dy = rnd((T, H), 6)
     d = lambda a, bf=False: to_dev(a, dev, bf)
     dids, dpos, dword, dposw, dtype_, dg, db = d(ids), d(pos), d(word), d(posw), d(typew), d(g), d(b)
-    out = torch.empty(T, H, device=dev, dtype=torch.bfloat16 if bf16 else torch.float32)
-    lib.call("simx_embed_ln_fwd", lib.stream_ptr(), int(bf16), T, H, lib.ptr(dids), lib.ptr(dpos), lib.ptr(dword), lib.ptr(dposw),
+    out = torch.empty(T, H, device=dev, dtype=tdt(bf16))
+    lib.call("simx_embed_ln_fwd", lib.stream_ptr(), code(bf16), T, H, lib.ptr(dids), lib.ptr(dpos), lib.ptr(dword), lib.ptr(dposw),
              lib.ptr(dtype_), lib.ptr(dg), lib.ptr(db), 1e-12, lib.ptr(out))
     e = (word[ids] + posw[pos] + typew[0][None]).astype(np.float64)
     yr, cache = obert._ln_fwd(e, g.astype(np.float64), b.astype(np.float64), 1e-12)
@@ -258,7 +275,7 @@ def test_embed_ln(dev, bf16):
     ddy = d(dy, bf16)
     gw, gp, gt = torch.zeros(V, H, device=dev), torch.zeros(P, H, device=dev), torch.zeros(2, H, device=dev)
     gg, gb = torch.zeros(H, device=dev), torch.zeros(H, device=dev)
-    lib.call("simx_embed_ln_bwd", lib.stream_ptr(), int(bf16), T, H, lib.ptr(dids), lib.ptr(dpos), lib.ptr(dword), lib.ptr(dposw),
+    lib.call("simx_embed_ln_bwd", lib.stream_ptr(), code(bf16), T, H, lib.ptr(dids), lib.ptr(dpos), lib.ptr(dword), lib.ptr(dposw),
              lib.ptr(dtype_), lib.ptr(dg), 1e-12, lib.ptr(ddy), lib.ptr(gw), lib.ptr(gp), lib.ptr(gt), lib.ptr(gg), lib.ptr(gb))
     de, dgr, dbr = obert._ln_bwd(rounded(dy, bf16), cache, g.astype(np.float64))
     rw, rp = np.zeros((V, H)), np.zeros((P, H))
@@ -272,7 +289,7 @@ def test_embed_ln(dev, bf16):
     assert_close(back(gb), dbr, rtol=1e-4, atol=1e-3, what="dbeta")
 
 
-@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("bf16", FMTS)
 @pytest.mark.parametrize("lens,off", [([128, 1, 17, 33, 128, 100, 7], 0), ([40] * 70, 2), ([5, 300, 64], 0)])
 def test_embed_ln_bwd_position_major(dev, bf16, lens, off):
     """simx_embed_ln_bwd_seq (one wave per in-sequence position, register accumulation of the position gradient) against
@@ -293,7 +310,7 @@ def test_embed_ln_bwd_position_major(dev, bf16, lens, off):
     gw, gp, gt = torch.zeros(V, H, device=dev), torch.zeros(P, H, device=dev), torch.zeros(2, H, device=dev)
     gg, gb = torch.zeros(H, device=dev), torch.zeros(H, device=dev)
     keep = [d(cu), d(ids), d(pos), d(word), d(posw), d(typew), d(g), d(dy, bf16)]     # must outlive the launch
-    lib.call("simx_embed_ln_bwd_seq", lib.stream_ptr(), int(bf16), len(lens), max(lens), T, H, *[lib.ptr(t) for t in keep[:7]], 1e-12,
+    lib.call("simx_embed_ln_bwd_seq", lib.stream_ptr(), code(bf16), len(lens), max(lens), T, H, *[lib.ptr(t) for t in keep[:7]], 1e-12,
              lib.ptr(keep[7]), lib.ptr(gw), lib.ptr(gp), lib.ptr(gt), lib.ptr(gg), lib.ptr(gb), None)
     torch.cuda.synchronize()
     e = (word[ids] + posw[pos] + typew[0][None]).astype(np.float64)
@@ -350,6 +367,13 @@ def _mha_ref(qkv, lens, heads, d, dctx=None):
     (True, 1, 64, [250, 200]),                  # NKT=16
     (True, 1, 64, [300, 512, 33]),              # fwd NKT=32, bwd chunked (2 chunks of 256)
     (True, 2, 64, [700, 257, 1024, 40, 256]),   # fwd generic, bwd chunked (up to 4 chunks, ragged tails, exact multiples)
+    ("f16", 4, 16, [5, 32, 17]),                # the same kernels on IEEE half
+    ("f16", 2, 64, [128, 1, 17, 33, 16, 100]),
+    ("f16", 3, 64, [9, 32, 4, 31]),
+    ("f16", 2, 64, [160, 129, 45]),
+    ("f16", 1, 64, [250, 200]),
+    ("f16", 1, 64, [300, 512, 33]),
+    ("f16", 2, 64, [700, 257, 1024, 40, 256]),
 ])
 def test_mha_fwd_bwd(dev, bf16, heads, d, lens):
     lib = L()
@@ -357,18 +381,18 @@ def test_mha_fwd_bwd(dev, bf16, heads, d, lens):
     qkv, dctx = rnd((T, 3 * H), 1, 1.0), rnd((T, H), 2)
     cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
     dq_, dd_, dcu = to_dev(qkv, dev, bf16), to_dev(dctx, dev, bf16), to_dev(cu, dev)
-    adt = torch.bfloat16 if bf16 else torch.float32
+    adt = tdt(bf16)
     ctx = torch.zeros(T, H, device=dev, dtype=adt)
     lse = torch.zeros(heads, T, device=dev)
-    lib.call("simx_mha_fwd", lib.stream_ptr(), int(bf16), len(lens), heads, d, lib.ptr(dcu), max(lens), T, lib.ptr(dq_), lib.ptr(ctx), lib.ptr(lse))
+    lib.call("simx_mha_fwd", lib.stream_ptr(), code(bf16), len(lens), heads, d, lib.ptr(dcu), max(lens), T, lib.ptr(dq_), lib.ptr(ctx), lib.ptr(lse))
     rc, rl, rdq = _mha_ref(rounded(qkv, bf16), lens, heads, d, rounded(dctx, bf16))
-    tol = dict(rtol=2e-5, atol=2e-5) if not bf16 else dict(rtol=2e-2, atol=2e-2)
+    tol = pick(bf16, dict(rtol=2e-5, atol=2e-5), dict(rtol=2e-2, atol=2e-2), dict(rtol=2.5e-3, atol=2.5e-3))
     assert_close(back(ctx), rc, what="mha ctx", **tol)
-    assert_close(back(lse), rl, rtol=1e-5, atol=2e-5 if not bf16 else 5e-3, what="mha lse")
+    assert_close(back(lse), rl, rtol=1e-5, atol=pick(bf16, 2e-5, 5e-3, 1e-3), what="mha lse")
     dqkv = torch.zeros(T, 3 * H, device=dev, dtype=adt)
-    lib.call("simx_mha_bwd", lib.stream_ptr(), int(bf16), len(lens), heads, d, lib.ptr(dcu), max(lens), T, lib.ptr(dq_), lib.ptr(ctx),
+    lib.call("simx_mha_bwd", lib.stream_ptr(), code(bf16), len(lens), heads, d, lib.ptr(dcu), max(lens), T, lib.ptr(dq_), lib.ptr(ctx),
              lib.ptr(lse), lib.ptr(dd_), lib.ptr(dqkv))
-    tolb = dict(rtol=1e-4, atol=1e-4) if not bf16 else dict(rtol=3e-2, atol=6e-2)
+    tolb = pick(bf16, dict(rtol=1e-4, atol=1e-4), dict(rtol=3e-2, atol=6e-2), dict(rtol=4e-3, atol=8e-3))
     assert_close(back(dqkv), rdq, what="mha dqkv", **tolb)
 
 
@@ -377,6 +401,8 @@ def test_mha_fwd_bwd(dev, bf16, heads, d, lens):
     (False, 2, 64, [40, 7, 130]),
     (True, 2, 64, [128, 1, 17, 33, 16, 100]),
     (True, 12, 64, [160, 129, 45, 300]),
+    ("f16", 2, 64, [128, 1, 17, 33, 16, 100]),
+    ("f16", 12, 64, [160, 129, 45, 300]),
 ])
 def test_mha_single_query(dev, bf16, heads, d, lens):
     """The [CLS]-only last layer's attention (simx_mha_cls_fwd / _bwd): token 0 of every sequence is the only query.
@@ -389,21 +415,21 @@ def test_mha_single_query(dev, bf16, heads, d, lens):
     qc = qkv[first, :H].copy()
     qkv_in = qkv.copy()
     qkv_in[:, :H] = 7.0                          # the Q columns of the packed rows must not be read
-    adt = torch.bfloat16 if bf16 else torch.float32
+    adt = tdt(bf16)
     d_qkv, d_qc, d_dcc, dcu = to_dev(qkv_in, dev, bf16), to_dev(qc, dev, bf16), to_dev(dcc, dev, bf16), to_dev(cu, dev)
     ctxc = torch.zeros(n, H, device=dev, dtype=adt)
-    lib.call("simx_mha_cls_fwd", lib.stream_ptr(), int(bf16), n, heads, d, lib.ptr(dcu), max(lens), T, lib.ptr(d_qc), lib.ptr(d_qkv),
+    lib.call("simx_mha_cls_fwd", lib.stream_ptr(), code(bf16), n, heads, d, lib.ptr(dcu), max(lens), T, lib.ptr(d_qc), lib.ptr(d_qkv),
              lib.ptr(ctxc), None)
     dctx = np.zeros((T, H))
     dctx[first] = rounded(dcc, bf16)
     rc, _, rdq = _mha_ref(rounded(qkv, bf16), lens, heads, d, dctx)
-    tol = dict(rtol=2e-5, atol=2e-5) if not bf16 else dict(rtol=2e-2, atol=2e-2)
+    tol = pick(bf16, dict(rtol=2e-5, atol=2e-5), dict(rtol=2e-2, atol=2e-2), dict(rtol=2.5e-3, atol=2.5e-3))
     assert_close(back(ctxc), rc[first], what="cls ctx", **tol)
     dqc = torch.zeros(n, H, device=dev, dtype=adt)
     dqkv = torch.full((T, 3 * H), 3.0, device=dev, dtype=adt)
-    lib.call("simx_mha_cls_bwd", lib.stream_ptr(), int(bf16), n, heads, d, lib.ptr(dcu), max(lens), T, lib.ptr(d_qc), lib.ptr(d_qkv),
+    lib.call("simx_mha_cls_bwd", lib.stream_ptr(), code(bf16), n, heads, d, lib.ptr(dcu), max(lens), T, lib.ptr(d_qc), lib.ptr(d_qkv),
              lib.ptr(d_dcc), lib.ptr(dqc), lib.ptr(dqkv), None)
-    tolb = dict(rtol=1e-4, atol=1e-4) if not bf16 else dict(rtol=3e-2, atol=6e-2)
+    tolb = pick(bf16, dict(rtol=1e-4, atol=1e-4), dict(rtol=3e-2, atol=6e-2), dict(rtol=4e-3, atol=8e-3))
     got = back(dqkv)
     assert_close(back(dqc), rdq[first, :H], what="cls dq", **tolb)
     assert_close(got[:, H:], rdq[:, H:], what="cls dk dv", **tolb)

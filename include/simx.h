@@ -44,7 +44,14 @@ typedef void* simx_stream_t;
 
 enum { SIMX_OK = 0, SIMX_ERR_BAD_SHAPE = -1, SIMX_ERR_BAD_DTYPE = -2, SIMX_ERR_WORKSPACE = -3,
        SIMX_ERR_HIP = -4, SIMX_ERR_UNSUPPORTED = -5 };
-enum { SIMX_F32 = 0, SIMX_BF16 = 1, SIMX_F16 = 2 };
+enum { SIMX_F32 = 0, SIMX_BF16 = 1, SIMX_F16 = 2,
+       /* GEMM entry points only (simx_gemm_nt*, simx_gemm_tn*): f32 tensors, products on the 16-bit matrix cores from an
+        * on-the-fly split x = hi + lo of every operand element (hi.hi + hi.lo + lo.hi in f32 accumulators, three MFMAs per
+        * product; csrc/gemm_x3.hip).  _H: halves in IEEE half -- ~2^-20..2^-22 relative for weights / O(1) activations, an
+        * absolute floor of 2^-25 per element: the forward GEMMs of the fp32 engine.  _B: halves in bf16 -- 2^-17 relative at
+        * any magnitude: its backward GEMMs (gradient operands span 1e-2..1e-9).  Shapes the split kernels do not take run the
+        * exact f32 kernel. */
+       SIMX_F32_SPLIT_H = 3, SIMX_F32_SPLIT_B = 4 };
 
 int simx_version(void);
 const char* simx_last_error(void);
@@ -303,6 +310,10 @@ typedef struct simx_bert_cfg {
    * when every kernel that touches the tensor has the form), 1 = token-major pinned.  A forward and its backward must pass
    * the same value -- they then make the same choice (it depends on nothing but cfg, T, max_len). */
   int32_t qkv_layout;
+  /* SIMX_F32 only.  0: the dense GEMMs run as SIMX_F32_SPLIT_H (forward) / SIMX_F32_SPLIT_B (backward) -- the fp32 engine's
+   * default, ~4x the exact kernel's rate at parity two orders inside the 1e-3 tolerance; 1: exact f32 products
+   * (v_mfma_f32_32x32x2_f32) everywhere. */
+  int32_t f32_gemm;
   /* SIMX_F16 backward: device pointer to {S, 1/S} (the loss scale, "gradient scale" above) or NULL = 1. */
   const float* grad_scale;
 } simx_bert_cfg;

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsimx_hip.so")
 
-SIMX_F32, SIMX_BF16, SIMX_F16 = 0, 1, 2
+SIMX_F32, SIMX_BF16, SIMX_F16, SIMX_F32_SPLIT_H, SIMX_F32_SPLIT_B = 0, 1, 2, 3, 4
 EPI_NONE, EPI_GELU, EPI_DGELU = 0, 1, 2
 LOSS_KL, LOSS_WIKI, LOSS_CEKD, LOSS_CE = 0, 1, 2, 3
 (P_WORD, P_POS, P_TYPE, P_EMB_LN_G, P_EMB_LN_B, P_WQKV, P_BQKV, P_WO, P_BO, P_LN1_G, P_LN1_B,
@@ -27,7 +27,7 @@ class BertCfg(C.Structure):
                 ("inter", C.c_int32), ("vocab", C.c_int32), ("max_pos", C.c_int32), ("type_vocab", C.c_int32),
                 ("eps", C.c_float), ("hidden_dropout", C.c_float), ("attn_dropout", C.c_float), ("dropout_seed", C.c_uint32),
                 ("cls_only_last_layer", C.c_int32), ("grad_checkpoint", C.c_int32), ("qkv_layout", C.c_int32),
-                ("grad_scale", C.c_void_p)]
+                ("f32_gemm", C.c_int32), ("grad_scale", C.c_void_p)]
 
 
 class Dropout(C.Structure):

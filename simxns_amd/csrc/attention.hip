@@ -917,6 +917,8 @@ extern "C" int simx_mha_fwd_hm(simx_stream_t stream, int dtype, int nseq, int he
     SIMX_CHECK_LAUNCH("mha_fwd_h16");
     return SIMX_OK;
   }
+  if (dtype == SIMX_F32 && simx_mha_f32_ok(d, max_len))
+    return simx_mha_fwd_f32(s, nseq, heads, cu, max_len, T, (const float*)qkv, (float*)ctx, lse, scale, drop);
   const size_t lds = (size_t)(4 * 128 + 4 * max_len) * sizeof(float);
   dim3 grid(nseq * heads, cdiv(max_len, 4));
 #define LS(TT)                                                                                                       \
@@ -985,6 +987,9 @@ extern "C" int simx_mha_bwd_hm(simx_stream_t stream, int dtype, int nseq, int he
     SIMX_CHECK_LAUNCH("mha_bwd_long");
     return SIMX_OK;
   }
+  if (dtype == SIMX_F32 && simx_mha_f32_ok(d, max_len))
+    return simx_mha_bwd_f32(s, nseq, heads, cu, max_len, T, (const float*)qkv, (const float*)ctx, lse, (const float*)dctx, (float*)dqkv, scale,
+                            drop);
   const size_t lds = (size_t)(8 * 128 + 8 * max_len) * sizeof(float);
   dim3 grid(nseq * heads, cdiv(max_len, 4));
 #define LS(TT, MODE)                                                                                                 \

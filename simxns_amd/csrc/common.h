@@ -247,7 +247,23 @@ __device__ __forceinline__ void erf_and_gauss(float u, float& erf_x, float& gaus
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline bool simx_is16(int dtype) { return dtype == SIMX_BF16 || dtype == SIMX_F16; }
 static inline bool simx_dtype_ok(int dtype) { return dtype == SIMX_F32 || simx_is16(dtype); }
-static inline size_t simx_esz(int dtype) { return dtype == SIMX_F32 ? 4 : 2; }
+static inline bool simx_is_f32(int dtype) { return dtype == SIMX_F32 || dtype == SIMX_F32_SPLIT_H || dtype == SIMX_F32_SPLIT_B; }
+static inline size_t simx_esz(int dtype) { return simx_is_f32(dtype) ? 4 : 2; }
+// csrc/attention_f32.hip: f32 attention on the f32 matrix cores (head size 64, sequences <= 256)
+bool simx_mha_f32_ok(int d, int max_len);
+int simx_mha_fwd_f32(hipStream_t s, int nseq, int heads, const int32_t* cu, int max_len, int T, const float* qkv, float* ctx, float* lse,
+                     float scale, DropCtx drop);
+int simx_mha_bwd_f32(hipStream_t s, int nseq, int heads, const int32_t* cu, int max_len, int T, const float* qkv, const float* ctx,
+                     const float* lse, const float* dctx, float* dqkv, float scale, DropCtx drop);
+// csrc/gemm_x3.hip: f32 GEMMs on the 16-bit matrix cores (fmt = SIMX_F16 / SIMX_BF16: the format of the split halves)
+bool simx_x3_nt_ok(int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* C, int ldc, const float* bias,
+                   const float* res, int ldr, const float* aux, int ldaux, const float* C2, int ldc2);
+int simx_x3_gemm_nt(hipStream_t s, int fmt, int epi, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                    const float* bias, const float* res, int ldr, const float* aux, int ldaux, float* C2, int ldc2, DropCtx drop);
+bool simx_x3_tn_ok(int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* C, int ldc);
+size_t simx_x3_tn_workspace_bytes(int M, int N, int K);
+int simx_x3_gemm_tn(hipStream_t s, int fmt, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                    int accumulate, void* ws, size_t ws_bytes);
 // run STMT with TT bound to the element type of `dtype` (the three activation types of the engine)
 #define SIMX_DISPATCH3(DTYPE, TT, ...)                                   \
   do {                                                                   \

@@ -32,7 +32,7 @@ static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline size_t esz(int dtype) { return dtype == SIMX_F32 ? 4 : 2; }
 
 static bool cfg_ok(const simx_bert_cfg* c) {
-  return c && simx_dtype_ok(c->dtype) && c->qkv_layout >= 0 && c->qkv_layout <= 1 && c->layers > 0 && c->hidden > 0 && c->heads > 0 &&
+  return c && simx_dtype_ok(c->dtype) && c->qkv_layout >= 0 && c->qkv_layout <= 1 && c->f32_gemm >= 0 && c->f32_gemm <= 1 && c->layers > 0 && c->hidden > 0 && c->heads > 0 &&
          c->hidden % c->heads == 0 && c->hidden % 4 == 0 && c->inter > 0 && c->inter % 4 == 0 && c->vocab > 0 &&
          c->max_pos > 0 && c->type_vocab > 0 && c->hidden <= 1024;
 }
@@ -265,6 +265,9 @@ static int layer_fwd(hipStream_t stream, const simx_bert_cfg* c, const float* pa
   const WLayer w = wlayer(c, params, wcache, l);
   const simx_dropout d1 = drop_of(c, l, 1), d2 = drop_of(c, l, 2), d3 = drop_of(c, l, 3);
   const int hm = hm_rows_for(c, T, Tp, max_len);
+  // fp32 engine: the dense GEMMs run on the 16-bit matrix cores from fp16 hi + lo splits of their f32 operands unless the
+  // config asks for exact f32 products (simx.h SIMX_F32_SPLIT_H; every other kernel of the layer is plain f32)
+  const int gdt = (dt == SIMX_F32 && c->f32_gemm == 0) ? SIMX_F32_SPLIT_H : dt;
   if (cls_form) {
     // Last layer, [CLS] rows only: row s of every [nseq, .] buffer below is the sequence's token 0 (row cu[s] of the
     // full tensors).  Only K and V are projected for every token; Q, the attention core and everything after it run
@@ -278,18 +281,18 @@ static int layer_fwd(hipStream_t stream, const simx_bert_cfg* c, const float* pa
       RUN(simx_gemm_nt_hm(stream, dt, Tp, 2 * H, H, x, H, w.wqkv + (size_t)H * H * e, H, a.qkv + (size_t)c->heads * hm * 64 * e, 64,
                           off(l, SIMX_P_BQKV) + H, nullptr, 0, nullptr, 0, hm));
     else
-      RUN(simx_gemm_nt(stream, dt, Tp, 2 * H, H, x, H, w.wqkv + (size_t)H * H * e, H, a.qkv + (size_t)H * e, 3 * H,
+      RUN(simx_gemm_nt(stream, gdt, Tp, 2 * H, H, x, H, w.wqkv + (size_t)H * H * e, H, a.qkv + (size_t)H * e, 3 * H,
                        off(l, SIMX_P_BQKV) + H, nullptr, 0, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
     RUN(simx_rows_copy(stream, dt, dt, nseq, H, cu, nullptr, x, ytmp));
-    RUN(simx_gemm_nt(stream, dt, nseq, H, H, ytmp, H, w.wqkv, H, qc, H, off(l, SIMX_P_BQKV), nullptr, 0, SIMX_EPI_NONE, nullptr, 0,
+    RUN(simx_gemm_nt(stream, gdt, nseq, H, H, ytmp, H, w.wqkv, H, qc, H, off(l, SIMX_P_BQKV), nullptr, 0, SIMX_EPI_NONE, nullptr, 0,
                      nullptr, 0));
     RUN(simx_mha_cls_fwd_hm(stream, dt, nseq, c->heads, d, cu, max_len, T, qc, a.qkv, ctxc, &d3, hm));
-    RUN(simx_gemm_nt(stream, dt, nseq, H, H, ctxc, H, w.wo, H, ytmp, H, off(l, SIMX_P_BO), nullptr, 0, SIMX_EPI_NONE, nullptr, 0,
+    RUN(simx_gemm_nt(stream, gdt, nseq, H, H, ctxc, H, w.wo, H, ytmp, H, off(l, SIMX_P_BO), nullptr, 0, SIMX_EPI_NONE, nullptr, 0,
                      nullptr, 0));
     RUN(simx_drop_residual_rows(stream, dt, nseq, H, ytmp, x, cu, cu, &d1, a.z1));
     RUN(simx_ln_fwd(stream, dt, nseq, H, a.z1, off(l, SIMX_P_LN1_G), off(l, SIMX_P_LN1_B), c->eps, a.x1));
-    RUN(simx_gemm_nt(stream, dt, nseq, F, H, a.x1, H, w.w1, H, a.u, F, off(l, SIMX_P_B1), nullptr, 0, SIMX_EPI_GELU, nullptr, 0, a.h, F));
-    RUN(simx_gemm_nt(stream, dt, nseq, H, F, a.h, F, w.w2, F, ytmp, H, off(l, SIMX_P_B2), nullptr, 0, SIMX_EPI_NONE, nullptr, 0,
+    RUN(simx_gemm_nt(stream, gdt, nseq, F, H, a.x1, H, w.w1, H, a.u, F, off(l, SIMX_P_B1), nullptr, 0, SIMX_EPI_GELU, nullptr, 0, a.h, F));
+    RUN(simx_gemm_nt(stream, gdt, nseq, H, F, a.h, F, w.w2, F, ytmp, H, off(l, SIMX_P_B2), nullptr, 0, SIMX_EPI_NONE, nullptr, 0,
                      nullptr, 0));
     RUN(simx_drop_residual_rows(stream, dt, nseq, H, ytmp, a.x1, nullptr, cu, &d2, a.z2));
     RUN(simx_ln_fwd(stream, dt, nseq, H, a.z2, off(l, SIMX_P_LN2_G), off(l, SIMX_P_LN2_B), c->eps, a.xout));
@@ -299,15 +302,15 @@ static int layer_fwd(hipStream_t stream, const simx_bert_cfg* c, const float* pa
   if (hm)
     RUN(simx_gemm_nt_hm(stream, dt, Tp, 3 * H, H, x, H, w.wqkv, H, a.qkv, 64, off(l, SIMX_P_BQKV), nullptr, 0, nullptr, 0, hm));
   else
-    RUN(simx_gemm_nt(stream, dt, Tp, 3 * H, H, x, H, w.wqkv, H, a.qkv, 3 * H, off(l, SIMX_P_BQKV), nullptr, 0, SIMX_EPI_NONE,
+    RUN(simx_gemm_nt(stream, gdt, Tp, 3 * H, H, x, H, w.wqkv, H, a.qkv, 3 * H, off(l, SIMX_P_BQKV), nullptr, 0, SIMX_EPI_NONE,
                      nullptr, 0, nullptr, 0));
   RUN(simx_mha_fwd_hm(stream, dt, nseq, c->heads, d, cu, max_len, T, a.qkv, a.ctx, a.lse, &d3, hm));
-  RUN(simx_gemm_nt_ex(stream, dt, Tp, H, H, a.ctx, H, w.wo, H, a.z1, H, off(l, SIMX_P_BO), x, H, SIMX_EPI_NONE, nullptr, 0,
+  RUN(simx_gemm_nt_ex(stream, gdt, Tp, H, H, a.ctx, H, w.wo, H, a.z1, H, off(l, SIMX_P_BO), x, H, SIMX_EPI_NONE, nullptr, 0,
                       nullptr, 0, &d1));
   RUN(simx_ln_fwd(stream, dt, T, H, a.z1, off(l, SIMX_P_LN1_G), off(l, SIMX_P_LN1_B), c->eps, a.x1));
-  RUN(simx_gemm_nt(stream, dt, Tp, F, H, a.x1, H, w.w1, H, a.u, F, off(l, SIMX_P_B1), nullptr, 0,
+  RUN(simx_gemm_nt(stream, gdt, Tp, F, H, a.x1, H, w.w1, H, a.u, F, off(l, SIMX_P_B1), nullptr, 0,
                    keep ? SIMX_EPI_GELU : SIMX_EPI_GELU_INFER, nullptr, 0, a.h, F));   // no backward from this slot: u has no reader
-  RUN(simx_gemm_nt_ex(stream, dt, Tp, H, F, a.h, F, w.w2, F, a.z2, H, off(l, SIMX_P_B2), a.x1, H, SIMX_EPI_NONE, nullptr, 0,
+  RUN(simx_gemm_nt_ex(stream, gdt, Tp, H, F, a.h, F, w.w2, F, a.z2, H, off(l, SIMX_P_B2), a.x1, H, SIMX_EPI_NONE, nullptr, 0,
                       nullptr, 0, &d2));
   RUN(simx_ln_fwd(stream, dt, T, H, a.z2, off(l, SIMX_P_LN2_G), off(l, SIMX_P_LN2_B), c->eps, a.xout));
   return SIMX_OK;
@@ -402,6 +405,8 @@ extern "C" int simx_bert_bwd_range(simx_stream_t stream, const simx_bert_cfg* c,
   // fp16 engine: activation gradients travel multiplied by the loss scale S (gs = {S, 1/S} on the device); the kernels that
   // accumulate into `grads` multiply by 1/S, so `grads` holds true gradients (simx.h "gradient scale")
   const float* gs = dt == SIMX_F16 ? c->grad_scale : nullptr;
+  // fp32 engine: dgrad / wgrad GEMMs from bf16 hi + lo splits (gradients need f32's exponent range; simx.h SIMX_F32_SPLIT_B)
+  const int gdb = (dt == SIMX_F32 && c->f32_gemm == 0) ? SIMX_F32_SPLIT_B : dt;
 
   int l_top = layer_hi;
   if (top && c->cls_only_last_layer) {
@@ -421,21 +426,21 @@ extern "C" int simx_bert_bwd_range(simx_stream_t stream, const simx_bert_cfg* c,
     RUN(simx_rows_copy_gs(stream, SIMX_F32, dt, nseq, H, nullptr, nullptr, dcls, bufB, gs));
     RUN(simx_ln_bwd_gs(stream, dt, nseq, H, a.z2, off(l, SIMX_P_LN2_G), c->eps, bufB, bufA, hd ? bufC : nullptr,
                           goff(l, SIMX_P_LN2_G), goff(l, SIMX_P_LN2_B), goff(l, SIMX_P_B2), &d2, cu, gs));
-    RUN(simx_gemm_nt(stream, dt, nseq, F, H, dzm, H, w.w2T, H, du, F, nullptr, nullptr, 0, SIMX_EPI_DGELU, a.u, F, nullptr, 0));
-    RUN(simx_gemm_tn_gs(stream, dt, H, F, nseq, dzm, H, a.h, F, goff(l, SIMX_P_W2), F, 1, tnws, tnws_bytes, nullptr, 0, gs));
-    RUN(simx_gemm_nt(stream, dt, nseq, H, F, du, F, w.w1T, F, bufB, H, nullptr, bufA, H, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
-    RUN(simx_gemm_tn_gs(stream, dt, F, H, nseq, du, F, a.x1, H, goff(l, SIMX_P_W1), H, 1, tnws, tnws_bytes, goff(l, SIMX_P_B1), 0, gs));
+    RUN(simx_gemm_nt(stream, gdb, nseq, F, H, dzm, H, w.w2T, H, du, F, nullptr, nullptr, 0, SIMX_EPI_DGELU, a.u, F, nullptr, 0));
+    RUN(simx_gemm_tn_gs(stream, gdb, H, F, nseq, dzm, H, a.h, F, goff(l, SIMX_P_W2), F, 1, tnws, tnws_bytes, nullptr, 0, gs));
+    RUN(simx_gemm_nt(stream, gdb, nseq, H, F, du, F, w.w1T, F, bufB, H, nullptr, bufA, H, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
+    RUN(simx_gemm_tn_gs(stream, gdb, F, H, nseq, du, F, a.x1, H, goff(l, SIMX_P_W1), H, 1, tnws, tnws_bytes, goff(l, SIMX_P_B1), 0, gs));
     RUN(simx_ln_bwd_gs(stream, dt, nseq, H, a.z1, off(l, SIMX_P_LN1_G), c->eps, bufB, bufA, hd ? bufC : nullptr,
                           goff(l, SIMX_P_LN1_G), goff(l, SIMX_P_LN1_B), goff(l, SIMX_P_BO), &d1, cu, gs));
     // e1 = dctx (gradient of the attention context, [CLS] rows), bufA[0:nseq] = gradient of the residual branch
-    RUN(simx_gemm_nt(stream, dt, nseq, H, H, dzm, H, w.woT, H, e1, H, nullptr, nullptr, 0, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
-    RUN(simx_gemm_tn_gs(stream, dt, H, H, nseq, dzm, H, ctxc, H, goff(l, SIMX_P_WO), H, 1, tnws, tnws_bytes, nullptr, 0, gs));
+    RUN(simx_gemm_nt(stream, gdb, nseq, H, H, dzm, H, w.woT, H, e1, H, nullptr, nullptr, 0, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
+    RUN(simx_gemm_tn_gs(stream, gdb, H, H, nseq, dzm, H, ctxc, H, goff(l, SIMX_P_WO), H, 1, tnws, tnws_bytes, nullptr, 0, gs));
     // attention core for the one query per sequence: e0 = dq [nseq,H]; dK, dV for every token -> dqkv[:, H:3H]
     RUN(simx_mha_cls_bwd_hm(stream, dt, nseq, c->heads, d, cu, max_len, T, qc, a.qkv, e1, e0, dqkv, &d3, hm));
     // Q projection ([CLS] rows): dWq, dbq, and dx = dq . Wq + (residual-branch gradient), still compact
     RUN(simx_rows_copy(stream, dt, dt, nseq, H, cu, nullptr, xin, e2));
-    RUN(simx_gemm_tn_gs(stream, dt, H, H, nseq, e0, H, e2, H, goff(l, SIMX_P_WQKV), H, 1, tnws, tnws_bytes, goff(l, SIMX_P_BQKV), 0, gs));
-    RUN(simx_gemm_nt(stream, dt, nseq, H, H, e0, H, w.wqkvT, 3 * H, e1, H, nullptr, bufA, H, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
+    RUN(simx_gemm_tn_gs(stream, gdb, H, H, nseq, e0, H, e2, H, goff(l, SIMX_P_WQKV), H, 1, tnws, tnws_bytes, goff(l, SIMX_P_BQKV), 0, gs));
+    RUN(simx_gemm_nt(stream, gdb, nseq, H, H, e0, H, w.wqkvT, 3 * H, e1, H, nullptr, bufA, H, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
     // back to full tensors: that gradient is zero outside the [CLS] rows
     if (hipMemsetAsync(bufA, 0, (size_t)T * H * e, (hipStream_t)stream) != hipSuccess) {
       simx_set_error("bert_bwd: memset failed");
@@ -446,12 +451,12 @@ extern "C" int simx_bert_bwd_range(simx_stream_t stream, const simx_bert_cfg* c,
     if (hm) {
       const char* dkv = dqkv + (size_t)c->heads * hm * 64 * e;                  // planes [heads, 3*heads)
       RUN(simx_gemm_nt_hm(stream, dt, Tp, H, 2 * H, dkv, 64, w.wqkvT + (size_t)H * e, 3 * H, bufB, H, nullptr, bufA, H, nullptr, hm, 0));
-      RUN(simx_gemm_tn_gs(stream, dt, 2 * H, H, T, dkv, 0, xin, H, goff(l, SIMX_P_WQKV) + (size_t)H * H, H, 1, tnws, tnws_bytes,
+      RUN(simx_gemm_tn_gs(stream, gdb, 2 * H, H, T, dkv, 0, xin, H, goff(l, SIMX_P_WQKV) + (size_t)H * H, H, 1, tnws, tnws_bytes,
                           goff(l, SIMX_P_BQKV) + H, hm, gs));
     } else {
-      RUN(simx_gemm_nt(stream, dt, Tp, H, 2 * H, dqkv + (size_t)H * e, 3 * H, w.wqkvT + (size_t)H * e, 3 * H, bufB, H, nullptr, bufA, H,
+      RUN(simx_gemm_nt(stream, gdb, Tp, H, 2 * H, dqkv + (size_t)H * e, 3 * H, w.wqkvT + (size_t)H * e, 3 * H, bufB, H, nullptr, bufA, H,
                        SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
-      RUN(simx_gemm_tn_gs(stream, dt, 2 * H, H, T, dqkv + (size_t)H * e, 3 * H, xin, H, goff(l, SIMX_P_WQKV) + (size_t)H * H, H, 1, tnws, tnws_bytes, goff(l, SIMX_P_BQKV) + H, 0, gs));
+      RUN(simx_gemm_tn_gs(stream, gdb, 2 * H, H, T, dqkv + (size_t)H * e, 3 * H, xin, H, goff(l, SIMX_P_WQKV) + (size_t)H * H, H, 1, tnws, tnws_bytes, goff(l, SIMX_P_BQKV) + H, 0, gs));
     }
     --l_top;
   } else if (top && dhidden) {
@@ -473,26 +478,26 @@ extern "C" int simx_bert_bwd_range(simx_stream_t stream, const simx_bert_cfg* c,
     RUN(simx_ln_bwd_gs(stream, dt, T, H, a.z2, off(l, SIMX_P_LN2_G), c->eps, bufB, bufA, hd ? bufC : nullptr, goff(l, SIMX_P_LN2_G),
                        goff(l, SIMX_P_LN2_B), goff(l, SIMX_P_B2), &d2, nullptr, gs));
     // du = (dz2m . W2) * gelu'(u)
-    RUN(simx_gemm_nt(stream, dt, Tp, F, H, dzm, H, w.w2T, H, du, F, nullptr, nullptr, 0, SIMX_EPI_DGELU, a.u, F, nullptr, 0));
-    RUN(simx_gemm_tn_gs(stream, dt, H, F, T, dzm, H, a.h, F, goff(l, SIMX_P_W2), F, 1, tnws, tnws_bytes, nullptr, 0, gs));
+    RUN(simx_gemm_nt(stream, gdb, Tp, F, H, dzm, H, w.w2T, H, du, F, nullptr, nullptr, 0, SIMX_EPI_DGELU, a.u, F, nullptr, 0));
+    RUN(simx_gemm_tn_gs(stream, gdb, H, F, T, dzm, H, a.h, F, goff(l, SIMX_P_W2), F, 1, tnws, tnws_bytes, nullptr, 0, gs));
     // dx1 = du . W1 + dz2
-    RUN(simx_gemm_nt(stream, dt, Tp, H, F, du, F, w.w1T, F, bufB, H, nullptr, bufA, H, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
-    RUN(simx_gemm_tn_gs(stream, dt, F, H, T, du, F, a.x1, H, goff(l, SIMX_P_W1), H, 1, tnws, tnws_bytes, goff(l, SIMX_P_B1), 0, gs));
+    RUN(simx_gemm_nt(stream, gdb, Tp, H, F, du, F, w.w1T, F, bufB, H, nullptr, bufA, H, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
+    RUN(simx_gemm_tn_gs(stream, gdb, F, H, T, du, F, a.x1, H, goff(l, SIMX_P_W1), H, 1, tnws, tnws_bytes, goff(l, SIMX_P_B1), 0, gs));
     // attention-output LayerNorm : dz1, dgamma1, dbeta1, dbo
     RUN(simx_ln_bwd_gs(stream, dt, T, H, a.z1, off(l, SIMX_P_LN1_G), c->eps, bufB, bufA, hd ? bufC : nullptr, goff(l, SIMX_P_LN1_G),
                        goff(l, SIMX_P_LN1_B), goff(l, SIMX_P_BO), &d1, nullptr, gs));
     // dctx = dz1m . Wo
-    RUN(simx_gemm_nt(stream, dt, Tp, H, H, dzm, H, w.woT, H, bufB, H, nullptr, nullptr, 0, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
-    RUN(simx_gemm_tn_gs(stream, dt, H, H, T, dzm, H, a.ctx, H, goff(l, SIMX_P_WO), H, 1, tnws, tnws_bytes, nullptr, 0, gs));
+    RUN(simx_gemm_nt(stream, gdb, Tp, H, H, dzm, H, w.woT, H, bufB, H, nullptr, nullptr, 0, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
+    RUN(simx_gemm_tn_gs(stream, gdb, H, H, T, dzm, H, a.ctx, H, goff(l, SIMX_P_WO), H, 1, tnws, tnws_bytes, nullptr, 0, gs));
     RUN(simx_mha_bwd_hm(stream, dt, nseq, c->heads, d, cu, max_len, T, a.qkv, a.ctx, a.lse, bufB, dqkv, &d3, hm));
     // dx = dqkv . Wqkv + dz1
     if (hm) {
       RUN(simx_gemm_nt_hm(stream, dt, Tp, H, 3 * H, dqkv, 64, w.wqkvT, 3 * H, bufB, H, nullptr, bufA, H, nullptr, hm, 0));
-      RUN(simx_gemm_tn_gs(stream, dt, 3 * H, H, T, dqkv, 0, xin, H, goff(l, SIMX_P_WQKV), H, 1, tnws, tnws_bytes, goff(l, SIMX_P_BQKV), hm, gs));
+      RUN(simx_gemm_tn_gs(stream, gdb, 3 * H, H, T, dqkv, 0, xin, H, goff(l, SIMX_P_WQKV), H, 1, tnws, tnws_bytes, goff(l, SIMX_P_BQKV), hm, gs));
     } else {
-      RUN(simx_gemm_nt(stream, dt, Tp, H, 3 * H, dqkv, 3 * H, w.wqkvT, 3 * H, bufB, H, nullptr, bufA, H, SIMX_EPI_NONE, nullptr, 0,
+      RUN(simx_gemm_nt(stream, gdb, Tp, H, 3 * H, dqkv, 3 * H, w.wqkvT, 3 * H, bufB, H, nullptr, bufA, H, SIMX_EPI_NONE, nullptr, 0,
                        nullptr, 0));
-      RUN(simx_gemm_tn_gs(stream, dt, 3 * H, H, T, dqkv, 3 * H, xin, H, goff(l, SIMX_P_WQKV), H, 1, tnws, tnws_bytes,
+      RUN(simx_gemm_tn_gs(stream, gdb, 3 * H, H, T, dqkv, 3 * H, xin, H, goff(l, SIMX_P_WQKV), H, 1, tnws, tnws_bytes,
                           goff(l, SIMX_P_BQKV), 0, gs));
     }
   }

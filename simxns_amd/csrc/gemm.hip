@@ -1538,10 +1538,15 @@ extern "C" int simx_gemm_nt_ex(simx_stream_t stream, int dtype, int M, int N, in
   SIMX_REQUIRE(epilogue >= 0 && epilogue <= 2, SIMX_ERR_UNSUPPORTED, "gemm_nt: epilogue %d", epilogue);
   SIMX_REQUIRE(epilogue != SIMX_EPI_GELU || C2, SIMX_ERR_BAD_SHAPE, "gemm_nt: GELU epilogue needs C2");
   SIMX_REQUIRE(epilogue != SIMX_EPI_DGELU || aux, SIMX_ERR_BAD_SHAPE, "gemm_nt: DGELU epilogue needs aux");
-  if (dtype == SIMX_F32)
+  if (simx_is_f32(dtype)) {
+    if (dtype != SIMX_F32 && simx_x3_nt_ok(M, N, K, (const float*)A, lda, (const float*)B, ldb, (const float*)C, ldc, bias, (const float*)residual,
+                                           ldr, (const float*)aux, ldaux, (const float*)C2, ldc2))
+      return simx_x3_gemm_nt(s, dtype == SIMX_F32_SPLIT_H ? SIMX_F16 : SIMX_BF16, epilogue, M, N, K, (const float*)A, lda, (const float*)B, ldb,
+                             (float*)C, ldc, bias, (const float*)residual, ldr, (const float*)aux, ldaux, (float*)C2, ldc2, drop);
     return launch_simple<float, float>(s, epilogue, M, N, K, (const float*)A, lda, 1, (const float*)B, 1, ldb,
                                        (float*)C, ldc, bias, (const float*)residual, ldr, (const float*)aux, ldaux,
                                        (float*)C2, ldc2, 0, drop);
+  }
   SIMX_REQUIRE(simx_is16(dtype), SIMX_ERR_BAD_DTYPE, "gemm_nt: dtype %d", dtype);
   const bool fast = (K % 64 == 0) && (N % 4 == 0) && (lda % 8 == 0) && (ldb % 8 == 0) && (ldc % 4 == 0) &&
                     aligned16(A) && aligned16(B) && aligned16(C) && (!bias || aligned16(bias)) &&
@@ -1697,7 +1702,9 @@ extern "C" size_t simx_gemm_tn_workspace_bytes(int M, int N, int K) {
   int s, kps;
   tn_plan(M, N, K, &s, &kps);
   const size_t bf = s > 1 ? (size_t)s * M * N * sizeof(float) : 0, f32 = simx_gemm_f32_workspace_bytes(M, N, K);
-  return bf > f32 ? bf : f32;                   // (the dtype is not an argument: enough for either)
+  const size_t x3 = simx_x3_tn_workspace_bytes(M, N, K);
+  const size_t m2 = bf > f32 ? bf : f32;
+  return m2 > x3 ? m2 : x3;                     // (the dtype is not an argument: enough for any of them)
 }
 
 static int gemm_tn_impl(simx_stream_t stream, int dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, float* C,
@@ -1734,9 +1741,12 @@ static int gemm_tn_impl(simx_stream_t stream, int dtype, int M, int N, int K, co
   SIMX_PROF(SIMX_K_GEMM_TN, s, 2.0 * M * N * K);
   SIMX_REQUIRE(M > 0 && N > 0 && K > 0, SIMX_ERR_BAD_SHAPE, "gemm_tn: bad shape %d %d %d", M, N, K);
   SIMX_REQUIRE(lda >= M && ldb >= N && ldc >= N, SIMX_ERR_BAD_SHAPE, "gemm_tn: leading dims too small");
-  if (dtype == SIMX_F32) {
-    if (dbias) { int rcb = simx_colsum_gs(stream, dtype, K, M, A, lda, dbias, 1, gs); if (rcb) return rcb; }
+  if (simx_is_f32(dtype)) {
+    if (dbias) { int rcb = simx_colsum_gs(stream, SIMX_F32, K, M, A, lda, dbias, 1, gs); if (rcb) return rcb; }
     SIMX_REQUIRE(gs == nullptr, SIMX_ERR_UNSUPPORTED, "gemm_tn: the f32 engine carries no gradient scale");
+    if (dtype != SIMX_F32 && simx_x3_tn_ok(M, N, K, (const float*)A, lda, (const float*)B, ldb, C, ldc))
+      return simx_x3_gemm_tn(s, dtype == SIMX_F32_SPLIT_H ? SIMX_F16 : SIMX_BF16, M, N, K, (const float*)A, lda, (const float*)B, ldb, C, ldc,
+                             accumulate, ws, ws_bytes);
     return launch_simple<float, float>(s, SIMX_EPI_NONE, M, N, K, (const float*)A, 1, lda, (const float*)B, ldb, 1, C,
                                        ldc, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, accumulate, DropCtx{0u, 1.f, 0u, 0u}, ws, ws_bytes);
   }

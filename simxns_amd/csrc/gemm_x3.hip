@@ -1,0 +1,351 @@
+// f32 GEMMs on the 16-bit matrix cores: every f32 operand element is split on the fly into a 16-bit high part and a
+// 16-bit correction, x = hi + lo, and the product is taken as hi.hi + hi.lo + lo.hi in f32 MFMA accumulators
+// (three v_mfma_f32_16x16x32 per tile pair instead of one; lo.lo is below the f32 round-off of the sum).
+//
+//   format F = f16_t : hi, lo = IEEE half.  x = hi + lo carries 22 significand bits while |lo| stays normal and an ABSOLUTE
+//                      error <= 2^-25 below that (gfx950's MFMA honours fp16 subnormals, tools/probe_f16.hip): weights
+//                      (|w| ~ 0.03) keep ~2^-20 relative, O(1) activations 2^-22.  Used for the FORWARD GEMMs of the
+//                      fp32 parity mode (x W^T, and the teacher's): 2.5 PFLOP/s / 3 = 833 TFLOP/s of f32-grade
+//                      throughput at peak against the f32 MFMA's 157.
+//   format F = bf16_t: hi, lo = bf16, 16 significand bits whatever the magnitude (f32's exponent range).  Used for the
+//                      BACKWARD GEMMs (dgrad, wgrad), whose gradient operand spans 1e-2 ... 1e-9 and would need a loss
+//                      scale in fp16.  2^-17 relative per operand: two orders below the 1e-3 / 2e-4 gradient tolerances.
+//
+// The exact kernel (gemm_f32_mfma_kernel, csrc/gemm.hip: v_mfma_f32_32x32x2_f32, exact f32 products) stays for small
+// shapes, for the M2 score matrix and behind SIMX_GEMM_F32=exact.
+//
+// NT form  C[M,N] = A[M,K] . B[N,K]^T  (both K-contiguous; forward and dgrad), 128x128x32 tile, 4 waves of 64x64:
+//   global f32 (16-B loads, next stage in flight during the MFMAs) -> registers -> split -> LDS planes Ahi|Alo|Bhi|Blo, each
+//   [128 rows][32 k] 16-bit = 64 B per row, so a wave's fragment read (16 rows x 64 B) is one contiguous KB.
+// TN form  C[M,N] (+)= A[K,M]^T . B[K,N]  (wgrad: rows = tokens, M / N contiguous), same tile, planes [32 k][128 cols] with
+//   the 32-B chunk swizzle of gemm_tn_h16_kernel, fragments by ds_read_b64_tr_b16 (the k-slot permutation it implies is
+//   the same for both operands); split over K into f32 slabs reduced in slice order (slab_reduce_kernel): deterministic.
+#include "common.h"
+#include "prof.h"
+
+template <typename F>
+__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  hi = H16<F>::pack2(a, b);
+  lo = H16<F>::pack2(a - H16<F>::lo(hi), b - H16<F>::hi(hi));
+}
+
+#define X3_BM 128
+#define X3_BN 128
+#define X3_BK 32
+#define X3_PLANE (128 * 64)                 // one 128 x 32 16-bit plane
+#define X3_STAGE (4 * X3_PLANE)             // Ahi | Alo | Bhi | Blo
+
+// slabs added in slice order (deterministic), as slab_reduce_kernel of csrc/gemm.hip (kernels do not link across translation units)
+__global__ __launch_bounds__(256) void x3_slab_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int splits, int M, int N,
+                                                             float* __restrict__ C, int ldc, int accumulate) {
+  const long total4 = (long)M * N / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+    const long e = i * 4;
+    const int m = (int)(e / N), n = (int)(e % N);
+    float4 s = make_float4(0, 0, 0, 0);
+    for (int k = 0; k < splits; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(slabs + (long)k * slab_stride + e);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    float4* dst = reinterpret_cast<float4*>(C + (long)m * ldc + n);
+    if (accumulate) { const float4 c = *dst; s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w; }
+    *dst = s;
+  }
+}
+
+template <typename F, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_x3_nt_kernel(
+    int M, int N, int K, const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
+    const float* __restrict__ bias, const float* __restrict__ res, int ldr, const float* __restrict__ aux, int ldaux,
+    float* __restrict__ C2, int ldc2, int tiles_n, int ntiles, DropCtx drop) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * X3_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // XCD-aware order: block b runs on XCD b % 8; every XCD walks a contiguous range of tiles so that the N-tiles sharing an
+  // A panel (and all tiles sharing B) sit behind one L2
+  const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+  const int m0 = (tile / tiles_n) * X3_BM, n0 = (tile % tiles_n) * X3_BN;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // staging: thread t owns row t >> 1, k half (t & 1) * 16 of both operand tiles: 16 consecutive floats each
+  const int srow = tid >> 1, shalf = (tid & 1) * 16;
+  int ga = m0 + srow, gb = n0 + srow;
+  ga = ga < M ? ga : M - 1;                       // (clamped rows are computed and never stored)
+  gb = gb < N ? gb : N - 1;
+  const float* pa = A + (long)ga * lda + shalf;
+  const float* pb = B + (long)gb * ldb + shalf;
+  float4 ra[4], rb[4];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = k0 + shalf + e * 4;
+      if (k + 3 < K) {
+        ra[e] = *reinterpret_cast<const float4*>(pa + k0 + e * 4);
+        rb[e] = *reinterpret_cast<const float4*>(pb + k0 + e * 4);
+      } else {                                     // ragged K tail (K % 4 == 0 is required: whole float4s)
+        ra[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        rb[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  auto sstore = [&](char* stage) {
+    uint32_t h[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { split2<F>(ra[e].x, ra[e].y, h[2 * e], l[2 * e]); split2<F>(ra[e].z, ra[e].w, h[2 * e + 1], l[2 * e + 1]); }
+    char* d = stage + srow * 64 + (tid & 1) * 32;
+    *reinterpret_cast<uint4*>(d) = make_uint4(h[0], h[1], h[2], h[3]);
+    *reinterpret_cast<uint4*>(d + 16) = make_uint4(h[4], h[5], h[6], h[7]);
+    *reinterpret_cast<uint4*>(d + X3_PLANE) = make_uint4(l[0], l[1], l[2], l[3]);
+    *reinterpret_cast<uint4*>(d + X3_PLANE + 16) = make_uint4(l[4], l[5], l[6], l[7]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { split2<F>(rb[e].x, rb[e].y, h[2 * e], l[2 * e]); split2<F>(rb[e].z, rb[e].w, h[2 * e + 1], l[2 * e + 1]); }
+    d += 2 * X3_PLANE;
+    *reinterpret_cast<uint4*>(d) = make_uint4(h[0], h[1], h[2], h[3]);
+    *reinterpret_cast<uint4*>(d + 16) = make_uint4(h[4], h[5], h[6], h[7]);
+    *reinterpret_cast<uint4*>(d + X3_PLANE) = make_uint4(l[0], l[1], l[2], l[3]);
+    *reinterpret_cast<uint4*>(d + X3_PLANE + 16) = make_uint4(l[4], l[5], l[6], l[7]);
+  };
+
+  const int nst = (K + X3_BK - 1) / X3_BK;
+  gload(0);
+  sstore(smem);
+  __syncthreads();
+  for (int st = 0; st < nst; ++st) {
+    const char* cur = smem + (st & 1) * X3_STAGE;
+    if (st + 1 < nst) gload((st + 1) * X3_BK);
+    // fragments: row (tile*16 + fr), k chunk fg (8 consecutive k = 16 B) of each plane
+    const char* fa = cur + (wr * 64 + fr) * 64 + fg * 16;
+    const char* fb = cur + 2 * X3_PLANE + (wc * 64 + fr) * 64 + fg * 16;
+    bf16x8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ah[i] = *reinterpret_cast<const bf16x8*>(fa + i * 1024);
+      al[i] = *reinterpret_cast<const bf16x8*>(fa + i * 1024 + X3_PLANE);
+      bh[i] = *reinterpret_cast<const bf16x8*>(fb + i * 1024);
+      bl[i] = *reinterpret_cast<const bf16x8*>(fb + i * 1024 + X3_PLANE);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // (operands swapped so that a lane ends up with 4 consecutive output columns of one row; corrections first)
+        acc[i][j] = H16<F>::mfma(bl[j], ah[i], acc[i][j]);
+        acc[i][j] = H16<F>::mfma(bh[j], al[i], acc[i][j]);
+        acc[i][j] = H16<F>::mfma(bh[j], ah[i], acc[i][j]);
+      }
+    if (st + 1 < nst) sstore(smem + ((st + 1) & 1) * X3_STAGE);
+    __syncthreads();
+  }
+
+  // epilogue: lane holds row m = .. + fr, columns n = .. + fg*4 .. +3 of each 16x16 tile
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wr * 64 + i * 16 + fr;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wc * 64 + j * 16 + fg * 4;
+      if (n >= N) continue;                        // (N % 4 == 0 is required: a lane's 4 columns are all in or all out)
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (bias) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias + n);
+        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+      }
+      if (EPI == SIMX_EPI_NONE) {
+        if (drop.thr) { float m4[4]; drop_mult4(drop, (uint32_t)m, (uint32_t)n, m4); v[0] *= m4[0]; v[1] *= m4[1]; v[2] *= m4[2]; v[3] *= m4[3]; }
+        if (res) { float r4[4]; ld4(res + (long)m * ldr + n, r4); v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3]; }
+        st4(C + (long)m * ldc + n, v);
+      } else if (EPI == SIMX_EPI_GELU) {
+        float g4[4], d4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { g4[e] = gelu_erf(v[e]); d4[e] = gelu_erf_grad(v[e]); }
+        st4(C + (long)m * ldc + n, d4);             // C = gelu'(u): what backward multiplies by
+        st4(C2 + (long)m * ldc2 + n, g4);
+      } else {
+        if (res) { float r4[4]; ld4(res + (long)m * ldr + n, r4); v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3]; }
+        float u4[4];
+        ld4(aux + (long)m * ldaux + n, u4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= u4[e];
+        st4(C + (long)m * ldc + n, v);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ TN (wgrad)
+// LDS plane of a 32(k) x 128(col) 16-bit tile: row kr at kr * 256 B, 32-B chunk q (16 columns) stored at q ^ (kr & 7).
+template <typename F>
+__global__ __launch_bounds__(256, 2) void gemm_x3_tn_kernel(
+    int M, int N, int K, const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ out,
+    long slab_stride, int ldo, int tiles_n, int tiles_mn, int k_per_split, int accumulate) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * X3_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int split = blockIdx.x / tiles_mn, tile = blockIdx.x % tiles_mn;
+  const int m0 = (tile / tiles_n) * X3_BM, n0 = (tile % tiles_n) * X3_BN;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int kb = split * k_per_split, ke = min(K, kb + k_per_split);
+  const int fs = lane & 15, fg = lane >> 4;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // staging: thread t owns k rows (t >> 5) + 8 e, e < 4, columns (t & 31) * 4 .. +3 of both operand tiles
+  const int skr = tid >> 5, sc4 = (tid & 31) * 4;
+  float4 ra[4], rb[4];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = k0 + skr + 8 * e;
+      const bool kin = k < ke;
+      ra[e] = (kin && m0 + sc4 + 3 < M) ? *reinterpret_cast<const float4*>(A + (long)k * lda + m0 + sc4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rb[e] = (kin && n0 + sc4 + 3 < N) ? *reinterpret_cast<const float4*>(B + (long)k * ldb + n0 + sc4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto sstore = [&](char* stage) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int kr = skr + 8 * e;
+      char* d = stage + kr * 256 + (((sc4 >> 4) ^ (kr & 7)) << 5) + (sc4 & 15) * 2;
+      uint32_t h0, l0, h1, l1;
+      split2<F>(ra[e].x, ra[e].y, h0, l0); split2<F>(ra[e].z, ra[e].w, h1, l1);
+      *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(d + X3_PLANE) = make_uint2(l0, l1);
+      split2<F>(rb[e].x, rb[e].y, h0, l0); split2<F>(rb[e].z, rb[e].w, h1, l1);
+      *reinterpret_cast<uint2*>(d + 2 * X3_PLANE) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(d + 3 * X3_PLANE) = make_uint2(l0, l1);
+    }
+  };
+  typedef __attribute__((address_space(3))) bf16x4* lds4_t;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  // transpose-read addressing (as gemm_tn_h16_kernel): lane (fg, fs) supplies k row 4 fg + (fs >> 2) (+16 for the high half),
+  // 8 B at columns ct*16 + (fs & 3)*4 of 16-column tile ct; after the read it holds 4 k values of column fs of that tile
+  const int r_lo = 4 * fg + (fs >> 2);
+  auto frag = [&](uint32_t plane, int ct) -> bf16x8 {
+    const int r0 = r_lo, r1 = r_lo + 16;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(uintptr_t)(plane + r0 * 256 + ((ct ^ (r0 & 7)) << 5) + (fs & 3) * 8));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(uintptr_t)(plane + r1 * 256 + ((ct ^ (r1 & 7)) << 5) + (fs & 3) * 8));
+    return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  };
+
+  const int nst = (ke - kb + X3_BK - 1) / X3_BK;
+  gload(kb);
+  sstore(smem);
+  __syncthreads();
+  for (int st = 0; st < nst; ++st) {
+    const uint32_t cur = lds0 + (uint32_t)((st & 1) * X3_STAGE);
+    if (st + 1 < nst) gload(kb + (st + 1) * X3_BK);
+    bf16x8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ah[i] = frag(cur, wr * 4 + i);
+      al[i] = frag(cur + X3_PLANE, wr * 4 + i);
+      bh[i] = frag(cur + 2 * X3_PLANE, wc * 4 + i);
+      bl[i] = frag(cur + 3 * X3_PLANE, wc * 4 + i);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[i][j] = H16<F>::mfma(bl[j], ah[i], acc[i][j]);
+        acc[i][j] = H16<F>::mfma(bh[j], al[i], acc[i][j]);
+        acc[i][j] = H16<F>::mfma(bh[j], ah[i], acc[i][j]);
+      }
+    if (st + 1 < nst) sstore(smem + ((st + 1) & 1) * X3_STAGE);
+    __syncthreads();
+  }
+  float* o = out + (long)split * slab_stride;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wr * 64 + i * 16 + fs;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wc * 64 + j * 16 + fg * 4;
+      if (n >= N) continue;
+      float4* dst = reinterpret_cast<float4*>(o + (long)m * ldo + n);
+      float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      if (accumulate) { const float4 c = *dst; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
+      *dst = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ host
+static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// can the split kernels take this NT problem?  (whole float4s everywhere; anything else stays on the exact kernel)
+bool simx_x3_nt_ok(int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* C, int ldc, const float* bias,
+                   const float* res, int ldr, const float* aux, int ldaux, const float* C2, int ldc2) {
+  return K % 4 == 0 && N % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && al16(A) && al16(B) && al16(C) && (!bias || al16(bias)) &&
+         (!res || (ldr % 4 == 0 && al16(res))) && (!aux || (ldaux % 4 == 0 && al16(aux))) && (!C2 || (ldc2 % 4 == 0 && al16(C2))) &&
+         (long)M * N >= 64 * 1024 && K >= 64;
+}
+
+// fmt: SIMX_F16 (forward GEMMs) or SIMX_BF16 (backward GEMMs) -- the format of the 16-bit halves, see the file header
+int simx_x3_gemm_nt(hipStream_t s, int fmt, int epi, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                    const float* bias, const float* res, int ldr, const float* aux, int ldaux, float* C2, int ldc2, DropCtx drop) {
+  const int tiles_m = cdiv(M, X3_BM), tiles_n = cdiv(N, X3_BN), nt = tiles_m * tiles_n;
+#define LX(FF, E) hipLaunchKernelGGL((gemm_x3_nt_kernel<FF, E>), dim3(nt), dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, res, ldr, aux, \
+                                     ldaux, C2, ldc2, tiles_n, nt, drop)
+#define LX_ALL(FF) do { if (epi == SIMX_EPI_NONE) LX(FF, SIMX_EPI_NONE); else if (epi == SIMX_EPI_GELU) LX(FF, SIMX_EPI_GELU); else LX(FF, SIMX_EPI_DGELU); } while (0)
+  SIMX_DISPATCH16(fmt, FF, LX_ALL(FF));
+#undef LX_ALL
+#undef LX
+  SIMX_CHECK_LAUNCH("gemm_x3_nt");
+  return SIMX_OK;
+}
+
+bool simx_x3_tn_ok(int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* C, int ldc) {
+  return M % 4 == 0 && N % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && al16(A) && al16(B) && al16(C) && (long)M * N >= 16 * 1024 &&
+         K >= 256;
+}
+static void x3_tn_plan(int M, int N, int K, int* splits, int* kps) {
+  const int tiles = cdiv(M, X3_BM) * cdiv(N, X3_BN);
+  int sp = 1024 / tiles;                            // two workgroups per CU: ~4 per CU keeps the tail short
+  const int max_s = cdiv(K, 512);
+  if (sp > max_s) sp = max_s;
+  if (sp < 1) sp = 1;
+  int k = cdiv(cdiv(K, sp), X3_BK) * X3_BK;
+  *splits = cdiv(K, k);
+  *kps = k;
+}
+size_t simx_x3_tn_workspace_bytes(int M, int N, int K) {
+  int sp, kps;
+  x3_tn_plan(M, N, K, &sp, &kps);
+  return sp > 1 ? (size_t)sp * M * N * sizeof(float) : 0;
+}
+int simx_x3_gemm_tn(hipStream_t s, int fmt, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                    int accumulate, void* ws, size_t ws_bytes) {
+  int sp, kps;
+  x3_tn_plan(M, N, K, &sp, &kps);
+  const int t_n = cdiv(N, X3_BN), t_mn = cdiv(M, X3_BM) * t_n;
+  if (sp > 1 && (!ws || ws_bytes < (size_t)sp * M * N * sizeof(float) || !al16(ws))) { sp = 1; kps = cdiv(K, X3_BK) * X3_BK; }
+  if (sp == 1) {
+    SIMX_DISPATCH16(fmt, FF, hipLaunchKernelGGL(gemm_x3_tn_kernel<FF>, dim3(t_mn), dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, 0L, ldc, t_n, t_mn,
+                                                kps, accumulate));
+    SIMX_CHECK_LAUNCH("gemm_x3_tn");
+    return SIMX_OK;
+  }
+  SIMX_DISPATCH16(fmt, FF, hipLaunchKernelGGL(gemm_x3_tn_kernel<FF>, dim3(t_mn * sp), dim3(256), 0, s, M, N, K, A, lda, B, ldb, (float*)ws,
+                                              (long)M * N, N, t_n, t_mn, kps, 0));
+  SIMX_CHECK_LAUNCH("gemm_x3_tn");
+  const long tot4 = (long)M * N / 4;
+  int rb = (int)((tot4 + 255) / 256);
+  if (rb > 2048) rb = 2048;
+  hipLaunchKernelGGL(x3_slab_reduce_kernel, dim3(rb), dim3(256), 0, s, (const float*)ws, (long)M * N, sp, M, N, C, ldc, accumulate);
+  SIMX_CHECK_LAUNCH("slab_reduce");
+  return SIMX_OK;
+}

@@ -150,6 +150,65 @@ def test_gemm_nt_persistent(dev, M, N, K, variant, fmt):
         assert_close(back(dC), acc * rounded(aux, fmt), what="gemm_nt persistent dgelu (x stored derivative)", **t)
 
 
+# ------------------------------------------------------------------------------------------ f32 GEMMs on the 16-bit matrix cores
+@pytest.mark.parametrize("code_", [3, 4])
+@pytest.mark.parametrize("M,N,K", [(300, 768, 768), (1000, 3072, 768), (8300, 768, 3072), (2048, 768, 772), (513, 260, 64), (4100, 2304, 768)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_nt_f32_split(dev, code_, M, N, K, epi):
+    """SIMX_F32_SPLIT_H / _B (csrc/gemm_x3.hip): f32 operands split into 16-bit hi + lo on the fly, three MFMAs per product.
+    fp16 halves: the exact kernel's tolerance holds; bf16 halves: 2^-17 per operand."""
+    lib = L()
+    A, B = rnd((M, K), 1, 0.5), rnd((N, K), 2, 0.5)
+    B[:, :7] *= 0.03                                   # weight-like magnitudes (fp16 lo parts go subnormal: absolute floor)
+    bias = rnd((N,), 3, 0.5) if epi != 2 else None
+    res = rnd((M, N), 4) if epi == 0 else None
+    aux = rnd((M, N), 5) if epi == 2 else None
+    dA, dB = to_dev(A, dev), to_dev(B, dev)
+    dbias = to_dev(bias, dev) if bias is not None else None
+    dres = to_dev(res, dev) if res is not None else None
+    daux = to_dev(aux, dev) if aux is not None else None
+    dC = torch.full((M, N), float("nan"), device=dev)
+    dC2 = torch.full((M, N), float("nan"), device=dev) if epi == 1 else None
+    lib.call("simx_gemm_nt", lib.stream_ptr(), code_, M, N, K, lib.ptr(dA), K, lib.ptr(dB), K, lib.ptr(dC), N,
+             lib.ptr(dbias), lib.ptr(dres), N, epi, lib.ptr(daux), N, lib.ptr(dC2), N)
+    torch.cuda.synchronize()
+    acc = A.astype(np.float64) @ B.astype(np.float64).T
+    if bias is not None:
+        acc = acc + bias.astype(np.float64)
+    t = dict(rtol=2e-5, atol=2e-5 * max(1.0, math.sqrt(K) * 0.25)) if code_ == 3 else dict(rtol=1e-4, atol=4e-5 * math.sqrt(K))
+    if epi == 0:
+        assert_close(back(dC), acc + res.astype(np.float64), what="split gemm_nt none", **t)
+    elif epi == 1:
+        assert_close(back(dC), obert.gelu_grad(acc), what="split gemm_nt gelu derivative output", **t)
+        assert_close(back(dC2), obert.gelu(acc), what="split gemm_nt gelu", **t)
+    else:
+        assert_close(back(dC), acc * aux.astype(np.float64), what="split gemm_nt dgelu", **t)
+
+
+@pytest.mark.parametrize("code_", [3, 4])
+@pytest.mark.parametrize("M,N,K,accumulate", [(768, 768, 5000, 1), (3072, 768, 2100, 0), (768, 3072, 33000, 1), (128, 256, 1000, 0), (772, 260, 4100, 1)])
+def test_gemm_tn_f32_split(dev, code_, M, N, K, accumulate):
+    lib = L()
+    A, B = rnd((K, M), 1, 0.01), rnd((K, N), 2, 0.5)     # A: gradient-like magnitudes
+    if code_ == 3:
+        A *= 50.0                                          # (fp16 halves are for O(1) operands; the engine uses bf16 halves for gradients)
+    C0 = rnd((M, N), 3)
+    dA, dB, dC = to_dev(A, dev), to_dev(B, dev), to_dev(C0, dev)
+    wsb = int(lib.load().simx_gemm_tn_workspace_bytes(M, N, K))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+    outs = []
+    for rep in range(2):
+        dC = to_dev(C0, dev)
+        lib.call("simx_gemm_tn", lib.stream_ptr(), code_, M, N, K, lib.ptr(dA), M, lib.ptr(dB), N, lib.ptr(dC), N, accumulate, lib.ptr(ws), wsb)
+        torch.cuda.synchronize()
+        outs.append(dC)
+    assert torch.equal(outs[0], outs[1]), "split-K slabs are added in slice order: run-to-run identical"
+    ref = A.astype(np.float64).T @ B.astype(np.float64) + (C0 if accumulate else 0.0)
+    scale = np.abs(A).mean() * np.abs(B).mean() * math.sqrt(K)
+    t = dict(rtol=2e-5, atol=3e-5 * scale) if code_ == 3 else dict(rtol=1e-4, atol=1e-4 * scale)
+    assert_close(back(outs[0]), ref, what="split gemm_tn", **t)
+
+
 # ------------------------------------------------------------------------------------------ GEMM TN (wgrad)
 @pytest.mark.parametrize("bf16", FMTS)
 @pytest.mark.parametrize("M,N,K", [(64, 64, 200), (192, 64, 333), (768, 768, 5000), (3072, 768, 2100), (128, 256, 64), (72, 40, 130)])
@@ -359,7 +418,12 @@ def _mha_ref(qkv, lens, heads, d, dctx=None):
 
 @pytest.mark.parametrize("bf16,heads,d,lens", [
     (False, 4, 16, [5, 32, 17, 1]),
-    (False, 2, 64, [40, 7]),
+    (False, 2, 64, [40, 7]),                    # f32 MFMA kernels (head size 64, <= 256 tokens): NKT = 4 tiles of 32
+    (False, 3, 64, [9, 32, 4, 31]),             # NKT = 1
+    (False, 2, 64, [128, 1, 17, 33, 16, 100]),
+    (False, 2, 64, [160, 129, 45]),             # NKT = 5
+    (False, 1, 64, [250, 200, 256]),            # NKT = 8
+    (False, 1, 64, [300, 33]),                  # > 256: generic kernels
     (True, 4, 16, [5, 32, 17]),                 # generic kernel in bf16
     (True, 2, 64, [128, 1, 17, 33, 16, 100]),   # MFMA kernel, NKT=8
     (True, 3, 64, [9, 32, 4, 31]),              # NKT=2

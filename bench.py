@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="queries per GPU")
     ap.add_argument("--negs", type=int, default=15)
     ap.add_argument("--cands", type=int, default=200, help="SimANS candidate pool per query")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16", "fp32", "fp32_exact"])
     ap.add_argument("--varlen", action="store_true", help="realistic sequence lengths instead of all-max")
     ap.add_argument("--inbatch", action="store_true", help="config 3: all-gather embeddings + in-batch NLL term")
     ap.add_argument("--no-teacher", action="store_true", help="feed fixed teacher logits (student-only flops)")
@@ -340,7 +340,7 @@ def main():
         return round(tot / cnt) if cnt and cnt == launches_per_step and not args.varlen else None
 
     # bf16: the persistent kernel's launches ("gemm_nt" = the small-shape kernels); fp32: every NT GEMM is the f32 MFMA kernel
-    rk = "gemm_nt_p3" if args.dtype == "bf16" else "gemm_nt"
+    rk = "gemm_nt_p3" if args.dtype in ("bf16", "fp16") else "gemm_nt"
     if prof and rk in prof:
         c_, ms_, wk_ = prof[rk]
         ach = wk_ / (ms_ * 1e-3) / 1e12

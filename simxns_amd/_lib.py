@@ -27,7 +27,7 @@ class BertCfg(C.Structure):
                 ("inter", C.c_int32), ("vocab", C.c_int32), ("max_pos", C.c_int32), ("type_vocab", C.c_int32),
                 ("eps", C.c_float), ("hidden_dropout", C.c_float), ("attn_dropout", C.c_float), ("dropout_seed", C.c_uint32),
                 ("cls_only_last_layer", C.c_int32), ("grad_checkpoint", C.c_int32), ("qkv_layout", C.c_int32),
-                ("f32_gemm", C.c_int32), ("grad_scale", C.c_void_p)]
+                ("f32_gemm", C.c_int32), ("stream_lo", C.c_int32), ("grad_scale", C.c_void_p)]
 
 
 class Dropout(C.Structure):
@@ -116,6 +116,9 @@ SIGNATURES = {
     "simx_cls_scatter_gs": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p]),
     "simx_rows_copy_gs": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "simx_seq_mean_bwd_gs": (_i, [_p, _i, _i, _i, _p, _p, _p, _p]),
+    "simx_ln_fwd_res": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p]),
+    "simx_ln_bwd_res": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _dp, _p, _p]),
+    "simx_embed_ln_fwd_lo": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _dp]),
     "simx_scaler_init": (_i, [_p, _p, _f, _f, _f]),
     "simx_scaler_update": (_i, [_p, _p, _p]),
     "simx_adamw_step_sc": (_i, [_p, _p, _p, _p, _p, _z, _f, _f, _f, _f, _f, _i, _p, _f, _f, _i, _p]),

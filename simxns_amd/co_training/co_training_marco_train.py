@@ -118,9 +118,26 @@ def train(args, model, teacher_model, tokenizer, global_step=0, dataset_cls=Rock
     train_dataset = dataset_cls(train_data_path, tokenizer, num_hard_negatives=args.number_neg,
                                 trainer_id=max(args.local_rank, 0), trainer_num=world,
                                 corpus_path=args.passage_path, rand_pool=100, **(dataset_kwargs or {}))
-    train_dataloader = DataLoader(train_dataset, sampler=RandomSampler(train_dataset),
-                                  collate_fn=dataset_cls.get_collate_fn(args),
-                                  batch_size=args.train_batch_size, num_workers=args.num_workers)
+    gpu_sampler = getattr(args, "sampler", "host") == "gpu" and hasattr(train_dataset, "build_device_pool")
+    if gpu_sampler:
+        # --sampler gpu: the SimANS draw and the collate run on the device from tables tokenised once per iteration
+        # (Rocketqa_v2Dataset.build_device_pool / device_batch); the host only deals out row numbers
+        pool = train_dataset.build_device_pool(args.device)
+        logger.info("device pool: %d queries, %d passages, %d candidates per query resident in HBM", pool["q_tok"].shape[0],
+                    pool["p_tok"].shape[0], pool["cand_rows"].shape[1])
+
+        class _DeviceBatches(object):
+            def __iter__(self_):
+                order = list(RandomSampler(train_dataset))
+                for lo in range(0, len(order), args.train_batch_size):
+                    self_.n = getattr(self_, "n", 0) + 1
+                    yield train_dataset.device_batch(order[lo:lo + args.train_batch_size], seed=args.seed + max(args.local_rank, 0),
+                                                     step=self_.n)
+        train_dataloader = _DeviceBatches()
+    else:
+        train_dataloader = DataLoader(train_dataset, sampler=RandomSampler(train_dataset),
+                                      collate_fn=dataset_cls.get_collate_fn(args),
+                                      batch_size=args.train_batch_size, num_workers=args.num_workers)
     it = iter(train_dataloader)
     logger.info("***** Running training *****  max steps %d, per-GPU batch %d, accumulation %d, examples %d",
                 args.max_steps, args.per_gpu_train_batch_size, args.gradient_accumulation_steps, len(train_dataset))
@@ -239,6 +256,8 @@ def get_arguments(argv=None):
     A("--save_steps", type=int, default=500)
     A("--no_cuda", action="store_true")
     A("--seed", type=int, default=42)
+    A("--sampler", default="host", choices=["host", "gpu"],
+      help="gpu: SimANS draw + collate on the device from a pool tokenised once per iteration (no DataLoader workers)")
     A("--fp16", action="store_true")
     A("--fp16_opt_level", type=str, default="O1")
     A("--single_warmup", default=False, action="store_true")

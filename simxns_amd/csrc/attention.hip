@@ -44,11 +44,14 @@ __device__ __forceinline__ bf16x8 lds_row_frag(const char* tile, int row, int c1
 
 // In the MFMA kernels below `bf16_t` is the raw 16-bit storage of EITHER operand format; the template parameter
 // F in {bf16_t, f16_t} (H16<F>, common.h) selects the conversions and the MFMA instruction.
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 template <typename F>
 __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
-  const u32x4_t w = {H16<F>::pack2(a[0], a[1]), H16<F>::pack2(a[2], a[3]), H16<F>::pack2(b[0], b[1]), H16<F>::pack2(b[2], b[3])};
-  return __builtin_bit_cast(bf16x8, w);
+  // (element by element on purpose: built from four packed words and bit-cast, hipcc kept every score tile of the forward
+  // kernel live across the softmax and mha_fwd<8> went from 114 to 239 VGPRs = half the occupancy, +30 % time)
+  bf16x8 r;
+  r[0] = H16<F>::bits(a[0]); r[1] = H16<F>::bits(a[1]); r[2] = H16<F>::bits(a[2]); r[3] = H16<F>::bits(a[3]);
+  r[4] = H16<F>::bits(b[0]); r[5] = H16<F>::bits(b[1]); r[6] = H16<F>::bits(b[2]); r[7] = H16<F>::bits(b[3]);
+  return r;
 }
 
 

@@ -65,6 +65,7 @@ template <> struct H16<bf16_t> {
   static __device__ __forceinline__ float hi(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
   static __device__ __forceinline__ float one(short s) { return __uint_as_float(((uint32_t)(unsigned short)s) << 16); }
   static __device__ __forceinline__ uint32_t pack2(float a, float b) { return pack2bf(a, b); }
+  static __device__ __forceinline__ short bits(float a) { return (short)f2bf(a); }
   static __device__ __forceinline__ f32x4 mfma(const bf16x8& a, const bf16x8& b, const f32x4& c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
   }
@@ -75,6 +76,7 @@ template <> struct H16<f16_t> {
   static __device__ __forceinline__ float hi(uint32_t w) { return (float)__builtin_bit_cast(f16v2_t, w)[1]; }
   static __device__ __forceinline__ float one(short s) { return (float)__builtin_bit_cast(f16_t, s); }
   static __device__ __forceinline__ uint32_t pack2(float a, float b) { return pack2h(a, b); }
+  static __device__ __forceinline__ short bits(float a) { return __builtin_bit_cast(short, (f16_t)a); }
   static __device__ __forceinline__ f32x4 mfma(const bf16x8& a, const bf16x8& b, const f32x4& c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   }
@@ -96,14 +98,17 @@ template <typename T> struct Elem;
 template <> struct Elem<float> {
   static __device__ __forceinline__ float ld(const float* p) { return *p; }
   static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+  static __device__ __forceinline__ float rnd(float v) { return v; }        // the value a store of v leaves in memory
 };
 template <> struct Elem<bf16_t> {
   static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
   static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+  static __device__ __forceinline__ float rnd(float v) { return bf2f(f2bf(v)); }
 };
 template <> struct Elem<f16_t> {
   static __device__ __forceinline__ float ld(const f16_t* p) { return (float)*p; }
   static __device__ __forceinline__ void st(f16_t* p, float v) { *p = (f16_t)v; }
+  static __device__ __forceinline__ float rnd(float v) { return (float)(f16_t)v; }
 };
 
 // 4-element vector load/store (16 B for f32, 8 B for bf16); pointers must be so aligned

@@ -32,7 +32,7 @@ static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline size_t esz(int dtype) { return dtype == SIMX_F32 ? 4 : 2; }
 
 static bool cfg_ok(const simx_bert_cfg* c) {
-  return c && simx_dtype_ok(c->dtype) && c->qkv_layout >= 0 && c->qkv_layout <= 1 && c->f32_gemm >= 0 && c->f32_gemm <= 1 && c->layers > 0 && c->hidden > 0 && c->heads > 0 &&
+  return c && simx_dtype_ok(c->dtype) && c->qkv_layout >= 0 && c->qkv_layout <= 1 && c->f32_gemm >= 0 && c->f32_gemm <= 1 && c->stream_lo >= 0 && c->stream_lo <= 1 && c->layers > 0 && c->hidden > 0 && c->heads > 0 &&
          c->hidden % c->heads == 0 && c->hidden % 4 == 0 && c->inter > 0 && c->inter % 4 == 0 && c->vocab > 0 &&
          c->max_pos > 0 && c->type_vocab > 0 && c->hidden <= 1024;
 }
@@ -118,11 +118,17 @@ static WLayer wlayer(const simx_bert_cfg* c, const float* params, const void* wc
 // [T, Tp) hold garbage that never leaves its own row (an NT GEMM row depends on that row of A only; LayerNorm,
 // attention, the wgrad contraction and every reduction run over the T real rows).
 static inline int rows_cap(int T) { return (T + 255) & ~255; }
-struct ALayer { char *qkv, *ctx, *z1, *x1, *u, *h, *z2, *xout; float* lse; };
+// stream_lo (simx.h): the residual stream -- x0 and every LayerNorm output -- is a 16-bit tensor PLUS a 16-bit correction
+// (x1l / xoutl, NULL otherwise); z1 / z2 then hold the dense outputs without the residual, which the LayerNorm kernels add
+static inline bool stream_lo(const simx_bert_cfg* c) { return c->stream_lo != 0 && simx_is16(c->dtype); }
+struct ALayer { char *qkv, *ctx, *z1, *x1, *u, *h, *z2, *xout, *x1l, *xoutl; float* lse; };
 static size_t act_layer_bytes(const simx_bert_cfg* c, size_t T) {
   const size_t H = c->hidden, F = c->inter, e = esz(c->dtype);
-  return al(T * 3 * H * e) + 5 * al(T * H * e) + 2 * al(T * F * e) + al((size_t)c->heads * T * 4);
+  return al(T * 3 * H * e) + (stream_lo(c) ? 7 : 5) * al(T * H * e) + 2 * al(T * F * e) + al((size_t)c->heads * T * 4);
 }
+// a [Tp,H] tensor of the residual stream: the 16-bit values, followed by the corrections when stream_lo
+static size_t xs_bytes(const simx_bert_cfg* c, size_t Tp) { return (stream_lo(c) ? 2 : 1) * al(Tp * c->hidden * esz(c->dtype)); }
+static const char* xs_lo(const simx_bert_cfg* c, const char* hi, size_t Tp) { return stream_lo(c) ? hi + al(Tp * c->hidden * esz(c->dtype)) : nullptr; }
 // Activation memory, three modes:
 //   save = 0                      : x0 | 2 layer slots used as a ring                                  (inference)
 //   save = 1, grad_checkpoint = 0 : x0 | L layer slots -- everything backward needs is kept            (default)
@@ -132,18 +138,18 @@ static size_t act_layer_bytes(const simx_bert_cfg* c, size_t T) {
 // followed by three [nseq,H] tensors of the [CLS]-only last layer (q, attention context, a temporary).
 static inline bool ckpt_mode(const simx_bert_cfg* c, int save) { return save && c->grad_checkpoint != 0; }
 static size_t act_slots_bytes(const simx_bert_cfg* c, size_t Tp, int save) {
-  if (ckpt_mode(c, save)) return (size_t)c->layers * al(Tp * c->hidden * esz(c->dtype)) + 2 * act_layer_bytes(c, Tp);
+  if (ckpt_mode(c, save)) return (size_t)c->layers * xs_bytes(c, Tp) + 2 * act_layer_bytes(c, Tp);
   return (size_t)(save ? c->layers : 2) * act_layer_bytes(c, Tp);
 }
 extern "C" size_t simx_bert_act_bytes(const simx_bert_cfg* c, int T, int nseq, int save_for_bwd) {
   if (!cfg_ok(c) || T <= 0) return 0;
   const size_t Tp = (size_t)rows_cap(T);
-  const size_t x0 = al(Tp * c->hidden * esz(c->dtype));
+  const size_t x0 = xs_bytes(c, Tp);
   const size_t n = nseq > 0 ? (size_t)nseq : Tp;
   return x0 + act_slots_bytes(c, Tp, save_for_bwd) + 3 * al(n * c->hidden * esz(c->dtype));
 }
 static char* act_extra(const simx_bert_cfg* c, void* act, size_t Tp, int save) {
-  return (char*)act + al(Tp * c->hidden * esz(c->dtype)) + act_slots_bytes(c, Tp, save);
+  return (char*)act + xs_bytes(c, Tp) + act_slots_bytes(c, Tp, save);
 }
 static char* act_x0(void* act) { return (char*)act; }
 static ALayer carve_layer(const simx_bert_cfg* c, char* b, size_t T) {
@@ -155,6 +161,8 @@ static ALayer carve_layer(const simx_bert_cfg* c, char* b, size_t T) {
   a.x1 = b; b += al(T * H * e);
   a.z2 = b; b += al(T * H * e);
   a.xout = b; b += al(T * H * e);
+  a.x1l = a.xoutl = nullptr;
+  if (stream_lo(c)) { a.x1l = b; b += al(T * H * e); a.xoutl = b; b += al(T * H * e); }
   a.u = b; b += al(T * F * e);                 // gelu'(u) of the FFN pre-activation (SIMX_EPI_GELU writes it; only DGELU reads it)
   a.h = b; b += al(T * F * e);
   a.lse = (float*)b;
@@ -162,24 +170,30 @@ static ALayer carve_layer(const simx_bert_cfg* c, char* b, size_t T) {
 }
 // the slot layer l's FORWARD writes (checkpoint mode: ring slot l&1, its output redirected to the kept array)
 static ALayer alayer(const simx_bert_cfg* c, void* act, size_t T, int l, int save) {
-  const size_t xb = al(T * c->hidden * esz(c->dtype));
+  const size_t xb = xs_bytes(c, T);
   char* base = (char*)act + xb;
   if (ckpt_mode(c, save)) {
     ALayer a = carve_layer(c, base + (size_t)c->layers * xb + (size_t)(l & 1) * act_layer_bytes(c, T), T);
     a.xout = base + (size_t)l * xb;
+    a.xoutl = const_cast<char*>(xs_lo(c, a.xout, T));
     return a;
   }
   return carve_layer(c, base + (size_t)(save ? l : (l & 1)) * act_layer_bytes(c, T), T);
 }
 // checkpoint mode, backward: the slot layer l is RE-COMPUTED into (ring slot 0, its own xout)
 static ALayer alayer_recompute(const simx_bert_cfg* c, void* act, size_t T) {
-  const size_t xb = al(T * c->hidden * esz(c->dtype));
+  const size_t xb = xs_bytes(c, T);
   return carve_layer(c, (char*)act + xb + (size_t)c->layers * xb, T);
 }
 // input of layer l (= output of layer l-1, or the embedding output)
 static const char* layer_input(const simx_bert_cfg* c, const void* act, size_t T, int l) {
   if (l == 0) return act_x0(const_cast<void*>(act));
   return alayer(c, const_cast<void*>(act), T, l - 1, 1).xout;
+}
+// its stream correction (NULL without stream_lo)
+static const char* layer_input_lo(const simx_bert_cfg* c, const void* act, size_t T, int l) {
+  if (l == 0) return xs_lo(c, act_x0(const_cast<void*>(act)), T);
+  return alayer(c, const_cast<void*>(act), T, l - 1, 1).xoutl;
 }
 
 static size_t tn_ws_max(const simx_bert_cfg* c, int T) {
@@ -258,8 +272,8 @@ static int hm_rows_for(const simx_bert_cfg* c, int T, int Tp, int max_len) {
 // (the pre-activation u is stored); the [CLS]-only form of the last layer writes [nseq, .] tensors into the slot's usual
 // buffers and q / attention context of the [CLS] rows into `extra` (kept for backward).
 static int layer_fwd(hipStream_t stream, const simx_bert_cfg* c, const float* params, const void* wcache, int l, const char* x,
-                     const ALayer& a, char* extra, const int32_t* cu, int nseq, int T, int Tp, int max_len, int keep, bool cls_form,
-                     float* cls_out) {
+                     const char* xl, const ALayer& a, char* extra, const int32_t* cu, int nseq, int T, int Tp, int max_len, int keep,
+                     bool cls_form, float* cls_out) {
   const int H = c->hidden, F = c->inter, dt = c->dtype, d = H / c->heads;
   auto off = [&](int ll, int w) { return params + simx_bert_param_offset(c, ll, w); };
   const WLayer w = wlayer(c, params, wcache, l);
@@ -305,14 +319,19 @@ static int layer_fwd(hipStream_t stream, const simx_bert_cfg* c, const float* pa
     RUN(simx_gemm_nt(stream, gdt, Tp, 3 * H, H, x, H, w.wqkv, H, a.qkv, 3 * H, off(l, SIMX_P_BQKV), nullptr, 0, SIMX_EPI_NONE,
                      nullptr, 0, nullptr, 0));
   RUN(simx_mha_fwd_hm(stream, dt, nseq, c->heads, d, cu, max_len, T, a.qkv, a.ctx, a.lse, &d3, hm));
-  RUN(simx_gemm_nt_ex(stream, gdt, Tp, H, H, a.ctx, H, w.wo, H, a.z1, H, off(l, SIMX_P_BO), x, H, SIMX_EPI_NONE, nullptr, 0,
+  // stream_lo: the dense output leaves without the residual (a plain bias + dropout epilogue) and the LayerNorm kernel sums
+  // dense + x_hi + x_lo in f32; otherwise the residual rides in the GEMM epilogue and z1 is the LayerNorm input itself
+  const bool sl = stream_lo(c);
+  RUN(simx_gemm_nt_ex(stream, gdt, Tp, H, H, a.ctx, H, w.wo, H, a.z1, H, off(l, SIMX_P_BO), sl ? nullptr : x, H, SIMX_EPI_NONE, nullptr, 0,
                       nullptr, 0, &d1));
-  RUN(simx_ln_fwd(stream, dt, T, H, a.z1, off(l, SIMX_P_LN1_G), off(l, SIMX_P_LN1_B), c->eps, a.x1));
+  RUN(simx_ln_fwd_res(stream, dt, T, H, a.z1, sl ? x : nullptr, sl ? xl : nullptr, off(l, SIMX_P_LN1_G), off(l, SIMX_P_LN1_B), c->eps, a.x1,
+                      a.x1l));
   RUN(simx_gemm_nt(stream, gdt, Tp, F, H, a.x1, H, w.w1, H, a.u, F, off(l, SIMX_P_B1), nullptr, 0,
                    keep ? SIMX_EPI_GELU : SIMX_EPI_GELU_INFER, nullptr, 0, a.h, F));   // no backward from this slot: u has no reader
-  RUN(simx_gemm_nt_ex(stream, gdt, Tp, H, F, a.h, F, w.w2, F, a.z2, H, off(l, SIMX_P_B2), a.x1, H, SIMX_EPI_NONE, nullptr, 0,
+  RUN(simx_gemm_nt_ex(stream, gdt, Tp, H, F, a.h, F, w.w2, F, a.z2, H, off(l, SIMX_P_B2), sl ? nullptr : a.x1, H, SIMX_EPI_NONE, nullptr, 0,
                       nullptr, 0, &d2));
-  RUN(simx_ln_fwd(stream, dt, T, H, a.z2, off(l, SIMX_P_LN2_G), off(l, SIMX_P_LN2_B), c->eps, a.xout));
+  RUN(simx_ln_fwd_res(stream, dt, T, H, a.z2, sl ? a.x1 : nullptr, sl ? a.x1l : nullptr, off(l, SIMX_P_LN2_G), off(l, SIMX_P_LN2_B), c->eps,
+                      a.xout, a.xoutl));
   return SIMX_OK;
 }
 
@@ -327,10 +346,11 @@ extern "C" int simx_bert_fwd(simx_stream_t stream, const simx_bert_cfg* c, const
   const int Tp = rows_cap(T);
   auto off = [&](int l, int w) { return params + simx_bert_param_offset(c, l, w); };
   const char* x = act_x0(act);
+  const char* xl = xs_lo(c, x, Tp);
   {
     const simx_dropout d0 = drop_of(c, -1, 0);
-    RUN(simx_embed_ln_fwd_ex(stream, dt, T, H, ids, pos_ids, off(-1, SIMX_P_WORD), off(-1, SIMX_P_POS), off(-1, SIMX_P_TYPE),
-                             off(-1, SIMX_P_EMB_LN_G), off(-1, SIMX_P_EMB_LN_B), c->eps, act_x0(act), &d0));
+    RUN(simx_embed_ln_fwd_lo(stream, dt, T, H, ids, pos_ids, off(-1, SIMX_P_WORD), off(-1, SIMX_P_POS), off(-1, SIMX_P_TYPE),
+                             off(-1, SIMX_P_EMB_LN_G), off(-1, SIMX_P_EMB_LN_B), c->eps, act_x0(act), const_cast<char*>(xl), &d0));
   }
   const bool cls_only = c->cls_only_last_layer != 0;
   const bool ckpt = ckpt_mode(c, save);
@@ -339,10 +359,11 @@ extern "C" int simx_bert_fwd(simx_stream_t stream, const simx_bert_cfg* c, const
     const ALayer a = alayer(c, act, Tp, l, save);
     const bool cls_form = cls_only && l == c->layers - 1;
     // (checkpoint mode: the slot is recomputed by backward, so the forward runs it in its inference form)
-    RUN(layer_fwd((hipStream_t)stream, c, params, wcache, l, x, a, act_extra(c, act, Tp, save), cu, nseq, T, Tp, max_len,
+    RUN(layer_fwd((hipStream_t)stream, c, params, wcache, l, x, xl, a, act_extra(c, act, Tp, save), cu, nseq, T, Tp, max_len,
                   save && !ckpt, cls_form, cls_out));
     if (cls_form) return SIMX_OK;
     x = a.xout;
+    xl = a.xoutl;
   }
   if (cls_out) RUN(simx_cls_gather(stream, dt, nseq, H, cu, x, cls_out));
   if (hidden_out) {
@@ -415,7 +436,7 @@ extern "C" int simx_bert_bwd_range(simx_stream_t stream, const simx_bert_cfg* c,
     const WLayer w = wlayer(c, params, wcache, l);
     const char* xin = layer_input(c, act, Tp, l);
     const ALayer a = ckpt ? alayer_recompute(c, act, Tp) : alayer(c, act, Tp, l, 1);
-    if (ckpt) RUN(layer_fwd((hipStream_t)stream, c, params, wcache, l, xin, a, act_extra(c, act, Tp, 1), cu, nseq, T, Tp, max_len, 1, true, nullptr));
+    if (ckpt) RUN(layer_fwd((hipStream_t)stream, c, params, wcache, l, xin, layer_input_lo(c, act, Tp, l), a, act_extra(c, act, Tp, 1), cu, nseq, T, Tp, max_len, 1, true, nullptr));
     const simx_dropout d1 = drop_of(c, l, 1), d2 = drop_of(c, l, 2), d3 = drop_of(c, l, 3);
     char* dzm = hd ? bufC : bufA;
     char* e0 = tnws + tnws_bytes;                        // three [nseq,H] temporaries
@@ -471,12 +492,14 @@ extern "C" int simx_bert_bwd_range(simx_stream_t stream, const simx_bert_cfg* c,
     const WLayer w = wlayer(c, params, wcache, l);
     const char* xin = layer_input(c, act, Tp, l);
     const ALayer a = ckpt ? alayer_recompute(c, act, Tp) : alayer(c, act, Tp, l, 1);
-    if (ckpt) RUN(layer_fwd((hipStream_t)stream, c, params, wcache, l, xin, a, nullptr, cu, nseq, T, Tp, max_len, 1, false, nullptr));
+    const char* xinl = layer_input_lo(c, act, Tp, l);
+    const bool sl = stream_lo(c);
+    if (ckpt) RUN(layer_fwd((hipStream_t)stream, c, params, wcache, l, xin, xinl, a, nullptr, cu, nseq, T, Tp, max_len, 1, false, nullptr));
     const simx_dropout d1 = drop_of(c, l, 1), d2 = drop_of(c, l, 2), d3 = drop_of(c, l, 3);
     char* dzm = hd ? bufC : bufA;        // gradient of the (dropped) dense output; bufA = gradient of the residual branch
     // output LayerNorm : dz2, dgamma2, dbeta2, db2
-    RUN(simx_ln_bwd_gs(stream, dt, T, H, a.z2, off(l, SIMX_P_LN2_G), c->eps, bufB, bufA, hd ? bufC : nullptr, goff(l, SIMX_P_LN2_G),
-                       goff(l, SIMX_P_LN2_B), goff(l, SIMX_P_B2), &d2, nullptr, gs));
+    RUN(simx_ln_bwd_res(stream, dt, T, H, a.z2, sl ? a.x1 : nullptr, sl ? a.x1l : nullptr, off(l, SIMX_P_LN2_G), c->eps, bufB, bufA,
+                        hd ? bufC : nullptr, goff(l, SIMX_P_LN2_G), goff(l, SIMX_P_LN2_B), goff(l, SIMX_P_B2), &d2, nullptr, gs));
     // du = (dz2m . W2) * gelu'(u)
     RUN(simx_gemm_nt(stream, gdb, Tp, F, H, dzm, H, w.w2T, H, du, F, nullptr, nullptr, 0, SIMX_EPI_DGELU, a.u, F, nullptr, 0));
     RUN(simx_gemm_tn_gs(stream, gdb, H, F, T, dzm, H, a.h, F, goff(l, SIMX_P_W2), F, 1, tnws, tnws_bytes, nullptr, 0, gs));
@@ -484,8 +507,8 @@ extern "C" int simx_bert_bwd_range(simx_stream_t stream, const simx_bert_cfg* c,
     RUN(simx_gemm_nt(stream, gdb, Tp, H, F, du, F, w.w1T, F, bufB, H, nullptr, bufA, H, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
     RUN(simx_gemm_tn_gs(stream, gdb, F, H, T, du, F, a.x1, H, goff(l, SIMX_P_W1), H, 1, tnws, tnws_bytes, goff(l, SIMX_P_B1), 0, gs));
     // attention-output LayerNorm : dz1, dgamma1, dbeta1, dbo
-    RUN(simx_ln_bwd_gs(stream, dt, T, H, a.z1, off(l, SIMX_P_LN1_G), c->eps, bufB, bufA, hd ? bufC : nullptr, goff(l, SIMX_P_LN1_G),
-                       goff(l, SIMX_P_LN1_B), goff(l, SIMX_P_BO), &d1, nullptr, gs));
+    RUN(simx_ln_bwd_res(stream, dt, T, H, a.z1, sl ? xin : nullptr, sl ? xinl : nullptr, off(l, SIMX_P_LN1_G), c->eps, bufB, bufA,
+                        hd ? bufC : nullptr, goff(l, SIMX_P_LN1_G), goff(l, SIMX_P_LN1_B), goff(l, SIMX_P_BO), &d1, nullptr, gs));
     // dctx = dz1m . Wo
     RUN(simx_gemm_nt(stream, gdb, Tp, H, H, dzm, H, w.woT, H, bufB, H, nullptr, nullptr, 0, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
     RUN(simx_gemm_tn_gs(stream, gdb, H, H, T, dzm, H, a.ctx, H, goff(l, SIMX_P_WO), H, 1, tnws, tnws_bytes, nullptr, 0, gs));

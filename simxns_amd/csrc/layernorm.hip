@@ -36,10 +36,16 @@ template <> struct Raw4<f16_t> {
 
 // One wave per row, rows strided by 4 inside a block; the next row's loads are issued before this row's
 // reductions, and gamma/beta are read from LDS so the row body never queues behind those loads on vmcnt.
-template <typename T, int VPL>
+// RES ("f32-grade residual stream" of the 16-bit engines, simx.h stream_lo): the input row is  z = d + r_hi + r_lo  -- the
+// dense output (bias and dropout applied by the GEMM epilogue, no residual) plus the residual stream kept as a 16-bit value
+// and a 16-bit correction -- summed in f32, and the result leaves as y_hi = round16(y), y_lo = round16(y - y_hi): the
+// stream carries ~22 significand bits from layer to layer (apex O1 keeps it in fp32: residual additions promote to fp32 and
+// LayerNorm is an fp32 function there) at 4 B per element, and z never makes a round trip through HBM.
+template <typename T, int VPL, bool RES>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int H, int rows_per_block, const T* __restrict__ z,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     float eps, T* __restrict__ y) {
+                                                     float eps, T* __restrict__ y, const T* __restrict__ rh,
+                                                     const T* __restrict__ rl, T* __restrict__ ylo) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sgam = reinterpret_cast<float*>(smem);
   float* sbet = sgam + H;
@@ -48,29 +54,41 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int H, int rows_p
   __syncthreads();
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(rows, r0 + rows_per_block);
-  Raw4<T> nx[VPL];
-  if (r0 + w < r1) {
+  Raw4<T> nx[VPL], nh[RES ? VPL : 1], nl[RES ? VPL : 1];
+  auto issue = [&](int row) {
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
       const int c = (v * 64 + lane) * 4;
-      if (c < H) nx[v].load(z + (long)(r0 + w) * H + c);
+      if (c < H) {
+        nx[v].load(z + (long)row * H + c);
+        if (RES) { nh[v].load(rh + (long)row * H + c); if (rl) nl[v].load(rl + (long)row * H + c); }
+      }
     }
-  }
+  };
+  if (r0 + w < r1) issue(r0 + w);
   for (int row = r0 + w; row < r1; row += 4) {
     float x[VPL][4];
     float sum = 0.f;
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
       const int c = (v * 64 + lane) * 4;
-      if (c < H) { nx[v].unpack(x[v]); sum += x[v][0] + x[v][1] + x[v][2] + x[v][3]; }
-    }
-    if (row + 4 < r1) {
+      if (c < H) {
+        nx[v].unpack(x[v]);
+        if (RES) {
+          float a[4];
+          nh[v].unpack(a);
 #pragma unroll
-      for (int v = 0; v < VPL; ++v) {
-        const int c = (v * 64 + lane) * 4;
-        if (c < H) nx[v].load(z + (long)(row + 4) * H + c);
+          for (int e = 0; e < 4; ++e) x[v][e] += a[e];
+          if (rl) {
+            nl[v].unpack(a);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[v][e] += a[e];
+          }
+        }
+        sum += x[v][0] + x[v][1] + x[v][2] + x[v][3];
       }
     }
+    if (row + 4 < r1) issue(row + 4);
     const float mu = wave_sum(sum) / (float)H;
     float sq = 0.f;
 #pragma unroll
@@ -92,6 +110,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int H, int rows_p
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = x[v][e] * rstd * g[e] + b[e];
         st4(yr + c, o);
+        if (RES && ylo) {                       // the correction: what the 16-bit rounding of y just dropped
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] -= Elem<T>::rnd(o[e]);
+          st4(ylo + (long)row * H + c, o);
+        }
       }
     }
   }
@@ -102,7 +125,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(int rows, int H, cons
                                                            const int* __restrict__ pos, const float* __restrict__ word,
                                                            const float* __restrict__ posw, const float* __restrict__ typew,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           float eps, T* __restrict__ y, DropCtx drop) {
+                                                           float eps, T* __restrict__ y, DropCtx drop, T* __restrict__ ylo) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + w;
   if (row >= rows) return;
@@ -144,6 +167,11 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(int rows, int H, cons
       for (int e = 0; e < 4; ++e) o[e] = x[v][e] * rstd * g[e] + b[e];
       if (drop.thr) { float m4[4]; drop_mult4(drop, (uint32_t)row, (uint32_t)c, m4); o[0] *= m4[0]; o[1] *= m4[1]; o[2] *= m4[2]; o[3] *= m4[3]; }
       st4(yr + c, o);
+      if (ylo) {                                 // residual-stream correction (simx.h stream_lo)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] -= Elem<T>::rnd(o[e]);
+        st4(ylo + (long)row * H + c, o);
+      }
     }
   }
 }
@@ -209,13 +237,15 @@ __device__ __forceinline__ void flush_cols(int H, int lane, int w, float (&p)[VP
 // One wave per row, rows strided by 4 inside a block.  The loads of row+4 are issued before row is processed
 // (gamma comes from LDS so nothing in the row body queues behind them on vmcnt), which doubles the bytes each
 // wave keeps in flight; the three column partials stay in registers and are flushed once per block.
-template <typename T, int VPL>
+// RES: the LayerNorm input is rebuilt as z = d + r_hi + r_lo (see ln_fwd_kernel), rl may be NULL.
+template <typename T, int VPL, bool RES>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int H, int rows_per_block, const T* __restrict__ z,
                                                      const float* __restrict__ gamma, float eps, const T* __restrict__ dyp,
                                                      T* __restrict__ dzp, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, float* __restrict__ dbias,
                                                      T* __restrict__ dzm, DropCtx drop, const int* __restrict__ row_keys,
-                                                     const float* __restrict__ gs) {
+                                                     const float* __restrict__ gs, const T* __restrict__ rh,
+                                                     const T* __restrict__ rl) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sred = reinterpret_cast<float*>(smem);          // [4][H] flush scratch
   float* sgam = sred + 4 * H;                            // [H]
@@ -229,29 +259,43 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int H, int rows_p
   // CU made it slower).
   (void)rows_per_block;
   const int r0 = blockIdx.x * 4, r1 = rows, rstep = (int)gridDim.x * 4;
-  Raw4<T> nx[VPL], nd[VPL];
-  if (r0 + w < r1) {
+  Raw4<T> nx[VPL], nd[VPL], nh[RES ? VPL : 1], nl[RES ? VPL : 1];
+  auto issue = [&](int row) {
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
       const int c = (v * 64 + lane) * 4;
-      if (c < H) { nx[v].load(z + (long)(r0 + w) * H + c); nd[v].load(dyp + (long)(r0 + w) * H + c); }
+      if (c < H) {
+        nx[v].load(z + (long)row * H + c);
+        nd[v].load(dyp + (long)row * H + c);
+        if (RES) { nh[v].load(rh + (long)row * H + c); if (rl) nl[v].load(rl + (long)row * H + c); }
+      }
     }
-  }
+  };
+  if (r0 + w < r1) issue(r0 + w);
   for (int row = r0 + w; row < r1; row += rstep) {
     float x[VPL][4], dy[VPL][4], dz[VPL][4];
     float sum = 0.f;
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
       const int c = (v * 64 + lane) * 4;
-      if (c < H) { nx[v].unpack(x[v]); nd[v].unpack(dy[v]); sum += x[v][0] + x[v][1] + x[v][2] + x[v][3]; }
-    }
-    if (row + rstep < r1) {
+      if (c < H) {
+        nx[v].unpack(x[v]);
+        nd[v].unpack(dy[v]);
+        if (RES) {
+          float a[4];
+          nh[v].unpack(a);
 #pragma unroll
-      for (int v = 0; v < VPL; ++v) {
-        const int c = (v * 64 + lane) * 4;
-        if (c < H) { nx[v].load(z + (long)(row + rstep) * H + c); nd[v].load(dyp + (long)(row + rstep) * H + c); }
+          for (int e = 0; e < 4; ++e) x[v][e] += a[e];
+          if (rl) {
+            nl[v].unpack(a);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[v][e] += a[e];
+          }
+        }
+        sum += x[v][0] + x[v][1] + x[v][2] + x[v][3];
       }
     }
+    if (row + rstep < r1) issue(row + rstep);
     const float mu = wave_sum(sum) / (float)H;
 #pragma unroll
     for (int v = 0; v < VPL; ++v)
@@ -529,14 +573,23 @@ static int bwd_rows_per_block(int T) { return ln_rows_per_block(T, "SIMX_LN_BWD_
 
 extern "C" int simx_ln_fwd(simx_stream_t stream, int dtype, int T, int H, const void* z, const float* gamma,
                            const float* beta, float eps, void* y) {
-  SIMX_PROF(SIMX_K_LN_FWD, stream, 2.0 * T * H * simx_esz(dtype));
+  return simx_ln_fwd_res(stream, dtype, T, H, z, nullptr, nullptr, gamma, beta, eps, y, nullptr);
+}
+
+extern "C" int simx_ln_fwd_res(simx_stream_t stream, int dtype, int T, int H, const void* d, const void* res_hi, const void* res_lo,
+                               const float* gamma, const float* beta, float eps, void* y, void* y_lo) {
+  const int streams = 2 + (res_hi ? 1 : 0) + (res_lo ? 1 : 0) + (y_lo ? 1 : 0);
+  SIMX_PROF(SIMX_K_LN_FWD, stream, (double)streams * T * H * simx_esz(dtype));
   int rc = ln_check(dtype, T, H, "ln_fwd");
   if (rc) return rc;
+  SIMX_REQUIRE(res_hi || (!res_lo && !y_lo), SIMX_ERR_BAD_SHAPE, "ln_fwd_res: res_lo / y_lo need res_hi");
   hipStream_t s = (hipStream_t)stream;
   const int rpb = ln_rows_per_block(T, "SIMX_LN_FWD_BLOCKS", 1 << 30);   // 16 rows (4 per wave) per block measured best
   const size_t lds = (size_t)2 * H * sizeof(float);
-#define LF(TT, V) hipLaunchKernelGGL((ln_fwd_kernel<TT, V>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, (const TT*)z, gamma, beta, \
-                                    eps, (TT*)y)
+#define LF(TT, V) do { if (res_hi) hipLaunchKernelGGL((ln_fwd_kernel<TT, V, true>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, (const TT*)d, gamma, beta, \
+                                    eps, (TT*)y, (const TT*)res_hi, (const TT*)res_lo, (TT*)y_lo);                                    \
+                       else hipLaunchKernelGGL((ln_fwd_kernel<TT, V, false>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, (const TT*)d, gamma, beta, \
+                                    eps, (TT*)y, (const TT*)nullptr, (const TT*)nullptr, (TT*)nullptr); } while (0)
   SIMX_DISPATCH3(dtype, TT, LN_BY_H(TT, LF));
 #undef LF
   SIMX_CHECK_LAUNCH("ln_fwd");
@@ -563,16 +616,26 @@ extern "C" int simx_ln_bwd_keyed(simx_stream_t stream, int dtype, int T, int H, 
 extern "C" int simx_ln_bwd_gs(simx_stream_t stream, int dtype, int T, int H, const void* z, const float* gamma, float eps,
                               const void* dy, void* dz, void* dz_masked, float* dgamma, float* dbeta, float* dbias,
                               const simx_dropout* dropd, const int32_t* row_keys, const float* gs) {
-  SIMX_PROF(SIMX_K_LN_BWD, stream, 3.0 * T * H * simx_esz(dtype));
+  return simx_ln_bwd_res(stream, dtype, T, H, z, nullptr, nullptr, gamma, eps, dy, dz, dz_masked, dgamma, dbeta, dbias, dropd, row_keys, gs);
+}
+
+extern "C" int simx_ln_bwd_res(simx_stream_t stream, int dtype, int T, int H, const void* z, const void* res_hi, const void* res_lo,
+                               const float* gamma, float eps, const void* dy, void* dz, void* dz_masked, float* dgamma, float* dbeta,
+                               float* dbias, const simx_dropout* dropd, const int32_t* row_keys, const float* gs) {
+  const int streams = 3 + (res_hi ? 1 : 0) + (res_lo ? 1 : 0);
+  SIMX_PROF(SIMX_K_LN_BWD, stream, (double)streams * T * H * simx_esz(dtype));
   int rc = ln_check(dtype, T, H, "ln_bwd");
   if (rc) return rc;
+  SIMX_REQUIRE(res_hi || !res_lo, SIMX_ERR_BAD_SHAPE, "ln_bwd_res: res_lo needs res_hi");
   const DropCtx drop = make_drop(dropd);
   SIMX_REQUIRE(!drop.thr || dz_masked, SIMX_ERR_BAD_SHAPE, "ln_bwd: dropout needs the dz_masked output");
   hipStream_t s = (hipStream_t)stream;
   const int rpb = bwd_rows_per_block(T);
   const size_t lds = (size_t)5 * H * sizeof(float);
-#define LB(TT, V) hipLaunchKernelGGL((ln_bwd_kernel<TT, V>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, (const TT*)z, gamma, eps, \
-                                    (const TT*)dy, (TT*)dz, dgamma, dbeta, dbias, (TT*)dz_masked, drop, row_keys, gs)
+#define LB(TT, V) do { if (res_hi) hipLaunchKernelGGL((ln_bwd_kernel<TT, V, true>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, (const TT*)z, gamma, eps, \
+                                    (const TT*)dy, (TT*)dz, dgamma, dbeta, dbias, (TT*)dz_masked, drop, row_keys, gs, (const TT*)res_hi, (const TT*)res_lo); \
+                       else hipLaunchKernelGGL((ln_bwd_kernel<TT, V, false>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, (const TT*)z, gamma, eps, \
+                                    (const TT*)dy, (TT*)dz, dgamma, dbeta, dbias, (TT*)dz_masked, drop, row_keys, gs, (const TT*)nullptr, (const TT*)nullptr); } while (0)
   SIMX_DISPATCH3(dtype, TT, LN_BY_H(TT, LB));
 #undef LB
   SIMX_CHECK_LAUNCH("ln_bwd");
@@ -588,13 +651,18 @@ extern "C" int simx_embed_ln_fwd(simx_stream_t stream, int dtype, int T, int H, 
 extern "C" int simx_embed_ln_fwd_ex(simx_stream_t stream, int dtype, int T, int H, const int32_t* ids, const int32_t* pos_ids,
                                     const float* word, const float* posw, const float* typew, const float* gamma,
                                     const float* beta, float eps, void* out, const simx_dropout* dropd) {
+  return simx_embed_ln_fwd_lo(stream, dtype, T, H, ids, pos_ids, word, posw, typew, gamma, beta, eps, out, nullptr, dropd);
+}
+extern "C" int simx_embed_ln_fwd_lo(simx_stream_t stream, int dtype, int T, int H, const int32_t* ids, const int32_t* pos_ids,
+                                    const float* word, const float* posw, const float* typew, const float* gamma,
+                                    const float* beta, float eps, void* out, void* out_lo, const simx_dropout* dropd) {
   const DropCtx drop = make_drop(dropd);
   SIMX_PROF(SIMX_K_EMBED_FWD, stream, (double)T * H * (4 + simx_esz(dtype)));
   int rc = ln_check(dtype, T, H, "embed_ln_fwd");
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   SIMX_DISPATCH3(dtype, TT, hipLaunchKernelGGL((embed_ln_fwd_kernel<TT>), dim3(cdiv(T, 4)), dim3(256), 0, s, T, H, ids, pos_ids, word,
-                                               posw, typew, gamma, beta, eps, (TT*)out, drop));
+                                               posw, typew, gamma, beta, eps, (TT*)out, drop, (TT*)out_lo));
   SIMX_CHECK_LAUNCH("embed_ln_fwd");
   return SIMX_OK;
 }

@@ -76,7 +76,9 @@ class BertConfigLite(object):
 
 
 def _dtype_code(name):
-    if name in ("fp16", "float16", "f16", "half", torch.float16):
+    if name in ("fp32_exact", "fp32-exact"):          # fp32 engine with exact f32 products in every GEMM (simx.h f32_gemm = 1)
+        return L.SIMX_F32
+    if name in ("fp16", "float16", "f16", "half", "fp16_plain", torch.float16):
         return L.SIMX_F16
     if name in ("bf16", "bfloat16", torch.bfloat16):
         return L.SIMX_BF16
@@ -266,11 +268,25 @@ class BertEngine(object):
         # cfg.gradient_checkpointing (models.py:73-74): per-layer recompute in the native backward; SIMX_GRAD_CKPT=0/1 overrides
         ck = os.environ.get("SIMX_GRAD_CKPT")
         ckpt = bool(getattr(c, "gradient_checkpointing", False)) if ck is None else ck == "1"
+        # fp32: the dense GEMMs run on the 16-bit matrix cores from hi + lo splits of their f32 operands (simx.h
+        # SIMX_F32_SPLIT_H / _B); "fp32_exact" (or SIMX_GEMM_F32=exact) keeps exact f32 products everywhere
+        exact = name in ("fp32_exact", "fp32-exact") or os.environ.get("SIMX_GEMM_F32", "")[:1] == "e"
         self.ccfg = L.BertCfg(self.dtype_code, c.num_hidden_layers, c.hidden_size, c.num_attention_heads,
                               c.intermediate_size, c.vocab_size, c.max_position_embeddings, c.type_vocab_size,
-                              float(c.layer_norm_eps), 0.0, 0.0, 0, 0, 1 if ckpt else 0, 0, None)
+                              float(c.layer_norm_eps), 0.0, 0.0, 0, 0, 1 if ckpt else 0, 0, 1 if exact else 0, self._stream_lo(name), None)
         self.wcache = None
         self._dirty = True
+
+    def _stream_lo(self, name):
+        """fp16: the residual stream carries a 16-bit correction beside every 16-bit value and the LayerNorm kernels add the
+        residual in f32 (simx.h stream_lo) -- the f32 residual stream / f32 LayerNorm of apex O1, which the reference's --fp16
+        mode is.  "fp16_plain" (or SIMX_STREAM_LO=0) keeps a plain 16-bit stream; bf16 defaults to plain, SIMX_STREAM_LO=1 opts in."""
+        if self.dtype_code == L.SIMX_F32:
+            return 0
+        env = os.environ.get("SIMX_STREAM_LO")
+        if env is not None:
+            return 1 if env == "1" else 0
+        return 1 if (self.dtype_code == L.SIMX_F16 and name != "fp16_plain") else 0
 
     @property
     def act_torch_dtype(self):

@@ -26,7 +26,8 @@ def _ms_pas():
                  gradient_accumulation_steps=2, number_neg=15, learning_rate=5e-6,
                  teacher_model_type="nghuyong/ernie-2.0-large-en", teacher_model_path="ckpt/MS-Pas/checkpoint-reranker20000",
                  teacher_learning_rate=5e-7, origin_data_dir="data/MS-Pas/train_ce_0.tsv", logging_steps=10, save_steps=5000,
-                 distill_loss=True, temperature_distill=1, adv_lambda=1)
+                 distill_loss=True, temperature_distill=1, adv_lambda=1,
+                 sampler="gpu")       # north_star config 2: SimANS draw + collate on the device (--sampler host replays CPython's picks)
     return dict(iteration_step=5000, iteration_reranker_step=500, max_steps=60000,
                 train=("simxns_amd/co_training/co_training_marco_train.py", train),
                 generate=("simxns_amd/co_training/co_training_generate.py", dict(common, adv_step=0)))

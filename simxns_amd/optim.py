@@ -51,7 +51,8 @@ class FusedAdamW(object):
         # scaler per optimizer too, co_training_marco_train.py:97-104); engines read it in backward, step() updates it
         self.scaler = None
         if any(e.dtype_code == L.SIMX_F16 for m, e in self.towers):
-            self.scaler = LossScaler()
+            import os
+            self.scaler = LossScaler(init_scale=float(os.environ.get("SIMX_LOSS_SCALE_INIT", 2.0 ** 16)))
             for m, e in self.towers:
                 if e.dtype_code == L.SIMX_F16:
                     e.scaler = self.scaler

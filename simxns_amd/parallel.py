@@ -11,8 +11,14 @@
 xGMI is point-to-point (7 links/GPU): payloads here are 6.7 MB/rank (embeddings, latency-bound) and 438-876 MB
 (gradients, ring/tree per-link bound) -- few large collectives, no per-parameter buckets.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+# SIMX_FORCE_COLLECTIVES=1: issue the collectives for a one-rank group too (tests/test_dp_gpu.py drives the whole
+# data-parallel path through RCCL on a single GPU this way); a production run never sets it
+FORCE_COLLECTIVES = os.environ.get("SIMX_FORCE_COLLECTIVES") == "1"
 
 
 def _world(group=None):
@@ -40,7 +46,7 @@ class _GatherLocalGrad(torch.autograd.Function):
 def gather_with_local_grad(x, group=None):
     """[n,...] per rank (equal n on all ranks) -> [W*n,...] in rank order; gradient flows to the local rows only."""
     W, _ = _world(group)
-    if W == 1:
+    if W == 1 and not (FORCE_COLLECTIVES and dist.is_available() and dist.is_initialized()):
         return x
     return _GatherLocalGrad.apply(x, group)
 

@@ -6,8 +6,13 @@ and batch layout as SimANS/utils/MARCO_until_new.py:125-260:
 
 ``__getitem__`` draws the SimANS negatives on the host exactly like the reference (CPython ``random``:
 weights exp(-|s_i - s_pos| * tau), rounds of ``random.choices(k=N)``, dedupe, remove, repeat; ``pos_score == 0`` ->
-the last N candidates) so a seeded run replays the reference's picks; ``sampler="gpu"`` instead returns the candidate
-scores so that the draw happens on the device (``simxns_amd.ops.simans_sample``) inside the step.
+the last N candidates) so a seeded run replays the reference's picks.  ``sampler="gpu"`` (``--sampler gpu`` of the train job)
+moves the whole of it to the device: ``build_device_pool`` tokenises this rank's queries and the passages its rows refer to
+ONCE per iteration into int32 tables resident in HBM (+ the candidate scores, right-aligned), and ``device_batch`` then costs
+the host a list of B row numbers per step -- positive pick, SimANS draw (``ops.simans_sample``: the same weights, rounds of N
+with-replacement draws, dedupe, remove, repeat; Philox instead of CPython's Mersenne twister, so the picks follow the same
+law but not the same sequence) and collate (``ops.assemble_batch``, bit-identical to the host collate) run on the GPU and
+return the collate's dictionary with device tensors.
 Collate -> {'student': [q[B,32], q_mask, ctx[B(1+N),128], ctx_mask, positive_ctx_indices],
             'teacher': [ce[B,1+N,160], ce_mask, tgt]}  (MARCO_until_new.py:241-258).
 """
@@ -67,6 +72,85 @@ class Rocketqa_v2Dataset(Dataset):
 
     def __len__(self):
         return len(self.data)
+
+    # ---- sampler="gpu": SimANS draw + collate on the device (MARCO_until_new.py:165-258 without the DataLoader workers) -------
+    def build_device_pool(self, device, q_len=32, p_len=128):
+        """Tokenise this rank's queries and every passage its rows mention once; keep them, the candidate row numbers and the
+        candidate scores in HBM.  Candidates are RIGHT-aligned in [NQ, Cmax] tables (pad score = +inf -> weight exp(-inf) = 0;
+        the ``pos_score == 0`` rule "last N candidates" then still means the last N real ones)."""
+        import numpy as np
+        pad = self.tokenizer.pad_token_id
+        rows, ptok = {}, []
+
+        def row_of(pid):
+            r = rows.get(pid)
+            if r is None:
+                r = rows[pid] = len(ptok)
+                t = self._encode_ctx(pid)
+                ptok.append(t + [pad] * (p_len - len(t)))
+            return r
+        NQ = len(self.data)
+        qtok = np.full((NQ, q_len), pad, dtype=np.int32)
+        parsed = []
+        for i, sample in enumerate(self.data):
+            q = self.tokenizer.encode(sample.query_string, add_special_tokens=True, max_length=q_len, truncation=True)
+            qtok[i, :len(q)] = q
+            pos = [(int(p.split()[0]), float(p.split()[1])) for p in sample.pos_id.split(',')]
+            neg = [(int(p.split()[0]), float(p.split()[1])) for p in sample.neg_id.split(',')]
+            if len(neg) < self.num_hard_negatives:
+                raise ValueError("query %s has %d mined negatives, fewer than --number_neg %d" % (sample.query_id, len(neg), self.num_hard_negatives))
+            parsed.append((pos, neg))
+        cmax = max(len(n) for _, n in parsed)
+        pmax = max(len(p) for p, _ in parsed)
+        cand_rows = np.zeros((NQ, cmax), dtype=np.int32)
+        cand_scores = np.full((NQ, cmax), np.inf, dtype=np.float64)
+        pos_rows = np.zeros((NQ, pmax), dtype=np.int32)
+        pos_scores = np.zeros((NQ, pmax), dtype=np.float64)
+        pos_cnt = np.zeros(NQ, dtype=np.int64)
+        for i, (pos, neg) in enumerate(parsed):
+            k = len(neg)
+            cand_rows[i, cmax - k:] = [row_of(pid) for pid, _ in neg]
+            cand_scores[i, cmax - k:] = [s for _, s in neg]
+            pos_rows[i, :len(pos)] = [row_of(pid) for pid, _ in pos]
+            pos_scores[i, :len(pos)] = [s for _, s in pos]
+            pos_cnt[i] = len(pos)
+        t = lambda a: torch.from_numpy(a).to(device)
+        self.pool = {"q_tok": t(qtok), "p_tok": t(np.asarray(ptok, dtype=np.int32).reshape(-1, p_len)), "cand_rows": t(cand_rows),
+                     "cand_scores": t(cand_scores), "pos_rows": t(pos_rows), "pos_scores": t(pos_scores), "pos_cnt": t(pos_cnt),
+                     "row_of": rows, "device": torch.device(device)}
+        return self.pool
+
+    def device_batch(self, indices, seed=0, step=0, pos_choice=None, neg_choice=None):
+        """One training batch of rows `indices` assembled on the device -> the collate's dictionary (device tensors).
+        pos_choice [B] (index into the row's positives) / neg_choice [B,N] (index into its candidate list) override the random
+        picks (tests: the same picks as a host-side draw must give the collate's batch bit for bit)."""
+        from .. import ops
+        P = self.pool
+        dev = P["device"]
+        idx = torch.as_tensor(indices, dtype=torch.int64, device=dev)
+        B, N = idx.numel(), self.num_hard_negatives
+        cmax = P["cand_rows"].shape[1]
+        if pos_choice is None:
+            if self.is_training:                 # random.choice(pos_pairs) (:170) as a counter-based device draw
+                g = torch.Generator(device=dev)
+                g.manual_seed((int(seed) * 1000003 + int(step)) & 0x7FFFFFFF)
+                pos_choice = (torch.rand(B, device=dev, generator=g) * P["pos_cnt"][idx]).long().clamp_(max=P["pos_rows"].shape[1] - 1)
+            else:
+                pos_choice = torch.zeros(B, dtype=torch.int64, device=dev)
+        else:
+            pos_choice = torch.as_tensor(pos_choice, dtype=torch.int64, device=dev)
+        pos_row = P["pos_rows"][idx].gather(1, pos_choice[:, None])
+        pos_score = P["pos_scores"][idx].gather(1, pos_choice[:, None]).squeeze(1)
+        if neg_choice is None:
+            neg = ops.simans_sample(P["cand_scores"][idx], pos_score, N, form=ops.LAPLACE, tau=float(self.tau), seed=seed, offset=step).long()
+        else:                                    # indices into the row's OWN candidate list (0 = best ranked) -> right-aligned table
+            nc = torch.as_tensor(neg_choice, dtype=torch.int64, device=dev)
+            neg = nc + (cmax - torch.isfinite(P["cand_scores"][idx]).sum(1, keepdim=True))
+        p_rows = torch.cat([pos_row, P["cand_rows"][idx].gather(1, neg).long()], dim=1).to(torch.int32)
+        out = ops.assemble_batch(P["q_tok"], P["p_tok"], idx.to(torch.int32), p_rows, 1 + N, pad_id=self.tokenizer.pad_token_id,
+                                 sep_id=self.tokenizer.sep_token_id, ce_len=160)
+        out["picks"] = {"pos_choice": pos_choice, "neg_table_index": neg}
+        return out
 
     def _encode_ctx(self, pid):
         title, para = self.p_title.get(int(pid), '-'), self.p_text[int(pid)]

@@ -40,7 +40,11 @@ BF16_HOT_TOL = dict(emb_abs=0.2, logits_rel=0.12, teacher_logits_abs=0.1, loss_a
 # measurement where that is tighter; measured values: DESIGN.md 2.
 FP16_HOT_TOL = dict(emb_abs=0.04, logits_rel=0.01, teacher_logits_abs=0.02, loss_abs=5e-3, gnorm_rel_median=0.01, gnorm_rel_max=0.04,
                     gslice_cos_min=0.97, gslice_cos_median_all=0.995)
-HOT_TOL = {"bf16": BF16_HOT_TOL, "fp16": FP16_HOT_TOL}
+# plain 16-bit residual stream (residual added in the GEMM epilogue, the pre-LayerNorm sum rounded to fp16): measured logits
+# 0.69 %, embeddings 0.013, loss 0.010, gradient norms median 0.6 % / max 0.96 %, slice cosine min 0.9986
+FP16_PLAIN_HOT_TOL = dict(emb_abs=0.04, logits_rel=0.02, teacher_logits_abs=0.025, loss_abs=0.03, gnorm_rel_median=0.018, gnorm_rel_max=0.03,
+                          gslice_cos_min=0.995, gslice_cos_median_all=0.999)
+HOT_TOL = {"bf16": BF16_HOT_TOL, "fp16": FP16_HOT_TOL, "fp16_plain": FP16_PLAIN_HOT_TOL}
 
 
 def _cfg_from(G):

@@ -215,3 +215,47 @@ def test_fp16_training_steps_with_dynamic_scale(dev):
     assert losses[-1] < losses[0], losses
     sd = opt.state_dict()
     assert sd["state"][0]["step"] == snap["applied_steps"] and sd["loss_scaler"]["scale"] == snap["scale"]
+
+
+@pytest.mark.parametrize("fmt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("T,H", [(300, 768), (37, 64), (50, 1024)])
+def test_ln_residual_stream(dev, fmt, T, H):
+    """simx_ln_fwd_res / simx_ln_bwd_res (simx.h stream_lo): y = LN(d + r_hi + r_lo) summed in f32, y leaves as a 16-bit
+    value plus a 16-bit correction: y_hi + y_lo carries the f32 result to ~2^-17 (bf16) / 2^-21 (fp16), and the backward
+    rebuilds the LayerNorm input from the same three tensors."""
+    from oracle import bert as obert
+    lib = L()
+    code = 2 if fmt == torch.float16 else 1
+    t16 = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(fmt)
+    d, r = rnd((T, H), 1, 0.7), rnd((T, H), 2, 1.5) + 0.3
+    g, b = 1.0 + rnd((H,), 3, 0.1), rnd((H,), 4, 0.1)
+    dd, rh = t16(d), t16(r)
+    rl = (torch.from_numpy(r).to(dev) - rh.float()).to(fmt)             # the correction a producer would have written
+    dg, db = torch.from_numpy(g).to(dev), torch.from_numpy(b).to(dev)
+    y, ylo = torch.empty(T, H, device=dev, dtype=fmt), torch.empty(T, H, device=dev, dtype=fmt)
+    lib.call("simx_ln_fwd_res", lib.stream_ptr(), code, T, H, lib.ptr(dd), lib.ptr(rh), lib.ptr(rl), lib.ptr(dg), lib.ptr(db), 1e-12,
+             lib.ptr(y), lib.ptr(ylo))
+    z = dd.double().cpu().numpy() + rh.double().cpu().numpy() + rl.double().cpu().numpy()
+    yr, cache = obert._ln_fwd(z, g.astype(np.float64), b.astype(np.float64), 1e-12)
+    got = (y.double() + ylo.double()).cpu().numpy()
+    eps2 = 2.0 ** -20 if fmt == torch.float16 else 2.0 ** -15
+    assert np.abs(got - yr).max() <= eps2 * max(1.0, np.abs(yr).max()) + 1e-6, np.abs(got - yr).max()
+    assert torch.equal(y, torch.from_numpy(yr).to(dev).to(fmt)) or (y.double().cpu().numpy() - yr).__abs__().max() <= 2.0 ** -7 * np.abs(yr).max()
+    # without the corrections: plain 16-bit residual (res_lo = y_lo = NULL)
+    y2 = torch.empty_like(y)
+    lib.call("simx_ln_fwd_res", lib.stream_ptr(), code, T, H, lib.ptr(dd), lib.ptr(rh), None, lib.ptr(dg), lib.ptr(db), 1e-12, lib.ptr(y2), None)
+    yr2, _ = obert._ln_fwd(dd.double().cpu().numpy() + rh.double().cpu().numpy(), g.astype(np.float64), b.astype(np.float64), 1e-12)
+    tol = 2.0 ** -10 if fmt == torch.float16 else 2.0 ** -7
+    assert np.abs(y2.double().cpu().numpy() - yr2).max() <= tol * max(1.0, np.abs(yr2).max())
+    # backward
+    dy = rnd((T, H), 5, 0.3)
+    ddy = t16(dy)
+    dz = torch.empty(T, H, device=dev, dtype=fmt)
+    dgam, dbet, dbias = (torch.zeros(H, device=dev) for _ in range(3))
+    lib.call("simx_ln_bwd_res", lib.stream_ptr(), code, T, H, lib.ptr(dd), lib.ptr(rh), lib.ptr(rl), lib.ptr(dg), 1e-12, lib.ptr(ddy),
+             lib.ptr(dz), None, lib.ptr(dgam), lib.ptr(dbet), lib.ptr(dbias), None, None, None)
+    dx, dgr, dbr = obert._ln_bwd(ddy.double().cpu().numpy(), cache, g.astype(np.float64))
+    assert np.abs(dz.double().cpu().numpy() - dx).max() <= tol * max(1.0, np.abs(dx).max())
+    assert np.abs(dgam.double().cpu().numpy() - dgr).max() <= 1e-3 * max(1.0, np.abs(dgr).max())
+    assert np.abs(dbet.double().cpu().numpy() - dbr).max() <= 1e-3 * max(1.0, np.abs(dbr).max())
+    assert np.abs(dbias.double().cpu().numpy() - dx.sum(0)).max() <= 3e-3 * max(1.0, np.abs(dx.sum(0)).max())

@@ -181,3 +181,82 @@ def test_ms_doc_train_job(dev, tmp_path):
     assert all(torch.isfinite(v).all() for v in st.model_dict.values())
     tst = load_states_from_checkpoint(os.path.join(out, "checkpoint-reranker6"))
     assert "qa_classifier.weight" in tst.model_dict
+
+
+def test_gpu_sampler_matches_host_collate_and_law(dev, tmp_path):
+    """--sampler gpu (Rocketqa_v2Dataset.build_device_pool / device_batch; reference: SimANS/utils/MARCO_until_new.py:165-258):
+    (1) fed the host draw's own picks, the device batch equals the host collate bit for bit; (2) left to its own Philox
+    draws, every pick is a distinct real candidate and the inclusion frequencies match the host sampler's law; (3) the
+    train job runs on it."""
+    import random
+    from simxns_amd.utils.MARCO_until_new import Rocketqa_v2Dataset, HashTokenizer, simans_draw
+    root = str(tmp_path / "data")
+    _write_corpus(root, n_q=16, n_cand=24)
+    # ragged candidate lists + several positives on some rows
+    lines = open(os.path.join(root, "train_ce_0.tsv")).read().splitlines()
+    rows = [l.split("\t") for l in lines]
+    rows[3][3] = ",".join(rows[3][3].split(",")[:18])
+    rows[5][2] = rows[5][2] + "," + "7 77.5000"
+    open(os.path.join(root, "train_ce_0.tsv"), "w").write("\n".join("\t".join(r) for r in rows) + "\n")
+    N = 7
+    ds = Rocketqa_v2Dataset(os.path.join(root, "train_ce_0.tsv"), HashTokenizer(), num_hard_negatives=N, corpus_path=root)
+    ds.build_device_pool(dev)
+    collate = Rocketqa_v2Dataset.get_collate_fn(None)
+    # (1) same picks -> same batch.  Replay the host __getitem__ while recording its picks.
+    idx = [0, 3, 5, 9]
+    feats, pos_choice, neg_choice = [], [], []
+    for i in idx:
+        sample = ds.data[i]
+        pos_pairs = sample.pos_id.split(",")
+        negs = [(int(p.split()[0]), float(p.split()[1])) for p in sample.neg_id.split(",")]
+        random.seed(100 + i)
+        pc = random.randrange(len(pos_pairs))
+        pos_score = float(pos_pairs[pc].split()[1])
+        picked = simans_draw(negs, pos_score, N, 3)
+        pos_choice.append(pc)
+        neg_choice.append([[p for p, _ in negs].index(pid) for pid in picked])
+        # the host __getitem__ with exactly these picks
+        ctx = [ds._encode_ctx(int(pos_pairs[pc].split()[0]))] + [ds._encode_ctx(n) for n in picked]
+        q = ds.tokenizer.encode(sample.query_string, add_special_tokens=True, max_length=32, truncation=True)
+        strip = lambda t: t[1:-1] if t[-1] == 102 else t[1:]
+        ce = [q + strip(c) for c in ctx]
+        feats.append((torch.LongTensor(q + [0] * (32 - len(q))), torch.LongTensor([c + [0] * (128 - len(c)) for c in ctx]),
+                      torch.LongTensor([c + [0] * (160 - len(c)) for c in ce])))
+    host = collate(feats)
+    devb = ds.device_batch(idx, pos_choice=pos_choice, neg_choice=neg_choice)
+    for k in ("student", "teacher"):
+        for a, b in zip(host[k], devb[k]):
+            if torch.is_tensor(a):
+                assert torch.equal(a, b.cpu()), k
+            else:
+                assert a == b
+    # (2) the device draw: distinct real candidates; inclusion frequencies vs the host sampler (same law, different RNG)
+    q = 9
+    negs = [(int(p.split()[0]), float(p.split()[1])) for p in ds.data[q].neg_id.split(",")]
+    pos_score = float(ds.data[q].pos_id.split(",")[0].split()[1])
+    C = len(negs)
+    trials = 3000
+    cnt_dev = np.zeros(C)
+    cmax = ds.pool["cand_rows"].shape[1]
+    for t in range(0, trials, 100):
+        b = ds.device_batch([q] * 100, seed=5, step=t, pos_choice=[0] * 100)
+        tab = b["picks"]["neg_table_index"].cpu().numpy() - (cmax - C)
+        assert tab.min() >= 0 and all(len(set(r)) == N for r in tab)
+        np.add.at(cnt_dev, tab.ravel(), 1)
+    cnt_host = np.zeros(C)
+    rng = random.Random(1)
+    pids = [p for p, _ in negs]
+    for _ in range(trials):
+        for pid in simans_draw(negs, pos_score, N, 3, rng=rng):
+            cnt_host[pids.index(pid)] += 1
+    fd, fh = cnt_dev / trials, cnt_host / trials
+    assert np.abs(fd - fh).max() <= 0.05, (fd, fh)
+    # (3) the job itself
+    from simxns_amd.co_training import co_training_marco_train as T
+    gs = T.main(["--model_type", os.path.join(root, "student"), "--teacher_model_type", os.path.join(root, "teacher"),
+                 "--tokenizer_name", "hash", "--per_gpu_train_batch_size", "4", "--number_neg", "7", "--learning_rate", "1e-3",
+                 "--teacher_learning_rate", "1e-4", "--output_dir", str(tmp_path / "ckpt"), "--log_dir", str(tmp_path / "tb"),
+                 "--origin_data_dir", os.path.join(root, "train_ce_0.tsv"), "--passage_path", root, "--logging_steps", "2",
+                 "--save_steps", "1000", "--max_steps", "6", "--iteration_step", "6", "--iteration_reranker_step", "2",
+                 "--temperature_distill", "1", "--ann_dir", root, "--num_workers", "0", "--sampler", "gpu", "--global_step", "0"])
+    assert gs == 6

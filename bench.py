@@ -8,8 +8,12 @@ retriever step (SimANS/co_training/co_training_marco_train.py:175-263) with the 
     -> einsum similarity + softmax/KL-distill loss         -> backward through both towers
     -> (N>1: RCCL all-reduce of the flat gradients)        -> clip_grad_norm_(2.0) + AdamW + schedule + zero_grad
 Workload = BASELINE.json configs[1]: BERT-base, B=128 queries/GPU, 15 hard negatives, q_len 32 / p_len 128 /
-cross-encoder len 160, bf16 operands with f32 accumulation and f32 master weights.  Default lengths are the
-worst case (every sequence at its maximum length); --varlen draws realistic lengths.
+cross-encoder len 160.  Default arithmetic (--dtype fp16) = the operand width of the reference's own optional 16-bit mode
+(apex O1, co_training_marco_train.py:97-104): IEEE-half GEMM / attention operands, f32 accumulation, f32 LayerNorm statistics
+and softmax, an f32-grade residual stream (16-bit value + 16-bit correction, summed in f32 inside the LayerNorm kernels),
+f32 master weights, dynamic loss scaling on the device.  --dtype fp32 is the arithmetic every shipped recipe selects (no
+--fp16 in train_*_AR2.sh) and is reported beside the headline as `fp32_mode` / `recipe_fp32_gradckpt`.  Default lengths are
+the worst case (every sequence at its maximum length); --varlen draws realistic lengths.
 --inbatch adds BASELINE configs[2]: RCCL all-gather of the [CLS] embeddings and the in-batch NLL term
 (MASTER fused loss, KL + 0.2*NLL) over the global score matrix.
 
@@ -38,7 +42,7 @@ def fwd_flops_seq(S, L=L_, H=H_, F=F_):
     return L * S * (8 * H * H + 4 * H * F + 4 * S * H)
 
 
-def cpu_baseline(timeout_s=300):
+def cpu_baseline(timeout_s=420):
     """The reference's CPU path, restated operator for operator on torch CPU (oracle/torch_cpu.py: the reference itself
     cannot travel to the GPU box; oracle/time_reference.py shows the restatement within ~10 % of the imported reference in
     the build container), timed on this box's host CPUs -- the ones this process may use (affinity and cgroup quota), fp32,
@@ -46,7 +50,7 @@ def cpu_baseline(timeout_s=300):
       * BASELINE configs[0] (B=4, N=1, q32/p128, student step without teacher -- BASELINE.md section 2's measurement):
         3 warm-up + 10 timed steps;
       * the benchmarked workload reduced to B=8 queries x 16 passages INCLUDING the cross-encoder teacher forward (the
-        same step the GPU runs, 1/16 of its batch): 1 warm-up + 2 timed steps.
+        same step the GPU runs, 1/16 of its batch): 3 warm-up + 5 timed steps.
     `value` is the second (same metric as the GPU line: scored pairs per second of the full step)."""
     import subprocess
     r = subprocess.run([sys.executable, "-m", "oracle.torch_cpu"], cwd=ROOT, capture_output=True, timeout=timeout_s)
@@ -56,9 +60,9 @@ def cpu_baseline(timeout_s=300):
     s1, p1, s2, p2, thr = d["cfg0_s_per_step"], d["cfg0_pairs"], d["cfg1r_s_per_step"], d["cfg1r_pairs"], d["threads"]
     return {"value": round(p2 / s2, 2), "unit": "query+passage pairs/sec", "cores": thr, "kind": "port",
             "sample": "torch-CPU fp32 restatement of the reference step on %d threads (the CPUs this container may use): reduced "
-                      "configs[1] (B=8 x 16 passages, q32/p128/ce160, teacher fwd + student fwd/bwd) %.2f s/step over 2 steps after "
-                      "1 warm-up; configs[0] (B=4, N=1, student only) %.3f s/step = %.1f pairs/s over 10 steps after 3 warm-up; "
-                      "%.0f s of CPU wall in total" % (thr, s2, s1, p1 / s1, d["wall_s"]),
+                      "configs[1] (B=8 x 16 passages, q32/p128/ce160, teacher fwd + student fwd/bwd) %.2f s/step over %d steps after "
+                      "%d warm-up; configs[0] (B=4, N=1, student only) %.3f s/step = %.1f pairs/s over 10 steps after 3 warm-up; "
+                      "%.0f s of CPU wall in total" % (thr, s2, d.get("cfg1r_steps", 2), d.get("cfg1r_warmup", 1), s1, p1 / s1, d["wall_s"]),
             "config0_pairs_per_s": round(p1 / s1, 2), "config0_s_per_step": round(s1, 4)}
 
 
@@ -70,7 +74,14 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="queries per GPU")
     ap.add_argument("--negs", type=int, default=15)
     ap.add_argument("--cands", type=int, default=200, help="SimANS candidate pool per query")
-    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16", "fp32", "fp32_exact"])
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp16_plain", "bf16", "fp32", "fp32_exact"],
+                    help="fp16: apex-O1-like (f32-grade residual stream); fp16_plain / bf16: plain 16-bit stream; fp32: f32 tensors, "
+                         "GEMMs from 16-bit hi+lo splits on the matrix cores; fp32_exact: exact f32 products")
+    ap.add_argument("--accum", type=int, default=1, help="gradient accumulation: micro-steps of --batch queries per optimiser step")
+    ap.add_argument("--teacher-arch", default="base", choices=["base", "large"],
+                    help="large: the recipe's ernie-2.0-large-en cross-encoder geometry (24 layers, H=1024, F=4096)")
+    ap.add_argument("--grad-ckpt", action="store_true", help="gradient checkpointing (every train_*_AR2.sh passes it)")
+    ap.add_argument("--side", action="store_true", help="(internal) this run IS a side line: no side lines of its own")
     ap.add_argument("--varlen", action="store_true", help="realistic sequence lengths instead of all-max")
     ap.add_argument("--inbatch", action="store_true", help="config 3: all-gather embeddings + in-batch NLL term")
     ap.add_argument("--no-teacher", action="store_true", help="feed fixed teacher logits (student-only flops)")
@@ -81,6 +92,9 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the bf16-vs-reference-golden error report")
     ap.add_argument("--no-fp32-side", action="store_true", help="skip the fp32-mode throughput side line")
     args = ap.parse_args()
+    if args.side:
+        args.no_cpu_baseline = args.no_realistic = args.no_parity = args.no_fp32_side = True
+    is16 = args.dtype in ("fp16", "fp16_plain", "bf16")
 
     import torch
     import torch.distributed as dist
@@ -119,16 +133,18 @@ def main():
     P = B * (1 + N)
     QL, PL, CL = 32, 128, 160
     pdrop = 0.0 if args.no_dropout else 0.1
-    cfg = BertConfigLite(hidden_dropout_prob=pdrop, attention_probs_dropout_prob=pdrop)
+    cfg = BertConfigLite(hidden_dropout_prob=pdrop, attention_probs_dropout_prob=pdrop, gradient_checkpointing=args.grad_ckpt)
+    tkw = dict(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096) if args.teacher_arch == "large" else {}
+    tcfg = BertConfigLite(hidden_dropout_prob=pdrop, attention_probs_dropout_prob=pdrop, **tkw)
     torch.manual_seed(1234 + rank)
 
-    def tower():
-        return HFBertEncoder(cfg, compute_dtype=args.dtype)
+    def tower(c=cfg):
+        return HFBertEncoder(c, compute_dtype=args.dtype)
 
     bi = BiBertEncoder.__new__(BiBertEncoder)
     torch.nn.Module.__init__(bi)
     bi.question_model, bi.ctx_model = tower(), tower()
-    teacher = Reranker(tower(), cfg.hidden_size)
+    teacher = Reranker(tower(tcfg), tcfg.hidden_size)
     if world > 1:                                   # identical replicas on every rank
         torch.manual_seed(1234)
         for m in (bi.question_model, bi.ctx_model, teacher.encoder):
@@ -139,7 +155,8 @@ def main():
     sch = LinearWarmupSchedule(opt, 5400, 54000, last_step=1)     # (step 0 of the schedule has lr = 0: start one in)
     if world > 1:
         # gradient slices are all-reduced on a communication stream while the rest of the backward runs
-        opt.enable_overlap(world, parts=int(os.environ.get("SIMX_BWD_PARTS", "2")))
+        opt.enable_overlap(world, parts=int(os.environ.get("SIMX_BWD_PARTS", "2")), payload=os.environ.get("SIMX_GRAD_PAYLOAD", "fp32"))
+        opt.profile_comm = True
 
     # ---- synthetic, PRE-TOKENISED candidate pool in HBM (per rank: B queries x (1 positive + Cn candidates)); the
     # per-step batch (passage rows, masks, cross-encoder rows q + ctx[1:-1]) is assembled on the device by
@@ -169,10 +186,9 @@ def main():
     step_no = [0]
     teacher_stream = torch.cuda.Stream(device=dev) if os.environ.get("SIMX_TEACHER_STREAM", "1") == "1" else None
 
-    def one_step():
-        step_no[0] += 1
+    def micro_step(mi):
         # S1+S2 on the GPU, then device-side batch assembly (gather of pre-tokenised passages)
-        neg = ops.simans_sample(d_scores, d_spos, N, form=ops.LAPLACE, tau=3.0, seed=42 + rank, offset=step_no[0])
+        neg = ops.simans_sample(d_scores, d_spos, N, form=ops.LAPLACE, tau=3.0, seed=42 + rank, offset=step_no[0] * args.accum + mi)
         sel = torch.cat([zero_col, neg.long() + 1], dim=1)                         # [B,1+N] rows of the query's pool
         batch = ops.assemble_batch(pool["q"], pool["p"], q_rows, (row_base + sel).to(torch.int32), 1 + N, pad_id=0, sep_id=102, ce_len=CL)
         q_ids, q_mask, c_ids, c_mask, _ = batch["student"]
@@ -193,11 +209,18 @@ def main():
             q, c = bi(q_ids, q_mask, c_ids, c_mask)
             with torch.no_grad():
                 z = teacher(batch["teacher"][0], batch["teacher"][1])
-        loss, distill, sim = ops.kl_distill_loss(q, c, z, 1.0, False, 1)
+        loss, distill, sim = ops.kl_distill_loss(q, c, z, 1.0, False, args.accum)
         if args.inbatch:
             from simxns_amd import parallel
             loss = loss + 0.2 * parallel.inbatch_nll_allgather(q, c, 1 + N)
         loss.backward()
+        return loss
+
+    def one_step():
+        step_no[0] += 1
+        for mi in range(args.accum):
+            opt.armed = mi == args.accum - 1       # an accumulated buffer is all-reduced once, by the last micro-step's backward
+            loss = micro_step(mi)
         opt.step(max_grad_norm=2.0, world_size=world)      # optimizer first, scheduler second (co_training_marco_train.py:250-252)
         sch.step()
         return loss
@@ -262,7 +285,7 @@ def main():
             tt = torch.tensor([dr], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dr = float(tt.item())
-        real = {"value": round(world * P * 4 / dr, 1), "ms_per_step": round(dr / 4 * 1e3, 2), "steps": 4,
+        real = {"value": round(world * P * args.accum * 4 / dr, 1), "ms_per_step": round(dr / 4 * 1e3, 2), "steps": 4,
                 "lengths": "query ~ N(9,3) clipped to [4,32], passage ~ N(80,25) clipped to [16,128] (SURVEY 8d)",
                 "real_token_fraction": round(float((np.sum(pool["ql"]) / (B * QL) * B * QL + np.mean(pool["pl"]) * P) / (B * QL + P * PL)), 3)}
     # the same all-max job with EVERY row of the last layer computed (SIMX_FULL_LAST_LAYER=1): the conservative figure
@@ -284,37 +307,52 @@ def main():
             tt = torch.tensor([df], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             df = float(tt.item())
-        full_rows = {"value": round(world * P * 3 / df, 1), "ms_per_step": round(df / 3 * 1e3, 2), "steps": 3,
-                     "step_mfma_util": round((3 * (B * fwd_flops_seq(QL) + P * fwd_flops_seq(PL)) + (0 if args.no_teacher else P * fwd_flops_seq(ce_tokens)))
-                                             / (df / 3) / 2.5e15, 4) if args.dtype == "bf16" else None}
+        full_rows = {"value": round(world * P * args.accum * 3 / df, 1), "ms_per_step": round(df / 3 * 1e3, 2), "steps": 3,
+                     "step_mfma_util": round(args.accum * (3 * (B * fwd_flops_seq(QL) + P * fwd_flops_seq(PL)) +
+                                                           (0 if args.no_teacher else P * fwd_flops_seq(ce_tokens, tcfg.num_hidden_layers, tcfg.hidden_size, tcfg.intermediate_size)))
+                                             / (df / 3) / 2.5e15, 4) if is16 else None}
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
     ms_step = dt / args.steps * 1e3
-    pairs_per_s = world * P * args.steps / dt
-    stu = 3 * (B * fwd_flops_seq(QL) + P * fwd_flops_seq(PL))
-    tea = 0 if args.no_teacher else P * fwd_flops_seq(ce_tokens)
+    PP = P * args.accum                                   # scored pairs per optimiser step and GPU
+    pairs_per_s = world * PP * args.steps / dt
+    TL, TH, TF = tcfg.num_hidden_layers, tcfg.hidden_size, tcfg.intermediate_size
+    stu = args.accum * 3 * (B * fwd_flops_seq(QL) + P * fwd_flops_seq(PL))
+    tea = 0 if args.no_teacher else args.accum * P * fwd_flops_seq(ce_tokens, TL, TH, TF)
     # FLOPs actually issued: the towers read sequence_output[:, 0, :] only (models.py:81), so in the last layer the
     # engine projects K and V for every token but runs the Q projection, the attention core, the attention-output and
     # the FFN blocks for the [CLS] row alone -- for the other S-1 rows of a sequence 4H^2 + 4HF + 4SH FLOPs are dead
     # code on this path and are skipped (forward, dgrad and wgrad).  SIMX_FULL_LAST_LAYER=1 computes them anyway.
     full_last = os.environ.get("SIMX_FULL_LAST_LAYER", "0") == "1"
-    dead = (lambda S: 0) if full_last else (lambda S: (S - 1) * (4 * H_ * H_ + 4 * H_ * F_ + 4 * S * H_))
-    stu_issued = stu - 3 * (B * dead(QL) + P * dead(PL))
-    tea_issued = 0 if args.no_teacher else tea - P * dead(ce_tokens)
+    dead = (lambda S, H=H_, F=F_: 0) if full_last else (lambda S, H=H_, F=F_: (S - 1) * (4 * H * H + 4 * H * F + 4 * S * H))
+    ckpt_extra = args.accum * (B * fwd_flops_seq(QL) + P * fwd_flops_seq(PL)) if args.grad_ckpt else 0     # the recomputed forward
+    stu_issued = stu - args.accum * 3 * (B * dead(QL) + P * dead(PL)) + ckpt_extra
+    tea_issued = 0 if args.no_teacher else tea - args.accum * P * dead(ce_tokens, TH, TF)
+    util_ok = is16 and not args.varlen
+    arith = {"fp16": "IEEE-half GEMM / attention operands (the operand width of apex O1, the reference's --fp16 mode), f32 accumulation, "
+                     "f32 LayerNorm / softmax, f32-grade residual stream (16-bit value + 16-bit correction), f32 master weights, dynamic "
+                     "loss scale on the device",
+             "fp16_plain": "as fp16 with a plain 16-bit residual stream (residual added in the GEMM epilogue)",
+             "bf16": "bf16 operands and residual stream, f32 accumulation / statistics / master weights",
+             "fp32": "f32 tensors everywhere; dense GEMMs on the 16-bit matrix cores from hi+lo splits of their f32 operands (three MFMAs "
+                     "per product: fp16 halves forward, bf16 halves backward), f32 MFMA attention",
+             "fp32_exact": "f32 tensors, exact f32 products (v_mfma_f32_32x32x2_f32) in every GEMM"}[args.dtype]
     out = {"metric": "query+passage pairs/sec (bi-encoder step)", "value": round(pairs_per_s, 1),
            "unit": "query+passage pairs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(ms_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": args.dtype, "data": "synthetic",
+           "dtype": args.dtype, "arithmetic": arith, "data": "synthetic",
            "config": {"workload": "SimANS MS-MARCO Passage retriever step (BASELINE configs[%d]): BERT-base x2 towers + "
-                                  "BERT-base cross-encoder teacher fwd, B=%d/GPU, %d hard negs from %d candidates (SimANS "
+                                  "%s cross-encoder teacher fwd, B=%d/GPU%s, %d hard negs from %d candidates (SimANS "
                                   "sampler + batch assembly on GPU), q%d/p%d/ce%d (= q + ctx[1:-1], padded to %d), %s lengths, KL-distill%s "
-                                  "loss, clip 2.0 + AdamW"
-                                  % (2 if args.inbatch else 1, B, N, Cn, QL, PL, ce_tokens, CL, "realistic" if args.varlen else "all-max",
-                                     " + 0.2*in-batch NLL (all-gather)" if args.inbatch else ""),
-                      "global_batch": world * B, "pairs_per_step_per_gpu": P, "parallelism": "dp%d" % world,
+                                  "loss, clip 2.0 + AdamW%s"
+                                  % (2 if args.inbatch else 1, "BERT-base" if args.teacher_arch == "base" else "ernie-2.0-large-geometry (24L, H=1024)",
+                                     B, " x %d accumulated micro-steps" % args.accum if args.accum > 1 else "", N, Cn, QL, PL, ce_tokens, CL,
+                                     "realistic" if args.varlen else "all-max", " + 0.2*in-batch NLL (all-gather)" if args.inbatch else "",
+                                     ", gradient checkpointing" if args.grad_ckpt else ""),
+                      "global_batch": world * B * args.accum, "pairs_per_step_per_gpu": PP, "parallelism": "dp%d" % world,
                       "teacher_in_step": not args.no_teacher, "dropout": pdrop,
                       "last_layer": "all rows" if full_last else "K/V for all rows, everything else for the [CLS] row only"},
            "algorithmic_tflop_per_step_per_gpu": {"student_fwd_bwd": round(stu / 1e12, 2), "teacher_fwd": round(tea / 1e12, 2)},
@@ -322,13 +360,20 @@ def main():
                                              "note": "algorithmic minus the last layer's non-[CLS] rows of the Q projection, attention core, "
                                                      "attention-output and FFN blocks (dead code behind sequence_output[:, 0, :]); "
                                                      "SIMX_FULL_LAST_LAYER=1 issues them"},
-           # hardware utilisation = FLOPs the MFMA pipes really executed / dense bf16 peak
-           "step_mfma_util": round((stu_issued + tea_issued) / (ms_step * 1e-3) / 2.5e15, 4) if args.dtype == "bf16" and not args.varlen else None,
+           # hardware utilisation = FLOPs the MFMA pipes really executed / dense 16-bit peak (bf16 and fp16 issue at the same rate)
+           "step_mfma_util": round((stu_issued + tea_issued) / (ms_step * 1e-3) / 2.5e15, 4) if util_ok else None,
            # the same step priced at the reference's full FLOP count (SURVEY 8d formula)
-           "step_mfma_util_reference_flops": round((stu + tea) / (ms_step * 1e-3) / 2.5e15, 4) if args.dtype == "bf16" and not args.varlen else None,
+           "step_mfma_util_reference_flops": round((stu + tea) / (ms_step * 1e-3) / 2.5e15, 4) if util_ok else None,
            "final_loss": round(final_loss, 5)}
+    if opt.scaler is not None:
+        snap = opt.scaler.snapshot()
+        out["loss_scaler"] = {"scale": snap["scale"], "applied_steps": snap["applied_steps"], "skipped_steps": snap["skipped_steps"],
+                              "note": "apex-style dynamic loss scale kept on the device; skipped steps (overflow at the initial 2^16) all "
+                                      "fall in the warm-up when applied_steps - skipped_steps bookkeeping shows none later"}
+    if world > 1:
+        out["comm"] = opt.comm_stats()
     busy = pmc_mfma_busy()
-    if busy is not None and args.dtype == "bf16":
+    if busy is not None and is16:
         out["mfma_busy_pmc"] = busy
     if real is not None:
         out["realistic_lengths"] = real
@@ -337,41 +382,64 @@ def main():
     def alg_bytes_per_launch(launches_per_step):
         tot, cnt = p3_algorithmic_bytes(B, P, QL, PL, ce_tokens, not args.no_teacher, full_last)
         # (the enumeration must describe the launches that were measured; otherwise report nothing rather than a guess)
-        return round(tot / cnt) if cnt and cnt == launches_per_step and not args.varlen else None
+        plain = args.accum == 1 and args.teacher_arch == "base" and not args.grad_ckpt and not args.varlen
+        return round(tot / cnt) if cnt and cnt == launches_per_step and plain else None
 
-    # bf16: the persistent kernel's launches ("gemm_nt" = the small-shape kernels); fp32: every NT GEMM is the f32 MFMA kernel
-    rk = "gemm_nt_p3" if args.dtype in ("bf16", "fp16") else "gemm_nt"
+    # 16-bit: the persistent kernel's launches ("gemm_nt" = the small-shape kernels); fp32: every NT GEMM of the step (the split
+    # kernel gemm_x3_nt_kernel for the dense layers, priced against 1/3 of the 16-bit MFMA peak: three MFMAs per product)
+    rk = "gemm_nt_p3" if is16 else "gemm_nt"
     if prof and rk in prof:
         c_, ms_, wk_ = prof[rk]
         ach = wk_ / (ms_ * 1e-3) / 1e12
-        peak = 2500.0 if args.dtype == "bf16" else 157.3
-        kname = "gemm_nt_bf16_p3_kernel" if args.dtype == "bf16" else "gemm_f32_mfma_kernel"
+        peak = 2500.0 if is16 else (157.3 if args.dtype == "fp32_exact" else 833.3)
+        kname = "gemm_nt_p3_kernel" if is16 else ("gemm_f32_mfma_kernel" if args.dtype == "fp32_exact" else "gemm_x3_nt_kernel")
         out["roofline"] = {"bound": "mfma", "kernel": kname + " (simx_gemm_nt: forward + dgrad GEMMs)",
                            "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                           "traffic": pmc_traffic("gemm_nt_bf16_p3_kernel") if args.dtype == "bf16" else None, "launches": c_,
-                           "algorithmic_bytes_per_launch": alg_bytes_per_launch(c_ // max(1, args.steps)) if args.dtype == "bf16" else None,
+                           "traffic": pmc_traffic("gemm_nt_p3_kernel") if is16 else None, "launches": c_,
+                           "algorithmic_bytes_per_launch": alg_bytes_per_launch(c_ // max(1, args.steps)) if is16 else None,
                            "avg_launch_ms": round(ms_ / c_, 4), "algorithmic_flop_per_launch": round(wk_ / c_),
                            "measured": "HIP events on the launch stream over %d steps of the same job run right after the timed "
                                        "region, towers on one stream (%.2f ms/step with the events); the timed region itself is "
                                        "not instrumented and overlaps the two towers on two streams" % (args.steps, ms_prof)}
+        if not is16 and args.dtype != "fp32_exact":
+            out["roofline"]["peak_note"] = "2500 / 3: an f32-grade product costs three 16-bit MFMAs (hi.hi + hi.lo + lo.hi)"
         out["kernel_breakdown_ms_per_step"] = {k: round(v[1] / args.steps, 3) for k, v in prof.items()}
         out["kernel_rates"] = {k: round(v[2] / (v[1] * 1e-3) / 1e12, 2) for k, v in prof.items() if v[1] > 0}
-    if args.dtype == "bf16" and not args.no_parity:
-        # measured distance of THIS engine (the benchmarked bf16 kernels) from the reference on the hot-shape golden
+    if is16 and not args.no_parity:
+        # measured distance of THIS engine (the benchmarked kernels) from the reference on the hot-shape golden, next to the
+        # distance of the reference's OWN 16-bit mode (an emulation of apex O1 on the imported modules, oracle/o1_emulation.py,
+        # run in the build container: profiles/r03_o1_emulation.json) from the same golden
         try:
             from simxns_amd.utils.parity import parity_report
-            out["parity_bf16"] = parity_report(dev, "bf16")
+            out["parity_16bit"] = parity_report(dev, args.dtype)
+            o1 = os.path.join(ROOT, "profiles", "r03_o1_emulation.json")
+            if out["parity_16bit"] is not None and os.path.exists(o1):
+                out["parity_16bit"]["reference_own_fp16_mode_apex_O1_emulated"] = {k: round(v, 6) for k, v in json.load(open(o1))["summary"].items()}
         except Exception as e:
-            out["parity_bf16"] = {"error": repr(e)}
-    if args.dtype == "bf16" and not args.no_fp32_side and world == 1 and not args.varlen:
-        # the mode that meets north_star's 1e-3 tolerance (f32 storage, f32 MFMA GEMMs, tests/test_encoder_gpu.py fp32
-        # goldens), timed on the SAME workload in a child process after this one has released its HBM.  Never `value`.
+            out["parity_16bit"] = {"error": repr(e)}
+    if is16 and not args.no_fp32_side and world == 1 and not args.varlen:
+        # Beside the headline, never `value`: the same workload (a) in the arithmetic every shipped recipe selects -- fp32, the
+        # mode the reference goldens are checked in at north_star's 1e-3 -- as a first-class measurement (>= 10 timed steps,
+        # its own roofline), (b) exactly as train_MS_Pas_AR2.sh runs it (fp32 + --gradient_checkpointing), (c) at the recipe's
+        # own shapes (micro-batch 16 x 16 passages, accumulation 2, ernie-2.0-large teacher geometry), (d) the headline batch
+        # with that large teacher.  Child processes, after this one has released its HBM.
         bi = teacher = opt = sch = loss = None
         pool.clear()
         import gc
         gc.collect()
         torch.cuda.empty_cache()
-        out["fp32_mode"] = fp32_side_line(args)
+        out["fp32_mode"] = side_line(args, ["--dtype", "fp32", "--steps", "10", "--warmup", "2"],
+                                     "f32 tensors, dense GEMMs from 16-bit hi+lo splits on the matrix cores, f32 MFMA attention: the mode the "
+                                     "fp32 reference goldens are checked in at 1e-3 (tests/test_encoder_gpu.py)")
+        out["recipe_fp32_gradckpt"] = side_line(args, ["--dtype", "fp32", "--grad-ckpt", "--steps", "5", "--warmup", "1"],
+                                                "the arithmetic train_MS_Pas_AR2.sh selects (no --fp16, --gradient_checkpointing) on the "
+                                                "headline batch")
+        out["recipe_shapes"] = side_line(args, ["--dtype", args.dtype, "--batch", "16", "--accum", "2", "--teacher-arch", "large",
+                                                "--steps", "10", "--warmup", "3"],
+                                         "train_MS_Pas_AR2.sh:10-14 geometry: micro-batch 16 queries x 16 passages (32768 passage tokens = 384 "
+                                         "tiles of 256 x 256 for N = 768: 1.5 waves of the chip), accumulation 2, ernie-2.0-large teacher")
+        out["teacher_large"] = side_line(args, ["--dtype", args.dtype, "--teacher-arch", "large", "--steps", "5", "--warmup", "2"],
+                                         "headline batch with the recipe's cross-encoder geometry (24 layers, H = 1024, F = 4096, S = 160)")
     if not args.no_cpu_baseline and world == 1:
         try:
             out["cpu_baseline"] = cpu_baseline()
@@ -406,13 +474,13 @@ def p3_algorithmic_bytes(B, P, QL, PL, CE, teacher, full_last, L=L_, H=H_, F=F_)
     return tot, cnt
 
 
-def fp32_side_line(args, steps=2, warmup=1, timeout_s=240):
-    """`python bench.py --dtype fp32` on the same batch geometry in a child process; returns its headline numbers."""
+def side_line(args, argv, what, timeout_s=300):
+    """`python bench.py <argv> --side` on the same GPU in a child process; returns its headline numbers (never `value`)."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--dtype", "fp32", "--steps", str(steps), "--warmup", str(warmup),
-           "--batch", str(args.batch), "--negs", str(args.negs), "--cands", str(args.cands), "--no-realistic",
-           "--no-cpu-baseline", "--no-parity", "--no-fp32-side"] + (["--no-teacher"] if args.no_teacher else []) \
-        + (["--no-dropout"] if args.no_dropout else []) + (["--inbatch"] if args.inbatch else [])
+    cmd = [sys.executable, os.path.abspath(__file__), "--side", "--negs", str(args.negs), "--cands", str(args.cands)] + argv
+    if "--batch" not in argv:
+        cmd += ["--batch", str(args.batch)]
+    cmd += (["--no-teacher"] if args.no_teacher else []) + (["--no-dropout"] if args.no_dropout else []) + (["--inbatch"] if args.inbatch else [])
     try:
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s, text=True)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -420,13 +488,16 @@ def fp32_side_line(args, steps=2, warmup=1, timeout_s=240):
             return {"value": None, "error": (r.stderr or "no output")[-400:]}
         d = json.loads(line[-1])
         rf = d.get("roofline") or {}
-        return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": steps, "warmup": warmup,
-                "dtype": "fp32 storage and arithmetic, f32 MFMA GEMMs (v_mfma_f32_32x32x2_f32)",
-                "gemm_nt_tflops": rf.get("achieved"), "gemm_nt_frac_of_f32_mfma_peak": rf.get("frac"), "f32_mfma_peak_tflops": rf.get("peak"),
-                "final_loss": d.get("final_loss"),
-                "note": "same workload as the headline; this is the mode the fp32 reference goldens are checked in at 1e-3"}
+        out = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"],
+               "dtype": d["dtype"], "what": what, "pairs_per_step": d["config"]["pairs_per_step_per_gpu"],
+               "step_mfma_util": d.get("step_mfma_util"), "final_loss": d.get("final_loss"),
+               "roofline": {k: rf.get(k) for k in ("kernel", "achieved", "peak", "frac", "avg_launch_ms", "launches", "peak_note") if k in rf},
+               "kernel_breakdown_ms_per_step": d.get("kernel_breakdown_ms_per_step"), "kernel_rates": d.get("kernel_rates")}
+        if d.get("loss_scaler"):
+            out["loss_scaler"] = d["loss_scaler"]
+        return out
     except subprocess.TimeoutExpired:
-        return {"value": None, "error": "fp32 side run exceeded %d s" % timeout_s}
+        return {"value": None, "error": "side run exceeded %d s" % timeout_s}
 
 
 def spawn_ranks(n):
@@ -460,10 +531,10 @@ def pmc_mfma_busy():
             d = json.load(open(f))
         except Exception:
             continue
-        p3 = [v for k, v in d.get("kernels", {}).items() if "gemm_nt_bf16_p3_kernel" in k]
+        p3 = [v for k, v in d.get("kernels", {}).items() if "gemm_nt_bf16_p3_kernel" in k or "gemm_nt_p3_kernel" in k]
         n = sum(v["launches"] for v in p3)
         best = {"step": d.get("step_mfma_busy_frac"), "step_clock_ghz": d.get("step_clock_ghz"),
-                "gemm_nt_bf16_p3_kernel": round(sum(v["mfma_busy_frac"] * v["launches"] for v in p3) / n, 4) if n else None,
+                "gemm_nt_p3_kernel": round(sum(v["mfma_busy_frac"] * v["launches"] for v in p3) / n, 4) if n else None,
                 "source": os.path.basename(f)}
     return best
 
@@ -482,7 +553,7 @@ def pmc_traffic(kernel):
             continue
         tot, n = 0.0, 0
         for k, v in ks.items():
-            if kernel in k:
+            if kernel in k or kernel.replace("gemm_nt_p3", "gemm_nt_bf16_p3") in k:     # (round-2 profiles carry the old kernel name)
                 tot += v["hbm_bytes_per_launch"] * v["launches"]
                 n += v["launches"]
         if n:

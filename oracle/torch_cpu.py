@@ -137,14 +137,16 @@ def main():
     """`python -m oracle.torch_cpu` -- the CPU-baseline measurement of bench.py, run in its own process (its own OpenMP pool,
     a hard timeout on the caller's side): prints one JSON line."""
     import json
+    import os
     import sys
     thr = usable_cpus()
     torch.set_num_threads(thr)
     t0 = time.time()
     s1, p1, _ = time_step(4, 1, with_teacher=False, warmup=3, steps=10)
-    s2, p2, _ = time_step(8, 15, with_teacher=True, warmup=1, steps=2)
+    w2, n2 = int(os.environ.get("SIMX_CPU_BASE_WARMUP", 3)), int(os.environ.get("SIMX_CPU_BASE_STEPS", 5))
+    s2, p2, _ = time_step(8, 15, with_teacher=True, warmup=w2, steps=n2)
     print(json.dumps({"threads": thr, "cfg0_s_per_step": s1, "cfg0_pairs": p1, "cfg1r_s_per_step": s2, "cfg1r_pairs": p2,
-                      "wall_s": time.time() - t0}))
+                      "cfg1r_warmup": w2, "cfg1r_steps": n2, "wall_s": time.time() - t0}))
     sys.stdout.flush()
 
 

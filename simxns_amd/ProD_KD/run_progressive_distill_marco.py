@@ -8,11 +8,15 @@ from .model.models import CrossBERTKDLoss
 
 
 def cross_encoder_distill_step(args, model, teacher_model, inputs_retriever, inputs_reranker, student_copy=None,
-                               optimizer=None, scheduler=None, world_size=1):
+                               optimizer=None, scheduler=None, world_size=1, last_micro_step=True):
     """-> (loss, is_correct).  ``inputs_retriever``: query_ids, attention_mask_q, input_ids_a, attention_mask_a;
-    ``inputs_reranker``: input_ids [B,1+N,L], attention_mask.  With ``optimizer`` the step is completed
-    (clip_grad_norm_(args.max_grad_norm) -> optimizer.step -> scheduler.step -> zero_grad, :321-329)."""
+    ``inputs_reranker``: input_ids [B,1+N,L], attention_mask.  With ``optimizer`` and ``last_micro_step`` the step is completed
+    (clip_grad_norm_(args.max_grad_norm) -> optimizer.step -> scheduler.step -> zero_grad, :321-329); with
+    gradient_accumulation_steps > 1 pass ``last_micro_step=False`` for all but the last micro-step: the optimiser is then
+    neither stepped nor allowed to all-reduce the still-accumulating gradient buffers (FusedAdamW.armed)."""
     teacher_model.eval()
+    if optimizer is not None:
+        optimizer.armed = bool(last_micro_step)
     local_q_vector, local_ctx_vectors = model(**inputs_retriever)
     with torch.no_grad():
         binary_logits, relevance_logits, _ = teacher_model(**inputs_reranker)
@@ -28,7 +32,7 @@ def cross_encoder_distill_step(args, model, teacher_model, inputs_retriever, inp
         loss, is_correct = CrossBERTKDLoss().calc(args, local_q_vector, local_ctx_vectors, relevance_logits)
     loss = loss / getattr(args, "gradient_accumulation_steps", 1)
     loss.backward()
-    if optimizer is not None:
+    if optimizer is not None and last_micro_step:
         optimizer.step(max_grad_norm=getattr(args, "max_grad_norm", 0.0), world_size=world_size)
         if scheduler is not None:
             scheduler.step()

@@ -55,7 +55,9 @@ def test_train_job_runs_and_resumes(dev, tmp_path):
     assert "qa_classifier.weight" in tst.model_dict and "encoder.embeddings.word_embeddings.weight" in tst.model_dict
     assert all(torch.isfinite(v).all() for v in st.model_dict.values())
     # optimizer / scheduler state in the reference's on-disk formats (torch Optimizer.state_dict, LambdaLR.state_dict)
-    assert set(st.optimizer_dict) == {"state", "param_groups"} and len(st.optimizer_dict["param_groups"]) == 2
+    # (+ "loss_scaler" with --fp16: an extra top-level key, which torch's Optimizer.load_state_dict ignores)
+    assert set(st.optimizer_dict) >= {"state", "param_groups"} and len(st.optimizer_dict["param_groups"]) == 2
+    assert st.optimizer_dict["loss_scaler"]["applied_steps"] + st.optimizer_dict["loss_scaler"]["skipped_steps"] == 6
     assert st.optimizer_dict["state"][0]["exp_avg"].shape == st.model_dict["question_model.embeddings.word_embeddings.weight"].shape
     assert st.scheduler_dict["last_epoch"] == 6 and "base_lrs" in st.scheduler_dict         # first iteration: 6 student steps (:289-290)
     # second shell-loop iteration: resume from checkpoint-6 with the mined file train_ce_6.tsv; goes through a teacher phase
@@ -243,12 +245,23 @@ def test_gpu_sampler_matches_host_collate_and_law(dev, tmp_path):
         tab = b["picks"]["neg_table_index"].cpu().numpy() - (cmax - C)
         assert tab.min() >= 0 and all(len(set(r)) == N for r in tab)
         np.add.at(cnt_dev, tab.ravel(), 1)
+    # host side of the same law: the reference's rounds (weights, N with-replacement draws, dedupe, remove, repeat) with the
+    # surplus of the last round dropped in DRAW order -- the device rule; the reference drops it in CPython set order, a
+    # pid-hash-dependent subset (the documented deviation, SURVEY App. B / DESIGN.md 8), so its frequencies are not comparable
+    import math
     cnt_host = np.zeros(C)
     rng = random.Random(1)
-    pids = [p for p, _ in negs]
+    w0 = [math.exp(-abs(s_ - pos_score) * 3) for _, s_ in negs]
     for _ in range(trials):
-        for pid in simans_draw(negs, pos_score, N, 3, rng=rng):
-            cnt_host[pids.index(pid)] += 1
+        cand, w, chosen = list(range(C)), list(w0), []
+        while len(chosen) < N:
+            for c in rng.choices(cand, weights=w, k=N):
+                if c not in chosen:
+                    chosen.append(c)
+            keep = [(c, wi) for c, wi in zip(cand, w) if c not in chosen]
+            cand, w = [c for c, _ in keep], [wi for _, wi in keep]
+        for c in chosen[:N]:
+            cnt_host[c] += 1
     fd, fh = cnt_dev / trials, cnt_host / trials
     assert np.abs(fd - fh).max() <= 0.05, (fd, fh)
     # (3) the job itself

@@ -87,7 +87,8 @@ def _cmp(tag, a, b, tol):
     assert err <= tol * ref, (tag, err, tol * ref)
 
 
-def gen_encoder_step(tmp, cfg_kw, tag, B, N, q_len, p_len, ce_len, seeds, full_grads, tol, std=0.02, extras=True):
+def gen_encoder_step(tmp, cfg_kw, tag, B, N, q_len, p_len, ce_len, seeds, full_grads, tol, std=0.02, extras=True,
+                     q_stats=(9, 3, 4), p_stats=(80, 25, 16), t_stats=(90, 25, 20)):
     """Config-1 shaped retriever step of co_training_marco_train.py / co_training_wiki_train.py.
     extras=False keeps only the retriever step proper (L1): no NQ/TQ loss variants, no teacher train step -- used for
     the larger "hot" fixture whose only purpose is to put the persistent GEMM / wgrad / attention kernels, which need
@@ -115,9 +116,9 @@ def gen_encoder_step(tmp, cfg_kw, tag, B, N, q_len, p_len, ce_len, seeds, full_g
     _no_dropout(teacher)
 
     P = B * (1 + N)
-    q_ids, q_mask, _ = make_batch(seeds[0] + 100, B, q_len, cfg.vocab, 9, 3, 4)
-    c_ids, c_mask, _ = make_batch(seeds[1] + 100, P, p_len, cfg.vocab, 80, 25, 16)
-    t_ids, t_mask, _ = make_batch(seeds[2] + 100, P, ce_len, cfg.vocab, 90, 25, 20)
+    q_ids, q_mask, _ = make_batch(seeds[0] + 100, B, q_len, cfg.vocab, *q_stats)
+    c_ids, c_mask, _ = make_batch(seeds[1] + 100, P, p_len, cfg.vocab, *p_stats)
+    t_ids, t_mask, _ = make_batch(seeds[2] + 100, P, ce_len, cfg.vocab, *t_stats)
     t_ids3, t_mask3 = t_ids.reshape(B, 1 + N, ce_len), t_mask.reshape(B, 1 + N, ce_len)
     tt = lambda a: torch.from_numpy(a)
 
@@ -818,6 +819,13 @@ def main():
             return
         if "--only-prod" in sys.argv:
             gen_prod_step(tmp)
+            return
+        if "--only-large" in sys.argv:
+            # BASELINE config 5's geometry at full depth: BERT-large (24 layers, H = 1024, 16 heads, F = 4096), one query of up
+            # to 128 tokens and two documents of up to 512 (MS-Doc lengths), cross-encoder rows of up to 512; fp64 reference
+            gen_encoder_step(tmp, dict(hidden=1024, layers=24, heads=16, inter=4096), "large_cfg5", B=1, N=1, q_len=128, p_len=512,
+                             ce_len=512, seeds=(3234, 3235, 3236), full_grads=False, tol=1e-9, extras=False,
+                             q_stats=(40, 20, 8), p_stats=(470, 40, 300), t_stats=(480, 30, 300))
             return
         if "--only-hot" in sys.argv:
             gen_encoder_step(tmp, {}, "base_hot", B=16, N=15, q_len=32, p_len=128, ce_len=160,

@@ -237,6 +237,30 @@ __device__ __forceinline__ void gelu_both_fast(float u, float& g, float& dg) {
   g = u * r;
   dg = r * fmaf(u * (1.0f - r), up, 1.0f);
 }
+// The same on a PAIR of elements with explicitly packed arithmetic (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: two f32 per
+// lane per instruction): the GELU epilogue of the persistent GEMM is VALU-bound -- no MFMA runs beside it -- and left to the
+// SLP vectoriser about half of its multiplies stayed scalar.  Coefficients carry the -log2(e) of the exponent already.
+typedef float f32p_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_both_fast2(f32p_t u, f32p_t& g, f32p_t& dg) {
+  const f32p_t uc = {__builtin_amdgcn_fmed3f(u.x, -7.0f, 7.0f), __builtin_amdgcn_fmed3f(u.y, -7.0f, 7.0f)};
+  const f32p_t s = uc * uc;
+  constexpr float L2E = -1.4426950408889634f;
+  const f32p_t p = (s * (GELU_C2 * L2E) + (GELU_C1 * L2E)) * s + (GELU_C0 * L2E);
+  const f32p_t t = uc * p;
+  const f32p_t d = {1.0f + __builtin_amdgcn_exp2f(t.x), 1.0f + __builtin_amdgcn_exp2f(t.y)};
+  const f32p_t r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  const f32p_t up = (s * (5.0f * GELU_C2) + (3.0f * GELU_C1)) * s + GELU_C0;       // d/du [u p(u^2)]
+  g = u * r;
+  dg = r * ((u - g) * up + 1.0f);                                                     // u (1 - r) = u - g
+}
+__device__ __forceinline__ f32p_t gelu_fast2(f32p_t u) {
+  const f32p_t uc = {__builtin_amdgcn_fmed3f(u.x, -7.0f, 7.0f), __builtin_amdgcn_fmed3f(u.y, -7.0f, 7.0f)};
+  const f32p_t s = uc * uc;
+  constexpr float L2E = -1.4426950408889634f;
+  const f32p_t t = uc * ((s * (GELU_C2 * L2E) + (GELU_C1 * L2E)) * s + (GELU_C0 * L2E));
+  const f32p_t r = {__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t.x)), __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t.y))};
+  return u * r;
+}
 // Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7): one v_rcp + one v_exp + 7 FMAs; the exponential is shared with the derivative.
 __device__ __forceinline__ void erf_and_gauss(float u, float& erf_x, float& gauss) {
   const float x = fabsf(u) * 0.70710678118654752f;

@@ -844,10 +844,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p3_kernel(
             float g[4];
             if (store_pre) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) gelu_both_fast(vv[e], g[e], vv[e]);
+              for (int e = 0; e < 4; e += 2) {
+                f32p_t gp, dp;
+                gelu_both_fast2((f32p_t){vv[e], vv[e + 1]}, gp, dp);
+                g[e] = gp.x; g[e + 1] = gp.y; vv[e] = dp.x; vv[e + 1] = dp.y;
+              }
             } else {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) g[e] = gelu_fast(vv[e]);
+              for (int e = 0; e < 4; e += 2) {
+                const f32p_t gp = gelu_fast2((f32p_t){vv[e], vv[e + 1]});
+                g[e] = gp.x; g[e + 1] = gp.y;
+              }
             }
             const uint2 og = make_uint2(H16<F>::pack2(g[0], g[1]), H16<F>::pack2(g[2], g[3]));
             asm volatile("ds_write_b64 %0, %1 offset:2048" ::"v"(ad), "v"(og) : "memory");

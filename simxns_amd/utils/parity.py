@@ -36,10 +36,15 @@ BF16_HOT_TOL = dict(emb_abs=0.2, logits_rel=0.12, teacher_logits_abs=0.1, loss_a
                     gslice_cos_min=0.80, gslice_cos_median_all=0.96)
 # fp16 engine (IEEE half operands = the operand width of the reference's own optional apex-O1 mode; f32 accumulation,
 # statistics, master weights; loss-scaled backward).  11-bit significands instead of 8: every figure above shrinks ~8x.
-# Bounds are the round-2 verdict's targets (logits <= 1 % of scale, loss <= 5e-3, slice cosine >= 0.97) or ~3x the
-# measurement where that is tighter; measured values: DESIGN.md 2.
-FP16_HOT_TOL = dict(emb_abs=0.04, logits_rel=0.01, teacher_logits_abs=0.02, loss_abs=5e-3, gnorm_rel_median=0.01, gnorm_rel_max=0.04,
-                    gslice_cos_min=0.97, gslice_cos_median_all=0.995)
+# With the f32-grade residual stream (the default, apex O1's arithmetic).  Measured ([CLS]-only / full last layer): embeddings
+# 0.0061 / 0.0042, student logits 0.075 / 0.071 on a scale of 28 (0.27 % / 0.25 %), teacher logits 0.0029 / 0.0026, loss 0.0028,
+# gradient norms median 0.11 % / 0.03 %, max 0.31 % / 0.23 %, slice cosine min 0.99957 / 0.99983, median 0.99994 -- the
+# distance of the reference's OWN fp16 mode from its fp64 run is 0.0036 / 0.24 % / 0.0023 / 0.0019 / 0.18 % / 0.44 % / 0.99979
+# (apex O1 emulated on the imported modules, oracle/o1_emulation.py -> profiles/r03_o1_emulation.json).  Bounds ~3x the
+# measurement, never looser than the round-2 verdict's targets (logits <= 1 %, loss <= 5e-3 x 1.6 for its one-draw noise,
+# cosine >= 0.97).
+FP16_HOT_TOL = dict(emb_abs=0.02, logits_rel=0.008, teacher_logits_abs=0.009, loss_abs=8e-3, gnorm_rel_median=0.004, gnorm_rel_max=0.01,
+                    gslice_cos_min=0.998, gslice_cos_median_all=0.9998)
 # plain 16-bit residual stream (residual added in the GEMM epilogue, the pre-LayerNorm sum rounded to fp16): measured logits
 # 0.69 %, embeddings 0.013, loss 0.010, gradient norms median 0.6 % / max 0.96 %, slice cosine min 0.9986
 FP16_PLAIN_HOT_TOL = dict(emb_abs=0.04, logits_rel=0.02, teacher_logits_abs=0.025, loss_abs=0.03, gnorm_rel_median=0.018, gnorm_rel_max=0.03,

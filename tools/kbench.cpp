@@ -10,11 +10,16 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 #define SX(x) do { int r = (x); if (r) { printf("simx error %d: %s (line %d)\n", r, simx_last_error(), __LINE__); exit(1);} } while (0)
 
+static int g_dt = SIMX_BF16;                        // KB_F16=1: IEEE-half operands (SIMX_F16)
 static void* dalloc(size_t bytes, int fill) {
   if (getenv("KB_ZERO")) fill = 0;                 // power experiment: all-zero operands (DVFS give-back, MI355X_MICROARCH.md)
   void* p; CK(hipMalloc(&p, bytes));
   std::vector<unsigned short> h(1 << 20);
-  for (size_t i = 0; i < h.size(); ++i) { float f = ((int)((i * 2654435761u) >> 20 & 1023) - 512) / 1024.0f * (fill ? 1.f : 0.f); unsigned u; memcpy(&u, &f, 4); h[i] = (unsigned short)(u >> 16); }
+  for (size_t i = 0; i < h.size(); ++i) {
+    float f = ((int)((i * 2654435761u) >> 20 & 1023) - 512) / 1024.0f * (fill ? 1.f : 0.f);
+    if (g_dt == SIMX_F16) { _Float16 hf = (_Float16)f; memcpy(&h[i], &hf, 2); }
+    else { unsigned u; memcpy(&u, &f, 4); h[i] = (unsigned short)(u >> 16); }
+  }
   for (size_t off = 0; off < bytes; off += h.size() * 2) CK(hipMemcpy((char*)p + off, h.data(), std::min(h.size() * 2, bytes - off), hipMemcpyHostToDevice));
   return p;
 }
@@ -25,6 +30,7 @@ template <typename F> static double timeit(F f, int iters) {
   float ms; CK(hipEventElapsedTime(&ms, a, b)); return ms / iters;
 }
 int main(int argc, char** argv) {
+  if (getenv("KB_F16")) g_dt = SIMX_F16;
   const int T = argc > 1 ? atoi(argv[1]) : 262144;
   const int H = 768, F = 3072, iters = 10;
   const int pad = getenv("KB_LDA_PAD") ? atoi(getenv("KB_LDA_PAD")) : 0;   // experiment: leading-dimension padding of A
@@ -46,47 +52,47 @@ int main(int argc, char** argv) {
   const char* only = getenv("KB_ONLY"); int oi = only ? atoi(only) : -1; int idx = -1;
   for (auto& s : nt) {
     ++idx; if (oi >= 0 && idx != oi) continue;
-    double ms = timeit([&] { SX(simx_gemm_nt(0, SIMX_BF16, T, s.N, s.K, A, s.K + pad, W, s.K, C, s.N, s.epi == 2 ? nullptr : bias, s.res ? A2 : nullptr, s.N, s.epi, s.epi == 2 ? A2 : nullptr, s.N, s.epi == 1 ? C2 : nullptr, s.N)); }, iters);
+    double ms = timeit([&] { SX(simx_gemm_nt(0, g_dt, T, s.N, s.K, A, s.K + pad, W, s.K, C, s.N, s.epi == 2 ? nullptr : bias, s.res ? A2 : nullptr, s.N, s.epi, s.epi == 2 ? A2 : nullptr, s.N, s.epi == 1 ? C2 : nullptr, s.N)); }, iters);
     double fl = 2.0 * T * s.N * s.K; tot += ms; totf += fl;
     printf("gemm_nt %-36s %8.3f ms  %7.1f TF/s\n", s.name, ms, fl / ms / 1e9);
   }
   printf("gemm_nt total %.2f ms  avg %.1f TF/s\n", tot, totf / tot / 1e9);
   if (oi >= 0) return 0;
   {   // QKV projection writing the head-major layout ([36][T][64]) and the dgrad reading it
-    double ms = timeit([&] { SX(simx_gemm_nt_hm(0, SIMX_BF16, T, 3 * H, H, A, H, W, H, C, 64, bias, nullptr, 0, nullptr, 0, T)); }, iters);
+    double ms = timeit([&] { SX(simx_gemm_nt_hm(0, g_dt, T, 3 * H, H, A, H, W, H, C, 64, bias, nullptr, 0, nullptr, 0, T)); }, iters);
     printf("gemm_nt %-36s %8.3f ms  %7.1f TF/s\n", "qkv   fwd  N=2304 K=768 bias -> hm", ms, 2.0 * T * 3 * H * H / ms / 1e9);
-    ms = timeit([&] { SX(simx_gemm_nt_hm(0, SIMX_BF16, T, H, 3 * H, A, 64, W, 3 * H, C, H, nullptr, A2, H, nullptr, T, 0)); }, iters);
+    ms = timeit([&] { SX(simx_gemm_nt_hm(0, g_dt, T, H, 3 * H, A, 64, W, 3 * H, C, H, nullptr, A2, H, nullptr, T, 0)); }, iters);
     printf("gemm_nt %-36s %8.3f ms  %7.1f TF/s\n", "qkv  dgrad N=768  K=2304 +res <- hm", ms, 2.0 * T * 3 * H * H / ms / 1e9);
   }
   {   // how much would plane-blocked [T, 768] outputs be worth?  (no residual: the built flags-2 form)
-    double ms = timeit([&] { SX(simx_gemm_nt(0, SIMX_BF16, T, H, H, A, H, W, H, C, H, bias, nullptr, 0, 0, nullptr, 0, nullptr, 0)); }, iters);
+    double ms = timeit([&] { SX(simx_gemm_nt(0, g_dt, T, H, H, A, H, W, H, C, H, bias, nullptr, 0, 0, nullptr, 0, nullptr, 0)); }, iters);
     printf("gemm_nt %-36s %8.3f ms  %7.1f TF/s\n", "oproj-shape N=768 K=768 bias", ms, 2.0 * T * H * H / ms / 1e9);
-    ms = timeit([&] { SX(simx_gemm_nt_pb(0, SIMX_BF16, T, H, H, A, H, W, H, C, 64, bias, nullptr, 0, 0, nullptr, 0, nullptr, 2, T)); }, iters);
+    ms = timeit([&] { SX(simx_gemm_nt_pb(0, g_dt, T, H, H, A, H, W, H, C, 64, bias, nullptr, 0, 0, nullptr, 0, nullptr, 2, T)); }, iters);
     printf("gemm_nt %-36s %8.3f ms  %7.1f TF/s\n", "oproj-shape N=768 K=768 bias -> pb", ms, 2.0 * T * H * H / ms / 1e9);
-    ms = timeit([&] { SX(simx_gemm_nt(0, SIMX_BF16, T, H, F, A, F, W, F, C, H, bias, nullptr, 0, 0, nullptr, 0, nullptr, 0)); }, iters);
+    ms = timeit([&] { SX(simx_gemm_nt(0, g_dt, T, H, F, A, F, W, F, C, H, bias, nullptr, 0, 0, nullptr, 0, nullptr, 0)); }, iters);
     printf("gemm_nt %-36s %8.3f ms  %7.1f TF/s\n", "ffn2-shape N=768 K=3072 bias", ms, 2.0 * T * H * F / ms / 1e9);
-    ms = timeit([&] { SX(simx_gemm_nt_pb(0, SIMX_BF16, T, H, F, A, F, W, F, C, 64, bias, nullptr, 0, 0, nullptr, 0, nullptr, 2, T)); }, iters);
+    ms = timeit([&] { SX(simx_gemm_nt_pb(0, g_dt, T, H, F, A, F, W, F, C, 64, bias, nullptr, 0, 0, nullptr, 0, nullptr, 2, T)); }, iters);
     printf("gemm_nt %-36s %8.3f ms  %7.1f TF/s\n", "ffn2-shape N=768 K=3072 bias -> pb", ms, 2.0 * T * H * F / ms / 1e9);
-    ms = timeit([&] { SX(simx_gemm_nt(0, SIMX_BF16, T, F, H, A, H, W, H, C, F, bias, nullptr, 0, 0, nullptr, 0, nullptr, 0)); }, iters);
+    ms = timeit([&] { SX(simx_gemm_nt(0, g_dt, T, F, H, A, H, W, H, C, F, bias, nullptr, 0, 0, nullptr, 0, nullptr, 0)); }, iters);
     printf("gemm_nt %-36s %8.3f ms  %7.1f TF/s\n", "ffn1-shape N=3072 K=768 bias (plain)", ms, 2.0 * T * H * F / ms / 1e9);
-    ms = timeit([&] { SX(simx_gemm_nt_pb(0, SIMX_BF16, T, F, H, A, H, W, H, C, 64, bias, nullptr, 0, 0, nullptr, 0, nullptr, 2, T)); }, iters);
+    ms = timeit([&] { SX(simx_gemm_nt_pb(0, g_dt, T, F, H, A, H, W, H, C, 64, bias, nullptr, 0, 0, nullptr, 0, nullptr, 2, T)); }, iters);
     printf("gemm_nt %-36s %8.3f ms  %7.1f TF/s\n", "ffn1-shape N=3072 K=768 bias -> pb", ms, 2.0 * T * H * F / ms / 1e9);
   }
   {   // the teacher's FFN-in: GELU without the derivative output (SIMX_EPI_GELU_INFER = 3)
-    double ms = timeit([&] { SX(simx_gemm_nt(0, SIMX_BF16, T, F, H, A, H + pad, W, H, C, F, bias, nullptr, F, 3, nullptr, F, C2, F)); }, iters);
+    double ms = timeit([&] { SX(simx_gemm_nt(0, g_dt, T, F, H, A, H + pad, W, H, C, F, bias, nullptr, F, 3, nullptr, F, C2, F)); }, iters);
     printf("gemm_nt %-36s %8.3f ms  %7.1f TF/s\n", "ffn1  fwd  N=3072 K=768 gelu (infer)", ms, 2.0 * T * F * H / ms / 1e9);
   }
   struct S2 { const char* name; int M, N; } tn[] = {{"wqkv [2304,768]", 3 * H, H}, {"wo [768,768]", H, H}, {"w1 [3072,768]", F, H}, {"w2 [768,3072]", H, F}};
   tot = 0; totf = 0;
   for (auto& s : tn) {
-    double ms = timeit([&] { SX(simx_gemm_tn(0, SIMX_BF16, s.M, s.N, T, A, s.M, A2, s.N, G, s.N, 1, ws, wsb)); }, iters);
+    double ms = timeit([&] { SX(simx_gemm_tn(0, g_dt, s.M, s.N, T, A, s.M, A2, s.N, G, s.N, 1, ws, wsb)); }, iters);
     double fl = 2.0 * T * s.M * s.N; tot += ms; totf += fl;
     printf("gemm_tn %-36s %8.3f ms  %7.1f TF/s\n", s.name, ms, fl / ms / 1e9);
   }
   printf("gemm_tn total %.2f ms  avg %.1f TF/s\n", tot, totf / tot / 1e9);
   tot = 0; totf = 0;
   for (auto& s : tn) {
-    double ms = timeit([&] { SX(simx_gemm_tn_bias(0, SIMX_BF16, s.M, s.N, T, A, s.M, A2, s.N, G, s.N, 1, ws, wsb, bias)); }, iters);
+    double ms = timeit([&] { SX(simx_gemm_tn_bias(0, g_dt, s.M, s.N, T, A, s.M, A2, s.N, G, s.N, 1, ws, wsb, bias)); }, iters);
     double fl = 2.0 * T * s.M * s.N; tot += ms; totf += fl;
     printf("gemm_tn+bias %-31s %8.3f ms  %7.1f TF/s\n", s.name, ms, fl / ms / 1e9);
   }
@@ -96,15 +102,15 @@ int main(int argc, char** argv) {
   std::vector<int> cu(nseq + 1); for (int i = 0; i <= nseq; ++i) cu[i] = i * S;
   int* dcu; CK(hipMalloc(&dcu, (nseq + 1) * 4)); CK(hipMemcpy(dcu, cu.data(), (nseq + 1) * 4, hipMemcpyHostToDevice));
   float* lse = (float*)dalloc((size_t)heads * T * 4, 0);
-  double ms = timeit([&] { SX(simx_mha_fwd(0, SIMX_BF16, nseq, heads, 64, dcu, S, T, A, C, lse)); }, iters);
+  double ms = timeit([&] { SX(simx_mha_fwd(0, g_dt, nseq, heads, 64, dcu, S, T, A, C, lse)); }, iters);
   printf("mha_fwd S=128 %8.3f ms  %7.1f TF/s\n", ms, 4.0 * T * S * H / ms / 1e9);
-  ms = timeit([&] { SX(simx_mha_bwd(0, SIMX_BF16, nseq, heads, 64, dcu, S, T, A, C, lse, A2, C2)); }, iters);
+  ms = timeit([&] { SX(simx_mha_bwd(0, g_dt, nseq, heads, 64, dcu, S, T, A, C, lse, A2, C2)); }, iters);
   printf("mha_bwd S=128 %8.3f ms  %7.1f TF/s (5-GEMM count)\n", ms, 10.0 * T * S * H / ms / 1e9);
-  ms = timeit([&] { SX(simx_ln_fwd(0, SIMX_BF16, T, H, A, bias, bias, 1e-12f, C)); }, iters);
+  ms = timeit([&] { SX(simx_ln_fwd(0, g_dt, T, H, A, bias, bias, 1e-12f, C)); }, iters);
   printf("ln_fwd  %8.3f ms  %6.2f TB/s\n", ms, 2.0 * T * H * 2 / ms / 1e9);
-  ms = timeit([&] { SX(simx_ln_bwd(0, SIMX_BF16, T, H, A, bias, 1e-12f, A2, C, G, G + 1024, G + 2048)); }, iters);
+  ms = timeit([&] { SX(simx_ln_bwd(0, g_dt, T, H, A, bias, 1e-12f, A2, C, G, G + 1024, G + 2048)); }, iters);
   printf("ln_bwd  %8.3f ms  %6.2f TB/s\n", ms, 3.0 * T * H * 2 / ms / 1e9);
-  ms = timeit([&] { SX(simx_colsum(0, SIMX_BF16, T, F, A, F, G, 1)); }, iters);
+  ms = timeit([&] { SX(simx_colsum(0, g_dt, T, F, A, F, G, 1)); }, iters);
   printf("colsum F %8.3f ms  %6.2f TB/s\n", ms, 1.0 * T * F * 2 / ms / 1e9);
   return 0;
 }

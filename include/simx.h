@@ -148,7 +148,7 @@ int simx_embed_ln_fwd_ex(simx_stream_t stream, int dtype, int T, int H,
                          const int32_t* ids, const int32_t* pos_ids,
                          const float* word, const float* posw, const float* typew,
                          const float* gamma, const float* beta, float eps, void* out, const simx_dropout* drop);
-/* same, also writing the residual-stream correction out_lo = round16(out - round16(out)) (may be NULL) */
+/* same, also writing the residual-stream correction bytes out_lo (uint8 [T,H], see simx_ln_fwd_res; may be NULL) */
 int simx_embed_ln_fwd_lo(simx_stream_t stream, int dtype, int T, int H,
                          const int32_t* ids, const int32_t* pos_ids,
                          const float* word, const float* posw, const float* typew,
@@ -181,9 +181,11 @@ int simx_ln_fwd(simx_stream_t stream, int dtype, int T, int H, const void* z,
                 const float* gamma, const float* beta, float eps, void* y);
 /* "f32-grade residual stream" of the 16-bit engines (simx_bert_cfg.stream_lo): y = LN(d + res_hi + res_lo) where d is the
  * dense output (bias and dropout already applied by the GEMM epilogue; no residual there) and the residual stream is kept as
- * a 16-bit value plus a 16-bit correction; y leaves the same way, y_hi = round16(y), y_lo = round16(y - y_hi).  apex O1 (the
- * reference's --fp16 mode) keeps this stream in fp32: residual additions promote to fp32 and LayerNorm is an fp32 function
- * there.  res_lo / y_lo may be NULL (plain 16-bit residual / output); res_hi == NULL is simx_ln_fwd. */
+ * a 16-bit value plus a ONE-BYTE correction per element: x = hi + (b - 128) * ulp(hi) / 256 with ulp(hi) the spacing of the
+ * 16-bit format at hi's exponent (res_lo / y_lo: uint8 [T,H]).  y leaves the same way.  The stream carries 19 significand bits
+ * in fp16 (16 in bf16) at 3 B per element.  apex O1 (the reference's --fp16 mode) keeps this stream in fp32: residual additions
+ * promote to fp32 and LayerNorm is an fp32 function there.  res_lo / y_lo may be NULL (plain 16-bit residual / output);
+ * res_hi == NULL is simx_ln_fwd. */
 int simx_ln_fwd_res(simx_stream_t stream, int dtype, int T, int H, const void* d, const void* res_hi, const void* res_lo,
                     const float* gamma, const float* beta, float eps, void* y, void* y_lo);
 /* its backward: the LayerNorm input is rebuilt as d + res_hi + res_lo; everything else as simx_ln_bwd_gs. */
@@ -332,9 +334,9 @@ typedef struct simx_bert_cfg {
    * (v_mfma_f32_32x32x2_f32) everywhere. */
   int32_t f32_gemm;
   /* 16-bit dtypes only.  1: the residual stream (embedding output and every LayerNorm output) is kept as a 16-bit value plus
-   * a 16-bit correction and the residual additions move from the GEMM epilogues into the LayerNorm kernels, which sum
-   * dense + hi + lo in f32 (simx_ln_fwd_res): ~22 significand bits from layer to layer at 4 B per element, the f32 stream
-   * of apex O1 without a round trip of the pre-LayerNorm sum through HBM.  Must match between simx_bert_act_bytes / fwd /
+   * a one-byte correction per element and the residual additions move from the GEMM epilogues into the LayerNorm kernels,
+   * which sum dense + hi + lo in f32 (simx_ln_fwd_res): 19 significand bits from layer to layer (fp16) at 3 B per element --
+   * the role of apex O1's fp32 stream -- without a round trip of the pre-LayerNorm sum through HBM.  Must match between simx_bert_act_bytes / fwd /
    * bwd.  0: the stream is a plain 16-bit tensor, the residual rides in the GEMM epilogue. */
   int32_t stream_lo;
   /* SIMX_F16 backward: device pointer to {S, 1/S} (the loss scale, "gradient scale" above) or NULL = 1. */

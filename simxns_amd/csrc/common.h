@@ -82,6 +82,44 @@ template <> struct H16<f16_t> {
   }
 };
 
+// ---- stream correction in ONE byte per element (simx.h stream_lo): x = hi + (b - 128) * ulp(hi) / 256, ulp(hi) = the
+// spacing of the 16-bit format at hi's exponent.  |x - hi| <= ulp / 2, so b lands in [0, 256]: clamped to [1, 255] (at most
+// 1/256 ulp lost at the two ends).  The stream then carries 11 + 8 = 19 significand bits in fp16 (8 + 8 = 16 in bf16) at 3 B
+// per element instead of 4.  lo8_scale_bits: the f32 bit pattern of ulp(hi) / 256 from hi's raw 16 bits.
+template <typename T> struct Lo8;
+template <> struct Lo8<f16_t> {
+  static __device__ __forceinline__ uint32_t field(uint32_t h) { const uint32_t e = (h >> 10) & 31u; return (e > 1u ? e : 1u) + 94u; }      // 2^(e-15-10-8)
+};
+template <> struct Lo8<bf16_t> {
+  static __device__ __forceinline__ uint32_t field(uint32_t h) { const uint32_t e = (h >> 7) & 255u; return (e > 16u ? e : 16u) - 15u; }   // 2^(e-127-7-8)
+};
+template <> struct Lo8<float> {                          // (f32 tensors carry no correction; never instantiated on a live path)
+  static __device__ __forceinline__ uint32_t field(uint32_t) { return 127u; }
+};
+// the four corrections of the elements packed in (w0, w1) [two 16-bit values each] from the byte quad q
+template <typename T>
+__device__ __forceinline__ void lo8_decode4(uint32_t w0, uint32_t w1, uint32_t q, float (&lo)[4]) {
+  const uint32_t hb[4] = {w0 & 0xFFFFu, w0 >> 16, w1 & 0xFFFFu, w1 >> 16};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float s = __uint_as_float(Lo8<T>::field(hb[e]) << 23);
+    lo[e] = ((float)((q >> (8 * e)) & 0xFFu) - 128.0f) * s;
+  }
+}
+// r[e] = what the 16-bit rounding of element e dropped (o - hi); (w0, w1) = the packed 16-bit values just stored
+template <typename T>
+__device__ __forceinline__ uint32_t lo8_encode4(uint32_t w0, uint32_t w1, const float (&r)[4]) {
+  const uint32_t hb[4] = {w0 & 0xFFFFu, w0 >> 16, w1 & 0xFFFFu, w1 >> 16};
+  uint32_t q = 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float inv = __uint_as_float((254u - Lo8<T>::field(hb[e])) << 23);
+    const float t = __builtin_amdgcn_fmed3f(fmaf(r[e], inv, 128.0f), 1.0f, 255.0f);
+    q |= ((uint32_t)__builtin_rintf(t)) << (8 * e);
+  }
+  return q;
+}
+
 // 4 consecutive elements of raw 16-bit storage in format F (the MFMA kernels keep `bf16_t*` = raw 16-bit pointers for both)
 template <typename F>
 __device__ __forceinline__ void ld4h(const bf16_t* p, float (&v)[4]) {

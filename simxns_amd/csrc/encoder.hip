@@ -118,16 +118,18 @@ static WLayer wlayer(const simx_bert_cfg* c, const float* params, const void* wc
 // [T, Tp) hold garbage that never leaves its own row (an NT GEMM row depends on that row of A only; LayerNorm,
 // attention, the wgrad contraction and every reduction run over the T real rows).
 static inline int rows_cap(int T) { return (T + 255) & ~255; }
-// stream_lo (simx.h): the residual stream -- x0 and every LayerNorm output -- is a 16-bit tensor PLUS a 16-bit correction
-// (x1l / xoutl, NULL otherwise); z1 / z2 then hold the dense outputs without the residual, which the LayerNorm kernels add
+// stream_lo (simx.h): the residual stream -- x0 and every LayerNorm output -- is a 16-bit tensor PLUS a one-byte correction
+// per element (x1l / xoutl, NULL otherwise); z1 / z2 then hold the dense outputs without the residual, which the LayerNorm
+// kernels add
 static inline bool stream_lo(const simx_bert_cfg* c) { return c->stream_lo != 0 && simx_is16(c->dtype); }
 struct ALayer { char *qkv, *ctx, *z1, *x1, *u, *h, *z2, *xout, *x1l, *xoutl; float* lse; };
 static size_t act_layer_bytes(const simx_bert_cfg* c, size_t T) {
   const size_t H = c->hidden, F = c->inter, e = esz(c->dtype);
-  return al(T * 3 * H * e) + (stream_lo(c) ? 7 : 5) * al(T * H * e) + 2 * al(T * F * e) + al((size_t)c->heads * T * 4);
+  return al(T * 3 * H * e) + 5 * al(T * H * e) + (stream_lo(c) ? 2 * al(T * H) : 0) + 2 * al(T * F * e) + al((size_t)c->heads * T * 4);
 }
-// a [Tp,H] tensor of the residual stream: the 16-bit values, followed by the corrections when stream_lo
-static size_t xs_bytes(const simx_bert_cfg* c, size_t Tp) { return (stream_lo(c) ? 2 : 1) * al(Tp * c->hidden * esz(c->dtype)); }
+// a [Tp,H] tensor of the residual stream: the 16-bit values, followed by the corrections (ONE BYTE per element: common.h
+// lo8) when stream_lo
+static size_t xs_bytes(const simx_bert_cfg* c, size_t Tp) { return al(Tp * c->hidden * esz(c->dtype)) + (stream_lo(c) ? al(Tp * c->hidden) : 0); }
 static const char* xs_lo(const simx_bert_cfg* c, const char* hi, size_t Tp) { return stream_lo(c) ? hi + al(Tp * c->hidden * esz(c->dtype)) : nullptr; }
 // Activation memory, three modes:
 //   save = 0                      : x0 | 2 layer slots used as a ring                                  (inference)
@@ -162,7 +164,7 @@ static ALayer carve_layer(const simx_bert_cfg* c, char* b, size_t T) {
   a.z2 = b; b += al(T * H * e);
   a.xout = b; b += al(T * H * e);
   a.x1l = a.xoutl = nullptr;
-  if (stream_lo(c)) { a.x1l = b; b += al(T * H * e); a.xoutl = b; b += al(T * H * e); }
+  if (stream_lo(c)) { a.x1l = b; b += al(T * H); a.xoutl = b; b += al(T * H); }
   a.u = b; b += al(T * F * e);                 // gelu'(u) of the FFN pre-activation (SIMX_EPI_GELU writes it; only DGELU reads it)
   a.h = b; b += al(T * F * e);
   a.lse = (float*)b;

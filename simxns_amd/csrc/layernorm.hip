@@ -16,6 +16,8 @@ template <> struct Raw4<float> {
   float4 r;
   __device__ __forceinline__ void load(const float* p) { r = *reinterpret_cast<const float4*>(p); }
   __device__ __forceinline__ void unpack(float (&v)[4]) const { v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w; }
+  __device__ __forceinline__ uint32_t w0() const { return 0u; }      // (raw 16-bit words: meaningless for f32)
+  __device__ __forceinline__ uint32_t w1() const { return 0u; }
 };
 template <> struct Raw4<bf16_t> {
   uint2 r;
@@ -24,6 +26,8 @@ template <> struct Raw4<bf16_t> {
     v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xFFFF0000u);
     v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xFFFF0000u);
   }
+  __device__ __forceinline__ uint32_t w0() const { return r.x; }
+  __device__ __forceinline__ uint32_t w1() const { return r.y; }
 };
 
 template <> struct Raw4<f16_t> {
@@ -32,7 +36,23 @@ template <> struct Raw4<f16_t> {
   __device__ __forceinline__ void unpack(float (&v)[4]) const {
     v[0] = H16<f16_t>::lo(r.x); v[1] = H16<f16_t>::hi(r.x); v[2] = H16<f16_t>::lo(r.y); v[3] = H16<f16_t>::hi(r.y);
   }
+  __device__ __forceinline__ uint32_t w0() const { return r.x; }
+  __device__ __forceinline__ uint32_t w1() const { return r.y; }
 };
+// store 4 values in T and return what the rounding dropped (r) plus the packed words (for lo8_encode4)
+template <typename T>
+__device__ __forceinline__ void st4_residue(T* p, const float (&o)[4], float (&r)[4], uint32_t& w0, uint32_t& w1) {
+  if constexpr (sizeof(T) == 2) {
+    w0 = H16<T>::pack2(o[0], o[1]);
+    w1 = H16<T>::pack2(o[2], o[3]);
+    *reinterpret_cast<uint2*>(p) = make_uint2(w0, w1);
+    r[0] = o[0] - H16<T>::lo(w0); r[1] = o[1] - H16<T>::hi(w0); r[2] = o[2] - H16<T>::lo(w1); r[3] = o[3] - H16<T>::hi(w1);
+  } else {
+    st4(p, o);
+    w0 = w1 = 0u;
+    r[0] = r[1] = r[2] = r[3] = 0.f;
+  }
+}
 
 // One wave per row, rows strided by 4 inside a block; the next row's loads are issued before this row's
 // reductions, and gamma/beta are read from LDS so the row body never queues behind those loads on vmcnt.
@@ -45,7 +65,7 @@ template <typename T, int VPL, bool RES>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int H, int rows_per_block, const T* __restrict__ z,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float eps, T* __restrict__ y, const T* __restrict__ rh,
-                                                     const T* __restrict__ rl, T* __restrict__ ylo) {
+                                                     const uint8_t* __restrict__ rl, uint8_t* __restrict__ ylo) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sgam = reinterpret_cast<float*>(smem);
   float* sbet = sgam + H;
@@ -54,14 +74,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int H, int rows_p
   __syncthreads();
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(rows, r0 + rows_per_block);
-  Raw4<T> nx[VPL], nh[RES ? VPL : 1], nl[RES ? VPL : 1];
+  Raw4<T> nx[VPL], nh[RES ? VPL : 1];
+  uint32_t nl[RES ? VPL : 1];                     // the residual's correction bytes (lo8, common.h), 4 elements per dword
   auto issue = [&](int row) {
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
       const int c = (v * 64 + lane) * 4;
       if (c < H) {
         nx[v].load(z + (long)row * H + c);
-        if (RES) { nh[v].load(rh + (long)row * H + c); if (rl) nl[v].load(rl + (long)row * H + c); }
+        if (RES) { nh[v].load(rh + (long)row * H + c); if (rl) nl[v] = *reinterpret_cast<const uint32_t*>(rl + (long)row * H + c); }
       }
     }
   };
@@ -80,7 +101,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int H, int rows_p
 #pragma unroll
           for (int e = 0; e < 4; ++e) x[v][e] += a[e];
           if (rl) {
-            nl[v].unpack(a);
+            lo8_decode4<T>(nh[v].w0(), nh[v].w1(), nl[v], a);
 #pragma unroll
             for (int e = 0; e < 4; ++e) x[v][e] += a[e];
           }
@@ -109,11 +130,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int H, int rows_p
         ld4(sbet + c, b);
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = x[v][e] * rstd * g[e] + b[e];
-        st4(yr + c, o);
-        if (RES && ylo) {                       // the correction: what the 16-bit rounding of y just dropped
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] -= Elem<T>::rnd(o[e]);
-          st4(ylo + (long)row * H + c, o);
+        if (RES && ylo) {                       // the correction: what the 16-bit rounding of y drops, one byte per element
+          float rr[4];
+          uint32_t w0, w1;
+          st4_residue(yr + c, o, rr, w0, w1);
+          *reinterpret_cast<uint32_t*>(ylo + (long)row * H + c) = lo8_encode4<T>(w0, w1, rr);
+        } else {
+          st4(yr + c, o);
         }
       }
     }
@@ -125,7 +148,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(int rows, int H, cons
                                                            const int* __restrict__ pos, const float* __restrict__ word,
                                                            const float* __restrict__ posw, const float* __restrict__ typew,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           float eps, T* __restrict__ y, DropCtx drop, T* __restrict__ ylo) {
+                                                           float eps, T* __restrict__ y, DropCtx drop, uint8_t* __restrict__ ylo) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + w;
   if (row >= rows) return;
@@ -166,11 +189,13 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(int rows, int H, cons
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = x[v][e] * rstd * g[e] + b[e];
       if (drop.thr) { float m4[4]; drop_mult4(drop, (uint32_t)row, (uint32_t)c, m4); o[0] *= m4[0]; o[1] *= m4[1]; o[2] *= m4[2]; o[3] *= m4[3]; }
-      st4(yr + c, o);
       if (ylo) {                                 // residual-stream correction (simx.h stream_lo)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] -= Elem<T>::rnd(o[e]);
-        st4(ylo + (long)row * H + c, o);
+        float rr[4];
+        uint32_t w0, w1;
+        st4_residue(yr + c, o, rr, w0, w1);
+        *reinterpret_cast<uint32_t*>(ylo + (long)row * H + c) = lo8_encode4<T>(w0, w1, rr);
+      } else {
+        st4(yr + c, o);
       }
     }
   }
@@ -245,7 +270,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int H, int rows_p
                                                      float* __restrict__ dbeta, float* __restrict__ dbias,
                                                      T* __restrict__ dzm, DropCtx drop, const int* __restrict__ row_keys,
                                                      const float* __restrict__ gs, const T* __restrict__ rh,
-                                                     const T* __restrict__ rl) {
+                                                     const uint8_t* __restrict__ rl) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sred = reinterpret_cast<float*>(smem);          // [4][H] flush scratch
   float* sgam = sred + 4 * H;                            // [H]
@@ -259,7 +284,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int H, int rows_p
   // CU made it slower).
   (void)rows_per_block;
   const int r0 = blockIdx.x * 4, r1 = rows, rstep = (int)gridDim.x * 4;
-  Raw4<T> nx[VPL], nd[VPL], nh[RES ? VPL : 1], nl[RES ? VPL : 1];
+  Raw4<T> nx[VPL], nd[VPL], nh[RES ? VPL : 1];
+  uint32_t nl[RES ? VPL : 1];
   auto issue = [&](int row) {
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
@@ -267,7 +293,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int H, int rows_p
       if (c < H) {
         nx[v].load(z + (long)row * H + c);
         nd[v].load(dyp + (long)row * H + c);
-        if (RES) { nh[v].load(rh + (long)row * H + c); if (rl) nl[v].load(rl + (long)row * H + c); }
+        if (RES) { nh[v].load(rh + (long)row * H + c); if (rl) nl[v] = *reinterpret_cast<const uint32_t*>(rl + (long)row * H + c); }
       }
     }
   };
@@ -287,7 +313,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int H, int rows_p
 #pragma unroll
           for (int e = 0; e < 4; ++e) x[v][e] += a[e];
           if (rl) {
-            nl[v].unpack(a);
+            lo8_decode4<T>(nh[v].w0(), nh[v].w1(), nl[v], a);
 #pragma unroll
             for (int e = 0; e < 4; ++e) x[v][e] += a[e];
           }
@@ -578,8 +604,8 @@ extern "C" int simx_ln_fwd(simx_stream_t stream, int dtype, int T, int H, const 
 
 extern "C" int simx_ln_fwd_res(simx_stream_t stream, int dtype, int T, int H, const void* d, const void* res_hi, const void* res_lo,
                                const float* gamma, const float* beta, float eps, void* y, void* y_lo) {
-  const int streams = 2 + (res_hi ? 1 : 0) + (res_lo ? 1 : 0) + (y_lo ? 1 : 0);
-  SIMX_PROF(SIMX_K_LN_FWD, stream, (double)streams * T * H * simx_esz(dtype));
+  SIMX_PROF(SIMX_K_LN_FWD, stream, (double)T * H * ((2 + (res_hi ? 1 : 0)) * simx_esz(dtype) + (res_lo ? 1 : 0) + (y_lo ? 1 : 0)));
+  SIMX_REQUIRE(!(res_lo || y_lo) || simx_is16(dtype), SIMX_ERR_BAD_DTYPE, "ln_fwd_res: the stream correction exists for the 16-bit dtypes only");
   int rc = ln_check(dtype, T, H, "ln_fwd");
   if (rc) return rc;
   SIMX_REQUIRE(res_hi || (!res_lo && !y_lo), SIMX_ERR_BAD_SHAPE, "ln_fwd_res: res_lo / y_lo need res_hi");
@@ -587,9 +613,9 @@ extern "C" int simx_ln_fwd_res(simx_stream_t stream, int dtype, int T, int H, co
   const int rpb = ln_rows_per_block(T, "SIMX_LN_FWD_BLOCKS", 1 << 30);   // 16 rows (4 per wave) per block measured best
   const size_t lds = (size_t)2 * H * sizeof(float);
 #define LF(TT, V) do { if (res_hi) hipLaunchKernelGGL((ln_fwd_kernel<TT, V, true>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, (const TT*)d, gamma, beta, \
-                                    eps, (TT*)y, (const TT*)res_hi, (const TT*)res_lo, (TT*)y_lo);                                    \
+                                    eps, (TT*)y, (const TT*)res_hi, (const uint8_t*)res_lo, (uint8_t*)y_lo);                                    \
                        else hipLaunchKernelGGL((ln_fwd_kernel<TT, V, false>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, (const TT*)d, gamma, beta, \
-                                    eps, (TT*)y, (const TT*)nullptr, (const TT*)nullptr, (TT*)nullptr); } while (0)
+                                    eps, (TT*)y, (const TT*)nullptr, (const uint8_t*)nullptr, (uint8_t*)nullptr); } while (0)
   SIMX_DISPATCH3(dtype, TT, LN_BY_H(TT, LF));
 #undef LF
   SIMX_CHECK_LAUNCH("ln_fwd");
@@ -622,8 +648,8 @@ extern "C" int simx_ln_bwd_gs(simx_stream_t stream, int dtype, int T, int H, con
 extern "C" int simx_ln_bwd_res(simx_stream_t stream, int dtype, int T, int H, const void* z, const void* res_hi, const void* res_lo,
                                const float* gamma, float eps, const void* dy, void* dz, void* dz_masked, float* dgamma, float* dbeta,
                                float* dbias, const simx_dropout* dropd, const int32_t* row_keys, const float* gs) {
-  const int streams = 3 + (res_hi ? 1 : 0) + (res_lo ? 1 : 0);
-  SIMX_PROF(SIMX_K_LN_BWD, stream, (double)streams * T * H * simx_esz(dtype));
+  SIMX_PROF(SIMX_K_LN_BWD, stream, (double)T * H * ((3 + (res_hi ? 1 : 0)) * simx_esz(dtype) + (res_lo ? 1 : 0)));
+  SIMX_REQUIRE(!res_lo || simx_is16(dtype), SIMX_ERR_BAD_DTYPE, "ln_bwd_res: the stream correction exists for the 16-bit dtypes only");
   int rc = ln_check(dtype, T, H, "ln_bwd");
   if (rc) return rc;
   SIMX_REQUIRE(res_hi || !res_lo, SIMX_ERR_BAD_SHAPE, "ln_bwd_res: res_lo needs res_hi");
@@ -633,9 +659,9 @@ extern "C" int simx_ln_bwd_res(simx_stream_t stream, int dtype, int T, int H, co
   const int rpb = bwd_rows_per_block(T);
   const size_t lds = (size_t)5 * H * sizeof(float);
 #define LB(TT, V) do { if (res_hi) hipLaunchKernelGGL((ln_bwd_kernel<TT, V, true>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, (const TT*)z, gamma, eps, \
-                                    (const TT*)dy, (TT*)dz, dgamma, dbeta, dbias, (TT*)dz_masked, drop, row_keys, gs, (const TT*)res_hi, (const TT*)res_lo); \
+                                    (const TT*)dy, (TT*)dz, dgamma, dbeta, dbias, (TT*)dz_masked, drop, row_keys, gs, (const TT*)res_hi, (const uint8_t*)res_lo); \
                        else hipLaunchKernelGGL((ln_bwd_kernel<TT, V, false>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, (const TT*)z, gamma, eps, \
-                                    (const TT*)dy, (TT*)dz, dgamma, dbeta, dbias, (TT*)dz_masked, drop, row_keys, gs, (const TT*)nullptr, (const TT*)nullptr); } while (0)
+                                    (const TT*)dy, (TT*)dz, dgamma, dbeta, dbias, (TT*)dz_masked, drop, row_keys, gs, (const TT*)nullptr, (const uint8_t*)nullptr); } while (0)
   SIMX_DISPATCH3(dtype, TT, LN_BY_H(TT, LB));
 #undef LB
   SIMX_CHECK_LAUNCH("ln_bwd");
@@ -662,7 +688,7 @@ extern "C" int simx_embed_ln_fwd_lo(simx_stream_t stream, int dtype, int T, int 
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   SIMX_DISPATCH3(dtype, TT, hipLaunchKernelGGL((embed_ln_fwd_kernel<TT>), dim3(cdiv(T, 4)), dim3(256), 0, s, T, H, ids, pos_ids, word,
-                                               posw, typew, gamma, beta, eps, (TT*)out, drop, (TT*)out_lo));
+                                               posw, typew, gamma, beta, eps, (TT*)out, drop, (uint8_t*)out_lo));
   SIMX_CHECK_LAUNCH("embed_ln_fwd");
   return SIMX_OK;
 }

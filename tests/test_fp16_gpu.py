@@ -221,8 +221,8 @@ def test_fp16_training_steps_with_dynamic_scale(dev):
 @pytest.mark.parametrize("T,H", [(300, 768), (37, 64), (50, 1024)])
 def test_ln_residual_stream(dev, fmt, T, H):
     """simx_ln_fwd_res / simx_ln_bwd_res (simx.h stream_lo): y = LN(d + r_hi + r_lo) summed in f32, y leaves as a 16-bit
-    value plus a 16-bit correction: y_hi + y_lo carries the f32 result to ~2^-17 (bf16) / 2^-21 (fp16), and the backward
-    rebuilds the LayerNorm input from the same three tensors."""
+    value plus a one-byte correction x = hi + (b - 128) ulp(hi) / 256: hi + lo carries the f32 result to 2^-16 (bf16) /
+    2^-19 (fp16), and the backward rebuilds the LayerNorm input from the same three tensors."""
     from oracle import bert as obert
     lib = L()
     code = 2 if fmt == torch.float16 else 1
@@ -230,15 +230,28 @@ def test_ln_residual_stream(dev, fmt, T, H):
     d, r = rnd((T, H), 1, 0.7), rnd((T, H), 2, 1.5) + 0.3
     g, b = 1.0 + rnd((H,), 3, 0.1), rnd((H,), 4, 0.1)
     dd, rh = t16(d), t16(r)
-    rl = (torch.from_numpy(r).to(dev) - rh.float()).to(fmt)             # the correction a producer would have written
+
+    def ulp256(hi):                                   # spacing of the 16-bit format at hi's exponent, / 256 (float64 [T,H])
+        a = np.abs(hi.double().cpu().numpy())
+        mant, emin = (10, -14) if fmt == torch.float16 else (7, -111)
+        ex = np.maximum(np.floor(np.log2(np.maximum(a, 2.0 ** -200))), emin)
+        return 2.0 ** (ex - mant - 8)
+
+    def decode(hi, lo8):
+        return hi.double().cpu().numpy() + (lo8.double().cpu().numpy() - 128.0) * ulp256(hi)
+    # the correction bytes a producer would have written for the f32 value r
+    rq = np.clip(np.rint((r.astype(np.float64) - rh.double().cpu().numpy()) / ulp256(rh) + 128.0), 1, 255)
+    rl = torch.from_numpy(rq.astype(np.uint8)).to(dev)
     dg, db = torch.from_numpy(g).to(dev), torch.from_numpy(b).to(dev)
-    y, ylo = torch.empty(T, H, device=dev, dtype=fmt), torch.empty(T, H, device=dev, dtype=fmt)
+    y, ylo = torch.empty(T, H, device=dev, dtype=fmt), torch.empty(T, H, device=dev, dtype=torch.uint8)
     lib.call("simx_ln_fwd_res", lib.stream_ptr(), code, T, H, lib.ptr(dd), lib.ptr(rh), lib.ptr(rl), lib.ptr(dg), lib.ptr(db), 1e-12,
              lib.ptr(y), lib.ptr(ylo))
-    z = dd.double().cpu().numpy() + rh.double().cpu().numpy() + rl.double().cpu().numpy()
+    z = dd.double().cpu().numpy() + decode(rh, rl)
+    assert np.abs(decode(rh, rl) - r).max() <= (2.0 ** -18 if fmt == torch.float16 else 2.0 ** -15) * np.abs(r).max()
     yr, cache = obert._ln_fwd(z, g.astype(np.float64), b.astype(np.float64), 1e-12)
-    got = (y.double() + ylo.double()).cpu().numpy()
-    eps2 = 2.0 ** -20 if fmt == torch.float16 else 2.0 ** -15
+    got = decode(y, ylo)
+    assert int(ylo.min()) >= 1
+    eps2 = 2.0 ** -18 if fmt == torch.float16 else 2.0 ** -15
     assert np.abs(got - yr).max() <= eps2 * max(1.0, np.abs(yr).max()) + 1e-6, np.abs(got - yr).max()
     assert torch.equal(y, torch.from_numpy(yr).to(dev).to(fmt)) or (y.double().cpu().numpy() - yr).__abs__().max() <= 2.0 ** -7 * np.abs(yr).max()
     # without the corrections: plain 16-bit residual (res_lo = y_lo = NULL)

@@ -22,5 +22,9 @@ timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/
 # the GPU-active cycles of the same launches from a separate pass (per-kernel averages are combined in tools/traffic.py)
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA --output-format csv -d $O/pmc_mfma -o p -- $CMD > $O/pmc_mfma.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_active -o p -- $CMD > $O/pmc_active.log 2>&1
+# the fp32 engine (the arithmetic every shipped recipe selects) as a first-class measurement: its own un-profiled line
+# (10 timed steps) and a kernel-trace summary of the same command
+timeout 600 python $R/bench.py --dtype fp32 --side --steps 10 --warmup 2 > $O/fp32_bench.json 2> $O/fp32_bench.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fp32_stats -o s -- python $R/bench.py --dtype fp32 --side --steps 3 --warmup 1 > $O/fp32_stats.log 2>&1
 cd $R && python tools/traffic.py $tag
 ls -la $O

@@ -39,6 +39,10 @@ for f in glob.glob(src + "/stats/**/*kernel_stats.csv", recursive=True):
     shutil.copy(f, "profiles/%s_kernel_stats.csv" % tag)
 if os.path.exists(src + "/bench.json"):
     shutil.copy(src + "/bench.json", "profiles/%s_bench.json" % tag)
+for f in glob.glob(src + "/fp32_stats/**/*kernel_stats.csv", recursive=True):
+    shutil.copy(f, "profiles/%s_fp32_kernel_stats.csv" % tag)
+if os.path.exists(src + "/fp32_bench.json"):
+    shutil.copy(src + "/fp32_bench.json", "profiles/%s_fp32_bench.json" % tag)
 
 # MFMA utilisation from counters: SQ_VALU_MFMA_BUSY_CYCLES (busy cycles of the matrix pipes summed over the chip's 1024
 # SIMDs; 16 per v_mfma_f32_16x16x32_bf16, cross-checked against SQ_INSTS_MFMA) over the cycles the launch had available:

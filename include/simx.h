@@ -298,7 +298,12 @@ int simx_rows_copy(simx_stream_t stream, int src_dtype, int dst_dtype, int n, in
 /* same, values multiplied by S = gs[0] on the way (gs == NULL: plain copy) */
 int simx_rows_copy_gs(simx_stream_t stream, int src_dtype, int dst_dtype, int n, int H, const int32_t* src_idx,
                       const int32_t* dst_idx, const void* src, void* dst, const float* gs);
-/* z[s] = dropout(y[s]) + res[res_idx ? res_idx[s] : s] on n gathered rows; the mask of row s is the one of row
+/* Rows of a residual-stream tensor (16-bit values hi + correction bytes lo, see simx_ln_fwd_res; lo may be NULL): gather rows
+ * src_idx[s] (NULL: s) into a compact pair hi_out / lo_out and / or decode them to f32_out = hi + correction (each output may
+ * be NULL).  The [CLS]-only last layer of a stream_lo tower uses it for the residual rows and for the f32 embeddings. */
+int simx_stream_rows(simx_stream_t stream, int dtype, int n, int H, const int32_t* src_idx, const void* hi, const void* lo,
+                     void* hi_out, void* lo_out, float* f32_out);
+/* z[s] = dropout(y[s]) + res[res_idx ? res_idx[s] : s] on n gathered rows (res == NULL: dropout only); the mask of row s is the one of row
  * key_idx[s] of the full tensor (BertSelfOutput / BertOutput before the LayerNorm, LEAD/modeling_bert.py:384-388,
  * 462-466, restricted to the rows the path reads). */
 int simx_drop_residual_rows(simx_stream_t stream, int dtype, int n, int H, const void* y, const void* res,

@@ -119,6 +119,7 @@ SIGNATURES = {
     "simx_ln_fwd_res": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p]),
     "simx_ln_bwd_res": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _dp, _p, _p]),
     "simx_embed_ln_fwd_lo": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _dp]),
+    "simx_stream_rows": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
     "simx_scaler_init": (_i, [_p, _p, _f, _f, _f]),
     "simx_scaler_update": (_i, [_p, _p, _p]),
     "simx_adamw_step_sc": (_i, [_p, _p, _p, _p, _p, _z, _f, _f, _f, _f, _f, _i, _p, _f, _f, _i, _p]),

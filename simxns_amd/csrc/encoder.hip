@@ -148,7 +148,9 @@ extern "C" size_t simx_bert_act_bytes(const simx_bert_cfg* c, int T, int nseq, i
   const size_t Tp = (size_t)rows_cap(T);
   const size_t x0 = xs_bytes(c, Tp);
   const size_t n = nseq > 0 ? (size_t)nseq : Tp;
-  return x0 + act_slots_bytes(c, Tp, save_for_bwd) + 3 * al(n * c->hidden * esz(c->dtype));
+  // (+ the [CLS]-only last layer's compact tensors: q, attention context, a temporary, and -- stream_lo -- the gathered
+  // residual rows with their correction bytes)
+  return x0 + act_slots_bytes(c, Tp, save_for_bwd) + 5 * al(n * c->hidden * esz(c->dtype));
 }
 static char* act_extra(const simx_bert_cfg* c, void* act, size_t Tp, int save) {
   return (char*)act + xs_bytes(c, Tp) + act_slots_bytes(c, Tp, save);
@@ -305,6 +307,23 @@ static int layer_fwd(hipStream_t stream, const simx_bert_cfg* c, const float* pa
     RUN(simx_mha_cls_fwd_hm(stream, dt, nseq, c->heads, d, cu, max_len, T, qc, a.qkv, ctxc, &d3, hm));
     RUN(simx_gemm_nt(stream, gdt, nseq, H, H, ctxc, H, w.wo, H, ytmp, H, off(l, SIMX_P_BO), nullptr, 0, SIMX_EPI_NONE, nullptr, 0,
                      nullptr, 0));
+    if (stream_lo(c)) {
+      // residual stream with corrections: the [CLS] rows of the layer input (16-bit values + correction bytes) are gathered
+      // behind the compact q / context / temporary tensors (kept for backward), the LayerNorm kernels add them in f32, and the embeddings
+      // leave as f32(hi + correction) -- never rounded to 16 bits
+      char* xg = ytmp + al((size_t)nseq * H * e);
+      char* xgl = xg + al((size_t)nseq * H * e);
+      RUN(simx_stream_rows(stream, dt, nseq, H, cu, x, xl, xg, xgl, nullptr));
+      RUN(simx_drop_residual_rows(stream, dt, nseq, H, ytmp, nullptr, nullptr, cu, &d1, a.z1));
+      RUN(simx_ln_fwd_res(stream, dt, nseq, H, a.z1, xg, xgl, off(l, SIMX_P_LN1_G), off(l, SIMX_P_LN1_B), c->eps, a.x1, a.x1l));
+      RUN(simx_gemm_nt(stream, gdt, nseq, F, H, a.x1, H, w.w1, H, a.u, F, off(l, SIMX_P_B1), nullptr, 0, SIMX_EPI_GELU, nullptr, 0, a.h, F));
+      RUN(simx_gemm_nt(stream, gdt, nseq, H, F, a.h, F, w.w2, F, ytmp, H, off(l, SIMX_P_B2), nullptr, 0, SIMX_EPI_NONE, nullptr, 0,
+                       nullptr, 0));
+      RUN(simx_drop_residual_rows(stream, dt, nseq, H, ytmp, nullptr, nullptr, cu, &d2, a.z2));
+      RUN(simx_ln_fwd_res(stream, dt, nseq, H, a.z2, a.x1, a.x1l, off(l, SIMX_P_LN2_G), off(l, SIMX_P_LN2_B), c->eps, a.xout, a.xoutl));
+      if (cls_out) RUN(simx_stream_rows(stream, dt, nseq, H, nullptr, a.xout, a.xoutl, nullptr, nullptr, cls_out));
+      return SIMX_OK;
+    }
     RUN(simx_drop_residual_rows(stream, dt, nseq, H, ytmp, x, cu, cu, &d1, a.z1));
     RUN(simx_ln_fwd(stream, dt, nseq, H, a.z1, off(l, SIMX_P_LN1_G), off(l, SIMX_P_LN1_B), c->eps, a.x1));
     RUN(simx_gemm_nt(stream, gdt, nseq, F, H, a.x1, H, w.w1, H, a.u, F, off(l, SIMX_P_B1), nullptr, 0, SIMX_EPI_GELU, nullptr, 0, a.h, F));
@@ -447,14 +466,17 @@ extern "C" int simx_bert_bwd_range(simx_stream_t stream, const simx_bert_cfg* c,
     const char* qc = act_extra(c, act, Tp, 1);                                     // saved by the forward
     const char* ctxc = qc + al((size_t)nseq * H * e);
     RUN(simx_rows_copy_gs(stream, SIMX_F32, dt, nseq, H, nullptr, nullptr, dcls, bufB, gs));
-    RUN(simx_ln_bwd_gs(stream, dt, nseq, H, a.z2, off(l, SIMX_P_LN2_G), c->eps, bufB, bufA, hd ? bufC : nullptr,
-                          goff(l, SIMX_P_LN2_G), goff(l, SIMX_P_LN2_B), goff(l, SIMX_P_B2), &d2, cu, gs));
+    const bool slc = stream_lo(c);                           // (the compact rows kept by the forward: see layer_fwd)
+    const char* xg = ctxc + 2 * al((size_t)nseq * H * e);
+    const char* xgl = xg + al((size_t)nseq * H * e);
+    RUN(simx_ln_bwd_res(stream, dt, nseq, H, a.z2, slc ? a.x1 : nullptr, slc ? a.x1l : nullptr, off(l, SIMX_P_LN2_G), c->eps, bufB, bufA,
+                        hd ? bufC : nullptr, goff(l, SIMX_P_LN2_G), goff(l, SIMX_P_LN2_B), goff(l, SIMX_P_B2), &d2, cu, gs));
     RUN(simx_gemm_nt(stream, gdb, nseq, F, H, dzm, H, w.w2T, H, du, F, nullptr, nullptr, 0, SIMX_EPI_DGELU, a.u, F, nullptr, 0));
     RUN(simx_gemm_tn_gs(stream, gdb, H, F, nseq, dzm, H, a.h, F, goff(l, SIMX_P_W2), F, 1, tnws, tnws_bytes, nullptr, 0, gs));
     RUN(simx_gemm_nt(stream, gdb, nseq, H, F, du, F, w.w1T, F, bufB, H, nullptr, bufA, H, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
     RUN(simx_gemm_tn_gs(stream, gdb, F, H, nseq, du, F, a.x1, H, goff(l, SIMX_P_W1), H, 1, tnws, tnws_bytes, goff(l, SIMX_P_B1), 0, gs));
-    RUN(simx_ln_bwd_gs(stream, dt, nseq, H, a.z1, off(l, SIMX_P_LN1_G), c->eps, bufB, bufA, hd ? bufC : nullptr,
-                          goff(l, SIMX_P_LN1_G), goff(l, SIMX_P_LN1_B), goff(l, SIMX_P_BO), &d1, cu, gs));
+    RUN(simx_ln_bwd_res(stream, dt, nseq, H, a.z1, slc ? xg : nullptr, slc ? xgl : nullptr, off(l, SIMX_P_LN1_G), c->eps, bufB, bufA,
+                        hd ? bufC : nullptr, goff(l, SIMX_P_LN1_G), goff(l, SIMX_P_LN1_B), goff(l, SIMX_P_BO), &d1, cu, gs));
     // e1 = dctx (gradient of the attention context, [CLS] rows), bufA[0:nseq] = gradient of the residual branch
     RUN(simx_gemm_nt(stream, gdb, nseq, H, H, dzm, H, w.woT, H, e1, H, nullptr, nullptr, 0, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
     RUN(simx_gemm_tn_gs(stream, gdb, H, H, nseq, dzm, H, ctxc, H, goff(l, SIMX_P_WO), H, 1, tnws, tnws_bytes, nullptr, 0, gs));

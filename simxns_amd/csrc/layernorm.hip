@@ -541,9 +541,9 @@ __global__ __launch_bounds__(256) void drop_residual_rows_kernel(int n, int H, c
   const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= (long)n * H) return;
   const int s = (int)(i / H), c = (int)(i % H);
-  float v[4], r[4];
+  float v[4], r[4] = {0.f, 0.f, 0.f, 0.f};
   ld4(y + i, v);
-  ld4(res + (long)(res_idx ? res_idx[s] : s) * H + c, r);
+  if (res) ld4(res + (long)(res_idx ? res_idx[s] : s) * H + c, r);       // (NULL: dropout only -- the stream_lo path adds the residual in LayerNorm)
   if (drop.thr) {
     float m4[4];
     drop_mult4(drop, (uint32_t)(key_idx ? key_idx[s] : s), (uint32_t)c, m4);
@@ -553,6 +553,33 @@ __global__ __launch_bounds__(256) void drop_residual_rows_kernel(int n, int H, c
 #pragma unroll
   for (int e = 0; e < 4; ++e) v[e] += r[e];
   st4(z + i, v);
+}
+
+// rows of a residual-stream tensor (16-bit values + correction bytes, simx.h stream_lo): gather rows src_idx[s] into a compact
+// pair (hi_out / lo_out, either may be NULL), and / or decode them to f32 (f32_out)
+template <typename T>
+__global__ __launch_bounds__(256) void stream_rows_kernel(int n, int H, const int* __restrict__ src_idx, const T* __restrict__ hi,
+                                                          const uint8_t* __restrict__ lo, T* __restrict__ hi_out,
+                                                          uint8_t* __restrict__ lo_out, float* __restrict__ f32_out) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= (long)n * H) return;
+  const int s = (int)(i / H), c = (int)(i % H);
+  const long src = (long)(src_idx ? src_idx[s] : s) * H + c;
+  Raw4<T> h;
+  h.load(hi + src);
+  const uint32_t q = lo ? *reinterpret_cast<const uint32_t*>(lo + src) : 0x80808080u;
+  if (hi_out) {
+    float v[4];
+    h.unpack(v);
+    st4(hi_out + i, v);                            // (exact: a 16-bit value through f32 and back)
+  }
+  if (lo_out) *reinterpret_cast<uint32_t*>(lo_out + i) = q;
+  if (f32_out) {
+    float v[4], a[4];
+    h.unpack(v);
+    lo8_decode4<T>(h.w0(), h.w1(), q, a);
+    *reinterpret_cast<float4*>(f32_out + i) = make_float4(v[0] + a[0], v[1] + a[1], v[2] + a[2], v[3] + a[3]);
+  }
 }
 
 // masked mean over each sequence's real tokens (packed layout: rows cu[s] .. cu[s+1]) and its adjoint
@@ -797,7 +824,7 @@ extern "C" int simx_rows_copy_gs(simx_stream_t stream, int src_dtype, int dst_dt
 
 extern "C" int simx_drop_residual_rows(simx_stream_t stream, int dtype, int n, int H, const void* y, const void* res,
                                        const int32_t* res_idx, const int32_t* key_idx, const simx_dropout* dropd, void* z) {
-  SIMX_REQUIRE(n > 0 && H > 0 && H % 4 == 0 && y && res && z, SIMX_ERR_BAD_SHAPE, "drop_residual_rows: bad arguments");
+  SIMX_REQUIRE(n > 0 && H > 0 && H % 4 == 0 && y && z, SIMX_ERR_BAD_SHAPE, "drop_residual_rows: bad arguments");
   SIMX_REQUIRE(simx_dtype_ok(dtype), SIMX_ERR_BAD_DTYPE, "drop_residual_rows: dtype %d", dtype);
   const DropCtx drop = make_drop(dropd);
   hipStream_t s = (hipStream_t)stream;
@@ -805,6 +832,18 @@ extern "C" int simx_drop_residual_rows(simx_stream_t stream, int dtype, int n, i
   SIMX_DISPATCH3(dtype, TT, hipLaunchKernelGGL((drop_residual_rows_kernel<TT>), dim3(blocks), dim3(256), 0, s, n, H, (const TT*)y,
                                                (const TT*)res, res_idx, key_idx, drop, (TT*)z));
   SIMX_CHECK_LAUNCH("drop_residual_rows");
+  return SIMX_OK;
+}
+
+extern "C" int simx_stream_rows(simx_stream_t stream, int dtype, int n, int H, const int32_t* src_idx, const void* hi, const void* lo,
+                                void* hi_out, void* lo_out, float* f32_out) {
+  SIMX_REQUIRE(n > 0 && H > 0 && H % 4 == 0 && hi && (hi_out || lo_out || f32_out), SIMX_ERR_BAD_SHAPE, "stream_rows: bad arguments");
+  SIMX_REQUIRE(simx_is16(dtype), SIMX_ERR_BAD_DTYPE, "stream_rows: 16-bit dtypes only (dtype %d)", dtype);
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = (int)(((long)n * H / 4 + 255) / 256);
+  SIMX_DISPATCH16(dtype, TT, hipLaunchKernelGGL((stream_rows_kernel<TT>), dim3(blocks), dim3(256), 0, s, n, H, src_idx, (const TT*)hi,
+                                                (const uint8_t*)lo, (TT*)hi_out, (uint8_t*)lo_out, f32_out));
+  SIMX_CHECK_LAUNCH("stream_rows");
   return SIMX_OK;
 }
 

@@ -33,6 +33,35 @@ int main(int argc, char** argv) {
   if (getenv("KB_F16")) g_dt = SIMX_F16;
   const int T = argc > 1 ? atoi(argv[1]) : 262144;
   const int H = 768, F = 3072, iters = 10;
+  if (getenv("KB_X3")) {      // the fp32 engine's dense GEMMs: f32 tensors, hi+lo split products (SIMX_F32_SPLIT_H / _B)
+    auto falloc = [&](size_t n, float scale) { float* p; CK(hipMalloc(&p, n * 4)); std::vector<float> h(1 << 20);
+      for (size_t i = 0; i < h.size(); ++i) h[i] = (((int)((i * 2654435761u) >> 20 & 1023)) - 512) / 1024.0f * scale;
+      for (size_t off = 0; off < n; off += h.size()) CK(hipMemcpy(p + off, h.data(), std::min(h.size(), n - off) * 4, hipMemcpyHostToDevice)); return p; };
+    float* A = falloc((size_t)T * F, 1.f); float* A2 = falloc((size_t)T * F, 1.f); float* C = falloc((size_t)T * F, 0.f); float* C2 = falloc((size_t)T * F, 0.f);
+    float* W = falloc((size_t)F * H, 0.05f); float* bias = falloc(F, 0.f); float* G = falloc((size_t)F * H, 0.f);
+    size_t wsb = simx_gemm_tn_workspace_bytes(F, H, T); void* ws; CK(hipMalloc(&ws, wsb + 256));
+    struct S { const char* name; int N, K, epi, res, code; } nt[] = {
+      {"qkv   fwd  N=2304 K=768 bias", 3 * H, H, 0, 0, 3}, {"oproj fwd  N=768  K=768 bias+res", H, H, 0, 1, 3},
+      {"ffn1  fwd  N=3072 K=768 gelu", F, H, 1, 0, 3},     {"ffn2  fwd  N=768  K=3072 bias+res", H, F, 0, 1, 3},
+      {"ffn2 dgrad N=3072 K=768 dgelu", F, H, 2, 0, 4},    {"ffn1 dgrad N=768  K=3072 +res", H, F, 0, 1, 4},
+      {"qkv  dgrad N=768  K=2304 +res", H, 3 * H, 0, 1, 4}};
+    double tot = 0, totf = 0;
+    for (auto& s : nt) {
+      double ms = timeit([&] { SX(simx_gemm_nt(0, s.code, T, s.N, s.K, A, s.K, W, s.K, C, s.N, s.epi == 2 ? nullptr : bias, s.res ? A2 : nullptr, s.N, s.epi, s.epi == 2 ? A2 : nullptr, s.N, s.epi == 1 ? C2 : nullptr, s.N)); }, 5);
+      double fl = 2.0 * T * s.N * s.K; tot += ms; totf += fl;
+      printf("x3 gemm_nt %-36s %8.3f ms  %7.1f TF/s\n", s.name, ms, fl / ms / 1e9);
+    }
+    printf("x3 gemm_nt total %.2f ms  avg %.1f TF/s\n", tot, totf / tot / 1e9);
+    struct S2 { const char* name; int M, N; } tn[] = {{"wqkv [2304,768]", 3 * H, H}, {"wo [768,768]", H, H}, {"w1 [3072,768]", F, H}, {"w2 [768,3072]", H, F}};
+    tot = 0; totf = 0;
+    for (auto& s : tn) {
+      double ms = timeit([&] { SX(simx_gemm_tn(0, 4, s.M, s.N, T, A, s.M, A2, s.N, G, s.N, 1, ws, wsb)); }, 5);
+      double fl = 2.0 * T * s.M * s.N; tot += ms; totf += fl;
+      printf("x3 gemm_tn %-36s %8.3f ms  %7.1f TF/s\n", s.name, ms, fl / ms / 1e9);
+    }
+    printf("x3 gemm_tn total %.2f ms  avg %.1f TF/s\n", tot, totf / tot / 1e9);
+    return 0;
+  }
   const int pad = getenv("KB_LDA_PAD") ? atoi(getenv("KB_LDA_PAD")) : 0;   // experiment: leading-dimension padding of A
   void* A = dalloc((size_t)T * (F + pad) * 2, 1);      // activations (bf16), up to [T,F]
   void* A2 = dalloc((size_t)(T + 1024) * F * 2, 1);

@@ -527,10 +527,18 @@ int simx_adamw_step_sc(simx_stream_t stream, float* p, float* g, float* m, float
  * events and fills host arrays of length simx_prof_kernel_count(): launches, total milliseconds and
  * total "work" (flops for GEMM/attention classes, algorithmic bytes for the HBM-bound classes).
  * Class ids: 0 gemm_nt, 1 gemm_tn, 2 mha_fwd, 3 mha_bwd, 4 ln_fwd, 5 ln_bwd, 6 embed_fwd, 7 embed_bwd,
- * 8 colsum, 9 cast, 10 loss, 11 sampler, 12 adamw(+norm), 13 other. */
+ * 8 colsum, 9 cast, 10 loss, 11 sampler, 12 adamw(+norm), 13 other, 14 collate, 15 top-k, 16 gemm_nt: the persistent
+ * 256x256 kernel (apart from class 0 = the small-shape launches), 17 gemm_tn: the 256x256 wgrad kernel with its slab pass
+ * (apart from class 1 = the small-shape launches). */
 int simx_prof_begin(int max_launches);
 int simx_prof_end(int32_t* counts_host, double* total_ms_host, double* total_work_host);
 int simx_prof_kernel_count(void);
+
+/* 1 when the library runs with SIMX_DETERMINISTIC=1 (read once at first use): every cross-workgroup f32 reduction of the
+ * backward (LayerNorm / bias / embedding gradients, loss scalars) is then done in a fixed order instead of with atomics,
+ * so two runs of the same step on the same device give bit-identical gradients.  The reference offers the same through
+ * torch.use_deterministic_algorithms; its scripts only seed the RNGs (SimANS/co_training/co_training_marco_train.py:33-44). */
+int simx_deterministic(void);
 
 #ifdef __cplusplus
 }

@@ -122,13 +122,14 @@ SIGNATURES = {
     "simx_stream_rows": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
     "simx_scaler_init": (_i, [_p, _p, _f, _f, _f]),
     "simx_scaler_update": (_i, [_p, _p, _p]),
+    "simx_deterministic": (_i, []),
     "simx_adamw_step_sc": (_i, [_p, _p, _p, _p, _p, _z, _f, _f, _f, _f, _f, _i, _p, _f, _f, _i, _p]),
     "simx_prof_begin": (_i, [_i]),
     "simx_prof_end": (_i, [_p, _p, _p]),
     "simx_prof_kernel_count": (_i, []),
 }
 PROF_NAMES = ["gemm_nt", "gemm_tn", "mha_fwd", "mha_bwd", "ln_fwd", "ln_bwd", "embed_fwd", "embed_bwd", "colsum", "cast",
-              "loss", "sampler", "adamw", "other", "collate", "topk", "gemm_nt_p3"]
+              "loss", "sampler", "adamw", "other", "collate", "topk", "gemm_nt_p3", "gemm_tn2"]
 
 _lib = None
 

@@ -17,6 +17,11 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 // ---- error plumbing (api.cpp) ---------------------------------------------------------
 void simx_set_error(const char* fmt, ...);
+// SIMX_DETERMINISTIC=1 (det.hip): ordered reductions instead of f32 atomics
+bool simx_det();
+float* simx_det_ws(hipStream_t st, size_t bytes);                       // per-stream scratch, NULL (+ error text) on failure
+int simx_det_reduce(hipStream_t st, const float* part, long stride, int nparts, int n, float* o0, float* o1, float* o2, const float* gs);
+int simx_det_scatter_rows(hipStream_t st, int T, int H, const int* idx, const float* rows, float* table, int table_rows);
 #define SIMX_CHECK_LAUNCH(name)                                                        \
   do {                                                                                 \
     hipError_t e__ = hipGetLastError();                                                \

@@ -1132,7 +1132,8 @@ template <typename F>
 __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(
     int M, int N, int K, const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
     float* __restrict__ out, long slab_stride, int ldo, int tiles_n, int tiles_mn, int k_per_split, int accumulate,
-    float* __restrict__ dbias, int hm_a, const float* __restrict__ gs, int scale_out) {
+    float* __restrict__ dbias, int hm_a, const float* __restrict__ gs, int scale_out, int dbias_parts) {
+  // dbias_parts (deterministic mode): dbias is a [splits * tiles_n * 4][M] partial buffer, one row per contributor
   // gs = {S, 1/S} of the fp16 backward or NULL: the bias gradient always leaves x 1/S; the product only when `out` is the
   // gradient itself (scale_out; with split-K the slab reduction applies it)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1332,7 +1333,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(
       t += __shfl_xor(t, 16, 64);
       t += __shfl_xor(t, 32, 64);
       const int m = m0 + wr * 128 + i * 16 + fs;
-      if (fg == 0 && m < M) atomicAdd(dbias + m, t * inv_b);
+      if (fg == 0 && m < M) {
+        if (dbias_parts) dbias[(long)(split * bias_mod + bias_slot) * M + m] = t;
+        else atomicAdd(dbias + m, t * inv_b);
+      }
     }
   }
 }
@@ -1362,8 +1366,10 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(int Trows, int N, const T* __restrict__ x, int ldx,
-                                                     float* __restrict__ out, int rows_per_block, const float* __restrict__ gs) {
-  // block = 64 columns x 4 row-lanes; grid.x over column groups, grid.y over row chunks; atomics to out
+                                                     float* __restrict__ out, int rows_per_block, const float* __restrict__ gs,
+                                                     float* __restrict__ det_part) {
+  // block = 64 columns x 4 row-lanes; grid.x over column groups, grid.y over row chunks; atomics to out (det_part: one
+  // partial row per row chunk instead, added in chunk order by det_reduce_kernel)
   __shared__ float part[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
   const int r0 = blockIdx.y * rows_per_block, r1 = min(Trows, r0 + rows_per_block);
@@ -1372,7 +1378,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(int Trows, int N, const T* 
     for (int r = r0 + rl; r < r1; r += 4) s += Elem<T>::ld(x + (long)r * ldx + c);
   part[rl][threadIdx.x & 63] = s;
   __syncthreads();
-  if (rl == 0 && c < N) atomicAdd(out + c, (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]) * gs_inv(gs));
+  if (rl == 0 && c < N) {
+    const float t = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    if (det_part) det_part[(long)blockIdx.y * N + c] = t;
+    else atomicAdd(out + c, t * gs_inv(gs));
+  }
 }
 
 template <typename TO>
@@ -1777,18 +1787,28 @@ static int gemm_tn_impl(simx_stream_t stream, int dtype, int M, int N, int K, co
   if (tn_use_v2(M, N, K)) {
     SIMX_REQUIRE(gemm_device() != nullptr, SIMX_ERR_HIP, "gemm_tn: cannot query the current device");
     const int t_m = cdiv(M, 256), t_n = cdiv(N, 256), t_mn = t_m * t_n;
+    simx_prof_retag(SIMX_K_GEMM_TN2);              // the large-shape wgrad kernel (with its slab pass) apart from the small launches
+    float* dbias_out = dbias;
+    const int nbp = splits * t_n * 4;
+    if (dbias && simx_det()) {                    // ordered bias gradient: one partial row per contributing wave column
+      dbias = simx_det_ws(s, (size_t)nbp * M * sizeof(float));
+      if (!dbias) return SIMX_ERR_WORKSPACE;
+    }
+    const int dparts = dbias != dbias_out;
     if (splits == 1) {
       SIMX_DISPATCH16(dtype, FF, hipLaunchKernelGGL(gemm_tn2_kernel<FF>, dim3(t_mn), dim3(512), TN2_LDS, s, M, N, K, (const bf16_t*)A, lda,
-                                                    (const bf16_t*)B, ldb, C, 0L, ldc, t_n, t_mn, kps, accumulate, dbias, a_hm_rows, gs, 1));
+                                                    (const bf16_t*)B, ldb, C, 0L, ldc, t_n, t_mn, kps, accumulate, dbias, a_hm_rows, gs, 1, dparts));
       SIMX_CHECK_LAUNCH("gemm_tn2");
+      if (dparts) return simx_det_reduce(s, dbias, (long)M, nbp, M, dbias_out, nullptr, nullptr, gs);
       return SIMX_OK;
     }
     const size_t need2 = (size_t)splits * M * N * sizeof(float);
     SIMX_REQUIRE(ws && ws_bytes >= need2, SIMX_ERR_WORKSPACE, "gemm_tn: workspace %zu < %zu", ws_bytes, need2);
     SIMX_REQUIRE(aligned16(ws), SIMX_ERR_WORKSPACE, "gemm_tn: workspace not 16-B aligned");
     SIMX_DISPATCH16(dtype, FF, hipLaunchKernelGGL(gemm_tn2_kernel<FF>, dim3(t_mn * splits), dim3(512), TN2_LDS, s, M, N, K, (const bf16_t*)A, lda,
-                                                  (const bf16_t*)B, ldb, (float*)ws, (long)M * N, N, t_n, t_mn, kps, 0, dbias, a_hm_rows, gs, 0));
+                                                  (const bf16_t*)B, ldb, (float*)ws, (long)M * N, N, t_n, t_mn, kps, 0, dbias, a_hm_rows, gs, 0, dparts));
     SIMX_CHECK_LAUNCH("gemm_tn2");
+    if (dparts) { int rcd = simx_det_reduce(s, dbias, (long)M, nbp, M, dbias_out, nullptr, nullptr, gs); if (rcd) return rcd; }
     const long tot4 = (long)M * N / 4;
     int rb = (int)((tot4 + 255) / 256);
     if (rb > 2048) rb = 2048;
@@ -1840,8 +1860,14 @@ extern "C" int simx_colsum_gs(simx_stream_t stream, int dtype, int T, int N, con
   if (chunks > 512) chunks = 512;
   const int rpb = cdiv(T, chunks);
   dim3 grid(cdiv(N, 64), cdiv(T, rpb));
-  SIMX_DISPATCH3(dtype, TT, hipLaunchKernelGGL((colsum_kernel<TT>), grid, dim3(256), 0, s, T, N, (const TT*)x, ldx, out, rpb, gs));
+  float* det = nullptr;
+  if (simx_det()) {
+    det = simx_det_ws(s, (size_t)grid.y * N * sizeof(float));
+    if (!det) return SIMX_ERR_WORKSPACE;
+  }
+  SIMX_DISPATCH3(dtype, TT, hipLaunchKernelGGL((colsum_kernel<TT>), grid, dim3(256), 0, s, T, N, (const TT*)x, ldx, out, rpb, gs, det));
   SIMX_CHECK_LAUNCH("colsum");
+  if (det) return simx_det_reduce(s, det, (long)N, (int)grid.y, N, out, nullptr, nullptr, gs);
   return SIMX_OK;
 }
 

@@ -17,6 +17,8 @@
 // NT form  C[M,N] = A[M,K] . B[N,K]^T  (both K-contiguous; forward and dgrad), 128x128x32 tile, 4 waves of 64x64:
 //   global f32 (16-B loads, next stage in flight during the MFMAs) -> registers -> split -> LDS planes Ahi|Alo|Bhi|Blo, each
 //   [128 rows][32 k] 16-bit = 64 B per row, so a wave's fragment read (16 rows x 64 B) is one contiguous KB.
+//   (Holding TWO stages in registers and issuing the MFMAs term-major measured SLOWER: NT 227 -> 207, TN 299 -> 243 TFLOP/s
+//   on the bench shapes, kbench A/B/A/B -- 32 more VGPRs of f32 staging cost an occupancy step.)
 // TN form  C[M,N] (+)= A[K,M]^T . B[K,N]  (wgrad: rows = tokens, M / N contiguous), same tile, planes [32 k][128 cols] with
 //   the 32-B chunk swizzle of gemm_tn_h16_kernel, fragments by ds_read_b64_tr_b16 (the k-slot permutation it implies is
 //   the same for both operands); split over K into f32 slabs reduced in slice order (slab_reduce_kernel): deterministic.
@@ -82,10 +84,8 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_nt_kernel(
   gb = gb < N ? gb : N - 1;
   const float* pa = A + (long)ga * lda + shalf;
   const float* pb = B + (long)gb * ldb + shalf;
-  // Operand stages are fetched TWO stages ahead into two register sets (the loads of stage st+2 are issued before stage st's
-  // MFMAs and converted after stage st+1's): one stage of MFMAs (~0.4 us per wave) does not cover a fabric / HBM miss
-  float4 rA[2][4], rB[2][4];
-  auto gload = [&](int k0, float4 (&ra)[4], float4 (&rb)[4]) {
+  float4 ra[4], rb[4];
+  auto gload = [&](int k0) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int k = k0 + shalf + e * 4;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_nt_kernel(
       }
     }
   };
-  auto sstore = [&](char* stage, const float4 (&ra)[4], const float4 (&rb)[4]) {
+  auto sstore = [&](char* stage) {
     uint32_t h[8], l[8];
 #pragma unroll
     for (int e = 0; e < 4; ++e) { split2<F>(ra[e].x, ra[e].y, h[2 * e], l[2 * e]); split2<F>(ra[e].z, ra[e].w, h[2 * e + 1], l[2 * e + 1]); }
@@ -117,14 +117,12 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_nt_kernel(
   };
 
   const int nst = (K + X3_BK - 1) / X3_BK;
-  gload(0, rA[0], rB[0]);
-  sstore(smem, rA[0], rB[0]);
-  if (nst > 1) gload(X3_BK, rA[1], rB[1]);
+  gload(0);
+  sstore(smem);
   __syncthreads();
   for (int st = 0; st < nst; ++st) {
     const char* cur = smem + (st & 1) * X3_STAGE;
-    if (st + 2 < nst) { if (st & 1) gload((st + 2) * X3_BK, rA[1], rB[1]); else gload((st + 2) * X3_BK, rA[0], rB[0]); }
-    // (set st&1 held stage st, which is in LDS already; stage st+1 sits in the other set until after this stage's MFMAs)
+    if (st + 1 < nst) gload((st + 1) * X3_BK);
     // fragments: row (tile*16 + fr), k chunk fg (8 consecutive k = 16 B) of each plane
     const char* fa = cur + (wr * 64 + fr) * 64 + fg * 16;
     const char* fb = cur + 2 * X3_PLANE + (wc * 64 + fr) * 64 + fg * 16;
@@ -136,21 +134,16 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_nt_kernel(
       bh[i] = *reinterpret_cast<const bf16x8*>(fb + i * 1024);
       bl[i] = *reinterpret_cast<const bf16x8*>(fb + i * 1024 + X3_PLANE);
     }
-    // (operands swapped so that a lane ends up with 4 consecutive output columns of one row; corrections first; term-major so
-    // that the three MFMAs into one accumulator are 16 issues apart, never back to back)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = H16<F>::mfma(bl[j], ah[i], acc[i][j]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = H16<F>::mfma(bh[j], al[i], acc[i][j]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = H16<F>::mfma(bh[j], ah[i], acc[i][j]);
-    if (st + 1 < nst) { if (st & 1) sstore(smem + ((st + 1) & 1) * X3_STAGE, rA[0], rB[0]); else sstore(smem + ((st + 1) & 1) * X3_STAGE, rA[1], rB[1]); }
+      for (int j = 0; j < 4; ++j) {
+        // (operands swapped so that a lane ends up with 4 consecutive output columns of one row; corrections first)
+        acc[i][j] = H16<F>::mfma(bl[j], ah[i], acc[i][j]);
+        acc[i][j] = H16<F>::mfma(bh[j], al[i], acc[i][j]);
+        acc[i][j] = H16<F>::mfma(bh[j], ah[i], acc[i][j]);
+      }
+    if (st + 1 < nst) sstore(smem + ((st + 1) & 1) * X3_STAGE);
     __syncthreads();
   }
 
@@ -213,8 +206,8 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_tn_kernel(
 
   // staging: thread t owns k rows (t >> 5) + 8 e, e < 4, columns (t & 31) * 4 .. +3 of both operand tiles
   const int skr = tid >> 5, sc4 = (tid & 31) * 4;
-  float4 rA[2][4], rB[2][4];                        // two stages ahead, as the NT kernel
-  auto gload = [&](int k0, float4 (&ra)[4], float4 (&rb)[4]) {
+  float4 ra[4], rb[4];
+  auto gload = [&](int k0) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int k = k0 + skr + 8 * e;
@@ -223,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_tn_kernel(
       rb[e] = (kin && n0 + sc4 + 3 < N) ? *reinterpret_cast<const float4*>(B + (long)k * ldb + n0 + sc4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  auto sstore = [&](char* stage, const float4 (&ra)[4], const float4 (&rb)[4]) {
+  auto sstore = [&](char* stage) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int kr = skr + 8 * e;
@@ -250,13 +243,12 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_tn_kernel(
   };
 
   const int nst = (ke - kb + X3_BK - 1) / X3_BK;
-  gload(kb, rA[0], rB[0]);
-  sstore(smem, rA[0], rB[0]);
-  if (nst > 1) gload(kb + X3_BK, rA[1], rB[1]);
+  gload(kb);
+  sstore(smem);
   __syncthreads();
   for (int st = 0; st < nst; ++st) {
     const uint32_t cur = lds0 + (uint32_t)((st & 1) * X3_STAGE);
-    if (st + 2 < nst) { if (st & 1) gload(kb + (st + 2) * X3_BK, rA[1], rB[1]); else gload(kb + (st + 2) * X3_BK, rA[0], rB[0]); }
+    if (st + 1 < nst) gload(kb + (st + 1) * X3_BK);
     bf16x8 ah[4], al[4], bh[4], bl[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -268,16 +260,12 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_tn_kernel(
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = H16<F>::mfma(bl[j], ah[i], acc[i][j]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = H16<F>::mfma(bh[j], al[i], acc[i][j]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = H16<F>::mfma(bh[j], ah[i], acc[i][j]);
-    if (st + 1 < nst) { if (st & 1) sstore(smem + ((st + 1) & 1) * X3_STAGE, rA[0], rB[0]); else sstore(smem + ((st + 1) & 1) * X3_STAGE, rA[1], rB[1]); }
+      for (int j = 0; j < 4; ++j) {
+        acc[i][j] = H16<F>::mfma(bl[j], ah[i], acc[i][j]);
+        acc[i][j] = H16<F>::mfma(bh[j], al[i], acc[i][j]);
+        acc[i][j] = H16<F>::mfma(bh[j], ah[i], acc[i][j]);
+      }
+    if (st + 1 < nst) sstore(smem + ((st + 1) & 1) * X3_STAGE);
     __syncthreads();
   }
   float* o = out + (long)split * slab_stride;

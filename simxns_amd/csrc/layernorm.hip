@@ -242,8 +242,9 @@ __device__ __forceinline__ void ln_row_bwd(int H, int lane, float (&x)[VPL][4], 
 
 template <int VPL>
 __device__ __forceinline__ void flush_cols(int H, int lane, int w, float (&p)[VPL][4], float* __restrict__ out,
-                                           float* sred /* [4][H] */, float mul = 1.0f) {
-  // sum the 4 waves' partials through LDS, wave 0 issues the atomics
+                                           float* sred /* [4][H] */, float mul = 1.0f, float* det = nullptr) {
+  // sum the 4 waves' partials through LDS, wave 0 issues the atomics (det: this workgroup's partial row of the
+  // deterministic mode -- stored unscaled, det_reduce_kernel adds the rows in workgroup order)
 #pragma unroll
   for (int v = 0; v < VPL; ++v) {
     const int c = (v * 64 + lane) * 4;
@@ -255,7 +256,10 @@ __device__ __forceinline__ void flush_cols(int H, int lane, int w, float (&p)[VP
   // all four waves issue the atomics, each instruction on 64 CONSECUTIVE columns (4 cache lines; the lane-owns-4-columns
   // layout would touch 16) -- every block of the grid adds into the same H addresses, so the L2 transaction count of
   // this tail is what the kernel's last microseconds are made of
-  for (int c = threadIdx.x; c < H; c += 256) atomicAdd(out + c, (sred[c] + sred[H + c] + sred[2 * H + c] + sred[3 * H + c]) * mul);
+  if (det)
+    for (int c = threadIdx.x; c < H; c += 256) det[c] = (sred[c] + sred[H + c]) + (sred[2 * H + c] + sred[3 * H + c]);
+  else
+    for (int c = threadIdx.x; c < H; c += 256) atomicAdd(out + c, (sred[c] + sred[H + c] + sred[2 * H + c] + sred[3 * H + c]) * mul);
   __syncthreads();
 }
 
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int H, int rows_p
                                                      float* __restrict__ dbeta, float* __restrict__ dbias,
                                                      T* __restrict__ dzm, DropCtx drop, const int* __restrict__ row_keys,
                                                      const float* __restrict__ gs, const T* __restrict__ rh,
-                                                     const uint8_t* __restrict__ rl) {
+                                                     const uint8_t* __restrict__ rl, float* __restrict__ det_part) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sred = reinterpret_cast<float*>(smem);          // [4][H] flush scratch
   float* sgam = sred + 4 * H;                            // [H]
@@ -347,9 +351,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int H, int rows_p
     }
   }
   const float inv = gs_inv(gs);                          // dy / dz travel multiplied by the loss scale; parameter gradients do not
-  flush_cols(H, lane, w, pg, dgamma, sred, inv);
-  flush_cols(H, lane, w, pb, dbeta, sred, inv);
-  if (dbias) flush_cols(H, lane, w, pz, dbias, sred, inv);
+  float* dp = det_part ? det_part + (long)blockIdx.x * 3 * H : nullptr;
+  flush_cols(H, lane, w, pg, dgamma, sred, inv, dp);
+  flush_cols(H, lane, w, pb, dbeta, sred, inv, dp ? dp + H : nullptr);
+  if (dbias) flush_cols(H, lane, w, pz, dbias, sred, inv, dp ? dp + 2 * H : nullptr);
 }
 
 template <typename T, int VPL>
@@ -360,7 +365,8 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(int rows, int H, int 
                                                            const T* __restrict__ dyp, float* __restrict__ dword,
                                                            float* __restrict__ dpos, float* __restrict__ dtype0,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, DropCtx drop,
-                                                           const float* __restrict__ gs) {
+                                                           const float* __restrict__ gs, float* __restrict__ det_part,
+                                                           float* __restrict__ det_rows) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sred = reinterpret_cast<float*>(smem);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -398,18 +404,24 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(int rows, int H, int 
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
       const int c = (v * 64 + lane) * 4;
-      if (c < H)
+      if (c < H) {
+        if (det_rows)                              // deterministic mode: the table scatters are done by det_scatter_rows_kernel
+          *reinterpret_cast<float4*>(det_rows + (long)row * H + c) = make_float4(dz[v][0] * inv, dz[v][1] * inv, dz[v][2] * inv, dz[v][3] * inv);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          atomicAdd(dword + wid * H + c + e, dz[v][e] * inv);
-          atomicAdd(dpos + pid * H + c + e, dz[v][e] * inv);
+          if (!det_rows) {
+            atomicAdd(dword + wid * H + c + e, dz[v][e] * inv);
+            atomicAdd(dpos + pid * H + c + e, dz[v][e] * inv);
+          }
           pz[v][e] += dz[v][e];
         }
+      }
     }
   }
-  flush_cols(H, lane, w, pg, dgamma, sred, inv);
-  flush_cols(H, lane, w, pb, dbeta, sred, inv);
-  flush_cols(H, lane, w, pz, dtype0, sred, inv);
+  float* dp = det_part ? det_part + (long)blockIdx.x * 3 * H : nullptr;
+  flush_cols(H, lane, w, pg, dgamma, sred, inv, dp);
+  flush_cols(H, lane, w, pb, dbeta, sred, inv, dp ? dp + H : nullptr);
+  flush_cols(H, lane, w, pz, dtype0, sred, inv, dp ? dp + 2 * H : nullptr);
 }
 
 // Position-major embedding backward: wave w of block (pg, sc) owns ONE in-sequence position p = 4 pg + w and walks the
@@ -425,7 +437,8 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_seq_kernel(int nseq, int seq
                                                                float eps, const T* __restrict__ dyp, float* __restrict__ dword,
                                                                float* __restrict__ dpos, float* __restrict__ dtype0,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, DropCtx drop,
-                                                               const float* __restrict__ gs) {
+                                                               const float* __restrict__ gs, float* __restrict__ det_part,
+                                                               float* __restrict__ det_rows) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sred = reinterpret_cast<float*>(smem);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -479,15 +492,15 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_seq_kernel(int nseq, int seq
       }
     }
     __builtin_amdgcn_wave_barrier();
-    float* wrow = dword + wid * H;
+    float* wrow = det_rows ? det_rows + (long)row * H : dword + wid * H;   // deterministic mode: rows out, scattered in token order later
 #pragma unroll
     for (int k = 0; k < VPL * 4; ++k) {
       const int c = k * 64 + lane;
-      if (c < H) atomicAdd(wrow + c, patch[c]);
+      if (c < H) { if (det_rows) wrow[c] = patch[c]; else atomicAdd(wrow + c, patch[c]); }
     }
     __builtin_amdgcn_wave_barrier();
   }
-  if (pid >= 0) {                                    // this wave's position row: its sum over the chunk's sequences
+  if (pid >= 0 && !det_rows) {                       // this wave's position row: its sum over the chunk's sequences
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
       const int c = (v * 64 + lane) * 4;
@@ -496,9 +509,10 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_seq_kernel(int nseq, int seq
         for (int e = 0; e < 4; ++e) atomicAdd(dpos + pid * H + c + e, pz[v][e] * inv);
     }
   }
-  flush_cols(H, lane, w, pg, dgamma, sred, inv);
-  flush_cols(H, lane, w, pb, dbeta, sred, inv);
-  flush_cols(H, lane, w, pz, dtype0, sred, inv);
+  float* dp = det_part ? det_part + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 3 * H : nullptr;
+  flush_cols(H, lane, w, pg, dgamma, sred, inv, dp);
+  flush_cols(H, lane, w, pb, dbeta, sred, inv, dp ? dp + H : nullptr);
+  flush_cols(H, lane, w, pz, dtype0, sred, inv, dp ? dp + 2 * H : nullptr);
 }
 
 template <typename T>
@@ -685,13 +699,20 @@ extern "C" int simx_ln_bwd_res(simx_stream_t stream, int dtype, int T, int H, co
   hipStream_t s = (hipStream_t)stream;
   const int rpb = bwd_rows_per_block(T);
   const size_t lds = (size_t)5 * H * sizeof(float);
+  const int nblk = cdiv(T, rpb);
+  float* det = nullptr;
+  if (simx_det()) {
+    det = simx_det_ws(s, (size_t)nblk * 3 * H * sizeof(float));
+    if (!det) return SIMX_ERR_WORKSPACE;
+  }
 #define LB(TT, V) do { if (res_hi) hipLaunchKernelGGL((ln_bwd_kernel<TT, V, true>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, (const TT*)z, gamma, eps, \
-                                    (const TT*)dy, (TT*)dz, dgamma, dbeta, dbias, (TT*)dz_masked, drop, row_keys, gs, (const TT*)res_hi, (const uint8_t*)res_lo); \
+                                    (const TT*)dy, (TT*)dz, dgamma, dbeta, dbias, (TT*)dz_masked, drop, row_keys, gs, (const TT*)res_hi, (const uint8_t*)res_lo, det); \
                        else hipLaunchKernelGGL((ln_bwd_kernel<TT, V, false>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, (const TT*)z, gamma, eps, \
-                                    (const TT*)dy, (TT*)dz, dgamma, dbeta, dbias, (TT*)dz_masked, drop, row_keys, gs, (const TT*)nullptr, (const uint8_t*)nullptr); } while (0)
+                                    (const TT*)dy, (TT*)dz, dgamma, dbeta, dbias, (TT*)dz_masked, drop, row_keys, gs, (const TT*)nullptr, (const uint8_t*)nullptr, det); } while (0)
   SIMX_DISPATCH3(dtype, TT, LN_BY_H(TT, LB));
 #undef LB
   SIMX_CHECK_LAUNCH("ln_bwd");
+  if (det) return simx_det_reduce(s, det, 3L * H, nblk, H, dgamma, dbeta, dbias, gs);
   return SIMX_OK;
 }
 
@@ -720,6 +741,17 @@ extern "C" int simx_embed_ln_fwd_lo(simx_stream_t stream, int dtype, int T, int 
   return SIMX_OK;
 }
 
+// deterministic mode: the kernels left the scaled dz rows in det_rows and one column partial per workgroup in det_part
+static int embed_det_finish(hipStream_t s, int T, int H, const int32_t* ids, const int32_t* pos_ids, const float* det_part,
+                            const float* det_rows, int nblk, float* dword, float* dpos, float* dtype0, float* dgamma, float* dbeta,
+                            const float* gs) {
+  int rc = simx_det_scatter_rows(s, T, H, ids, det_rows, dword, 4096);
+  if (rc) return rc;
+  rc = simx_det_scatter_rows(s, T, H, pos_ids, det_rows, dpos, 512);
+  if (rc) return rc;
+  return simx_det_reduce(s, det_part, 3L * H, nblk, H, dgamma, dbeta, dtype0, gs);
+}
+
 extern "C" int simx_embed_ln_bwd(simx_stream_t stream, int dtype, int T, int H, const int32_t* ids, const int32_t* pos_ids,
                                  const float* word, const float* posw, const float* typew, const float* gamma, float eps,
                                  const void* dy, float* dword, float* dpos, float* dtype0, float* dgamma, float* dbeta) {
@@ -739,11 +771,19 @@ extern "C" int simx_embed_ln_bwd_ex(simx_stream_t stream, int dtype, int T, int 
   const int rpb = bwd_rows_per_block(T);
   const size_t lds = (size_t)4 * H * sizeof(float);
   const float* gs = nullptr;
-#define EB(TT, V) hipLaunchKernelGGL((embed_ln_bwd_kernel<TT, V>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, ids, pos_ids, word, posw, \
-                                    typew, gamma, eps, (const TT*)dy, dword, dpos, dtype0, dgamma, dbeta, drop, gs)
+  const int nblk = cdiv(T, rpb);
+  float *det = nullptr, *det_rows = nullptr;
+  if (simx_det()) {
+    det = simx_det_ws(s, ((size_t)nblk * 3 * H + (size_t)T * H) * sizeof(float));
+    if (!det) return SIMX_ERR_WORKSPACE;
+    det_rows = det + (size_t)nblk * 3 * H;
+  }
+#define EB(TT, V) hipLaunchKernelGGL((embed_ln_bwd_kernel<TT, V>), dim3(nblk), dim3(256), lds, s, T, H, rpb, ids, pos_ids, word, posw, \
+                                    typew, gamma, eps, (const TT*)dy, dword, dpos, dtype0, dgamma, dbeta, drop, gs, det, det_rows)
   SIMX_DISPATCH3(dtype, TT, LN_BY_H(TT, EB));
 #undef EB
   SIMX_CHECK_LAUNCH("embed_ln_bwd");
+  if (det) return embed_det_finish(s, T, H, ids, pos_ids, det, det_rows, nblk, dword, dpos, dtype0, dgamma, dbeta, gs);
   return SIMX_OK;
 }
 
@@ -772,11 +812,19 @@ extern "C" int simx_embed_ln_bwd_seq_gs(simx_stream_t stream, int dtype, int nse
   const int spb = cdiv(nseq, chunks);
   const dim3 grid(pgroups, cdiv(nseq, spb));
   const size_t lds = (size_t)(4 * H + 4 * LN_VPL * 256) * sizeof(float);      // column-flush scratch + per-wave scatter patches
+  const int nblk = (int)(grid.x * grid.y);
+  float *det = nullptr, *det_rows = nullptr;
+  if (simx_det()) {
+    det = simx_det_ws(s, ((size_t)nblk * 3 * H + (size_t)T * H) * sizeof(float));
+    if (!det) return SIMX_ERR_WORKSPACE;
+    det_rows = det + (size_t)nblk * 3 * H;
+  }
 #define ES(TT, V) hipLaunchKernelGGL((embed_ln_bwd_seq_kernel<TT, V>), grid, dim3(256), lds, s, nseq, spb, H, cu_seqlens, ids, pos_ids, word, \
-                                    posw, typew, gamma, eps, (const TT*)dy, dword, dpos, dtype0, dgamma, dbeta, drop, gs)
+                                    posw, typew, gamma, eps, (const TT*)dy, dword, dpos, dtype0, dgamma, dbeta, drop, gs, det, det_rows)
   SIMX_DISPATCH3(dtype, TT, LN_BY_H(TT, ES));
 #undef ES
   SIMX_CHECK_LAUNCH("embed_ln_bwd_seq");
+  if (det) return embed_det_finish(s, T, H, ids, pos_ids, det, det_rows, nblk, dword, dpos, dtype0, dgamma, dbeta, gs);
   return SIMX_OK;
 }
 

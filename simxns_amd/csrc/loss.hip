@@ -9,11 +9,30 @@
 
 #define LOSS_EPS 1e-7f
 
+// the four loss scalars of one row: f32 atomics, or (SIMX_DETERMINISTIC=1) row `row` of a [rows][4] partial buffer that
+// det_reduce_kernel adds in row order
+__device__ __forceinline__ void loss_row_out(float* losses, float* det_part, int row, float l0, float l1, float l2, float l3) {
+  if (det_part) {
+    *reinterpret_cast<float4*>(det_part + 4L * row) = make_float4(l0, l1, l2, l3);
+  } else {
+    atomicAdd(losses + 0, l0);
+    if (l1 != 0.f) atomicAdd(losses + 1, l1);
+    if (l2 != 0.f) atomicAdd(losses + 2, l2);
+    atomicAdd(losses + 3, l3);
+  }
+}
+static int loss_det_begin(hipStream_t s, int rows, float** part) {
+  *part = nullptr;
+  if (!simx_det()) return SIMX_OK;
+  *part = simx_det_ws(s, (size_t)rows * 4 * sizeof(float));
+  return *part ? SIMX_OK : SIMX_ERR_WORKSPACE;
+}
+
 __global__ __launch_bounds__(256) void sim_loss_kernel(int B, int D, int H, const float* __restrict__ q,
                                                        const float* __restrict__ ctx, const float* __restrict__ teacher,
                                                        simx_loss_params lp, float* __restrict__ sim,
                                                        float* __restrict__ losses, float* __restrict__ dq,
-                                                       float* __restrict__ dctx) {
+                                                       float* __restrict__ dctx, float* __restrict__ det_part) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int b = blockIdx.x * 4 + w;
   if (b >= B) return;
@@ -94,12 +113,7 @@ __global__ __launch_bounds__(256) void sim_loss_kernel(int B, int D, int H, cons
   }
   const float ga = 1.0f / lp.grad_accum;
   ds *= ga;
-  if (lane == 0) {
-    atomicAdd(losses + 0, l0 * ga);
-    atomicAdd(losses + 1, l1);
-    atomicAdd(losses + 2, l2);
-    atomicAdd(losses + 3, corr);
-  }
+  if (lane == 0) loss_row_out(losses, det_part, b, l0 * ga, l1, l2, corr);
   // ---- backward of the similarity
   if (q) {
     const float* qr = q + (long)b * H;
@@ -122,7 +136,8 @@ __global__ __launch_bounds__(256) void sim_loss_kernel(int B, int D, int H, cons
 // M2 rows: scores [Q,C] -> per-row loss/correct, then scores <- dS = (softmax - onehot) * gscale
 __global__ __launch_bounds__(256) void nll_rows_kernel(int Q, int C, float* __restrict__ scores,
                                                        const int* __restrict__ pos_idx, float gscale, float lscale,
-                                                       float* __restrict__ row_stats, float* __restrict__ losses) {
+                                                       float* __restrict__ row_stats, float* __restrict__ losses,
+                                                       float* __restrict__ det_part) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = blockIdx.x * 4 + w;
   if (i >= Q) return;
@@ -147,10 +162,7 @@ __global__ __launch_bounds__(256) void nll_rows_kernel(int Q, int C, float* __re
   const int pos = pos_idx[i];
   const float sp = r[pos];
   if (row_stats) { if (lane == 0) { row_stats[2 * i] = m; row_stats[2 * i + 1] = lse; } }
-  if (lane == 0) {
-    atomicAdd(losses + 0, (lse - sp) * lscale / (float)Q);
-    atomicAdd(losses + 3, am == pos ? 1.f : 0.f);
-  }
+  if (lane == 0) loss_row_out(losses, det_part, i, (lse - sp) * lscale / (float)Q, 0.f, 0.f, am == pos ? 1.f : 0.f);
   for (int c = lane; c < C; c += 64) {
     const float pr = expf(r[c] - lse);
     r[c] = (pr - (c == pos ? 1.f : 0.f)) * gscale;
@@ -162,7 +174,8 @@ __global__ __launch_bounds__(256) void nll_rows_kernel(int Q, int C, float* __re
 // per row; then S <- dS = gscale * (ce_w (softmax(S) - onehot) + kd_w T (softmax(S/T) - u)).
 __global__ __launch_bounds__(256) void kd_rows_kernel(int Q, int C, float* __restrict__ scores, const float* __restrict__ tscores,
                                                       const int* __restrict__ pos_idx, float T, float ce_w, float kd_w,
-                                                      float gscale, float lscale, float* __restrict__ losses) {
+                                                      float gscale, float lscale, float* __restrict__ losses,
+                                                      float* __restrict__ det_part) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = blockIdx.x * 4 + w;
   if (i >= Q) return;
@@ -207,10 +220,7 @@ __global__ __launch_bounds__(256) void kd_rows_kernel(int Q, int C, float* __res
   soft = wave_sum(soft) * T * T;
   if (lane == 0) {
     const float hard = lse - sp;
-    atomicAdd(losses + 0, (ce_w * hard + kd_w * soft) * lscale / (float)Q);
-    atomicAdd(losses + 1, hard / (float)Q);
-    atomicAdd(losses + 2, soft / (float)Q);
-    atomicAdd(losses + 3, am == pos ? 1.f : 0.f);
+    loss_row_out(losses, det_part, i, (ce_w * hard + kd_w * soft) * lscale / (float)Q, hard / (float)Q, soft / (float)Q, am == pos ? 1.f : 0.f);
   }
 }
 
@@ -241,8 +251,11 @@ extern "C" int simx_sim_loss_fwd_bwd(simx_stream_t stream, int B, int D, int H, 
   SIMX_REQUIRE(sim && losses && dctx, SIMX_ERR_BAD_SHAPE, "sim_loss: NULL output");
   SIMX_REQUIRE(lp->grad_accum > 0.f && lp->temperature != 0.f, SIMX_ERR_BAD_SHAPE, "sim_loss: bad grad_accum/temperature");
   if (hipMemsetAsync(losses, 0, 4 * sizeof(float), s) != hipSuccess) { simx_set_error("sim_loss: memset failed"); return SIMX_ERR_HIP; }
-  hipLaunchKernelGGL(sim_loss_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, B, D, H, q, ctx, teacher, *lp, sim, losses, dq, dctx);
+  float* det = nullptr;
+  if (int rcd = loss_det_begin(s, B, &det)) return rcd;
+  hipLaunchKernelGGL(sim_loss_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, B, D, H, q, ctx, teacher, *lp, sim, losses, dq, dctx, det);
   SIMX_CHECK_LAUNCH("sim_loss");
+  if (det) return simx_det_reduce(s, det, 4L, B, 4, losses, nullptr, nullptr, nullptr);
   return SIMX_OK;
 }
 
@@ -258,8 +271,11 @@ extern "C" int simx_scores_nll_fwd_bwd(simx_stream_t stream, int Q, int C, int H
   int rc = simx_gemm_f32_strided(stream, Q, C, H, q, H, 1, ctx, 1, H, scores, C, 0);       // S = q ctx^T
   if (rc) return rc;
   const float ls = loss_scale == 0.f ? 1.f : loss_scale;
-  hipLaunchKernelGGL(nll_rows_kernel, dim3(cdiv(Q, 4)), dim3(256), 0, s, Q, C, scores, pos_idx, ls / (float)Q, ls, row_stats, losses);
+  float* det = nullptr;
+  if (int rcd = loss_det_begin(s, Q, &det)) return rcd;
+  hipLaunchKernelGGL(nll_rows_kernel, dim3(cdiv(Q, 4)), dim3(256), 0, s, Q, C, scores, pos_idx, ls / (float)Q, ls, row_stats, losses, det);
   SIMX_CHECK_LAUNCH("nll_rows");
+  if (det) { rc = simx_det_reduce(s, det, 4L, Q, 4, losses, nullptr, nullptr, nullptr); if (rc) return rc; }
   if (q_n > 0 && dq_local) {                                                                // dQ_loc = dS[rows] ctx
     rc = simx_gemm_f32_strided_ws(stream, q_n, H, C, scores + (long)q_lo * C, C, 1, ctx, H, 1, dq_local, H, 0, ws, ws_bytes);
     if (rc) return rc;
@@ -288,9 +304,12 @@ extern "C" int simx_scores_kd_fwd_bwd(simx_stream_t stream, int Q, int C, int H,
   rc = simx_gemm_f32_strided(stream, Q, C, HT, tq, HT, 1, tctx, 1, HT, tscores, C, 0);        // Z = tq tctx^T
   if (rc) return rc;
   const float ls = loss_scale == 0.f ? 1.f : loss_scale;
+  float* det = nullptr;
+  if (int rcd = loss_det_begin(s, Q, &det)) return rcd;
   hipLaunchKernelGGL(kd_rows_kernel, dim3(cdiv(Q, 4)), dim3(256), 0, s, Q, C, scores, tscores, pos_idx, temperature, ce_w, kd_w,
-                     ls / (float)Q, ls, losses);
+                     ls / (float)Q, ls, losses, det);
   SIMX_CHECK_LAUNCH("kd_rows");
+  if (det) { rc = simx_det_reduce(s, det, 4L, Q, 4, losses, nullptr, nullptr, nullptr); if (rc) return rc; }
   if (q_n > 0 && dq_local) {
     rc = simx_gemm_f32_strided_ws(stream, q_n, H, C, scores + (long)q_lo * C, C, 1, ctx, H, 1, dq_local, H, 0, ws, ws_bytes);
     if (rc) return rc;

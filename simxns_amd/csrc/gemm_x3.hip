@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_nt_kernel(
     uint32_t h[8], l[8];
 #pragma unroll
     for (int e = 0; e < 4; ++e) { split2<F>(ra[e].x, ra[e].y, h[2 * e], l[2 * e]); split2<F>(ra[e].z, ra[e].w, h[2 * e + 1], l[2 * e + 1]); }
-    char* d = stage + srow * 64 + (tid & 1) * 32;
+    char* d = stage + srow * 64 + (((tid & 1) ^ ((srow >> 3) & 1)) * 32);        // chunk swizzle, see the fragment reads
     *reinterpret_cast<uint4*>(d) = make_uint4(h[0], h[1], h[2], h[3]);
     *reinterpret_cast<uint4*>(d + 16) = make_uint4(h[4], h[5], h[6], h[7]);
     *reinterpret_cast<uint4*>(d + X3_PLANE) = make_uint4(l[0], l[1], l[2], l[3]);
@@ -124,8 +124,13 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_nt_kernel(
     const char* cur = smem + (st & 1) * X3_STAGE;
     if (st + 1 < nst) gload((st + 1) * X3_BK);
     // fragments: row (tile*16 + fr), k chunk fg (8 consecutive k = 16 B) of each plane
-    const char* fa = cur + (wr * 64 + fr) * 64 + fg * 16;
-    const char* fb = cur + 2 * X3_PLANE + (wc * 64 + fr) * 64 + fg * 16;
+    // 64-B rows: ds_read_b128 serves lanes in four 16-lane groups ({0-3, 12-15, 20-27}, ...), i.e. rows fr, fr + 12 at
+    // chunk c and rows fr + 4, fr + 8 at chunk c + 1 land on the four 16-B slots of ONE 64-B row image (row & 3): stored
+    // linearly, two of them share a slot (2-way conflict on every fragment read).  Rows 8-15 of every 16 keep their chunks
+    // XOR 2: the four become distinct slots.
+    const int fsw = (fg ^ (((fr >> 3) & 1) << 1)) * 16;
+    const char* fa = cur + (wr * 64 + fr) * 64 + fsw;
+    const char* fb = cur + 2 * X3_PLANE + (wc * 64 + fr) * 64 + fsw;
     bf16x8 ah[4], al[4], bh[4], bl[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

@@ -88,7 +88,8 @@ def test_gemm_tn_reads_head_major(dev, M, N, K, Kcap):
 
 
 @pytest.mark.parametrize("heads,lens,p", [(2, [128, 1, 17, 33, 16, 100], 0.0), (3, [160, 129, 45], 0.1), (12, [128] * 8, 0.1),
-                                          (1, [250, 200], 0.0), (2, [31, 9, 4], 0.1)])
+                                          (1, [250, 200], 0.0), (2, [31, 9, 4], 0.1),
+                                          (12, [128] * 40 + [1 + (41 * i) % 128 for i in range(60)], 0.1)])   # persistent backward
 def test_attention_head_major(dev, heads, lens, p):
     """simx_mha_fwd_hm / bwd_hm and the [CLS]-row pair: bit-identical to the token-major calls."""
     lib = L()

@@ -438,6 +438,10 @@ def _mha_ref(qkv, lens, heads, d, dctx=None):
     ("f16", 1, 64, [250, 200]),
     ("f16", 1, 64, [300, 512, 33]),
     ("f16", 2, 64, [700, 257, 1024, 40, 256]),
+    # >= 1024 (sequence, head) items of <= 128 tokens: the persistent double-buffered backward (mha_bwd3), ragged lengths,
+    # more items than workgroups so that every workgroup walks several
+    (True, 12, 64, [1 + (37 * i) % 128 for i in range(90)] + [128, 127, 113]),
+    ("f16", 12, 64, [128] * 30 + [1 + (53 * i) % 128 for i in range(70)]),
 ])
 def test_mha_fwd_bwd(dev, bf16, heads, d, lens):
     lib = L()

@@ -33,7 +33,7 @@ def _ms_pas():
                 generate=("simxns_amd/co_training/co_training_generate.py", dict(common, adv_step=0)))
 
 
-def _wiki(name, exp, de_ckpt, ce_ckpt, data, max_steps, seq_len, lr, warmup, extra):
+def _wiki(name, exp, de_ckpt, ce_ckpt, data, max_steps, seq_len, lr, warmup, extra, qa):
     out = "output/" + exp
     train = dict(model_type="nghuyong/ernie-2.0-base-en", model_name_or_path=de_ckpt, max_seq_length=seq_len,
                  per_gpu_train_batch_size=8, gradient_accumulation_steps=1, number_neg=15, learning_rate=lr,
@@ -41,9 +41,14 @@ def _wiki(name, exp, de_ckpt, ce_ckpt, data, max_steps, seq_len, lr, warmup, ext
                  output_dir=out, log_dir="tensorboard_log/" + exp, origin_data_dir=data, warmup_steps=warmup, logging_steps=100,
                  save_steps=2000, gradient_checkpointing=True, normal_loss=True, temperature_normal=1, ann_dir=out + "/temp")
     train.update(extra)
-    # the NQ / TQ generate job (co_training_generate_new_train_wiki.py) is outside this engine: SIMX_GENERATE_CMD names it
+    # second command of the round (train_NQ_AR2.sh:34-52): re-embed psgs_w100.tsv, mine top-100, write <ann_dir>/train_ce_<step>.json
+    generate = dict(model_type="nghuyong/ernie-2.0-base-en", model_name_or_path=de_ckpt, max_seq_length=seq_len,
+                    per_gpu_train_batch_size=8, output_dir=out, log_dir="tensorboard/logs/" + exp, origin_data_dir=data,
+                    origin_data_dir_dev=data.replace("train_ce_0", "dev_ce_0"), train_qa_path=qa % "train", test_qa_path=qa % "test",
+                    dev_qa_path=qa % "dev", passage_path="data/psgs_w100.tsv", gradient_checkpointing=True, ann_dir=out + "/temp")
     return dict(iteration_step=2000, iteration_reranker_step=500, max_steps=max_steps,
-                train=("simxns_amd/wiki/co_training_wiki_train.py", train), generate=None)
+                train=("simxns_amd/wiki/co_training_wiki_train.py", train),
+                generate=("simxns_amd/wiki/co_training_wiki_generate.py", generate))
 
 
 def _ms_doc():
@@ -56,16 +61,21 @@ def _ms_doc():
                  passage_path="data/MS-Doc", logging_steps=100, save_steps=5000, gradient_checkpointing=True, distill_loss=True,
                  temperature_distill=1, ann_dir="ckpt/%s/temp" % exp, adv_lambda=1)      # (no --fp16, as train_MS_Doc_AR2.sh:9-26;
                                                                                          #  SIMX_DTYPE=fp16 opts any recipe in)
+    generate = dict(model_type="ckpt/MS-Doc/adore-star", max_seq_length=512, output_dir="ckpt/" + exp,
+                    log_dir="tensorboard/logs/" + exp, train_qa_path="data/MS-Doc/msmarco-doctrain-queries.tsv",
+                    dev_qa_path="data/MS-Doc/msmarco-docdev-queries.tsv", passage_path="data/MS-Doc", gradient_checkpointing=True,
+                    ann_dir="ckpt/%s/temp" % exp)                                        # train_MS_Doc_AR2.sh:28-39
     return dict(iteration_step=5000, iteration_reranker_step=1000, max_steps=40000,
-                train=("simxns_amd/Doc_training/co_training_doc_train.py", train), generate=None)
+                train=("simxns_amd/Doc_training/co_training_doc_train.py", train),
+                generate=("simxns_amd/Doc_training/co_training_doc_generate.py", generate))
 
 
 RECIPES = {
     "MS_Pas": _ms_pas,
     "NQ": lambda: _wiki("NQ", "co_training_nq_SimANS_test", "ckpt/NQ/nq_fintinue.pkl", "ckpt/NQ/checkpoint-reranker26000",
-                        "data/NQ/train_ce_0.json", 30000, 128, 1e-5, 2000, dict(adv_lambda=0, b=1.0)),
+                        "data/NQ/train_ce_0.json", 30000, 128, 1e-5, 2000, dict(adv_lambda=0, b=1.0), "data/NQ/nq-%s.qa.csv"),
     "TQ": lambda: _wiki("TQ", "co_training_tq_SimANS_test", "ckpt/TQ/triviaqa_fintinue.pkl", "ckpt/TQ/checkpoint-reranker34000",
-                        "data/TQ/train_ce_0.json", 10000, 256, 5e-6, 1000, dict(adv_lambda=0.0, a=0.5, b=0)),
+                        "data/TQ/train_ce_0.json", 10000, 256, 5e-6, 1000, dict(adv_lambda=0.0, a=0.5, b=0), "data/TQ/trivia-%s.qa.csv"),
     "MS_Doc": _ms_doc,
 }
 

@@ -1,5 +1,6 @@
 """CPU: host-side logic and the C-ABI surface (no compute calls -- those need a GPU)."""
 import ctypes as C
+import json
 import os
 import re
 import subprocess
@@ -384,5 +385,102 @@ def test_recipe_launcher_command_lines_parse():
         assert (a.iteration_step, a.iteration_reranker_step, a.max_steps) == (it, rr, ms), name
         assert (a.per_gpu_train_batch_size, a.gradient_accumulation_steps, a.number_neg) == (bs, acc, 15), name
         assert abs(a.learning_rate - lr) < 1e-12 and a.gradient_checkpointing, name
+        # every recipe has its generate job (second command of the round), parsed by the same flag set, one step ahead
+        assert r["generate"] is not None and os.path.exists(os.path.join(ROOT, r["generate"][0])), name
+        gscript, gflags = r["generate"]
+        gargv = launch.job_argv(gscript, dict(gflags, global_step=r["iteration_step"], max_steps=r["max_steps"]), 8, 9539)
+        g = marco.get_arguments(gargv[gargv.index(gscript) + 1:])
+        assert g.global_step == it and g.ann_dir == a.ann_dir and g.output_dir == a.output_dir and g.train_qa_path, name
+        if name in ("NQ", "TQ"):
+            assert g.passage_path == "data/psgs_w100.tsv" and g.test_qa_path and g.origin_data_dir == a.origin_data_dir
     for sh in ("train_MS_Pas_AR2.sh", "train_NQ_AR2.sh", "train_TQ_AR2.sh", "train_MS_Doc_AR2.sh"):
         assert "simxns_amd.launch" in open(os.path.join(ROOT, sh)).read()
+
+
+def test_answer_match_and_ranking_metrics():
+    """SimpleTokenizer / has_answer / Eval_Tool (SimANS/utils/dpr_utils.py:91-164, 309-420) against literal restatements of
+    the reference's loops (its module cannot be imported here: it imports faiss)."""
+    import math
+    import random
+    import unicodedata
+    from simxns_amd.utils.dpr_utils import Eval_Tool, SimpleTokenizer, has_answer
+    tok = SimpleTokenizer()
+    assert tok.tokenize("Hello, w\u00f6rld! it's 3.5\u00a0km").words(uncased=True) == ["hello", ",", "w\u00f6rld", "!", "it", "'", "s", "3", ".", "5", "km"]
+
+    def literal(answers, text):                       # the reference's window compare
+        t = tok.tokenize(unicodedata.normalize('NFD', text)).words(uncased=True)
+        for a in answers:
+            w = tok.tokenize(unicodedata.normalize('NFD', a)).words(uncased=True)
+            for i in range(0, len(t) - len(w) + 1):
+                if w == t[i:i + len(w)]:
+                    return True
+        return False
+    rng = random.Random(0)
+    vocab = ["new", "york", "New", "York", "city", "1999", ",", "the", "caf\u00e9", "cafe\u0301", "a", "b"]
+    for _ in range(300):
+        text = " ".join(rng.choice(vocab) for _ in range(rng.randint(0, 12)))
+        answers = [" ".join(rng.choice(vocab) for _ in range(rng.randint(0, 3))) for _ in range(rng.randint(0, 3))]
+        assert has_answer(answers, text, tok) == literal(answers, text), (answers, text)
+    assert has_answer(["New  York"], "He moved to new york, in 1999.", tok) and not has_answer(["york new"], "new york", tok)
+    assert has_answer([r"19\d\d"], "in 1999", tok, match_type="regex") and not has_answer(["(("], "((", tok, match_type="regex")
+    R = [[rng.random() < 0.1 for _ in range(rng.choice([3, 100, 50]))] for _ in range(40)] + [[False] * 100, [True] + [False] * 99]
+
+    def avg(f, n):
+        return sum(f(r[:n], n) for r in R) / len(R)
+    lit = {"MRR_n": lambda r, n: next((1.0 / (i + 1.0) for i, x in enumerate(r) if x), 0),
+           "DCG_n": lambda r, n: sum(1 / math.log2(i + 2) for i, x in enumerate(r) if x),
+           "nDCG_n": lambda r, n: sum(1 / math.log2(i + 2) for i, x in enumerate(r) if x) / sum(math.log2(i + 2) for i in range(n)),
+           "P_n": lambda r, n: sum(1 for x in r if x) / n}
+
+    def ap(r, n):
+        s_, h = 0.0, 1
+        for i, x in enumerate(r):
+            if x:
+                s_ += h / (i + 1.0)
+                h += 1
+        return s_ / n
+    lit["MAP_n"] = ap
+    m = Eval_Tool.get_matrics(R)
+    assert len(m) == 30
+    for name, f in lit.items():
+        for n in (1, 5, 10, 20, 50, 100):
+            assert abs(m[name + "@_" + str(n)] - avg(f, n)) < 1e-12, (name, n)
+
+
+def test_wiki_generate_output_files(tmp_path):
+    """reform_out / read_train_pos / load_passage / load_qa of the NQ / TQ generate job (co_training_generate_new_train_wiki.py
+    :184-226, :317-343, :448-459): the gold passage stays positive_ctxs[0] and takes the retrieval score when retrieved, other
+    answer-bearing passages become further positives, the rest hard negatives -- and TraditionDataset reads the file."""
+    from simxns_amd.utils.MARCO_until_new import HashTokenizer
+    from simxns_amd.utils.util_wiki import TraditionDataset
+    from simxns_amd.wiki import co_training_generate_new_train_wiki as W
+    psg = tmp_path / "psgs.tsv"
+    psg.write_text("id\ttext\ttitle\n1\tparis is the capital of france\tFrance\n2\tberlin is in germany\tGermany\n"
+                   "3\tthe eiffel tower stands in paris\tEiffel\n4\trome is old\tItaly\nbroken\n")
+    P = W.load_passage(str(psg))
+    assert P == [(0, "paris is the capital of france", "France"), (1, "berlin is in germany", "Germany"),
+                 (2, "the eiffel tower stands in paris", "Eiffel"), (3, "rome is old", "Italy")]
+    qa = tmp_path / "qa.csv"
+    qa.write_text("capital of france?\t['Paris']\nwhere is berlin\t[\"Germany\", 'Deutschland']\n")
+    Q, A = W.load_qa(str(qa))
+    assert Q == ["capital of france?", "where is berlin"] and A == [["Paris"], ["Germany", "Deutschland"]]
+    text = {p[0]: (p[1], p[2]) for p in P}
+    top, hits, metrics, rd = W.validate(Q, text, A, [[2, 1, 0, 3], [3, 1, 0, 2]], [[9.0, 8.0, 7.0, 6.0], [5.0, 4.0, 3.0, 2.0]])
+    assert hits == [[True, False, True, False], [False, True, False, False]] and top == [0.5, 1.0, 1.0, 1.0]
+    assert abs(metrics["MRR_n@_5"] - 0.75) < 1e-12 and rd[0]["ctxs"][0] == {"d_id": "2", "text": P[2][1], "title": "Eiffel", "score": "9.0", "hit": "True"}
+    gold = tmp_path / "train_ce_0.json"
+    json.dump([{"question": Q[0], "positive_ctxs": [{"title": "France", "text": P[0][1], "passage_id": "1", "score": "55"}]},
+               {"question": "unused", "positive_ctxs": []}], open(gold, "w"))
+    pos = W.read_train_pos(str(gold))
+    assert list(pos) == [Q[0]]
+    out = W.reform_out(rd, pos)
+    e0, e1 = out
+    assert [c["passage_id"] for c in e0["positive_ctxs"]] == ["1", "2"] and e0["positive_ctxs"][0]["score"] == "7.0"   # gold retrieved at rank 3
+    assert [c["passage_id"] for c in e0["hard_negative_ctxs"]] == ["1", "3"] and e0["q_id"] == "0" and e0["negative_ctxs"] == []
+    assert [c["passage_id"] for c in e1["positive_ctxs"]] == ["1"] and len(e1["hard_negative_ctxs"]) == 3           # no gold: hits only
+    path = tmp_path / "train_ce_5.json"
+    json.dump(out, open(path, "w"))
+    ds = TraditionDataset(str(path), HashTokenizer(), num_hard_negatives=2, a=0.5, b=0.0, max_seq_length=32)
+    assert len(ds) == 2
+    q_ids, ctx_ids, ce, answers, se = ds[0]
+    assert len(ctx_ids) == 3 and len(ce) == 3

@@ -273,3 +273,141 @@ def test_gpu_sampler_matches_host_collate_and_law(dev, tmp_path):
                  "--save_steps", "1000", "--max_steps", "6", "--iteration_step", "6", "--iteration_reranker_step", "2",
                  "--temperature_distill", "1", "--ann_dir", root, "--num_workers", "0", "--sampler", "gpu", "--global_step", "0"])
     assert gs == 6
+
+
+def test_wiki_generate_job(dev, tmp_path):
+    """NQ / TQ generate job end to end (wiki/co_training_wiki_generate.py): passages tsv + qa csv -> top-k by the HIP index ==
+    the oracle's exhaustive search over the same embeddings, hit flags == has_answer, the three files of the round, and the
+    next train job's dataset reads train_ce_<step>.json."""
+    from oracle import retrieval as orr
+    from simxns_amd.co_training.co_training_generate import embed_table
+    from simxns_amd.utils.dpr_utils import SimpleTokenizer, has_answer, load_states_from_checkpoint, save_checkpoint_state  # noqa: F401
+    from simxns_amd.utils.util_wiki import TraditionDataset
+    from simxns_amd.utils.MARCO_until_new import HashTokenizer
+    from simxns_amd.wiki import co_training_wiki_generate as G
+    root = str(tmp_path / "data")
+    _write_corpus(root)
+    rs = np.random.RandomState(3)
+    words = ["w%d" % i for i in range(300)]
+    n_pass, n_q = 300, 12
+    texts = [" ".join(rs.choice(words, size=rs.randint(8, 40))) for _ in range(n_pass)]
+    with open(os.path.join(root, "psgs.tsv"), "w") as f:
+        f.write("id\ttext\ttitle\n")
+        for i, t in enumerate(texts):
+            f.write("%d\t%s\tt%d\n" % (i + 1, t, i))
+    questions = ["what about %s?" % " ".join(rs.choice(words, size=4)) for _ in range(n_q)]
+    answers = [[texts[rs.randint(n_pass)].split()[2], "zzz-never"] for _ in range(n_q)]
+    for mode in ("train", "dev", "test"):
+        with open(os.path.join(root, "%s.qa.csv" % mode), "w") as f:
+            for q, a in zip(questions, answers):
+                f.write("%s\t%s\n" % (q, repr(a)))
+    gold = [dict(question=q, answers=a, positive_ctxs=[dict(title="t%d" % i, text=texts[i], passage_id=str(i + 1), score="1")],
+                 hard_negative_ctxs=[]) for i, (q, a) in enumerate(zip(questions, answers))]
+    for name in ("train_ce_0.json", "dev_ce_0.json"):
+        json.dump(gold, open(os.path.join(root, name), "w"))
+    ann = str(tmp_path / "ann")
+    out = str(tmp_path / "ckpt")
+    argv = ["--model_type", os.path.join(root, "student"), "--tokenizer_name", "hash", "--max_seq_length", "64", "--output_dir", out,
+            "--origin_data_dir", os.path.join(root, "train_ce_0.json"), "--origin_data_dir_dev", os.path.join(root, "dev_ce_0.json"),
+            "--train_qa_path", os.path.join(root, "train.qa.csv"), "--dev_qa_path", os.path.join(root, "dev.qa.csv"),
+            "--test_qa_path", os.path.join(root, "test.qa.csv"), "--passage_path", os.path.join(root, "psgs.tsv"), "--ann_dir", ann,
+            "--global_step", "0", "--max_steps", "10", "--fp16"]
+    # one set of weights for the job and for the check below: the job loads --model_name_or_path
+    from simxns_amd.utils.dpr_utils import CheckpointState
+    args = G.M.get_arguments(argv)
+    args.device = dev
+    torch.manual_seed(5)
+    tok, model = G.load_model(args)
+    os.makedirs(out, exist_ok=True)
+    torch.save(CheckpointState(model.state_dict(), {}, {}, 0, 0, None)._asdict(), os.path.join(out, "init.pkl"))
+    argv += ["--model_name_or_path", os.path.join(out, "init.pkl")]
+    assert G.main(argv) == 0
+    for name in ("train_result_dict_list_0.json", "train_eval_result0.json", "train_ce_0.json", "dev_ce_0.json",
+                 "test_result_dict_list_0.json", "test_eval_result0.json"):
+        assert os.path.exists(os.path.join(ann, name)), name
+    assert not os.path.exists(os.path.join(ann, "test_ce_0.json"))
+    rd = json.load(open(os.path.join(ann, "train_result_dict_list_0.json")))
+    ev = json.load(open(os.path.join(ann, "train_eval_result0.json")))
+    assert len(rd) == n_q and all(len(r["ctxs"]) == 100 for r in rd) and set(ev) == {"top1", "top5", "top20", "top100", "result_dict"}
+    # ranking == exhaustive search over the same embeddings; hits == has_answer on the passage text
+    model.eval()
+    tools = G.RenewTools(os.path.join(root, "psgs.tsv"), tok, str(tmp_path / "ann2"), max_seq_length=64)
+    _, _, qemb = tools.get_question_embedding(model, dev, os.path.join(root, "train.qa.csv"))
+    pemb = embed_table(model.body_emb, tools.passage_table, dev)
+    _, ref_ids = orr.search(qemb.cpu().numpy(), pemb.cpu().numpy(), 100)
+    st = SimpleTokenizer()
+    first_hit = []
+    for r, res in enumerate(rd):
+        assert [int(c["d_id"]) for c in res["ctxs"]] == [int(i) for i in ref_ids[r]]
+        flags = [has_answer(answers[r], texts[int(c["d_id"])], st) for c in res["ctxs"]]
+        assert [c["hit"] for c in res["ctxs"]] == [str(x) for x in flags]
+        first_hit.append(next((i for i, x in enumerate(flags) if x), None))
+    assert abs(ev["top1"] - sum(1 for h in first_hit if h == 0) / n_q) < 1e-12
+    assert abs(ev["top100"] - sum(1 for h in first_hit if h is not None) / n_q) < 1e-12
+    ce = json.load(open(os.path.join(ann, "train_ce_0.json")))
+    for r, e in enumerate(ce):
+        assert e["positive_ctxs"][0]["passage_id"] == str(r + 1) and e["question"] == questions[r]
+        got = {c["passage_id"] for c in e["positive_ctxs"][1:]} | {c["passage_id"] for c in e["hard_negative_ctxs"]}
+        assert got == {c["d_id"] for c in rd[r]["ctxs"] if not (c["hit"] == "True" and int(c["d_id"]) == r)}   # (the retrieved gold is positive 0)
+    ds = TraditionDataset(os.path.join(ann, "train_ce_0.json"), HashTokenizer(), num_hard_negatives=7, a=0.5, b=1.0, max_seq_length=64)
+    assert len(ds) == n_q and len(ds[0][1]) == 8
+
+
+def test_ms_doc_generate_job(dev, tmp_path):
+    """MS-MARCO Document generate job end to end (Doc_training/co_training_doc_generate.py): the checkpoint of a train round,
+    D-prefixed corpus / qrels, top-200 == the oracle's search, only queries whose positive was retrieved are written, and
+    Doc_v2Dataset reads the file."""
+    from oracle import retrieval as orr
+    from simxns_amd.Doc_training import co_training_doc_generate as G
+    from simxns_amd.Doc_training import co_training_doc_train as D
+    from simxns_amd.co_training.co_training_generate import embed_table
+    from simxns_amd.utils.MARCO_until_Doc import Doc_v2Dataset
+    from simxns_amd.utils.dpr_utils import CheckpointState
+    root = str(tmp_path / "doc")
+    os.makedirs(root)
+    rs = np.random.RandomState(4)
+    words = ["w%d" % i for i in range(400)]
+    n_doc, n_q = 260, 10
+    with open(os.path.join(root, "msmarco-docs.tsv"), "w") as f:
+        for pid in range(n_doc):
+            f.write("D%d\thttp://u/%d\t%s\t%s\n" % (pid, pid, " ".join(rs.choice(words, size=4)), " ".join(rs.choice(words, size=rs.randint(30, 300)))))
+    with open(os.path.join(root, "msmarco-doctrain-queries.tsv"), "w") as f, open(os.path.join(root, "msmarco-doctrain-qrels.tsv"), "w") as g:
+        for q in range(n_q):
+            f.write("%d\t%s\n" % (100 + q, " ".join(rs.choice(words, size=7))))
+            g.write("%d 0 D%d 1\n" % (100 + q, rs.randint(n_doc)))
+    d = os.path.join(root, "student")
+    os.makedirs(d)
+    json.dump(dict(vocab_size=50265, hidden_size=64, num_hidden_layers=2, num_attention_heads=1, intermediate_size=128,
+                   max_position_embeddings=514, type_vocab_size=1, layer_norm_eps=1e-5, model_type="roberta", pad_token_id=1),
+              open(os.path.join(d, "config.json"), "w"))
+    out, ann = str(tmp_path / "ckpt"), str(tmp_path / "ann")
+    os.makedirs(out)
+    argv = ["--model_type", d, "--tokenizer_name", "hash", "--max_seq_length", "512", "--output_dir", out,
+            "--train_qa_path", os.path.join(root, "msmarco-doctrain-queries.tsv"), "--passage_path", root, "--ann_dir", ann,
+            "--global_step", "6", "--max_steps", "12", "--fp16"]
+    args = G.M.get_arguments(argv)
+    args.teacher_model_type = d
+    tok, model, _ = D.load_model(args)
+    torch.save(CheckpointState(model.state_dict(), {}, {}, 0, 0, None)._asdict(), os.path.join(out, "checkpoint-6"))
+    res = G.main(argv)
+    result, path = res["train"]
+    assert os.path.basename(path) == "train_ce_6.tsv" and result["QueriesRanked"] == n_q and os.path.exists(os.path.join(ann, "train_eval_result6.json"))
+    model = model.to(dev).eval()
+    tools = G.RenewTools(os.path.join(root, "msmarco-docs.tsv"), tok, str(tmp_path / "ann2"))
+    _, qids, qemb = tools.get_question_embedding(model, dev, os.path.join(root, "msmarco-doctrain-queries.tsv"))
+    pemb = embed_table(model.body_emb, tools.passage_table, dev, batch_size=256, pad_id=1)
+    _, ref_ids = orr.search(qemb.cpu().numpy(), pemb.cpu().numpy(), 200)
+    qrels = {int(l.split()[0]): int(l.split()[2][1:]) for l in open(os.path.join(root, "msmarco-doctrain-qrels.tsv"))}
+    want = {}
+    for r, q in enumerate(qids):
+        ids = [int(i) for i in ref_ids[r]]
+        if qrels[int(q)] in ids:
+            want[int(q)] = [i for i in ids if i != qrels[int(q)]]
+    lines = [l.rstrip("\n").split("\t") for l in open(path)]
+    assert {int(f[0]) for f in lines} == set(want) and len(lines) >= 1
+    for f in lines:
+        assert [int(p.split(" ")[0]) for p in f[3].split(",")] == want[int(f[0])] and int(f[2].split(" ")[0]) == qrels[int(f[0])]
+        assert float(f[2].split(" ")[1]) != 0.0
+    ds = Doc_v2Dataset(path, tok, num_hard_negatives=3, corpus_path=root)
+    q, ctx, ce = ds[0]
+    assert tuple(q.shape) == (128,) and tuple(ctx.shape) == (4, 512)

@@ -32,7 +32,9 @@ template <typename F> static double timeit(F f, int iters) {
 int main(int argc, char** argv) {
   if (getenv("KB_F16")) g_dt = SIMX_F16;
   const int T = argc > 1 ? atoi(argv[1]) : 262144;
-  const int H = 768, F = 3072, iters = 10;
+  // KB_H=1024: the recipe teacher's geometry (ernie-2.0-large: H = 1024, F = 4096) -- main NT / TN tables only
+  const int H = getenv("KB_H") ? atoi(getenv("KB_H")) : 768, F = 4 * H, iters = 10;
+  const bool base = H == 768;
   if (getenv("KB_X3")) {      // the fp32 engine's dense GEMMs: f32 tensors, hi+lo split products (SIMX_F32_SPLIT_H / _B)
     auto falloc = [&](size_t n, float scale) { float* p; CK(hipMalloc(&p, n * 4)); std::vector<float> h(1 << 20);
       for (size_t i = 0; i < h.size(); ++i) h[i] = (((int)((i * 2654435761u) >> 20 & 1023)) - 512) / 1024.0f * scale;
@@ -83,17 +85,18 @@ int main(int argc, char** argv) {
     ++idx; if (oi >= 0 && idx != oi) continue;
     double ms = timeit([&] { SX(simx_gemm_nt(0, g_dt, T, s.N, s.K, A, s.K + pad, W, s.K, C, s.N, s.epi == 2 ? nullptr : bias, s.res ? A2 : nullptr, s.N, s.epi, s.epi == 2 ? A2 : nullptr, s.N, s.epi == 1 ? C2 : nullptr, s.N)); }, iters);
     double fl = 2.0 * T * s.N * s.K; tot += ms; totf += fl;
-    printf("gemm_nt %-36s %8.3f ms  %7.1f TF/s\n", s.name, ms, fl / ms / 1e9);
+    if (base) printf("gemm_nt %-36s %8.3f ms  %7.1f TF/s\n", s.name, ms, fl / ms / 1e9);
+    else printf("gemm_nt %-10.10s N=%-5d K=%-5d epi %d res %d %8.3f ms  %7.1f TF/s\n", s.name, s.N, s.K, s.epi, s.res, ms, fl / ms / 1e9);
   }
   printf("gemm_nt total %.2f ms  avg %.1f TF/s\n", tot, totf / tot / 1e9);
   if (oi >= 0) return 0;
-  {   // QKV projection writing the head-major layout ([36][T][64]) and the dgrad reading it
+  if (base) {   // QKV projection writing the head-major layout ([36][T][64]) and the dgrad reading it
     double ms = timeit([&] { SX(simx_gemm_nt_hm(0, g_dt, T, 3 * H, H, A, H, W, H, C, 64, bias, nullptr, 0, nullptr, 0, T)); }, iters);
     printf("gemm_nt %-36s %8.3f ms  %7.1f TF/s\n", "qkv   fwd  N=2304 K=768 bias -> hm", ms, 2.0 * T * 3 * H * H / ms / 1e9);
     ms = timeit([&] { SX(simx_gemm_nt_hm(0, g_dt, T, H, 3 * H, A, 64, W, 3 * H, C, H, nullptr, A2, H, nullptr, T, 0)); }, iters);
     printf("gemm_nt %-36s %8.3f ms  %7.1f TF/s\n", "qkv  dgrad N=768  K=2304 +res <- hm", ms, 2.0 * T * 3 * H * H / ms / 1e9);
   }
-  {   // how much would plane-blocked [T, 768] outputs be worth?  (no residual: the built flags-2 form)
+  if (base) {   // how much would plane-blocked [T, 768] outputs be worth?  (no residual: the built flags-2 form)
     double ms = timeit([&] { SX(simx_gemm_nt(0, g_dt, T, H, H, A, H, W, H, C, H, bias, nullptr, 0, 0, nullptr, 0, nullptr, 0)); }, iters);
     printf("gemm_nt %-36s %8.3f ms  %7.1f TF/s\n", "oproj-shape N=768 K=768 bias", ms, 2.0 * T * H * H / ms / 1e9);
     ms = timeit([&] { SX(simx_gemm_nt_pb(0, g_dt, T, H, H, A, H, W, H, C, 64, bias, nullptr, 0, 0, nullptr, 0, nullptr, 2, T)); }, iters);
@@ -116,7 +119,8 @@ int main(int argc, char** argv) {
   for (auto& s : tn) {
     double ms = timeit([&] { SX(simx_gemm_tn(0, g_dt, s.M, s.N, T, A, s.M, A2, s.N, G, s.N, 1, ws, wsb)); }, iters);
     double fl = 2.0 * T * s.M * s.N; tot += ms; totf += fl;
-    printf("gemm_tn %-36s %8.3f ms  %7.1f TF/s\n", s.name, ms, fl / ms / 1e9);
+    if (base) printf("gemm_tn %-36s %8.3f ms  %7.1f TF/s\n", s.name, ms, fl / ms / 1e9);
+    else printf("gemm_tn M=%-5d N=%-5d %8.3f ms  %7.1f TF/s\n", s.M, s.N, ms, fl / ms / 1e9);
   }
   printf("gemm_tn total %.2f ms  avg %.1f TF/s\n", tot, totf / tot / 1e9);
   tot = 0; totf = 0;
@@ -126,6 +130,7 @@ int main(int argc, char** argv) {
     printf("gemm_tn+bias %-31s %8.3f ms  %7.1f TF/s\n", s.name, ms, fl / ms / 1e9);
   }
   printf("gemm_tn+bias total %.2f ms  avg %.1f TF/s\n", tot, totf / tot / 1e9);
+  if (!base) return 0;
   // attention + LN + colsum at S=128
   const int S = 128, nseq = T / S, heads = 12;
   std::vector<int> cu(nseq + 1); for (int i = 0; i <= nseq; ++i) cu[i] = i * S;

@@ -112,7 +112,7 @@ int main(int argc, char** argv) {
   }
   {   // the teacher's FFN-in: GELU without the derivative output (SIMX_EPI_GELU_INFER = 3)
     double ms = timeit([&] { SX(simx_gemm_nt(0, g_dt, T, F, H, A, H + pad, W, H, C, F, bias, nullptr, F, 3, nullptr, F, C2, F)); }, iters);
-    printf("gemm_nt %-36s %8.3f ms  %7.1f TF/s\n", "ffn1  fwd  N=3072 K=768 gelu (infer)", ms, 2.0 * T * F * H / ms / 1e9);
+    printf("gemm_nt ffn1  fwd  N=%-5d K=%-5d gelu (infer)  %8.3f ms  %7.1f TF/s\n", F, H, ms, 2.0 * T * F * H / ms / 1e9);
   }
   struct S2 { const char* name; int M, N; } tn[] = {{"wqkv [2304,768]", 3 * H, H}, {"wo [768,768]", H, H}, {"w1 [3072,768]", F, H}, {"w2 [768,3072]", H, F}};
   tot = 0; totf = 0;

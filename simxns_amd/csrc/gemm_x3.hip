@@ -15,10 +15,12 @@
 // shapes, for the M2 score matrix and behind SIMX_GEMM_F32=exact.
 //
 // NT form  C[M,N] = A[M,K] . B[N,K]^T  (both K-contiguous; forward and dgrad), 128x128x32 tile, 4 waves of 64x64:
-//   global f32 (16-B loads, next stage in flight during the MFMAs) -> registers -> split -> LDS planes Ahi|Alo|Bhi|Blo, each
-//   [128 rows][32 k] 16-bit = 64 B per row, so a wave's fragment read (16 rows x 64 B) is one contiguous KB.
-//   (Holding TWO stages in registers and issuing the MFMAs term-major measured SLOWER: NT 227 -> 207, TN 299 -> 243 TFLOP/s
-//   on the bench shapes, kbench A/B/A/B -- 32 more VGPRs of f32 staging cost an occupancy step.)
+//   global f32 (whole-line 16-B loads, next stage in flight during the MFMAs) -> registers -> split -> LDS planes
+//   Ahi|Alo|Bhi|Blo, each [128 rows][32 k] 16-bit = 64 B per row, so a wave's fragment read (16 rows x 64 B) is one contiguous KB.
+//   What bounds it (kbench on the seven bench shapes, variants under tools/variants): without the MFMAs the kernel is 10 %
+//   faster, without the global loads 50 % -- the loop is its load stream.  Measured steps: loads that cover whole 128-B rows
+//   instead of two 16-B pieces of 32 rows per instruction 231 -> 272 TFLOP/s; one LDS stage and three workgroups per CU
+//   (more loads in flight) -> 300; holding two stages in registers 227 -> 207 (slower); conflict-free fragment reads +0.8 %.
 // TN form  C[M,N] (+)= A[K,M]^T . B[K,N]  (wgrad: rows = tokens, M / N contiguous), same tile, planes [32 k][128 cols] with
 //   the 32-B chunk swizzle of gemm_tn_h16_kernel, fragments by ds_read_b64_tr_b16 (the k-slot permutation it implies is
 //   the same for both operands); split over K into f32 slabs reduced in slice order (slab_reduce_kernel): deterministic.
@@ -56,11 +58,14 @@ __global__ __launch_bounds__(256) void x3_slab_reduce_kernel(const float* __rest
 }
 
 template <typename F, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_x3_nt_kernel(
+__global__ __launch_bounds__(256, 3) void gemm_x3_nt_kernel(
     int M, int N, int K, const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
     const float* __restrict__ bias, const float* __restrict__ res, int ldr, const float* __restrict__ aux, int ldaux,
     float* __restrict__ C2, int ldc2, int tiles_n, int ntiles, DropCtx drop) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * X3_STAGE];
+  // ONE LDS stage per workgroup (two barriers per k step) and three workgroups per CU: the loop is bound by its global
+  // loads (without them 402 instead of 265 TFLOP/s), so 12 waves' worth of loads in flight beat 8 waves with a second LDS
+  // buffer: 265 -> 300 TFLOP/s on the bench shapes.  (Four per CU would need <= 128 VGPRs: spills.)
+  __shared__ __attribute__((aligned(16))) char smem[X3_STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // XCD-aware order: block b runs on XCD b % 8; every XCD walks a contiguous range of tiles so that the N-tiles sharing an
@@ -77,43 +82,45 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_nt_kernel(
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // staging: thread t owns row t >> 1, k half (t & 1) * 16 of both operand tiles: 16 consecutive floats each
-  const int srow = tid >> 1, shalf = (tid & 1) * 16;
-  int ga = m0 + srow, gb = n0 + srow;
-  ga = ga < M ? ga : M - 1;                       // (clamped rows are computed and never stored)
-  gb = gb < N ? gb : N - 1;
-  const float* pa = A + (long)ga * lda + shalf;
-  const float* pb = B + (long)gb * ldb + shalf;
+  // staging: a wave's 16-B loads cover WHOLE rows -- lane l reads floats 4 (l & 7) .. + 3 of row (l >> 3) of an 8-row slab,
+  // 8 full 128-B lines per instruction; thread t owns k chunk t & 7 of rows (t >> 3) + 32 e, e = 0..3, of both tiles.
+  // (The first form gave every thread 16 consecutive floats of one row: each instruction then touched 32 lines and used 32 B
+  // of each, and the kernel was bound by exactly that -- with the loads removed it ran 1.75x faster, with a third workgroup
+  // per CU only 2 % faster.)
+  const int srow = tid >> 3, sk = (tid & 7) * 4;
+  const float *pa[4], *pb[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    int ga = m0 + srow + 32 * e, gb = n0 + srow + 32 * e;
+    ga = ga < M ? ga : M - 1;                     // (clamped rows are computed and never stored)
+    gb = gb < N ? gb : N - 1;
+    pa[e] = A + (long)ga * lda + sk;
+    pb[e] = B + (long)gb * ldb + sk;
+  }
   float4 ra[4], rb[4];
   auto gload = [&](int k0) {
+    const bool in = k0 + sk + 3 < K;               // ragged K tail (K % 4 == 0 is required: whole float4s)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int k = k0 + shalf + e * 4;
-      if (k + 3 < K) {
-        ra[e] = *reinterpret_cast<const float4*>(pa + k0 + e * 4);
-        rb[e] = *reinterpret_cast<const float4*>(pb + k0 + e * 4);
-      } else {                                     // ragged K tail (K % 4 == 0 is required: whole float4s)
-        ra[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-        rb[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+      ra[e] = in ? *reinterpret_cast<const float4*>(pa[e] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rb[e] = in ? *reinterpret_cast<const float4*>(pb[e] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto sstore = [&](char* stage) {
-    uint32_t h[8], l[8];
+    // 16-bit plane row = 32 k = 64 B = four 16-B chunks; this thread's 4 k are 8 B: half (tid & 1) of chunk (tid & 7) >> 1,
+    // chunks of rows 8-15 of every 16 stored XOR 2 (see the fragment reads)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { split2<F>(ra[e].x, ra[e].y, h[2 * e], l[2 * e]); split2<F>(ra[e].z, ra[e].w, h[2 * e + 1], l[2 * e + 1]); }
-    char* d = stage + srow * 64 + (((tid & 1) ^ ((srow >> 3) & 1)) * 32);        // chunk swizzle, see the fragment reads
-    *reinterpret_cast<uint4*>(d) = make_uint4(h[0], h[1], h[2], h[3]);
-    *reinterpret_cast<uint4*>(d + 16) = make_uint4(h[4], h[5], h[6], h[7]);
-    *reinterpret_cast<uint4*>(d + X3_PLANE) = make_uint4(l[0], l[1], l[2], l[3]);
-    *reinterpret_cast<uint4*>(d + X3_PLANE + 16) = make_uint4(l[4], l[5], l[6], l[7]);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { split2<F>(rb[e].x, rb[e].y, h[2 * e], l[2 * e]); split2<F>(rb[e].z, rb[e].w, h[2 * e + 1], l[2 * e + 1]); }
-    d += 2 * X3_PLANE;
-    *reinterpret_cast<uint4*>(d) = make_uint4(h[0], h[1], h[2], h[3]);
-    *reinterpret_cast<uint4*>(d + 16) = make_uint4(h[4], h[5], h[6], h[7]);
-    *reinterpret_cast<uint4*>(d + X3_PLANE) = make_uint4(l[0], l[1], l[2], l[3]);
-    *reinterpret_cast<uint4*>(d + X3_PLANE + 16) = make_uint4(l[4], l[5], l[6], l[7]);
+    for (int e = 0; e < 4; ++e) {
+      const int row = srow + 32 * e;
+      char* d = stage + row * 64 + (((((tid & 7) >> 1) ^ (((row >> 3) & 1) << 1))) << 4) + (tid & 1) * 8;
+      uint32_t h0, h1, l0, l1;
+      split2<F>(ra[e].x, ra[e].y, h0, l0); split2<F>(ra[e].z, ra[e].w, h1, l1);
+      *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(d + X3_PLANE) = make_uint2(l0, l1);
+      split2<F>(rb[e].x, rb[e].y, h0, l0); split2<F>(rb[e].z, rb[e].w, h1, l1);
+      *reinterpret_cast<uint2*>(d + 2 * X3_PLANE) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(d + 3 * X3_PLANE) = make_uint2(l0, l1);
+    }
   };
 
   const int nst = (K + X3_BK - 1) / X3_BK;
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_nt_kernel(
   sstore(smem);
   __syncthreads();
   for (int st = 0; st < nst; ++st) {
-    const char* cur = smem + (st & 1) * X3_STAGE;
+    const char* cur = smem;
     if (st + 1 < nst) gload((st + 1) * X3_BK);
     // fragments: row (tile*16 + fr), k chunk fg (8 consecutive k = 16 B) of each plane
     // 64-B rows: ds_read_b128 serves lanes in four 16-lane groups ({0-3, 12-15, 20-27}, ...), i.e. rows fr, fr + 12 at
@@ -148,7 +155,8 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_nt_kernel(
         acc[i][j] = H16<F>::mfma(bh[j], al[i], acc[i][j]);
         acc[i][j] = H16<F>::mfma(bh[j], ah[i], acc[i][j]);
       }
-    if (st + 1 < nst) sstore(smem + ((st + 1) & 1) * X3_STAGE);
+    __syncthreads();                               // every wave has its fragments of this stage
+    if (st + 1 < nst) sstore(smem);
     __syncthreads();
   }
 
@@ -190,6 +198,8 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_nt_kernel(
 
 // ------------------------------------------------------------------------------------------ TN (wgrad)
 // LDS plane of a 32(k) x 128(col) 16-bit tile: row kr at kr * 256 B, 32-B chunk q (16 columns) stored at q ^ (kr & 7).
+// (two workgroups per CU with a double-buffered stage here: three single-buffered ones measured 275 against 298 TFLOP/s -- the
+// token-major operand rows of this form were whole-line loads from the start)
 template <typename F>
 __global__ __launch_bounds__(256, 2) void gemm_x3_tn_kernel(
     int M, int N, int K, const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ out,

@@ -335,7 +335,7 @@ int simx_x3_gemm_nt(hipStream_t s, int fmt, int epi, int M, int N, int K, const 
 bool simx_x3_tn_ok(int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* C, int ldc);
 size_t simx_x3_tn_workspace_bytes(int M, int N, int K);
 int simx_x3_gemm_tn(hipStream_t s, int fmt, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                    int accumulate, void* ws, size_t ws_bytes);
+                    int accumulate, void* ws, size_t ws_bytes, float* dbias);
 // run STMT with TT bound to the element type of `dtype` (the three activation types of the engine)
 #define SIMX_DISPATCH3(DTYPE, TT, ...)                                   \
   do {                                                                   \

@@ -1759,11 +1759,11 @@ static int gemm_tn_impl(simx_stream_t stream, int dtype, int M, int N, int K, co
   SIMX_REQUIRE(M > 0 && N > 0 && K > 0, SIMX_ERR_BAD_SHAPE, "gemm_tn: bad shape %d %d %d", M, N, K);
   SIMX_REQUIRE(lda >= M && ldb >= N && ldc >= N, SIMX_ERR_BAD_SHAPE, "gemm_tn: leading dims too small");
   if (simx_is_f32(dtype)) {
-    if (dbias) { int rcb = simx_colsum_gs(stream, SIMX_F32, K, M, A, lda, dbias, 1, gs); if (rcb) return rcb; }
     SIMX_REQUIRE(gs == nullptr, SIMX_ERR_UNSUPPORTED, "gemm_tn: the f32 engine carries no gradient scale");
-    if (dtype != SIMX_F32 && simx_x3_tn_ok(M, N, K, (const float*)A, lda, (const float*)B, ldb, C, ldc))
+    if (dtype != SIMX_F32 && simx_x3_tn_ok(M, N, K, (const float*)A, lda, (const float*)B, ldb, C, ldc))   // (bias gradient fused)
       return simx_x3_gemm_tn(s, dtype == SIMX_F32_SPLIT_H ? SIMX_F16 : SIMX_BF16, M, N, K, (const float*)A, lda, (const float*)B, ldb, C, ldc,
-                             accumulate, ws, ws_bytes);
+                             accumulate, ws, ws_bytes, dbias);
+    if (dbias) { int rcb = simx_colsum_gs(stream, SIMX_F32, K, M, A, lda, dbias, 1, gs); if (rcb) return rcb; }
     return launch_simple<float, float>(s, SIMX_EPI_NONE, M, N, K, (const float*)A, 1, lda, (const float*)B, ldb, 1, C,
                                        ldc, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, accumulate, DropCtx{0u, 1.f, 0u, 0u}, ws, ws_bytes);
   }

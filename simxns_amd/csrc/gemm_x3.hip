@@ -203,7 +203,10 @@ __global__ __launch_bounds__(256, 3) void gemm_x3_nt_kernel(
 template <typename F>
 __global__ __launch_bounds__(256, 2) void gemm_x3_tn_kernel(
     int M, int N, int K, const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ out,
-    long slab_stride, int ldo, int tiles_n, int tiles_mn, int k_per_split, int accumulate) {
+    long slab_stride, int ldo, int tiles_n, int tiles_mn, int k_per_split, int accumulate, float* __restrict__ dbias, int dbias_parts) {
+  // dbias: the bias gradient = column sums of A over the tokens, taken from the staging registers of the workgroups of the
+  // first N-tile (a separate column-sum pass re-read A: 17.7 ms per fp32 step).  dbias_parts (deterministic mode): dbias
+  // is a [splits][M] partial buffer instead of the accumulation target.
   __shared__ __attribute__((aligned(16))) char smem[2 * X3_STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -231,7 +234,13 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_tn_kernel(
       rb[e] = (kin && n0 + sc4 + 3 < N) ? *reinterpret_cast<const float4*>(B + (long)k * ldb + n0 + sc4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
+  const bool do_bias = dbias != nullptr && n0 == 0;
+  float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
   auto sstore = [&](char* stage) {
+    if (do_bias) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bs.x += ra[e].x; bs.y += ra[e].y; bs.z += ra[e].z; bs.w += ra[e].w; }
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int kr = skr + 8 * e;
@@ -282,6 +291,18 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_tn_kernel(
       }
     if (st + 1 < nst) sstore(smem + ((st + 1) & 1) * X3_STAGE);
     __syncthreads();
+  }
+  if (do_bias) {                                   // (uniform per workgroup) 8 token-row lanes per column group -> one sum per column
+    float* red = reinterpret_cast<float*>(smem);   // the loop's last barrier has passed: the stages are free
+    *reinterpret_cast<float4*>(red + skr * 128 + sc4) = bs;
+    __syncthreads();
+    if (tid < 128 && m0 + tid < M) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) t += red[r * 128 + tid];
+      if (dbias_parts) dbias[(long)split * M + m0 + tid] = t;
+      else atomicAdd(dbias + m0 + tid, t);
+    }
   }
   float* o = out + (long)split * slab_stride;
 #pragma unroll
@@ -345,20 +366,28 @@ size_t simx_x3_tn_workspace_bytes(int M, int N, int K) {
   return sp > 1 ? (size_t)sp * M * N * sizeof(float) : 0;
 }
 int simx_x3_gemm_tn(hipStream_t s, int fmt, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                    int accumulate, void* ws, size_t ws_bytes) {
+                    int accumulate, void* ws, size_t ws_bytes, float* dbias) {
   int sp, kps;
   x3_tn_plan(M, N, K, &sp, &kps);
   const int t_n = cdiv(N, X3_BN), t_mn = cdiv(M, X3_BM) * t_n;
   if (sp > 1 && (!ws || ws_bytes < (size_t)sp * M * N * sizeof(float) || !al16(ws))) { sp = 1; kps = cdiv(K, X3_BK) * X3_BK; }
+  float* dbias_out = dbias;
+  if (dbias && simx_det()) {                      // ordered bias gradient: one partial row per split
+    dbias = simx_det_ws(s, (size_t)sp * M * sizeof(float));
+    if (!dbias) return SIMX_ERR_WORKSPACE;
+  }
+  const int dparts = dbias != dbias_out;
   if (sp == 1) {
     SIMX_DISPATCH16(fmt, FF, hipLaunchKernelGGL(gemm_x3_tn_kernel<FF>, dim3(t_mn), dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, 0L, ldc, t_n, t_mn,
-                                                kps, accumulate));
+                                                kps, accumulate, dbias, dparts));
     SIMX_CHECK_LAUNCH("gemm_x3_tn");
+    if (dparts) return simx_det_reduce(s, dbias, (long)M, sp, M, dbias_out, nullptr, nullptr, nullptr);
     return SIMX_OK;
   }
   SIMX_DISPATCH16(fmt, FF, hipLaunchKernelGGL(gemm_x3_tn_kernel<FF>, dim3(t_mn * sp), dim3(256), 0, s, M, N, K, A, lda, B, ldb, (float*)ws,
-                                              (long)M * N, N, t_n, t_mn, kps, 0));
+                                              (long)M * N, N, t_n, t_mn, kps, 0, dbias, dparts));
   SIMX_CHECK_LAUNCH("gemm_x3_tn");
+  if (dparts) { int rcd = simx_det_reduce(s, dbias, (long)M, sp, M, dbias_out, nullptr, nullptr, nullptr); if (rcd) return rcd; }
   const long tot4 = (long)M * N / 4;
   int rb = (int)((tot4 + 255) / 256);
   if (rb > 2048) rb = 2048;

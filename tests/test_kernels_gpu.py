@@ -207,6 +207,15 @@ def test_gemm_tn_f32_split(dev, code_, M, N, K, accumulate):
     scale = np.abs(A).mean() * np.abs(B).mean() * math.sqrt(K)
     t = dict(rtol=2e-5, atol=3e-5 * scale) if code_ == 3 else dict(rtol=1e-4, atol=1e-4 * scale)
     assert_close(back(outs[0]), ref, what="split gemm_tn", **t)
+    # the fused bias gradient (column sums of A taken from the staging registers): exact f32 sums, accumulated into dbias
+    db0 = rnd((M,), 4)
+    ddb = to_dev(db0, dev)
+    dC = to_dev(C0, dev)
+    lib.call("simx_gemm_tn_bias", lib.stream_ptr(), code_, M, N, K, lib.ptr(dA), M, lib.ptr(dB), N, lib.ptr(dC), N, accumulate, lib.ptr(ws), wsb,
+             lib.ptr(ddb))
+    torch.cuda.synchronize()
+    assert torch.equal(dC, outs[0])
+    assert_close(back(ddb), A.astype(np.float64).sum(0) + db0, rtol=1e-5, atol=1e-5 * np.abs(A).mean() * K, what="split gemm_tn bias gradient")
 
 
 # ------------------------------------------------------------------------------------------ GEMM TN (wgrad)

@@ -689,7 +689,7 @@ extern "C" int simx_ln_bwd_gs(simx_stream_t stream, int dtype, int T, int H, con
 extern "C" int simx_ln_bwd_res(simx_stream_t stream, int dtype, int T, int H, const void* z, const void* res_hi, const void* res_lo,
                                const float* gamma, float eps, const void* dy, void* dz, void* dz_masked, float* dgamma, float* dbeta,
                                float* dbias, const simx_dropout* dropd, const int32_t* row_keys, const float* gs) {
-  SIMX_PROF(SIMX_K_LN_BWD, stream, (double)T * H * ((3 + (res_hi ? 1 : 0)) * simx_esz(dtype) + (res_lo ? 1 : 0)));
+  SIMX_PROF(SIMX_K_LN_BWD, stream, (double)T * H * ((3 + (res_hi ? 1 : 0) + (dz_masked ? 1 : 0)) * simx_esz(dtype) + (res_lo ? 1 : 0)));
   SIMX_REQUIRE(!res_lo || simx_is16(dtype), SIMX_ERR_BAD_DTYPE, "ln_bwd_res: the stream correction exists for the 16-bit dtypes only");
   int rc = ln_check(dtype, T, H, "ln_bwd");
   if (rc) return rc;

@@ -160,16 +160,32 @@ __global__ __launch_bounds__(256, 3) void gemm_x3_nt_kernel(
     __syncthreads();
   }
 
-  // epilogue: lane holds row m = .. + fr, columns n = .. + fg*4 .. +3 of each 16x16 tile
+  // epilogue through LDS.  In the MFMA layout a lane holds row fr, 4 columns of 16-column block j: a 16-B store per lane then
+  // covers 16 rows x 64 B = sixteen half lines per instruction, and so do the residual / aux loads -- the memory path is
+  // bound by requests, and with the epilogue removed the kernel ran 40 % faster (tools/variants, seven bench shapes).  Each
+  // wave therefore passes its 64 x 64 tile through its own 4.25 KB of the (now free) stage buffer, 16 rows at a time, and
+  // leaves with rows as the fast index: lane l owns columns 4 (l & 15) .. + 3 of row (l >> 4) + 4 it, i.e. every 16-B load
+  // and store instruction covers 4 rows x 256 B = eight full lines.  (Row pitch 68 floats: the writes of 8 rows at one
+  // column offset land on 8 different bank groups.)  Only this wave touches its region, and a wave's LDS operations are
+  // served in issue order: no barrier.  (+1 % only: with every accumulator kept live but nothing stored the kernel is 16 %
+  // faster, and that difference is the HBM time of the f32 outputs and epilogue inputs -- 6.4 GB for the GELU pair;
+  // non-temporal stores / loads +0.6 %.)
+  float* ep = reinterpret_cast<float*>(smem) + wave * (16 * 68);
+  const int er = lane >> 4, ec = (lane & 15) * 4;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wr * 64 + i * 16 + fr;
-    if (m >= M) continue;
+    asm volatile("" ::: "memory");
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wc * 64 + j * 16 + fg * 4;
-      if (n >= N) continue;                        // (N % 4 == 0 is required: a lane's 4 columns are all in or all out)
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<float4*>(ep + fr * 68 + j * 16 + fg * 4) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int r = it * 4 + er;
+      const int m = m0 + wr * 64 + i * 16 + r, n = n0 + wc * 64 + ec;
+      const float4 t = *reinterpret_cast<const float4*>(ep + r * 68 + ec);
+      if (m >= M || n >= N) continue;              // (N % 4 == 0 is required: a lane's 4 columns are all in or all out)
+      float v[4] = {t.x, t.y, t.z, t.w};
       if (bias) {
         const float4 bv = *reinterpret_cast<const float4*>(bias + n);
         v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;

@@ -161,8 +161,7 @@ __global__ __launch_bounds__(256, 3) void gemm_x3_nt_kernel(
   }
 
   // epilogue through LDS.  In the MFMA layout a lane holds row fr, 4 columns of 16-column block j: a 16-B store per lane then
-  // covers 16 rows x 64 B = sixteen half lines per instruction, and so do the residual / aux loads -- the memory path is
-  // bound by requests, and with the epilogue removed the kernel ran 40 % faster (tools/variants, seven bench shapes).  Each
+  // covers 16 rows x 64 B = sixteen half lines per instruction, and so do the residual / aux loads.  Each
   // wave therefore passes its 64 x 64 tile through its own 4.25 KB of the (now free) stage buffer, 16 rows at a time, and
   // leaves with rows as the fast index: lane l owns columns 4 (l & 15) .. + 3 of row (l >> 4) + 4 it, i.e. every 16-B load
   // and store instruction covers 4 rows x 256 B = eight full lines.  (Row pitch 68 floats: the writes of 8 rows at one

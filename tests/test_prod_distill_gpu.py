@@ -85,17 +85,22 @@ def test_prod_cross_encoder_distill_step_fp32_vs_reference_golden(dev, golden_di
     assert abs(loss0 - float(G["loss_nolwf"])) <= 1e-3
 
 
-def test_prod_cross_encoder_distill_step_bf16(dev, golden_dir):
+# measured on MI355X (loss 3.63): fp16 (apex-O1 form) loss error 2e-4, gradient norms 0.03 % median / 0.2 % max; bf16 loss error
+# 0.16 (the T = 4 KD / LwF terms see the bf16 logit error of ~1.5 on scores of O(30)), gradient norms 3.2 % / 6.6 %.  Bounds = 2-5x.
+CFG4_TOL = {"fp16": dict(loss=2e-3, gmed=2e-3, gmax=0.01), "bf16": dict(loss=0.35, gmed=0.08, gmax=0.2)}
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_prod_cross_encoder_distill_step_16bit(dev, golden_dir, dtype):
     G = np.load(os.path.join(golden_dir, "step_prod_cfg4.npz"))
-    loss, correct, grads, _, _ = _step(G, dev, "bf16")
+    loss, correct, grads, _, _ = _step(G, dev, dtype)
     names = [str(n) for n in G["grad_names"]]
     norms = G["grad_norms"]
     live = norms > 1e-6 * norms.max()
     got = np.array([np.sqrt((grads[n] ** 2).sum()) for n in names])
     rel = np.abs(got - norms)[live] / norms[live]
-    print("cfg4 bf16: loss %.4f vs %.4f (err %.4f), correct %d vs %d, grad-norm rel err median %.4f max %.4f"
-          % (loss, float(G["loss"]), abs(loss - float(G["loss"])), correct, int(G["correct"]), np.median(rel), rel.max()))
-    # measured on MI355X: loss error 0.16 on 3.63 (the T=4 KD / LwF terms see the bf16 logit error of ~1.5 on scores of O(30)),
-    # gradient norms: see the printed line; tolerances = 3x measured
-    assert abs(loss - float(G["loss"])) <= 0.5, (loss, float(G["loss"]))
-    assert np.median(rel) <= 0.1 and rel.max() <= 0.5
+    print("cfg4 %s: loss %.4f vs %.4f (err %.4f), correct %d vs %d, grad-norm rel err median %.4f max %.4f"
+          % (dtype, loss, float(G["loss"]), abs(loss - float(G["loss"])), correct, int(G["correct"]), np.median(rel), rel.max()))
+    t = CFG4_TOL[dtype]
+    assert abs(loss - float(G["loss"])) <= t["loss"], (loss, float(G["loss"]))
+    assert np.median(rel) <= t["gmed"] and rel.max() <= t["gmax"]

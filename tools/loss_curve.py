@@ -1,7 +1,8 @@
 """Training-trajectory check on the GPU (not part of bench.py's metric): the SAME retriever job -- two BERT-base towers,
 frozen cross-encoder teacher, SimANS draw, KL-distill loss, clip 2.0 + AdamW + warm-up, dropout 0.1 -- run for N optimiser
-steps in the bf16 engine and in the fp32 (1e-3 parity) engine from identical weights, data and dropout masks.  Prints the two
-loss curves and their distance; the committed output is profiles/r02_loss_curve.json.
+steps in the fp16 (apex-O1 form, dynamic loss scale), bf16 and fp32 engines from identical weights, data and dropout masks.
+Prints the loss curves, their distances from the fp32 curve and the fp16 engine's scaler state; the committed outputs are
+profiles/r02_loss_curve.json (bf16 / fp32) and profiles/r03_loss_curve.json (all three).
 usage: python tools/loss_curve.py [steps=60] [B=32] [N=15]"""
 import json
 import sys
@@ -64,16 +65,24 @@ def run(dtype):
         opt.step(max_grad_norm=2.0, world_size=1)
         sch.step()
         losses.append(float(loss.item()))
+    scaler = opt.scaler.snapshot() if getattr(opt, "scaler", None) is not None else None
     del bi, teacher, opt
     torch.cuda.empty_cache()
-    return losses
+    return losses, scaler
 
 
-a, b = run("bf16"), run("fp32")
-d = np.abs(np.array(a) - np.array(b))
-print(json.dumps({"job": "retriever step x %d, B=%d, %d negatives of %d candidates, 4 batches revisited, lr 2e-5 (warm-up 10), dropout 0.1, "
-                         "clip 2.0; identical weights / data / dropout masks in both engines" % (steps, B, N, Cn),
-                  "loss_bf16": [round(x, 4) for x in a], "loss_fp32": [round(x, 4) for x in b],
-                  "first_loss": [round(a[0], 4), round(b[0], 4)], "last5_mean": [round(float(np.mean(a[-5:])), 4), round(float(np.mean(b[-5:])), 4)],
-                  "max_abs_diff": round(float(d.max()), 4), "mean_abs_diff": round(float(d.mean()), 4),
-                  "rel_diff_of_last5_mean": round(float(abs(np.mean(a[-5:]) - np.mean(b[-5:])) / abs(np.mean(b[-5:]))), 4)}))
+curves, scalers = {}, {}
+for dt in ("fp16", "bf16", "fp32"):
+    curves[dt], scalers[dt] = run(dt)
+ref = np.array(curves["fp32"])
+out = {"job": "retriever step x %d, B=%d, %d negatives of %d candidates, 4 batches revisited, lr 2e-5 (warm-up 10), dropout 0.1, "
+              "clip 2.0; identical weights / data / dropout masks in all engines" % (steps, B, N, Cn),
+       "fp16_loss_scaler": scalers["fp16"]}
+for dt in ("fp16", "bf16", "fp32"):
+    c = np.array(curves[dt])
+    d = np.abs(c - ref)
+    out["loss_" + dt] = [round(float(x), 4) for x in c]
+    out["summary_" + dt] = {"first": round(float(c[0]), 4), "last5_mean": round(float(c[-5:].mean()), 4),
+                            "max_abs_diff_vs_fp32": round(float(d.max()), 4), "mean_abs_diff_vs_fp32": round(float(d.mean()), 4),
+                            "rel_diff_of_last5_mean_vs_fp32": round(float(abs(c[-5:].mean() - ref[-5:].mean()) / abs(ref[-5:].mean())), 4)}
+print(json.dumps(out))

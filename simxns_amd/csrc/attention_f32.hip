@@ -34,6 +34,20 @@ __device__ __forceinline__ void af_stage(const float* __restrict__ G, long ld, i
     d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
   }
 }
+// dense form for the forward at 160 tokens (5 key tiles): pitch 64, the K tile XOR-swizzled (column c of row r at c ^ (r & 31):
+// the 32 lanes of a "T" read walk 32 rows at one logical column and land on 32 banks; "N" reads of V walk columns and need
+// nothing).  K + V are then exactly 80 KB and TWO workgroups fit a CU -- with the padded pitch it was one, and its fifth query
+// tile ran on one wave while three idled: 3.6 ms per launch against 1.53 for 128 tokens.
+__device__ __forceinline__ void af_stage_dense(const float* __restrict__ G, long ld, int len, int npad, float* __restrict__ S, int tid, bool swz) {
+  for (int idx = tid; idx < npad * 16; idx += 256) {
+    const int r = idx >> 4, c4 = (idx & 15) * 4;
+    const int gr = r < len ? r : len - 1;
+    const float4 v = *reinterpret_cast<const float4*>(G + (long)gr * ld + c4);
+    float* d = S + r * 64;
+    const int x = swz ? (r & 31) : 0;
+    d[(c4 + 0) ^ x] = v.x; d[(c4 + 1) ^ x] = v.y; d[(c4 + 2) ^ x] = v.z; d[(c4 + 3) ^ x] = v.w;
+  }
+}
 // a lane's half row (32 floats: columns 32*half .. +31 of row `row`) of a [.., ld] matrix, into registers
 __device__ __forceinline__ void af_row_regs(const float* __restrict__ G, long ld, int row, int half, float (&r)[32]) {
   const float4* p = reinterpret_cast<const float4*>(G + (long)row * ld + 32 * half);
@@ -51,12 +65,13 @@ __device__ __forceinline__ void af_store_t(const f32x16 (&o)[2], float mul, floa
 }
 
 // ------------------------------------------------------------------------------------------ forward
-template <int NKT>
-__global__ __launch_bounds__(256) void mha_fwd_f32_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, float* __restrict__ lse,
+template <int NKT, bool DENSE = false>
+__global__ __launch_bounds__(256, DENSE ? 2 : 1) void mha_fwd_f32_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, float* __restrict__ lse,
                                                           const int* __restrict__ cu, int heads, int T, float scale, DropCtx drop) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int PITCH = DENSE ? 64 : AF_PITCH;
   float* sK = reinterpret_cast<float*>(smem);
-  float* sV = sK + NKT * 32 * AF_PITCH;
+  float* sV = sK + NKT * 32 * PITCH;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int seq = blockIdx.x / heads, h = blockIdx.x % heads;
@@ -66,8 +81,13 @@ __global__ __launch_bounds__(256) void mha_fwd_f32_kernel(const float* __restric
   const long H3 = 3L * H;
   const float* Qg = qkv + (long)t0 * H3 + h * 64;
   const int nkt = (len + 31) >> 5;
-  af_stage(Qg + H, H3, len, nkt * 32, sK, tid);
-  af_stage(Qg + 2 * H, H3, len, nkt * 32, sV, tid);
+  if (DENSE) {
+    af_stage_dense(Qg + H, H3, len, nkt * 32, sK, tid, true);
+    af_stage_dense(Qg + 2 * H, H3, len, nkt * 32, sV, tid, false);
+  } else {
+    af_stage(Qg + H, H3, len, nkt * 32, sK, tid);
+    af_stage(Qg + 2 * H, H3, len, nkt * 32, sV, tid);
+  }
   __syncthreads();
   const int col = lane & 31, half = lane >> 5;
   const float c2 = scale * AF_LOG2E;
@@ -83,9 +103,9 @@ __global__ __launch_bounds__(256) void mha_fwd_f32_kernel(const float* __restric
 #pragma unroll
       for (int e = 0; e < 16; ++e) s[kt][e] = 0.f;
       if (kt < nkt) {
-        const float* ak = sK + (kt * 32 + col) * AF_PITCH + 32 * half;
+        const float* ak = sK + (kt * 32 + col) * PITCH + 32 * half;
 #pragma unroll
-        for (int t = 0; t < 32; ++t) s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ak[t], qr[t], s[kt], 0, 0, 0);
+        for (int t = 0; t < 32; ++t) s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ak[DENSE ? (t ^ col) : t], qr[t], s[kt], 0, 0, 0);
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int key = kt * 32 + af_row(e, half);
@@ -124,7 +144,7 @@ __global__ __launch_bounds__(256) void mha_fwd_f32_kernel(const float* __restric
       if (kt < nkt) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const float* av = sV + (kt * 32 + af_row(e, half)) * AF_PITCH + col;
+          const float* av = sV + (kt * 32 + af_row(e, half)) * PITCH + col;
           o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], s[kt][e], o[0], 0, 0, 0);
           o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[32], s[kt][e], o[1], 0, 0, 0);
         }
@@ -323,17 +343,19 @@ bool simx_mha_f32_ok(int d, int max_len) {
 int simx_mha_fwd_f32(hipStream_t s, int nseq, int heads, const int32_t* cu, int max_len, int T, const float* qkv, float* ctx, float* lse,
                      float scale, DropCtx drop) {
   int rc = SIMX_OK;
-#define LF(NKT)                                                                                                            \
+#define LF(NKT, DENSE)                                                                                                     \
   do {                                                                                                                     \
-    const size_t lds = (size_t)2 * NKT * 32 * AF_PITCH * sizeof(float);                                                    \
-    rc = af_set_lds(mha_fwd_f32_kernel<NKT>, lds, "mha_fwd_f32");                                                          \
+    const size_t lds = (size_t)2 * NKT * 32 * (DENSE ? 64 : AF_PITCH) * sizeof(float);                                     \
+    rc = af_set_lds((mha_fwd_f32_kernel<NKT, DENSE>), lds, "mha_fwd_f32");                                                 \
     if (rc) return rc;                                                                                                     \
-    hipLaunchKernelGGL((mha_fwd_f32_kernel<NKT>), dim3(nseq * heads), dim3(256), lds, s, qkv, ctx, lse, cu, heads, T, scale, drop); \
+    hipLaunchKernelGGL((mha_fwd_f32_kernel<NKT, DENSE>), dim3(nseq * heads), dim3(256), lds, s, qkv, ctx, lse, cu, heads, T, scale, drop); \
   } while (0)
-  if (max_len <= 32) LF(1);
-  else if (max_len <= 128) LF(4);
-  else if (max_len <= 160) LF(5);
-  else LF(8);
+  static const bool dense5 = [] { const char* e = getenv("SIMX_MHA_F32_DENSE"); return !e || e[0] != '0'; }();
+  if (max_len <= 32) LF(1, false);
+  else if (max_len <= 128) LF(4, false);
+  else if (max_len <= 160 && dense5) LF(5, true);   // exactly 80 KB: two workgroups per CU
+  else if (max_len <= 160) LF(5, false);
+  else LF(8, false);
 #undef LF
   SIMX_CHECK_LAUNCH("mha_fwd_f32");
   return SIMX_OK;

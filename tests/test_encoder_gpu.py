@@ -560,7 +560,9 @@ def test_gradient_checkpointing_and_ranged_backward_change_nothing(dev, golden_d
         if mode == "ranges":                  # slices tile the flat buffer top-down, no gap, no overlap
             assert len(fired) == 3 and fired[0][1] == enc.engine.n_params and fired[-1][0] == 0
             assert all(fired[i][0] == fired[i + 1][1] for i in range(2))
-    tol = 1e-6 if dtype == "fp32" else 2e-2
+    # (fp32: the largest gradient is the token-type row, an atomic f32 sum over every token of the batch: two runs of the SAME
+    # mode differ by up to ~1e-6 of it in the summation order; SIMX_DETERMINISTIC=1 removes that, tests/test_det_gpu.py)
+    tol = 5e-6 if dtype == "fp32" else 2e-2
     gscale = np.abs(res["keep"][1]).max()
     for mode in ("ckpt", "ranges"):
         assert np.array_equal(res[mode][0], res["keep"][0]), "embeddings differ (%s)" % mode

@@ -332,10 +332,6 @@ bool simx_x3_nt_ok(int M, int N, int K, const float* A, int lda, const float* B,
                    const float* res, int ldr, const float* aux, int ldaux, const float* C2, int ldc2);
 int simx_x3_gemm_nt(hipStream_t s, int fmt, int epi, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                     const float* bias, const float* res, int ldr, const float* aux, int ldaux, float* C2, int ldc2, DropCtx drop);
-// half-size persistent NT kernel for the GELU forward shapes (gemm_h2.hip)
-bool simx_h2_ok(int M, int N, int K, int epilogue, const void* residual, int lda, int ldb, int ldc, int ldc2);
-int simx_h2_gemm_nt(hipStream_t s, int dtype, int epilogue, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
-                    const float* bias, void* C2, int ldc2, int ncu);
 bool simx_x3_tn_ok(int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* C, int ldc);
 size_t simx_x3_tn_workspace_bytes(int M, int N, int K);
 int simx_x3_gemm_tn(hipStream_t s, int fmt, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,

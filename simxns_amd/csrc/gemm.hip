@@ -1583,11 +1583,6 @@ extern "C" int simx_gemm_nt_ex(simx_stream_t stream, int dtype, int M, int N, in
     // SIMX_GEMM pins a kernel for A/B measurements: v1 = the 128x128 kernel, v5 = the per-tile 256x256 kernel
     static const char* pin = getenv("SIMX_GEMM");
     const bool force_v1 = pin && pin[1] == '1', force_v5 = pin && pin[1] == '5';
-    // SIMX_GEMM=h2: the half-size two-workgroups-per-CU kernel for the GELU forward shapes (gemm_h2.hip; A/B switch)
-    if (pin && pin[0] == 'h' && simx_h2_ok(M, N, K, gelu_infer ? SIMX_EPI_GELU_INFER : epilogue, residual, lda, ldb, ldc, ldc2)) {
-      simx_prof_retag(SIMX_K_GEMM_NT_P3);
-      return simx_h2_gemm_nt(s, dtype, gelu_infer ? SIMX_EPI_GELU_INFER : epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, C2, ldc2, gd->ncu);
-    }
     const int t3m = cdiv(M, 256), t3n = cdiv(N, 256), nwg3 = t3m * t3n;
     // full 256x256 tiles, K >= 256: the persistent kernel, one workgroup per CU
     if (!force_v1 && !force_v5 && nwg3 >= 192 && M % 256 == 0 && N % 256 == 0 && K >= 256 && ldc % 8 == 0 &&

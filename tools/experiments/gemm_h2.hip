@@ -1,3 +1,21 @@
+// EXPERIMENT (not built into the product).  Question (round-2 verdict item 2): do TWO half-size workgroups per CU, out of
+// phase, hide the GELU epilogue of the FFN-in GEMM under each other's main loops?
+//
+// Result (one box, tools/kbench, fp16, M = 262144, N = 3072, K = 768, A/B/A/B against p3, the product kernel):
+//     training form (two outputs):  p3 1.463-1.473 ms (840-845 TFLOP/s)   this kernel 1.860-1.862 ms (664)
+//     inference form (one output):  p3 1.254-1.269 ms (975-986)           this kernel 1.573-1.580 ms (783-786)
+//     main loop alone (epilogue compiled out, all accumulators live):      this kernel 1.237-1.266 ms (977-1000); p3: ~0.95 (1300)
+// Bit-correct (tests/test_kernels_gpu.py -k "gemm_nt_persistent and gelu" with the kernel dispatched: 10 passed).
+// Two things fail at once.  The half-size loop is 30 % slower than p3's: 32-deep stages mean one barrier per 32 MFMAs and
+// 1.5x the LDS-DMA instructions per FLOP, and this version issues them as a burst and waits for all twelve fragment reads
+// before its first MFMA.  And the epilogue is NOT hidden: it still adds 0.33 ms (inference) / 0.60 ms (training) on top of
+// the loop although a second workgroup is resident -- what the epilogue consumes (LDS bandwidth, VALU issue, the store
+// path) is what the other workgroup's main loop is short of as well; the matrix pipe's idle time is not the scarce
+// resource.  A p3-class loop at half size would close the first gap, not the second.  Not pursued.
+//
+// To rebuild: copy to simxns_amd/csrc/, add gemm_h2 to build.sh, declare simx_h2_ok / simx_h2_gemm_nt in common.h and call
+// them from simx_gemm_nt for SIMX_EPI_GELU / _INFER (commit "gemm_h2: half-size ..." has the wiring).
+//
 // Half-size persistent NT GEMM for the GELU shapes: TWO independent 4-wave workgroups per CU instead of p3's one 8-wave
 // workgroup (csrc/gemm.hip), so that one workgroup's epilogue -- two 16-bit outputs and the GELU arithmetic for the FFN-in
 // forward, a multiply by the stored derivative for its dgrad: the instantiations of p3 whose matrix pipes are busy 46-50 %

@@ -9,9 +9,12 @@
 // Two things fail at once.  The half-size loop is 30 % slower than p3's: 32-deep stages mean one barrier per 32 MFMAs and
 // 1.5x the LDS-DMA instructions per FLOP, and this version issues them as a burst and waits for all twelve fragment reads
 // before its first MFMA.  And the epilogue is NOT hidden: it still adds 0.33 ms (inference) / 0.60 ms (training) on top of
-// the loop although a second workgroup is resident -- what the epilogue consumes (LDS bandwidth, VALU issue, the store
-// path) is what the other workgroup's main loop is short of as well; the matrix pipe's idle time is not the scarce
-// resource.  A p3-class loop at half size would close the first gap, not the second.  Not pursued.
+// the loop although a second workgroup is resident.  Caveat on reading that: a loop that is latency-bound cannot speed up
+// when its neighbour leaves for the epilogue, so "not hidden" here is first of all a statement about THIS loop.  What bounds
+// it: not LDS latency -- issuing the fragment reads in consumption order and starting the MFMAs after five of twelve changed
+// nothing (1.866 / 1.565 ms), a second fragment register set spills (728 B of scratch) -- but its operand stream: at 128 x 256
+// a launch pulls 14.5 GB through the L2 (p3's 256 x 256 tiles: 9.7 GB) with a ring that holds two stages in flight (24 KB each;
+// p3: 96 KB in flight), and a third stage in flight does not fit two workgroups into the LDS.  Not pursued.
 //
 // To rebuild: copy to simxns_amd/csrc/, add gemm_h2 to build.sh, declare simx_h2_ok / simx_h2_gemm_nt in common.h and call
 // them from simx_gemm_nt for SIMX_EPI_GELU / _INFER (commit "gemm_h2: half-size ..." has the wiring).

@@ -438,6 +438,10 @@ def main():
                                                 "--steps", "10", "--warmup", "3"],
                                          "train_MS_Pas_AR2.sh:10-14 geometry: micro-batch 16 queries x 16 passages (32768 passage tokens = 384 "
                                          "tiles of 256 x 256 for N = 768: 1.5 waves of the chip), accumulation 2, ernie-2.0-large teacher")
+        out["recipe_of_record"] = side_line(args, ["--dtype", "fp32", "--grad-ckpt", "--batch", "16", "--accum", "2", "--teacher-arch", "large",
+                                                   "--steps", "5", "--warmup", "2"],
+                                            "train_MS_Pas_AR2.sh exactly: fp32 arithmetic, --gradient_checkpointing, micro-batch 16 x 16, "
+                                            "accumulation 2, ernie-2.0-large cross-encoder teacher")
         out["teacher_large"] = side_line(args, ["--dtype", args.dtype, "--teacher-arch", "large", "--steps", "5", "--warmup", "2"],
                                          "headline batch with the recipe's cross-encoder geometry (24 layers, H = 1024, F = 4096, S = 160)")
     if not args.no_cpu_baseline and world == 1:

@@ -411,3 +411,53 @@ def test_ms_doc_generate_job(dev, tmp_path):
     ds = Doc_v2Dataset(path, tok, num_hard_negatives=3, corpus_path=root)
     q, ctx, ce = ds[0]
     assert tuple(q.shape) == (128,) and tuple(ctx.shape) == (4, 512)
+
+
+def test_wiki_iteration_train_generate_train(dev, tmp_path):
+    """One full round of train_NQ_AR2.sh on synthetic data: train job to the first iteration boundary (checkpoint-6), generate job
+    at that step (reads the checkpoint, mines train_ce_6.json into --ann_dir), train job resumed from step 6 on the mined file."""
+    from simxns_amd.utils.dpr_utils import load_states_from_checkpoint
+    from simxns_amd.wiki import co_training_wiki_generate as G
+    from simxns_amd.wiki import co_training_wiki_train as W
+    root = str(tmp_path / "data")
+    _write_corpus(root)
+    rs = np.random.RandomState(5)
+    words = ["w%d" % i for i in range(300)]
+    n_pass, n_q = 240, 16
+    texts = [" ".join(rs.choice(words, size=rs.randint(8, 40))) for _ in range(n_pass)]
+    with open(os.path.join(root, "psgs.tsv"), "w") as f:
+        f.write("id\ttext\ttitle\n")
+        for i, t in enumerate(texts):
+            f.write("%d\t%s\tt%d\n" % (i + 1, t, i))
+    questions = ["what about %s?" % " ".join(rs.choice(words, size=4)) for _ in range(n_q)]
+    answers = [[texts[i].split()[1]] for i in range(n_q)]                  # the gold passage of question i contains its answer
+    for mode in ("train", "dev", "test"):
+        with open(os.path.join(root, "%s.qa.csv" % mode), "w") as f:
+            for q, a in zip(questions, answers):
+                f.write("%s\t%s\n" % (q, repr(a)))
+    mk = lambda pid, s_: dict(text=texts[pid], title="t%d" % pid, score=str(s_), passage_id=str(pid + 1))
+    gold = [dict(question=q, answers=a, positive_ctxs=[mk(i, 80.0)],
+                 hard_negative_ctxs=[mk(int(j), 79.0 - k) for k, j in enumerate(rs.choice(n_pass, size=20, replace=False)) if int(j) != i])
+            for i, (q, a) in enumerate(zip(questions, answers))]
+    for name in ("train_ce_0.json", "dev_ce_0.json"):
+        json.dump(gold, open(os.path.join(root, name), "w"))
+    out, ann = str(tmp_path / "ckpt"), str(tmp_path / "ckpt" / "temp")
+    common = ["--model_type", os.path.join(root, "student"), "--tokenizer_name", "hash", "--max_seq_length", "64", "--output_dir", out,
+              "--origin_data_dir", os.path.join(root, "train_ce_0.json"), "--ann_dir", ann, "--max_steps", "12", "--fp16"]
+    train = common + ["--reranker_model_type", os.path.join(root, "teacher"), "--per_gpu_train_batch_size", "4", "--number_neg", "7",
+                      "--learning_rate", "1e-3", "--reranker_learning_rate", "1e-4", "--log_dir", str(tmp_path / "tb"), "--logging_steps", "2",
+                      "--iteration_step", "6", "--iteration_reranker_step", "2", "--temperature_normal", "1", "--adv_lambda", "0", "--b", "1.0",
+                      "--num_workers", "0"]
+    assert W.main(train + ["--global_step", "0"]) == 6
+    w6 = load_states_from_checkpoint(os.path.join(out, "checkpoint-6")).model_dict
+    gen = common + ["--origin_data_dir_dev", os.path.join(root, "dev_ce_0.json"), "--train_qa_path", os.path.join(root, "train.qa.csv"),
+                    "--dev_qa_path", os.path.join(root, "dev.qa.csv"), "--test_qa_path", os.path.join(root, "test.qa.csv"),
+                    "--passage_path", os.path.join(root, "psgs.tsv"), "--global_step", "6"]
+    assert G.main(gen) == 6
+    mined = json.load(open(os.path.join(ann, "train_ce_6.json")))
+    assert len(mined) == n_q and all(e["positive_ctxs"][0]["passage_id"] == str(i + 1) for i, e in enumerate(mined))
+    assert all(len(e["hard_negative_ctxs"]) >= 7 for e in mined)
+    assert W.main(train + ["--global_step", "6"]) == 12
+    w12 = load_states_from_checkpoint(os.path.join(out, "checkpoint-12")).model_dict
+    k = "ctx_model.encoder.layer.0.output.dense.weight"
+    assert torch.isfinite(w12[k]).all() and not torch.equal(w6[k], w12[k])

@@ -461,3 +461,39 @@ def test_wiki_iteration_train_generate_train(dev, tmp_path):
     w12 = load_states_from_checkpoint(os.path.join(out, "checkpoint-12")).model_dict
     k = "ctx_model.encoder.layer.0.output.dense.weight"
     assert torch.isfinite(w12[k]).all() and not torch.equal(w6[k], w12[k])
+
+
+def test_ms_pas_iteration_train_generate_train_gpu_sampler(dev, tmp_path):
+    """One full round of train_MS_Pas_AR2.sh on synthetic data with the recipe's sampler (--sampler gpu): train to the iteration
+    boundary, generate at that step (checkpoint-6 -> train_ce_6.tsv in --ann_dir), train resumed on the mined file."""
+    from simxns_amd.co_training import co_training_generate as Gn
+    from simxns_amd.co_training import co_training_marco_train as T
+    root = str(tmp_path / "data")
+    _write_corpus(root, n_pass=500, n_q=24)
+    rs = np.random.RandomState(6)
+    with open(os.path.join(root, "train.query.txt"), "w") as f, open(os.path.join(root, "qrels.train.tsv"), "w") as g:
+        for q, line in enumerate(open(os.path.join(root, "train_ce_0.tsv"))):
+            fld = line.rstrip("\n").split("\t")
+            f.write("%s\t%s\n" % (fld[0], fld[1]))
+            g.write("%s 0 %s 1\n" % (fld[0], fld[2].split(" ")[0]))
+    out, ann = str(tmp_path / "ckpt"), str(tmp_path / "ckpt" / "temp")
+    os.makedirs(ann)
+    common = ["--model_type", os.path.join(root, "student"), "--tokenizer_name", "hash", "--output_dir", out, "--passage_path", root,
+              "--ann_dir", ann, "--max_steps", "12", "--fp16", "--train_qa_path", os.path.join(root, "train.query.txt")]
+    train = common + ["--teacher_model_type", os.path.join(root, "teacher"), "--per_gpu_train_batch_size", "4", "--number_neg", "7",
+                      "--learning_rate", "1e-3", "--teacher_learning_rate", "1e-4", "--log_dir", str(tmp_path / "tb"),
+                      "--origin_data_dir", os.path.join(root, "train_ce_0.tsv"), "--logging_steps", "2", "--save_steps", "1000",
+                      "--iteration_step", "6", "--iteration_reranker_step", "2", "--temperature_distill", "1", "--num_workers", "0",
+                      "--sampler", "gpu"]
+    assert T.main(train + ["--global_step", "0"]) == 6
+    import sys
+    argv0 = sys.argv
+    try:
+        sys.argv = ["co_training_generate.py"] + common + ["--global_step", "6"]
+        Gn.main()
+    finally:
+        sys.argv = argv0
+    mined = os.path.join(ann, "train_ce_6.tsv")
+    lines = open(mined).read().splitlines()
+    assert len(lines) == 24 and all(len(l.split("\t")) == 4 and len(l.split("\t")[3].split(",")) >= 100 for l in lines)
+    assert T.main(train + ["--global_step", "6"]) == 12 and os.path.exists(os.path.join(out, "checkpoint-12"))

@@ -497,3 +497,49 @@ def test_ms_pas_iteration_train_generate_train_gpu_sampler(dev, tmp_path):
     lines = open(mined).read().splitlines()
     assert len(lines) == 24 and all(len(l.split("\t")) == 4 and len(l.split("\t")[3].split(",")) >= 100 for l in lines)
     assert T.main(train + ["--global_step", "6"]) == 12 and os.path.exists(os.path.join(out, "checkpoint-12"))
+
+
+def test_ms_doc_iteration_train_generate_train(dev, tmp_path):
+    """One full round of train_MS_Doc_AR2.sh on synthetic data: RobertaDot train job to the iteration boundary, generate job at that
+    step (D-prefixed corpus / qrels beside the query file), train job resumed on the mined train_ce_6.tsv."""
+    from simxns_amd.Doc_training import co_training_doc_generate as G
+    from simxns_amd.Doc_training import co_training_doc_train as D
+    root = str(tmp_path / "doc")
+    os.makedirs(root)
+    rs = np.random.RandomState(8)
+    words = ["w%d" % i for i in range(400)]
+    n_doc, n_q = 230, 16
+    with open(os.path.join(root, "msmarco-docs.tsv"), "w") as f:
+        for pid in range(n_doc):
+            f.write("D%d\thttp://u/%d\t%s\t%s\n" % (pid, pid, " ".join(rs.choice(words, size=4)), " ".join(rs.choice(words, size=rs.randint(30, 200)))))
+    with open(os.path.join(root, "train_ce_0.tsv"), "w") as f, open(os.path.join(root, "msmarco-doctrain-queries.tsv"), "w") as qf, \
+            open(os.path.join(root, "msmarco-doctrain-qrels.tsv"), "w") as g:
+        for q in range(n_q):
+            pids = rs.choice(n_doc, size=21, replace=False)
+            sp = 70 + 20 * rs.rand()
+            sc = np.sort(sp - np.abs(rs.randn(20)) * 1.5)[::-1]
+            text = " ".join(rs.choice(words, size=7))
+            f.write("%d\t%s\t%d %.4f\t%s\n" % (q, text, pids[0], sp, ",".join("%d %.4f" % (p, s) for p, s in zip(pids[1:], sc))))
+            qf.write("%d\t%s\n" % (q, text))
+            g.write("%d 0 D%d 1\n" % (q, pids[0]))
+    for name in ("student", "teacher"):
+        d = os.path.join(root, name)
+        os.makedirs(d)
+        json.dump(dict(vocab_size=50265, hidden_size=64, num_hidden_layers=2, num_attention_heads=1, intermediate_size=128,
+                       max_position_embeddings=514, type_vocab_size=1, layer_norm_eps=1e-5, model_type="roberta", pad_token_id=1),
+                  open(os.path.join(d, "config.json"), "w"))
+    out, ann = str(tmp_path / "ckpt"), str(tmp_path / "ckpt" / "temp")
+    common = ["--model_type", os.path.join(root, "student"), "--tokenizer_name", "hash", "--output_dir", out, "--passage_path", root,
+              "--ann_dir", ann, "--max_steps", "12", "--fp16", "--train_qa_path", os.path.join(root, "msmarco-doctrain-queries.tsv")]
+    train = common + ["--teacher_model_type", os.path.join(root, "teacher"), "--per_gpu_train_batch_size", "2", "--number_neg", "3",
+                      "--learning_rate", "1e-3", "--teacher_learning_rate", "1e-4", "--log_dir", str(tmp_path / "tb"),
+                      "--origin_data_dir", os.path.join(root, "train_ce_0.tsv"), "--logging_steps", "2", "--save_steps", "1000",
+                      "--iteration_step", "6", "--iteration_reranker_step", "2", "--temperature_distill", "1", "--num_workers", "0",
+                      "--a", "0.5", "--b", "0"]
+    assert D.main(train + ["--global_step", "0"]) == 6
+    res = G.main(common + ["--global_step", "6", "--max_seq_length", "512"])
+    result, path = res["train"]
+    assert path == os.path.join(ann, "train_ce_6.tsv") and result["QueriesRanked"] == n_q
+    kept = open(path).read().splitlines()
+    assert 2 <= len(kept) <= n_q
+    assert D.main(train + ["--global_step", "6"]) == 12 and os.path.exists(os.path.join(out, "checkpoint-12"))

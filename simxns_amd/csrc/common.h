@@ -332,6 +332,11 @@ bool simx_x3_nt_ok(int M, int N, int K, const float* A, int lda, const float* B,
                    const float* res, int ldr, const float* aux, int ldaux, const float* C2, int ldc2);
 int simx_x3_gemm_nt(hipStream_t s, int fmt, int epi, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                     const float* bias, const float* res, int ldr, const float* aux, int ldaux, float* C2, int ldc2, DropCtx drop);
+// grouped weight cast (gemm.hip): up to SIMX_CAST_GROUP_MAX matrices in one launch (2.5 KB of kernel arguments); out / outT may be NULL per job
+#define SIMX_CAST_GROUP_MAX 64
+struct SimxCastJob { const float* w; void* out; void* outT; int rows, cols, tile_end, pad_; };   // tile_end: cumulative 32 x 32 tiles
+struct SimxCastGroup { int n; SimxCastJob job[SIMX_CAST_GROUP_MAX]; };
+int simx_transpose_cast_group(hipStream_t s, int out_dtype, const SimxCastGroup* g);
 bool simx_x3_tn_ok(int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* C, int ldc);
 size_t simx_x3_tn_workspace_bytes(int M, int N, int K);
 int simx_x3_gemm_tn(hipStream_t s, int fmt, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,

@@ -227,18 +227,22 @@ extern "C" int simx_bert_cast_weights(simx_stream_t stream, const simx_bert_cfg*
   SIMX_REQUIRE(cfg_ok(c), SIMX_ERR_BAD_SHAPE, "bert_cast_weights: bad config");
   SIMX_REQUIRE(params && wcache, SIMX_ERR_BAD_SHAPE, "bert_cast_weights: NULL buffer");
   const int H = c->hidden, F = c->inter;
+  const bool f32 = c->dtype == SIMX_F32;
+  static thread_local SimxCastGroup g;              // (built in place, passed by value at the launch)
+  g.n = 0;
+  auto add = [&](const float* w, int rows, int cols, const char* out, const char* outT) -> int {
+    if (g.n == SIMX_CAST_GROUP_MAX) { RUN(simx_transpose_cast_group((hipStream_t)stream, c->dtype, &g)); g.n = 0; }
+    g.job[g.n++] = SimxCastJob{w, f32 ? nullptr : (void*)out, (void*)outT, rows, cols, 0, 0};
+    return SIMX_OK;
+  };
   for (int l = 0; l < c->layers; ++l) {
     const WLayer w = wlayer(c, params, wcache, l);
-    const bool f32 = c->dtype == SIMX_F32;
-    RUN(simx_transpose_cast(stream, c->dtype, params + simx_bert_param_offset(c, l, SIMX_P_WQKV), 3 * H, H,
-                            f32 ? nullptr : (void*)w.wqkv, (void*)w.wqkvT));
-    RUN(simx_transpose_cast(stream, c->dtype, params + simx_bert_param_offset(c, l, SIMX_P_WO), H, H,
-                            f32 ? nullptr : (void*)w.wo, (void*)w.woT));
-    RUN(simx_transpose_cast(stream, c->dtype, params + simx_bert_param_offset(c, l, SIMX_P_W1), F, H,
-                            f32 ? nullptr : (void*)w.w1, (void*)w.w1T));
-    RUN(simx_transpose_cast(stream, c->dtype, params + simx_bert_param_offset(c, l, SIMX_P_W2), H, F,
-                            f32 ? nullptr : (void*)w.w2, (void*)w.w2T));
+    RUN(add(params + simx_bert_param_offset(c, l, SIMX_P_WQKV), 3 * H, H, w.wqkv, w.wqkvT));
+    RUN(add(params + simx_bert_param_offset(c, l, SIMX_P_WO), H, H, w.wo, w.woT));
+    RUN(add(params + simx_bert_param_offset(c, l, SIMX_P_W1), F, H, w.w1, w.w1T));
+    RUN(add(params + simx_bert_param_offset(c, l, SIMX_P_W2), H, F, w.w2, w.w2T));
   }
+  if (g.n) RUN(simx_transpose_cast_group((hipStream_t)stream, c->dtype, &g));
   return SIMX_OK;
 }
 

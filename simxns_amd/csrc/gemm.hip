@@ -1883,6 +1883,50 @@ extern "C" int simx_transpose_cast(simx_stream_t stream, int out_dtype, const fl
   return SIMX_OK;
 }
 
+// One launch for all dense weights of an encoder (blockIdx.z = matrix): per-matrix launches of this 32 x 32-tile kernel take
+// 7.6 us each, 96 of them per step for the two trained towers = 0.8 ms of a 216 ms step for 0.7 GB of traffic.
+template <typename TO>
+__global__ __launch_bounds__(256) void cast_weight_group_kernel(SimxCastGroup g) {
+  int ji = 0;                                      // (uniform scan over the cumulative tile counts)
+  while (ji + 1 < g.n && (int)blockIdx.x >= g.job[ji].tile_end) ++ji;
+  const SimxCastJob j = g.job[ji];
+  const int t = (int)blockIdx.x - (ji ? g.job[ji - 1].tile_end : 0), tc = (j.cols + 31) >> 5;
+  __shared__ float tile[32][33];
+  const int c0 = (t % tc) * 32, r0 = (t / tc) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  TO* o = reinterpret_cast<TO*>(j.out);
+  TO* ot = reinterpret_cast<TO*>(j.outT);
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    float v = 0.f;
+    if (r < j.rows && c < j.cols) { v = j.w[(long)r * j.cols + c]; if (o) Elem<TO>::st(o + (long)r * j.cols + c, v); }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  if (ot)
+    for (int i = ty; i < 32; i += 8) {
+      const int c = c0 + i, r = r0 + tx;
+      if (r < j.rows && c < j.cols) Elem<TO>::st(ot + (long)c * j.rows + r, tile[tx][i]);
+    }
+}
+int simx_transpose_cast_group(hipStream_t s, int out_dtype, const SimxCastGroup* g) {
+  SIMX_REQUIRE(g && g->n > 0 && g->n <= SIMX_CAST_GROUP_MAX, SIMX_ERR_BAD_SHAPE, "transpose_cast_group: bad job count");
+  SIMX_REQUIRE(simx_dtype_ok(out_dtype), SIMX_ERR_BAD_DTYPE, "transpose_cast_group: dtype %d", out_dtype);
+  double bytes = 0;
+  SimxCastGroup gg = *g;
+  int tiles = 0;
+  for (int i = 0; i < gg.n; ++i) {
+    SIMX_REQUIRE(gg.job[i].rows > 0 && gg.job[i].cols > 0 && gg.job[i].w, SIMX_ERR_BAD_SHAPE, "transpose_cast_group: bad job %d", i);
+    tiles += cdiv(gg.job[i].rows, 32) * cdiv(gg.job[i].cols, 32);
+    gg.job[i].tile_end = tiles;
+    bytes += (double)gg.job[i].rows * gg.job[i].cols * 8;
+  }
+  SIMX_PROF(SIMX_K_CAST, s, bytes);
+  SIMX_DISPATCH3(out_dtype, TT, hipLaunchKernelGGL((cast_weight_group_kernel<TT>), dim3(tiles), dim3(256), 0, s, gg));
+  SIMX_CHECK_LAUNCH("cast_weight_group");
+  return SIMX_OK;
+}
+
 extern "C" int simx_cast_weight(simx_stream_t stream, const float* w, int rows, int cols, void* w_bf16, void* wT_bf16) {
   return simx_transpose_cast(stream, SIMX_BF16, w, rows, cols, w_bf16, wT_bf16);
 }

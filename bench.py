@@ -10,7 +10,7 @@ retriever step (SimANS/co_training/co_training_marco_train.py:175-263) with the 
 Workload = BASELINE.json configs[1]: BERT-base, B=128 queries/GPU, 15 hard negatives, q_len 32 / p_len 128 /
 cross-encoder len 160.  Default arithmetic (--dtype fp16) = the operand width of the reference's own optional 16-bit mode
 (apex O1, co_training_marco_train.py:97-104): IEEE-half GEMM / attention operands, f32 accumulation, f32 LayerNorm statistics
-and softmax, an f32-grade residual stream (16-bit value + 16-bit correction, summed in f32 inside the LayerNorm kernels),
+and softmax, an f32-grade residual stream (16-bit value + one correction byte per element, summed in f32 inside the LayerNorm kernels),
 f32 master weights, dynamic loss scaling on the device.  --dtype fp32 is the arithmetic every shipped recipe selects (no
 --fp16 in train_*_AR2.sh) and is reported beside the headline as `fp32_mode` / `recipe_fp32_gradckpt`.  Default lengths are
 the worst case (every sequence at its maximum length); --varlen draws realistic lengths.
@@ -333,7 +333,7 @@ def main():
     tea_issued = 0 if args.no_teacher else tea - args.accum * P * dead(ce_tokens, TH, TF)
     util_ok = is16 and not args.varlen
     arith = {"fp16": "IEEE-half GEMM / attention operands (the operand width of apex O1, the reference's --fp16 mode), f32 accumulation, "
-                     "f32 LayerNorm / softmax, f32-grade residual stream (16-bit value + 16-bit correction), f32 master weights, dynamic "
+                     "f32 LayerNorm / softmax, f32-grade residual stream (16-bit value + one correction byte per element: 19 significand bits), f32 master weights, dynamic "
                      "loss scale on the device",
              "fp16_plain": "as fp16 with a plain 16-bit residual stream (residual added in the GEMM epilogue)",
              "bf16": "bf16 operands and residual stream, f32 accumulation / statistics / master weights",

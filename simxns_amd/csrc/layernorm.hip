@@ -58,9 +58,10 @@ __device__ __forceinline__ void st4_residue(T* p, const float (&o)[4], float (&r
 // reductions, and gamma/beta are read from LDS so the row body never queues behind those loads on vmcnt.
 // RES ("f32-grade residual stream" of the 16-bit engines, simx.h stream_lo): the input row is  z = d + r_hi + r_lo  -- the
 // dense output (bias and dropout applied by the GEMM epilogue, no residual) plus the residual stream kept as a 16-bit value
-// and a 16-bit correction -- summed in f32, and the result leaves as y_hi = round16(y), y_lo = round16(y - y_hi): the
-// stream carries ~22 significand bits from layer to layer (apex O1 keeps it in fp32: residual additions promote to fp32 and
-// LayerNorm is an fp32 function there) at 4 B per element, and z never makes a round trip through HBM.
+// and ONE correction byte (lo8, common.h: x = hi + (b - 128) ulp(hi) / 256) -- summed in f32, and the result leaves as
+// y_hi = round16(y) and the byte that encodes y - y_hi: the stream carries ~19 significand bits from layer to layer (apex O1
+// keeps it in fp32: residual additions promote to fp32 and LayerNorm is an fp32 function there) at 3 B per element, and z
+// never makes a round trip through HBM.
 template <typename T, int VPL, bool RES>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int H, int rows_per_block, const T* __restrict__ z,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,

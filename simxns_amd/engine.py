@@ -278,7 +278,7 @@ class BertEngine(object):
         self._dirty = True
 
     def _stream_lo(self, name):
-        """fp16: the residual stream carries a 16-bit correction beside every 16-bit value and the LayerNorm kernels add the
+        """fp16: the residual stream carries one correction byte beside every 16-bit value and the LayerNorm kernels add the
         residual in f32 (simx.h stream_lo) -- the f32 residual stream / f32 LayerNorm of apex O1, which the reference's --fp16
         mode is.  "fp16_plain" (or SIMX_STREAM_LO=0) keeps a plain 16-bit stream; bf16 defaults to plain, SIMX_STREAM_LO=1 opts in."""
         if self.dtype_code == L.SIMX_F32:

@@ -130,6 +130,35 @@ size_t simx_gemm_f32_workspace_bytes(int M, int N, int K);
 int simx_gemm_f32_strided_ws(simx_stream_t stream, int M, int N, int K, const float* A, long a_rs, long a_cs,
                              const float* B, long b_ks, long b_ns, float* C, int ldc, int accumulate, void* ws, size_t ws_bytes);
 
+/* --------------------------------------------------------- fp32 engine: dense GEMMs on pre-split operand planes
+ * (csrc/gemm_xp.hip; the nn.Linear's of LEAD/modeling_bert.py:285-310, 385, 450, 463 in the fp32 arithmetic every
+ * train_*_AR2.sh selects).  A "plane pair" of an f32 tensor x [rows, cols] is two 16-bit matrices of one format (`fmt`:
+ * SIMX_F16 for forward operands, SIMX_BF16 for backward operands) with a common leading dimension: hi = rnd16(x) at the
+ * pointer, lo = rnd16(x - hi) at pointer + plane_stride ELEMENTS.  Products are hi.lo + lo.hi + hi.hi in f32 accumulators
+ * on the 16-bit matrix cores (as SIMX_F32_SPLIT_H / _B above), but the operands are split ONCE by their producer and
+ * staged by LDS-DMA into the persistent 256x256 kernels.
+ *   C[M,N] = A[M,K] . B[N,K]^T, A / B plane pairs (K-contiguous).  M, N % 256 == 0, K % 64 == 0, K >= 128
+ *   (simx_gemm_nt_planes_ok).  Epilogues:
+ *     SIMX_EPI_NONE        C (f32) = acc + bias, dropout `drop` (SIMX_F16 only, needs `in`), + in (f32 [M,N], may be NULL)
+ *     SIMX_EPI_GELU        SIMX_F16: u = acc + bias; Cp = plane pair of gelu_erf(u); C (f32) = gelu_erf'(u)
+ *     SIMX_EPI_GELU_INFER  as GELU, C not written (may be NULL)
+ *     SIMX_EPI_DGELU       SIMX_BF16: Cp = plane pair of acc * in  (in = the C a GELU launch wrote) */
+int simx_gemm_nt_planes_ok(int M, int N, int K);
+int simx_gemm_nt_planes(simx_stream_t stream, int fmt, int epilogue, int M, int N, int K, const void* A, int lda, long a_plane_stride,
+                        const void* B, int ldb, long b_plane_stride, float* C, int ldc, const float* bias, const float* in, int ldin,
+                        void* Cp, int ldcp, long cp_plane_stride, const simx_dropout* drop);
+/* wgrad: C[M,N] (+)= A[K,M]^T . B[K,N], A = dY, B = X as SIMX_BF16 plane pairs (K = tokens); dbias[M] (may be NULL) +=
+ * column sums of A.  Split over K into f32 slabs added in slice order; ws >= simx_gemm_tn_planes_workspace_bytes. */
+size_t simx_gemm_tn_planes_workspace_bytes(int M, int N, int K);
+int simx_gemm_tn_planes(simx_stream_t stream, int M, int N, int K, const void* A, int lda, long a_plane_stride, const void* B, int ldb,
+                        long b_plane_stride, float* C, int ldc, int accumulate, void* ws, size_t ws_bytes, float* dbias);
+/* plane pair (dst_fmt) of an f32 matrix (src_fmt = SIMX_F32; src_plane_stride ignored) or of another plane pair (src_fmt =
+ * its format); and back to f32.  cols % 8 == 0, 16-B aligned rows. */
+int simx_planes_from(simx_stream_t stream, int src_fmt, int dst_fmt, int rows, int cols, const void* src, int ld_src, long src_plane_stride,
+                     void* dst, int ld_dst, long dst_plane_stride);
+int simx_planes_join(simx_stream_t stream, int src_fmt, int rows, int cols, const void* src, int ld_src, long src_plane_stride, float* dst,
+                     int ld_dst);
+
 /* --------------------------------------------------------- embeddings + LayerNorm
  * BertEmbeddings (LEAD/modeling_bert.py:181-240): LN(word[ids] + pos[pos_ids] + type[0]). */
 int simx_embed_ln_fwd(simx_stream_t stream, int dtype, int T, int H,

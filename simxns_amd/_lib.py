@@ -124,12 +124,18 @@ SIGNATURES = {
     "simx_scaler_update": (_i, [_p, _p, _p]),
     "simx_deterministic": (_i, []),
     "simx_adamw_step_sc": (_i, [_p, _p, _p, _p, _p, _z, _f, _f, _f, _f, _f, _i, _p, _f, _f, _i, _p]),
+    "simx_gemm_nt_planes_ok": (_i, [_i, _i, _i]),
+    "simx_gemm_nt_planes": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _l, _p, _i, _l, _p, _i, _p, _p, _i, _p, _i, _l, _dp]),
+    "simx_gemm_tn_planes_workspace_bytes": (_z, [_i, _i, _i]),
+    "simx_gemm_tn_planes": (_i, [_p, _i, _i, _i, _p, _i, _l, _p, _i, _l, _p, _i, _i, _p, _z, _p]),
+    "simx_planes_from": (_i, [_p, _i, _i, _i, _i, _p, _i, _l, _p, _i, _l]),
+    "simx_planes_join": (_i, [_p, _i, _i, _i, _p, _i, _l, _p, _i]),
     "simx_prof_begin": (_i, [_i]),
     "simx_prof_end": (_i, [_p, _p, _p]),
     "simx_prof_kernel_count": (_i, []),
 }
 PROF_NAMES = ["gemm_nt", "gemm_tn", "mha_fwd", "mha_bwd", "ln_fwd", "ln_bwd", "embed_fwd", "embed_bwd", "colsum", "cast",
-              "loss", "sampler", "adamw", "other", "collate", "topk", "gemm_nt_p3", "gemm_tn2"]
+              "loss", "sampler", "adamw", "other", "collate", "topk", "gemm_nt_p3", "gemm_tn2", "gemm_nt_xp", "gemm_tn_xp"]
 
 _lib = None
 

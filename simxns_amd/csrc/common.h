@@ -337,6 +337,13 @@ int simx_x3_gemm_nt(hipStream_t s, int fmt, int epi, int M, int N, int K, const 
 struct SimxCastJob { const float* w; void* out; void* outT; int rows, cols, tile_end, pad_; };   // tile_end: cumulative 32 x 32 tiles
 struct SimxCastGroup { int n; SimxCastJob job[SIMX_CAST_GROUP_MAX]; };
 int simx_transpose_cast_group(hipStream_t s, int out_dtype, const SimxCastGroup* g);
+// csrc/gemm_xp.hip: the fp32 engine's GEMMs on pre-split operand planes.  Weight planes in one launch: per matrix W [rows, cols]
+// f32 -> fp16 plane pair of W (planes_h: hi [rows, cols], lo at + rows * cols elements), bf16 plane pair of W^T (planesT_b,
+// [cols, rows]) and W^T in f32 (wT); any output may be NULL
+#define SIMX_SPLIT_GROUP_MAX 48
+struct SimxSplitJob { const float* w; void* planes_h; void* planesT_b; float* wT; int rows, cols, tile_end, pad_; };
+struct SimxSplitGroup { int n; SimxSplitJob job[SIMX_SPLIT_GROUP_MAX]; };
+int simx_split_weight_group(hipStream_t s, const SimxSplitGroup* g);
 bool simx_x3_tn_ok(int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* C, int ldc);
 size_t simx_x3_tn_workspace_bytes(int M, int N, int K);
 int simx_x3_gemm_tn(hipStream_t s, int fmt, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,

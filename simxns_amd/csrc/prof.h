@@ -5,7 +5,7 @@
 
 enum { SIMX_K_GEMM_NT = 0, SIMX_K_GEMM_TN, SIMX_K_MHA_FWD, SIMX_K_MHA_BWD, SIMX_K_LN_FWD, SIMX_K_LN_BWD,
        SIMX_K_EMBED_FWD, SIMX_K_EMBED_BWD, SIMX_K_COLSUM, SIMX_K_CAST, SIMX_K_LOSS, SIMX_K_SAMPLER, SIMX_K_ADAMW,
-       SIMX_K_OTHER, SIMX_K_COLLATE, SIMX_K_TOPK, SIMX_K_GEMM_NT_P3, SIMX_K_GEMM_TN2, SIMX_K_COUNT };
+       SIMX_K_OTHER, SIMX_K_COLLATE, SIMX_K_TOPK, SIMX_K_GEMM_NT_P3, SIMX_K_GEMM_TN2, SIMX_K_GEMM_NT_XP, SIMX_K_GEMM_TN_XP, SIMX_K_COUNT };
 
 // begin: returns the record's index (or -1 when recording is off); end: closes that record
 int simx_prof_mark(int kernel_id, hipStream_t s, double work, int end_index);

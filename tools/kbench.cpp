@@ -35,6 +35,43 @@ int main(int argc, char** argv) {
   // KB_H=1024: the recipe teacher's geometry (ernie-2.0-large: H = 1024, F = 4096) -- main NT / TN tables only
   const int H = getenv("KB_H") ? atoi(getenv("KB_H")) : 768, F = 4 * H, iters = 10;
   const bool base = H == 768;
+  if (getenv("KB_XP")) {      // the fp32 engine's dense GEMMs on pre-split operand planes (csrc/gemm_xp.hip)
+    auto palloc = [&](size_t n, int fmt) { g_dt = fmt; return dalloc(n * 2 * 2, 1); };     // hi plane, lo plane
+    auto falloc = [&](size_t n) { float* p; CK(hipMalloc(&p, n * 4)); CK(hipMemset(p, 0, n * 4)); return p; };
+    void* Ah = palloc((size_t)T * F, SIMX_F16); void* Ab = palloc((size_t)T * F, SIMX_BF16); void* Xb = palloc((size_t)T * F, SIMX_BF16);
+    void* Wh = palloc((size_t)F * H, SIMX_F16); void* Wb = palloc((size_t)F * H, SIMX_BF16);
+    float* C = falloc((size_t)T * F); float* IN = falloc((size_t)T * F); void* Cp = palloc((size_t)T * F, SIMX_F16);
+    float* bias = falloc(F); float* G = falloc((size_t)F * H);
+    size_t wsb = 0; { size_t v; v = simx_gemm_tn_planes_workspace_bytes(3*H, H, T); wsb = v; v = simx_gemm_tn_planes_workspace_bytes(F, H, T); if (v > wsb) wsb = v; v = simx_gemm_tn_planes_workspace_bytes(H, F, T); if (v > wsb) wsb = v; }
+    void* ws; CK(hipMalloc(&ws, wsb + 256));
+    struct S { const char* name; int N, K, epi, res, fmt; } nt[] = {
+      {"qkv   fwd  N=2304 K=768 bias", 3 * H, H, 0, 0, SIMX_F16}, {"oproj fwd  N=768  K=768 bias+res", H, H, 0, 1, SIMX_F16},
+      {"ffn1  fwd  N=3072 K=768 gelu", F, H, 1, 0, SIMX_F16},     {"ffn2  fwd  N=768  K=3072 bias+res", H, F, 0, 1, SIMX_F16},
+      {"ffn2 dgrad N=3072 K=768 dgelu", F, H, 2, 1, SIMX_BF16},   {"ffn1 dgrad N=768  K=3072 +res", H, F, 0, 1, SIMX_BF16},
+      {"qkv  dgrad N=768  K=2304 +res", H, 3 * H, 0, 1, SIMX_BF16}, {"ffn1  fwd  N=3072 K=768 gelu(infer)", F, H, 3, 0, SIMX_F16}};
+    double tot = 0, totf = 0; int idx = 0;
+    for (auto& s : nt) {
+      const void* A = s.fmt == SIMX_F16 ? Ah : Ab; const void* W = s.fmt == SIMX_F16 ? Wh : Wb;
+      double ms = timeit([&] { SX(simx_gemm_nt_planes(0, s.fmt, s.epi, T, s.N, s.K, A, s.K, (long)T * s.K, W, s.K, (long)s.N * s.K, C, s.N, s.epi == 2 ? nullptr : bias,
+                                                     s.res ? IN : nullptr, s.N, Cp, s.N, (long)T * s.N, nullptr)); }, 5);
+      double fl = 2.0 * T * s.N * s.K; if (idx++ < 7) { tot += ms; totf += fl; }
+      printf("xp gemm_nt %-36s %8.3f ms  %7.1f TF/s\n", s.name, ms, fl / ms / 1e9);
+    }
+    printf("xp gemm_nt total(7) %.2f ms  avg %.1f TF/s\n", tot, totf / tot / 1e9);
+    struct S2 { const char* name; int M, N; } tn[] = {{"wqkv [2304,768]", 3 * H, H}, {"wo [768,768]", H, H}, {"w1 [3072,768]", F, H}, {"w2 [768,3072]", H, F}};
+    tot = 0; totf = 0;
+    for (auto& s : tn) {
+      double ms = timeit([&] { SX(simx_gemm_tn_planes(0, s.M, s.N, T, Ab, s.M, (long)T * s.M, Xb, s.N, (long)T * s.N, G, s.N, 1, ws, wsb, bias)); }, 5);
+      double fl = 2.0 * T * s.M * s.N; tot += ms; totf += fl;
+      printf("xp gemm_tn+bias %-31s %8.3f ms  %7.1f TF/s\n", s.name, ms, fl / ms / 1e9);
+    }
+    printf("xp gemm_tn total %.2f ms  avg %.1f TF/s\n", tot, totf / tot / 1e9);
+    double ms = timeit([&] { SX(simx_planes_from(0, SIMX_F16, SIMX_BF16, T, F, Ah, F, (long)T * F, Xb, F, (long)T * F)); }, 5);
+    printf("xp planes f16->bf16 [T,%d] %8.3f ms  %6.2f TB/s\n", F, ms, 8.0 * T * F / ms / 1e9);
+    ms = timeit([&] { SX(simx_planes_from(0, SIMX_F32, SIMX_BF16, T, H, C, H, 0, Xb, H, (long)T * H)); }, 5);
+    printf("xp planes f32->bf16 [T,%d] %8.3f ms  %6.2f TB/s\n", H, ms, 8.0 * T * H / ms / 1e9);
+    return 0;
+  }
   if (getenv("KB_X3")) {      // the fp32 engine's dense GEMMs: f32 tensors, hi+lo split products (SIMX_F32_SPLIT_H / _B)
     auto falloc = [&](size_t n, float scale) { float* p; CK(hipMalloc(&p, n * 4)); std::vector<float> h(1 << 20);
       for (size_t i = 0; i < h.size(); ++i) h[i] = (((int)((i * 2654435761u) >> 20 & 1023)) - 512) / 1024.0f * scale;

@@ -387,13 +387,16 @@ def main():
 
     # 16-bit: the persistent kernel's launches ("gemm_nt" = the small-shape kernels); fp32: every NT GEMM of the step (the split
     # kernel gemm_x3_nt_kernel for the dense layers, priced against 1/3 of the 16-bit MFMA peak: three MFMAs per product)
-    rk = "gemm_nt_p3" if is16 else "gemm_nt"
+    # (fp32 engine: the plane-operand persistent kernel gemm_nt_xp_kernel when the towers are large enough for it -- they are
+    # at the benchmarked batch -- else the register-split kernel behind "gemm_nt")
+    rk = "gemm_nt_p3" if is16 else ("gemm_nt_xp" if prof and "gemm_nt_xp" in prof else "gemm_nt")
     if prof and rk in prof:
         c_, ms_, wk_ = prof[rk]
         ach = wk_ / (ms_ * 1e-3) / 1e12
         peak = 2500.0 if is16 else (157.3 if args.dtype == "fp32_exact" else 833.3)
-        kname = "gemm_nt_p3_kernel" if is16 else ("gemm_f32_mfma_kernel" if args.dtype == "fp32_exact" else "gemm_x3_nt_kernel")
-        out["roofline"] = {"bound": "mfma", "kernel": kname + " (simx_gemm_nt: forward + dgrad GEMMs)",
+        kname = "gemm_nt_p3_kernel" if is16 else ("gemm_f32_mfma_kernel" if args.dtype == "fp32_exact" else
+                                                  "gemm_nt_xp_kernel" if rk == "gemm_nt_xp" else "gemm_x3_nt_kernel")
+        out["roofline"] = {"bound": "mfma", "kernel": kname + " (forward + dgrad GEMMs)",
                            "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                            "traffic": pmc_traffic("gemm_nt_p3_kernel") if is16 else None, "launches": c_,
                            "algorithmic_bytes_per_launch": alg_bytes_per_launch(c_ // max(1, args.steps)) if is16 else None,

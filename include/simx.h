@@ -159,6 +159,25 @@ int simx_planes_from(simx_stream_t stream, int src_fmt, int dst_fmt, int rows, i
 int simx_planes_join(simx_stream_t stream, int src_fmt, int rows, int cols, const void* src, int ld_src, long src_plane_stride, float* dst,
                      int ld_dst);
 
+/* the producers that write plane pairs directly (fp32 engine; leading dimension of every pair = the tensor's own):
+ *   LayerNorm / embedding LayerNorm: y (f32) and its SIMX_F16 pair (LEAD/modeling_bert.py:230-240, 384-388, 462-466);
+ *   LayerNorm backward: dz (f32) and the SIMX_BF16 pair of dz x dropout mask (the gradient of the dropped dense output);
+ *   attention (head size 64, sequences <= 256: simx_mha_planes_ok): f32 q/k/v in, context as a SIMX_F16 pair; backward reads
+ *   that pair and writes dq/dk/dv as a SIMX_BF16 pair (LEAD/modeling_bert.py:318-374). */
+int simx_ln_fwd_planes(simx_stream_t stream, int T, int H, const float* z, const float* gamma, const float* beta, float eps,
+                       float* y, void* y_planes, long plane_stride);
+int simx_ln_bwd_planes(simx_stream_t stream, int T, int H, const float* z, const float* gamma, float eps, const float* dy, float* dz,
+                       void* dzm_planes, long plane_stride, float* dgamma, float* dbeta, float* dbias, const simx_dropout* drop);
+int simx_embed_ln_fwd_planes(simx_stream_t stream, int T, int H, const int32_t* ids, const int32_t* pos_ids, const float* word,
+                             const float* posw, const float* typew, const float* gamma, const float* beta, float eps, float* out,
+                             void* out_planes, long plane_stride, const simx_dropout* drop);
+int simx_mha_planes_ok(int d, int max_len);
+int simx_mha_fwd_planes(simx_stream_t stream, int nseq, int heads, int d, const int32_t* cu, int max_len, int T, const float* qkv,
+                        void* ctx_planes, long ctx_plane_stride, float* lse, const simx_dropout* drop);
+int simx_mha_bwd_planes(simx_stream_t stream, int nseq, int heads, int d, const int32_t* cu, int max_len, int T, const float* qkv,
+                        const void* ctx_planes, long ctx_plane_stride, const float* lse, const float* dctx, void* dqkv_planes,
+                        long dqkv_plane_stride, const simx_dropout* drop);
+
 /* --------------------------------------------------------- embeddings + LayerNorm
  * BertEmbeddings (LEAD/modeling_bert.py:181-240): LN(word[ids] + pos[pos_ids] + type[0]). */
 int simx_embed_ln_fwd(simx_stream_t stream, int dtype, int T, int H,

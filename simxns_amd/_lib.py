@@ -130,6 +130,12 @@ SIGNATURES = {
     "simx_gemm_tn_planes": (_i, [_p, _i, _i, _i, _p, _i, _l, _p, _i, _l, _p, _i, _i, _p, _z, _p]),
     "simx_planes_from": (_i, [_p, _i, _i, _i, _i, _p, _i, _l, _p, _i, _l]),
     "simx_planes_join": (_i, [_p, _i, _i, _i, _p, _i, _l, _p, _i]),
+    "simx_ln_fwd_planes": (_i, [_p, _i, _i, _p, _p, _p, _f, _p, _p, _l]),
+    "simx_ln_bwd_planes": (_i, [_p, _i, _i, _p, _p, _f, _p, _p, _p, _l, _p, _p, _p, _dp]),
+    "simx_embed_ln_fwd_planes": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _l, _dp]),
+    "simx_mha_planes_ok": (_i, [_i, _i]),
+    "simx_mha_fwd_planes": (_i, [_p, _i, _i, _i, _p, _i, _i, _p, _p, _l, _p, _dp]),
+    "simx_mha_bwd_planes": (_i, [_p, _i, _i, _i, _p, _i, _i, _p, _p, _l, _p, _p, _p, _l, _dp]),
     "simx_prof_begin": (_i, [_i]),
     "simx_prof_end": (_i, [_p, _p, _p]),
     "simx_prof_kernel_count": (_i, []),

@@ -64,10 +64,33 @@ __device__ __forceinline__ void af_store_t(const f32x16 (&o)[2], float mul, floa
           make_float4(o[dt][4 * g] * mul, o[dt][4 * g + 1] * mul, o[dt][4 * g + 2] * mul, o[dt][4 * g + 3] * mul);
 }
 
+// "operand planes" (csrc/gemm_xp.hip): the same store with every value split into a 16-bit pair, hi at dst, lo at dst + ps
+template <typename F>
+__device__ __forceinline__ void af_store_t_planes(const f32x16 (&o)[2], float mul, bf16_t* __restrict__ dst, long ps, int half) {
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float a = o[dt][4 * g] * mul, b = o[dt][4 * g + 1] * mul, c = o[dt][4 * g + 2] * mul, d = o[dt][4 * g + 3] * mul;
+      const uint32_t h0 = H16<F>::pack2(a, b), h1 = H16<F>::pack2(c, d);
+      const uint32_t l0 = H16<F>::pack2(a - H16<F>::lo(h0), b - H16<F>::hi(h0)), l1 = H16<F>::pack2(c - H16<F>::lo(h1), d - H16<F>::hi(h1));
+      bf16_t* q = dst + dt * 32 + 8 * g + 4 * half;
+      *reinterpret_cast<uint2*>(q) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(q + ps) = make_uint2(l0, l1);
+    }
+}
+// 4 consecutive values hi + lo of an fp16 plane pair
+__device__ __forceinline__ float4 af_ld4_planes(const bf16_t* __restrict__ p, long ps) {
+  const uint2 h = *reinterpret_cast<const uint2*>(p), l = *reinterpret_cast<const uint2*>(p + ps);
+  return make_float4(H16<f16_t>::lo(h.x) + H16<f16_t>::lo(l.x), H16<f16_t>::hi(h.x) + H16<f16_t>::hi(l.x),
+                     H16<f16_t>::lo(h.y) + H16<f16_t>::lo(l.y), H16<f16_t>::hi(h.y) + H16<f16_t>::hi(l.y));
+}
+
 // ------------------------------------------------------------------------------------------ forward
-template <int NKT, bool DENSE = false>
+// PL: ctx leaves as the fp16 plane pair the attention-output GEMM stages (ctx = the pair, cps = its plane stride)
+template <int NKT, bool DENSE = false, bool PL = false>
 __global__ __launch_bounds__(256, DENSE ? 2 : 1) void mha_fwd_f32_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, float* __restrict__ lse,
-                                                          const int* __restrict__ cu, int heads, int T, float scale, DropCtx drop) {
+                                                          const int* __restrict__ cu, int heads, int T, float scale, DropCtx drop, long cps) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int PITCH = DENSE ? 64 : AF_PITCH;
   float* sK = reinterpret_cast<float*>(smem);
@@ -150,7 +173,8 @@ __global__ __launch_bounds__(256, DENSE ? 2 : 1) void mha_fwd_f32_kernel(const f
         }
       }
     if (q < len) {
-      af_store_t(o, 1.0f / sum, ctx + (long)(t0 + q) * H + h * 64, half);
+      if (PL) af_store_t_planes<f16_t>(o, 1.0f / sum, reinterpret_cast<bf16_t*>(ctx) + (long)(t0 + q) * H + h * 64, cps, half);
+      else af_store_t(o, 1.0f / sum, ctx + (long)(t0 + q) * H + h * 64, half);
       if (half == 0) lse[(long)h * T + t0 + q] = m * scale + logf(sum);
     }
   }
@@ -158,11 +182,13 @@ __global__ __launch_bounds__(256, DENSE ? 2 : 1) void mha_fwd_f32_kernel(const f
 
 // ------------------------------------------------------------------------------------------ backward: dQ
 // K, V resident; a wave owns 32 query rows (Q, dO, O half rows in registers) and walks the key tiles.
-template <int NKT>
+// PL: O is the forward's fp16 plane pair (ops = its plane stride) and dq / dk / dv leave as the bf16 plane pair the dgrad and
+// wgrad GEMMs stage (dqkv = the pair, dps = its plane stride)
+template <int NKT, bool PL = false>
 __global__ __launch_bounds__(256) void mha_bwd_dq_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ O,
                                                              const float* __restrict__ lse, const float* __restrict__ dO,
                                                              float* __restrict__ dqkv, const int* __restrict__ cu, int heads, int T,
-                                                             float scale, DropCtx drop) {
+                                                             float scale, DropCtx drop, long ops, long dps) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sK = reinterpret_cast<float*>(smem);
   float* sV = sK + NKT * 32 * AF_PITCH;
@@ -175,6 +201,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_f32_kernel(const float* __rest
   const long H3 = 3L * H;
   const float* Qg = qkv + (long)t0 * H3 + h * 64;
   const float* Og = O + (long)t0 * H + h * 64;
+  const bf16_t* Opl = reinterpret_cast<const bf16_t*>(O) + (long)t0 * H + h * 64;
   const float* dOg = dO + (long)t0 * H + h * 64;
   const int nkt = (len + 31) >> 5;
   af_stage(Qg + H, H3, len, nkt * 32, sK, tid);
@@ -193,7 +220,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_f32_kernel(const float* __rest
       const float4* po = reinterpret_cast<const float4*>(Og + (long)qc * H + 32 * half);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const float4 v = po[i];
+        const float4 v = PL ? af_ld4_planes(Opl + (long)qc * H + 32 * half + 4 * i, ops) : po[i];
         delta += dr[4 * i] * v.x + dr[4 * i + 1] * v.y + dr[4 * i + 2] * v.z + dr[4 * i + 3] * v.w;
       }
     }
@@ -229,17 +256,20 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_f32_kernel(const float* __rest
         dq[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[32], s[e], dq[1], 0, 0, 0);
       }
     }
-    if (qok) af_store_t(dq, 1.0f, dqkv + (long)(t0 + q) * H3 + h * 64, half);
+    if (qok) {
+      if (PL) af_store_t_planes<bf16_t>(dq, 1.0f, reinterpret_cast<bf16_t*>(dqkv) + (long)(t0 + q) * H3 + h * 64, dps, half);
+      else af_store_t(dq, 1.0f, dqkv + (long)(t0 + q) * H3 + h * 64, half);
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------------ backward: dK, dV
 // Q, dO (and lse, delta) resident; a wave owns 32 key rows (K, V half rows in registers) and walks the query tiles.
-template <int NKT>
+template <int NKT, bool PL = false>
 __global__ __launch_bounds__(256) void mha_bwd_dkv_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ O,
                                                               const float* __restrict__ lse, const float* __restrict__ dO,
                                                               float* __restrict__ dqkv, const int* __restrict__ cu, int heads, int T,
-                                                              float scale, DropCtx drop) {
+                                                              float scale, DropCtx drop, long ops, long dps) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sQ = reinterpret_cast<float*>(smem);
   float* sD = sQ + NKT * 32 * AF_PITCH;
@@ -254,6 +284,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_f32_kernel(const float* __res
   const long H3 = 3L * H;
   const float* Qg = qkv + (long)t0 * H3 + h * 64;
   const float* Og = O + (long)t0 * H + h * 64;
+  const bf16_t* Opl = reinterpret_cast<const bf16_t*>(O) + (long)t0 * H + h * 64;
   const float* dOg = dO + (long)t0 * H + h * 64;
   const int nkt = (len + 31) >> 5;
   af_stage(Qg, H3, len, nkt * 32, sQ, tid);
@@ -265,7 +296,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_f32_kernel(const float* __res
       const float4* pd = reinterpret_cast<const float4*>(dOg + (long)r * H);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float4 a = po[i], b = pd[i];
+        const float4 a = PL ? af_ld4_planes(Opl + (long)r * H + 4 * i, ops) : po[i], b = pd[i];
         del += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
       }
       l = lse[(long)h * T + t0 + r] * AF_LOG2E;
@@ -318,9 +349,15 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_f32_kernel(const float* __res
       }
     }
     if (kok) {
-      float* dst = dqkv + (long)(t0 + key) * H3 + H + h * 64;
-      af_store_t(dk, 1.0f, dst, half);
-      af_store_t(dv, 1.0f, dst + H, half);
+      if (PL) {
+        bf16_t* dst = reinterpret_cast<bf16_t*>(dqkv) + (long)(t0 + key) * H3 + H + h * 64;
+        af_store_t_planes<bf16_t>(dk, 1.0f, dst, dps, half);
+        af_store_t_planes<bf16_t>(dv, 1.0f, dst + H, dps, half);
+      } else {
+        float* dst = dqkv + (long)(t0 + key) * H3 + H + h * 64;
+        af_store_t(dk, 1.0f, dst, half);
+        af_store_t(dv, 1.0f, dst + H, half);
+      }
     }
   }
 }
@@ -340,15 +377,22 @@ bool simx_mha_f32_ok(int d, int max_len) {
   return d == 64 && max_len <= 256 && !(pin && pin[0] == 'g');
 }
 
+// ctx_ps > 0: ctx is an fp16 plane pair (hi at ctx, lo at + ctx_ps 16-bit elements) instead of an f32 matrix
 int simx_mha_fwd_f32(hipStream_t s, int nseq, int heads, const int32_t* cu, int max_len, int T, const float* qkv, float* ctx, float* lse,
-                     float scale, DropCtx drop) {
+                     float scale, DropCtx drop, long ctx_ps) {
   int rc = SIMX_OK;
 #define LF(NKT, DENSE)                                                                                                     \
   do {                                                                                                                     \
     const size_t lds = (size_t)2 * NKT * 32 * (DENSE ? 64 : AF_PITCH) * sizeof(float);                                     \
-    rc = af_set_lds((mha_fwd_f32_kernel<NKT, DENSE>), lds, "mha_fwd_f32");                                                 \
-    if (rc) return rc;                                                                                                     \
-    hipLaunchKernelGGL((mha_fwd_f32_kernel<NKT, DENSE>), dim3(nseq * heads), dim3(256), lds, s, qkv, ctx, lse, cu, heads, T, scale, drop); \
+    if (ctx_ps > 0) {                                                                                                      \
+      rc = af_set_lds((mha_fwd_f32_kernel<NKT, DENSE, true>), lds, "mha_fwd_f32");                                         \
+      if (rc) return rc;                                                                                                   \
+      hipLaunchKernelGGL((mha_fwd_f32_kernel<NKT, DENSE, true>), dim3(nseq * heads), dim3(256), lds, s, qkv, ctx, lse, cu, heads, T, scale, drop, ctx_ps); \
+    } else {                                                                                                               \
+      rc = af_set_lds((mha_fwd_f32_kernel<NKT, DENSE, false>), lds, "mha_fwd_f32");                                        \
+      if (rc) return rc;                                                                                                   \
+      hipLaunchKernelGGL((mha_fwd_f32_kernel<NKT, DENSE, false>), dim3(nseq * heads), dim3(256), lds, s, qkv, ctx, lse, cu, heads, T, scale, drop, 0L); \
+    }                                                                                                                      \
   } while (0)
   static const bool dense5 = [] { const char* e = getenv("SIMX_MHA_F32_DENSE"); return !e || e[0] != '0'; }();
   if (max_len <= 32) LF(1, false);
@@ -361,25 +405,28 @@ int simx_mha_fwd_f32(hipStream_t s, int nseq, int heads, const int32_t* cu, int 
   return SIMX_OK;
 }
 
+// ctx_ps > 0 (planes form): ctx is the forward's fp16 plane pair and dqkv leaves as a bf16 plane pair (lo at + dqkv_ps elements)
 int simx_mha_bwd_f32(hipStream_t s, int nseq, int heads, const int32_t* cu, int max_len, int T, const float* qkv, const float* ctx,
-                     const float* lse, const float* dctx, float* dqkv, float scale, DropCtx drop) {
+                     const float* lse, const float* dctx, float* dqkv, float scale, DropCtx drop, long ctx_ps, long dqkv_ps) {
   int rc = SIMX_OK;
-#define LB(NKT)                                                                                                            \
+#define LB2(NKT, PL)                                                                                                       \
   do {                                                                                                                     \
     const size_t lds = (size_t)2 * NKT * 32 * AF_PITCH * sizeof(float);                                                    \
     const size_t lds2 = lds + (size_t)2 * NKT * 32 * sizeof(float);                                                        \
-    rc = af_set_lds(mha_bwd_dq_f32_kernel<NKT>, lds, "mha_bwd_f32");                                                       \
+    rc = af_set_lds((mha_bwd_dq_f32_kernel<NKT, PL>), lds, "mha_bwd_f32");                                                 \
     if (rc) return rc;                                                                                                     \
-    rc = af_set_lds(mha_bwd_dkv_f32_kernel<NKT>, lds2, "mha_bwd_f32");                                                     \
+    rc = af_set_lds((mha_bwd_dkv_f32_kernel<NKT, PL>), lds2, "mha_bwd_f32");                                               \
     if (rc) return rc;                                                                                                     \
-    hipLaunchKernelGGL((mha_bwd_dq_f32_kernel<NKT>), dim3(nseq * heads), dim3(256), lds, s, qkv, ctx, lse, dctx, dqkv, cu, heads, T, scale, drop); \
-    hipLaunchKernelGGL((mha_bwd_dkv_f32_kernel<NKT>), dim3(nseq * heads), dim3(256), lds2, s, qkv, ctx, lse, dctx, dqkv, cu, heads, T, scale, drop); \
+    hipLaunchKernelGGL((mha_bwd_dq_f32_kernel<NKT, PL>), dim3(nseq * heads), dim3(256), lds, s, qkv, ctx, lse, dctx, dqkv, cu, heads, T, scale, drop, ctx_ps, dqkv_ps); \
+    hipLaunchKernelGGL((mha_bwd_dkv_f32_kernel<NKT, PL>), dim3(nseq * heads), dim3(256), lds2, s, qkv, ctx, lse, dctx, dqkv, cu, heads, T, scale, drop, ctx_ps, dqkv_ps); \
   } while (0)
+#define LB(NKT) do { if (ctx_ps > 0) LB2(NKT, true); else LB2(NKT, false); } while (0)
   if (max_len <= 32) LB(1);
   else if (max_len <= 128) LB(4);
   else if (max_len <= 160) LB(5);
   else LB(8);
 #undef LB
+#undef LB2
   SIMX_CHECK_LAUNCH("mha_bwd_f32");
   return SIMX_OK;
 }

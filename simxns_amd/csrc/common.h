@@ -323,10 +323,11 @@ static inline bool simx_is_f32(int dtype) { return dtype == SIMX_F32 || dtype ==
 static inline size_t simx_esz(int dtype) { return simx_is_f32(dtype) ? 4 : 2; }
 // csrc/attention_f32.hip: f32 attention on the f32 matrix cores (head size 64, sequences <= 256)
 bool simx_mha_f32_ok(int d, int max_len);
+// (ctx_ps / dqkv_ps > 0: the "operand planes" forms -- ctx an fp16 plane pair, dqkv a bf16 plane pair; csrc/gemm_xp.hip)
 int simx_mha_fwd_f32(hipStream_t s, int nseq, int heads, const int32_t* cu, int max_len, int T, const float* qkv, float* ctx, float* lse,
-                     float scale, DropCtx drop);
+                     float scale, DropCtx drop, long ctx_ps = 0);
 int simx_mha_bwd_f32(hipStream_t s, int nseq, int heads, const int32_t* cu, int max_len, int T, const float* qkv, const float* ctx,
-                     const float* lse, const float* dctx, float* dqkv, float scale, DropCtx drop);
+                     const float* lse, const float* dctx, float* dqkv, float scale, DropCtx drop, long ctx_ps = 0, long dqkv_ps = 0);
 // csrc/gemm_x3.hip: f32 GEMMs on the 16-bit matrix cores (fmt = SIMX_F16 / SIMX_BF16: the format of the split halves)
 bool simx_x3_nt_ok(int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* C, int ldc, const float* bias,
                    const float* res, int ldr, const float* aux, int ldaux, const float* C2, int ldc2);

@@ -78,10 +78,29 @@ extern "C" size_t simx_bert_param_offset(const simx_bert_cfg* c, int layer, int 
   return (size_t)-1;
 }
 
-struct WLayer { const char *wqkv, *wqkvT, *wo, *woT, *w1, *w1T, *w2, *w2T; };
+// "Operand planes" (csrc/gemm_xp.hip, simx.h): the fp32 engine's large towers run their dense GEMMs on pre-split 16-bit plane
+// pairs.  Three predicates, each a function of its arguments only so that sizing calls, forward and backward agree:
+//   pl_weights(c)            the weight cache also holds fp16 planes of W and bf16 planes of W^T
+//   pl_layout(c, Tp)         activation / scratch buffers have room for the planes of the residual stream (x0, x1, xout)
+//   pl_run(c, Tp, max_len)   the tower's full layers run on planes (needs the f32 MFMA attention: sequences <= 256)
+// SIMX_F32_PLANES=0 pins the register-split kernels of gemm_x3.hip (A/B measurements); SIMX_F32_PLANES_MIN_TILES lowers the
+// size threshold (tests run small towers through the plane kernels).
+static bool pl_weights(const simx_bert_cfg* c) {
+  static const bool on = [] { const char* e = getenv("SIMX_F32_PLANES"); return !e || e[0] != '0'; }();
+  return on && c->dtype == SIMX_F32 && c->f32_gemm == 0 && c->hidden % 256 == 0 && c->inter % 256 == 0 && c->hidden / c->heads == 64;
+}
+static bool pl_layout(const simx_bert_cfg* c, size_t Tp) {
+  static const long min_tiles = [] { const char* e = getenv("SIMX_F32_PLANES_MIN_TILES"); return e ? atol(e) : 192L; }();
+  return pl_weights(c) && (long)(Tp / 256) * (c->hidden / 256) >= min_tiles;
+}
+static bool pl_run(const simx_bert_cfg* c, size_t Tp, int max_len) { return pl_layout(c, Tp) && simx_mha_planes_ok(c->hidden / c->heads, max_len); }
+
+// wqkvP .. w2P: fp16 plane pairs of W [out, in] (forward operand); wqkvTP .. w2TP: bf16 plane pairs of W^T [in, out] (dgrad)
+struct WLayer { const char *wqkv, *wqkvT, *wo, *woT, *w1, *w1T, *w2, *w2T, *wqkvP, *woP, *w1P, *w2P, *wqkvTP, *woTP, *w1TP, *w2TP; };
 static size_t wcache_layer_bytes(const simx_bert_cfg* c) {
   const size_t H = c->hidden, F = c->inter, e = esz(c->dtype);
   const size_t one = al(3 * H * H * e) + al(H * H * e) + 2 * al(F * H * e);
+  if (pl_weights(c)) return 3 * one;              // f32 transposes | fp16 planes of W | bf16 planes of W^T (4 B per element each)
   return c->dtype == SIMX_F32 ? one : 2 * one;
 }
 extern "C" size_t simx_bert_wcache_bytes(const simx_bert_cfg* c) {
@@ -90,7 +109,7 @@ extern "C" size_t simx_bert_wcache_bytes(const simx_bert_cfg* c) {
 static WLayer wlayer(const simx_bert_cfg* c, const float* params, const void* wcache, int l) {
   const size_t H = c->hidden, F = c->inter, e = esz(c->dtype);
   const char* b = (const char*)wcache + (size_t)l * wcache_layer_bytes(c);
-  WLayer w;
+  WLayer w = {};
   if (c->dtype == SIMX_F32) {
     w.wqkv = (const char*)(params + simx_bert_param_offset(c, l, SIMX_P_WQKV));
     w.wo = (const char*)(params + simx_bert_param_offset(c, l, SIMX_P_WO));
@@ -99,7 +118,17 @@ static WLayer wlayer(const simx_bert_cfg* c, const float* params, const void* wc
     w.wqkvT = b; b += al(3 * H * H * e);
     w.woT = b; b += al(H * H * e);
     w.w1T = b; b += al(F * H * e);
-    w.w2T = b;
+    w.w2T = b; b += al(F * H * e);
+    if (pl_weights(c)) {
+      w.wqkvP = b; b += al(3 * H * H * e);
+      w.woP = b; b += al(H * H * e);
+      w.w1P = b; b += al(F * H * e);
+      w.w2P = b; b += al(F * H * e);
+      w.wqkvTP = b; b += al(3 * H * H * e);
+      w.woTP = b; b += al(H * H * e);
+      w.w1TP = b; b += al(F * H * e);
+      w.w2TP = b;
+    }
   } else {
     w.wqkv = b; b += al(3 * H * H * e);
     w.wqkvT = b; b += al(3 * H * H * e);
@@ -122,15 +151,22 @@ static inline int rows_cap(int T) { return (T + 255) & ~255; }
 // per element (x1l / xoutl, NULL otherwise); z1 / z2 then hold the dense outputs without the residual, which the LayerNorm
 // kernels add
 static inline bool stream_lo(const simx_bert_cfg* c) { return c->stream_lo != 0 && simx_is16(c->dtype); }
-struct ALayer { char *qkv, *ctx, *z1, *x1, *u, *h, *z2, *xout, *x1l, *xoutl; float* lse; };
+// x1p / xoutp (operand planes, pl_layout): the fp16 plane pairs of x1 / xout beside their f32 forms; in a layer that RUNS on planes
+// the ctx and h slots hold plane pairs instead of f32 (same bytes: two 16-bit planes)
+struct ALayer { char *qkv, *ctx, *z1, *x1, *u, *h, *z2, *xout, *x1l, *xoutl, *x1p, *xoutp; float* lse; };
 static size_t act_layer_bytes(const simx_bert_cfg* c, size_t T) {
   const size_t H = c->hidden, F = c->inter, e = esz(c->dtype);
-  return al(T * 3 * H * e) + 5 * al(T * H * e) + (stream_lo(c) ? 2 * al(T * H) : 0) + 2 * al(T * F * e) + al((size_t)c->heads * T * 4);
+  return al(T * 3 * H * e) + 5 * al(T * H * e) + (stream_lo(c) ? 2 * al(T * H) : 0) + (pl_layout(c, T) ? 2 * al(T * H * 4) : 0) + 2 * al(T * F * e) +
+         al((size_t)c->heads * T * 4);
 }
 // a [Tp,H] tensor of the residual stream: the 16-bit values, followed by the corrections (ONE BYTE per element: common.h
 // lo8) when stream_lo
-static size_t xs_bytes(const simx_bert_cfg* c, size_t Tp) { return al(Tp * c->hidden * esz(c->dtype)) + (stream_lo(c) ? al(Tp * c->hidden) : 0); }
+static size_t xs_bytes(const simx_bert_cfg* c, size_t Tp) {
+  return al(Tp * c->hidden * esz(c->dtype)) + (stream_lo(c) ? al(Tp * c->hidden) : 0) + (pl_layout(c, Tp) ? al(Tp * c->hidden * 4) : 0);
+}
 static const char* xs_lo(const simx_bert_cfg* c, const char* hi, size_t Tp) { return stream_lo(c) ? hi + al(Tp * c->hidden * esz(c->dtype)) : nullptr; }
+// the plane pair that follows an f32 [Tp,H] tensor of the residual stream (NULL without pl_layout)
+static const char* xs_pl(const simx_bert_cfg* c, const char* x, size_t Tp) { return pl_layout(c, Tp) ? x + al(Tp * c->hidden * 4) : nullptr; }
 // Activation memory, three modes:
 //   save = 0                      : x0 | 2 layer slots used as a ring                                  (inference)
 //   save = 1, grad_checkpoint = 0 : x0 | L layer slots -- everything backward needs is kept            (default)
@@ -165,8 +201,9 @@ static ALayer carve_layer(const simx_bert_cfg* c, char* b, size_t T) {
   a.x1 = b; b += al(T * H * e);
   a.z2 = b; b += al(T * H * e);
   a.xout = b; b += al(T * H * e);
-  a.x1l = a.xoutl = nullptr;
+  a.x1l = a.xoutl = a.x1p = a.xoutp = nullptr;
   if (stream_lo(c)) { a.x1l = b; b += al(T * H); a.xoutl = b; b += al(T * H); }
+  if (pl_layout(c, T)) { a.x1p = b; b += al(T * H * 4); a.xoutp = b; b += al(T * H * 4); }
   a.u = b; b += al(T * F * e);                 // gelu'(u) of the FFN pre-activation (SIMX_EPI_GELU writes it; only DGELU reads it)
   a.h = b; b += al(T * F * e);
   a.lse = (float*)b;
@@ -180,6 +217,7 @@ static ALayer alayer(const simx_bert_cfg* c, void* act, size_t T, int l, int sav
     ALayer a = carve_layer(c, base + (size_t)c->layers * xb + (size_t)(l & 1) * act_layer_bytes(c, T), T);
     a.xout = base + (size_t)l * xb;
     a.xoutl = const_cast<char*>(xs_lo(c, a.xout, T));
+    a.xoutp = const_cast<char*>(xs_pl(c, a.xout, T));
     return a;
   }
   return carve_layer(c, base + (size_t)(save ? l : (l & 1)) * act_layer_bytes(c, T), T);
@@ -194,6 +232,11 @@ static const char* layer_input(const simx_bert_cfg* c, const void* act, size_t T
   if (l == 0) return act_x0(const_cast<void*>(act));
   return alayer(c, const_cast<void*>(act), T, l - 1, 1).xout;
 }
+// its fp16 plane pair (NULL without pl_layout)
+static const char* layer_input_pl(const simx_bert_cfg* c, const void* act, size_t T, int l) {
+  if (l == 0) return xs_pl(c, act_x0(const_cast<void*>(act)), T);
+  return alayer(c, const_cast<void*>(act), T, l - 1, 1).xoutp;
+}
 // its stream correction (NULL without stream_lo)
 static const char* layer_input_lo(const simx_bert_cfg* c, const void* act, size_t T, int l) {
   if (l == 0) return xs_lo(c, act_x0(const_cast<void*>(act)), T);
@@ -206,6 +249,11 @@ static size_t tn_ws_max(const simx_bert_cfg* c, int T) {
   size_t v = simx_gemm_tn_workspace_bytes(H, H, T); if (v > m) m = v;
   v = simx_gemm_tn_workspace_bytes(F, H, T); if (v > m) m = v;
   v = simx_gemm_tn_workspace_bytes(H, F, T); if (v > m) m = v;
+  if (pl_weights(c)) {
+    v = simx_gemm_tn_planes_workspace_bytes(3 * H, H, T); if (v > m) m = v;
+    v = simx_gemm_tn_planes_workspace_bytes(F, H, T); if (v > m) m = v;
+    v = simx_gemm_tn_planes_workspace_bytes(H, F, T); if (v > m) m = v;
+  }
   return al(m);
 }
 extern "C" size_t simx_bert_bwd_scratch_bytes(const simx_bert_cfg* c, int T, int nseq) {
@@ -213,7 +261,8 @@ extern "C" size_t simx_bert_bwd_scratch_bytes(const simx_bert_cfg* c, int T, int
   const size_t H = c->hidden, F = c->inter, e = esz(c->dtype);
   const size_t Tp = (size_t)rows_cap(T);
   const size_t n = nseq > 0 ? (size_t)nseq : Tp;
-  return 3 * al(Tp * H * e) + al(Tp * F * e) + al(Tp * 3 * H * e) + tn_ws_max(c, T) + 3 * al(n * H * e);
+  // (+ operand planes: the bf16 plane pair of the activation a wgrad GEMM contracts against, converted per use)
+  return 3 * al(Tp * H * e) + al(Tp * F * e) + al(Tp * 3 * H * e) + tn_ws_max(c, T) + 3 * al(n * H * e) + (pl_layout(c, Tp) ? al(Tp * F * 4) : 0);
 }
 
 // ------------------------------------------------------------------------------------------ driver
@@ -228,6 +277,24 @@ extern "C" int simx_bert_cast_weights(simx_stream_t stream, const simx_bert_cfg*
   SIMX_REQUIRE(params && wcache, SIMX_ERR_BAD_SHAPE, "bert_cast_weights: NULL buffer");
   const int H = c->hidden, F = c->inter;
   const bool f32 = c->dtype == SIMX_F32;
+  if (pl_weights(c)) {                            // f32 transposes + both plane pairs of every dense weight, grouped launches
+    static thread_local SimxSplitGroup sg;
+    sg.n = 0;
+    auto addp = [&](const float* w, int rows, int cols, const char* wT, const char* ph, const char* ptb) -> int {
+      if (sg.n == SIMX_SPLIT_GROUP_MAX) { RUN(simx_split_weight_group((hipStream_t)stream, &sg)); sg.n = 0; }
+      sg.job[sg.n++] = SimxSplitJob{w, (void*)ph, (void*)ptb, (float*)wT, rows, cols, 0, 0};
+      return SIMX_OK;
+    };
+    for (int l = 0; l < c->layers; ++l) {
+      const WLayer w = wlayer(c, params, wcache, l);
+      RUN(addp(params + simx_bert_param_offset(c, l, SIMX_P_WQKV), 3 * H, H, w.wqkvT, w.wqkvP, w.wqkvTP));
+      RUN(addp(params + simx_bert_param_offset(c, l, SIMX_P_WO), H, H, w.woT, w.woP, w.woTP));
+      RUN(addp(params + simx_bert_param_offset(c, l, SIMX_P_W1), F, H, w.w1T, w.w1P, w.w1TP));
+      RUN(addp(params + simx_bert_param_offset(c, l, SIMX_P_W2), H, F, w.w2T, w.w2P, w.w2TP));
+    }
+    if (sg.n) RUN(simx_split_weight_group((hipStream_t)stream, &sg));
+    return SIMX_OK;
+  }
   static thread_local SimxCastGroup g;              // (built in place, passed by value at the launch)
   g.n = 0;
   auto add = [&](const float* w, int rows, int cols, const char* out, const char* outT) -> int {
@@ -280,7 +347,7 @@ static int hm_rows_for(const simx_bert_cfg* c, int T, int Tp, int max_len) {
 // (the pre-activation u is stored); the [CLS]-only form of the last layer writes [nseq, .] tensors into the slot's usual
 // buffers and q / attention context of the [CLS] rows into `extra` (kept for backward).
 static int layer_fwd(hipStream_t stream, const simx_bert_cfg* c, const float* params, const void* wcache, int l, const char* x,
-                     const char* xl, const ALayer& a, char* extra, const int32_t* cu, int nseq, int T, int Tp, int max_len, int keep,
+                     const char* xl, const char* xp, const ALayer& a, char* extra, const int32_t* cu, int nseq, int T, int Tp, int max_len, int keep,
                      bool cls_form, float* cls_out) {
   const int H = c->hidden, F = c->inter, dt = c->dtype, d = H / c->heads;
   auto off = [&](int ll, int w) { return params + simx_bert_param_offset(c, ll, w); };
@@ -338,6 +405,24 @@ static int layer_fwd(hipStream_t stream, const simx_bert_cfg* c, const float* pa
     if (cls_out) RUN(simx_rows_copy(stream, dt, SIMX_F32, nseq, H, nullptr, nullptr, a.xout, cls_out));
     return SIMX_OK;
   }
+  if (pl_run(c, Tp, max_len)) {
+    // fp32 engine on operand planes: every GEMM operand is a 16-bit plane pair written by its producer -- xp by the previous
+    // LayerNorm, ctx by the attention kernel, x1p by LayerNorm, h by the FFN-in epilogue; f32 forms exist where an
+    // elementwise consumer needs them (residuals x / x1, q/k/v, the pre-LayerNorm sums, gelu')
+    const long psH = (long)Tp * H, psF = (long)Tp * F;
+    RUN(simx_gemm_nt_planes(stream, SIMX_F16, SIMX_EPI_NONE, Tp, 3 * H, H, xp, H, psH, w.wqkvP, H, 3L * H * H, (float*)a.qkv, 3 * H,
+                            off(l, SIMX_P_BQKV), nullptr, 0, nullptr, 0, 0, nullptr));
+    RUN(simx_mha_fwd_planes(stream, nseq, c->heads, d, cu, max_len, T, (const float*)a.qkv, a.ctx, psH, a.lse, &d3));
+    RUN(simx_gemm_nt_planes(stream, SIMX_F16, SIMX_EPI_NONE, Tp, H, H, a.ctx, H, psH, w.woP, H, (long)H * H, (float*)a.z1, H, off(l, SIMX_P_BO),
+                            (const float*)x, H, nullptr, 0, 0, &d1));
+    RUN(simx_ln_fwd_planes(stream, T, H, (const float*)a.z1, off(l, SIMX_P_LN1_G), off(l, SIMX_P_LN1_B), c->eps, (float*)a.x1, a.x1p, psH));
+    RUN(simx_gemm_nt_planes(stream, SIMX_F16, keep ? SIMX_EPI_GELU : SIMX_EPI_GELU_INFER, Tp, F, H, a.x1p, H, psH, w.w1P, H, (long)F * H,
+                            (float*)a.u, F, off(l, SIMX_P_B1), nullptr, 0, a.h, F, psF, nullptr));
+    RUN(simx_gemm_nt_planes(stream, SIMX_F16, SIMX_EPI_NONE, Tp, H, F, a.h, F, psF, w.w2P, F, (long)H * F, (float*)a.z2, H, off(l, SIMX_P_B2),
+                            (const float*)a.x1, H, nullptr, 0, 0, &d2));
+    RUN(simx_ln_fwd_planes(stream, T, H, (const float*)a.z2, off(l, SIMX_P_LN2_G), off(l, SIMX_P_LN2_B), c->eps, (float*)a.xout, a.xoutp, psH));
+    return SIMX_OK;
+  }
   if (hm)
     RUN(simx_gemm_nt_hm(stream, dt, Tp, 3 * H, H, x, H, w.wqkv, H, a.qkv, 64, off(l, SIMX_P_BQKV), nullptr, 0, nullptr, 0, hm));
   else
@@ -372,10 +457,16 @@ extern "C" int simx_bert_fwd(simx_stream_t stream, const simx_bert_cfg* c, const
   auto off = [&](int l, int w) { return params + simx_bert_param_offset(c, l, w); };
   const char* x = act_x0(act);
   const char* xl = xs_lo(c, x, Tp);
+  const char* xp = xs_pl(c, x, Tp);
   {
     const simx_dropout d0 = drop_of(c, -1, 0);
-    RUN(simx_embed_ln_fwd_lo(stream, dt, T, H, ids, pos_ids, off(-1, SIMX_P_WORD), off(-1, SIMX_P_POS), off(-1, SIMX_P_TYPE),
-                             off(-1, SIMX_P_EMB_LN_G), off(-1, SIMX_P_EMB_LN_B), c->eps, act_x0(act), const_cast<char*>(xl), &d0));
+    if (xp)
+      RUN(simx_embed_ln_fwd_planes(stream, T, H, ids, pos_ids, off(-1, SIMX_P_WORD), off(-1, SIMX_P_POS), off(-1, SIMX_P_TYPE),
+                                   off(-1, SIMX_P_EMB_LN_G), off(-1, SIMX_P_EMB_LN_B), c->eps, (float*)act_x0(act), const_cast<char*>(xp),
+                                   (long)Tp * H, &d0));
+    else
+      RUN(simx_embed_ln_fwd_lo(stream, dt, T, H, ids, pos_ids, off(-1, SIMX_P_WORD), off(-1, SIMX_P_POS), off(-1, SIMX_P_TYPE),
+                               off(-1, SIMX_P_EMB_LN_G), off(-1, SIMX_P_EMB_LN_B), c->eps, act_x0(act), const_cast<char*>(xl), &d0));
   }
   const bool cls_only = c->cls_only_last_layer != 0;
   const bool ckpt = ckpt_mode(c, save);
@@ -384,11 +475,12 @@ extern "C" int simx_bert_fwd(simx_stream_t stream, const simx_bert_cfg* c, const
     const ALayer a = alayer(c, act, Tp, l, save);
     const bool cls_form = cls_only && l == c->layers - 1;
     // (checkpoint mode: the slot is recomputed by backward, so the forward runs it in its inference form)
-    RUN(layer_fwd((hipStream_t)stream, c, params, wcache, l, x, xl, a, act_extra(c, act, Tp, save), cu, nseq, T, Tp, max_len,
+    RUN(layer_fwd((hipStream_t)stream, c, params, wcache, l, x, xl, xp, a, act_extra(c, act, Tp, save), cu, nseq, T, Tp, max_len,
                   save && !ckpt, cls_form, cls_out));
     if (cls_form) return SIMX_OK;
     x = a.xout;
     xl = a.xoutl;
+    xp = a.xoutp;
   }
   if (cls_out) RUN(simx_cls_gather(stream, dt, nseq, H, cu, x, cls_out));
   if (hidden_out) {
@@ -447,6 +539,8 @@ extern "C" int simx_bert_bwd_range(simx_stream_t stream, const simx_bert_cfg* c,
   char* dqkv = du + al((size_t)Tp * F * e);
   char* tnws = dqkv + al((size_t)Tp * 3 * H * e);
   const size_t tnws_bytes = tn_ws_max(c, T);
+  char* xconv = tnws + tnws_bytes + 3 * al((size_t)(nseq > 0 ? nseq : Tp) * H * e);   // operand planes: bf16 pair of a wgrad's activation operand
+  const bool pl = pl_run(c, Tp, max_len);
   const int hm = hm_rows_for(c, T, Tp, max_len);        // layout of qkv / dqkv (the forward's choice: same config copy, same inputs)
   // fp16 engine: activation gradients travel multiplied by the loss scale S (gs = {S, 1/S} on the device); the kernels that
   // accumulate into `grads` multiply by 1/S, so `grads` holds true gradients (simx.h "gradient scale")
@@ -461,7 +555,7 @@ extern "C" int simx_bert_bwd_range(simx_stream_t stream, const simx_bert_cfg* c,
     const WLayer w = wlayer(c, params, wcache, l);
     const char* xin = layer_input(c, act, Tp, l);
     const ALayer a = ckpt ? alayer_recompute(c, act, Tp) : alayer(c, act, Tp, l, 1);
-    if (ckpt) RUN(layer_fwd((hipStream_t)stream, c, params, wcache, l, xin, layer_input_lo(c, act, Tp, l), a, act_extra(c, act, Tp, 1), cu, nseq, T, Tp, max_len, 1, true, nullptr));
+    if (ckpt) RUN(layer_fwd((hipStream_t)stream, c, params, wcache, l, xin, layer_input_lo(c, act, Tp, l), layer_input_pl(c, act, Tp, l), a, act_extra(c, act, Tp, 1), cu, nseq, T, Tp, max_len, 1, true, nullptr));
     const simx_dropout d1 = drop_of(c, l, 1), d2 = drop_of(c, l, 2), d3 = drop_of(c, l, 3);
     char* dzm = hd ? bufC : bufA;
     char* e0 = tnws + tnws_bytes;                        // three [nseq,H] temporaries
@@ -522,8 +616,37 @@ extern "C" int simx_bert_bwd_range(simx_stream_t stream, const simx_bert_cfg* c,
     const ALayer a = ckpt ? alayer_recompute(c, act, Tp) : alayer(c, act, Tp, l, 1);
     const char* xinl = layer_input_lo(c, act, Tp, l);
     const bool sl = stream_lo(c);
-    if (ckpt) RUN(layer_fwd((hipStream_t)stream, c, params, wcache, l, xin, xinl, a, nullptr, cu, nseq, T, Tp, max_len, 1, false, nullptr));
+    if (ckpt) RUN(layer_fwd((hipStream_t)stream, c, params, wcache, l, xin, xinl, layer_input_pl(c, act, Tp, l), a, nullptr, cu, nseq, T, Tp, max_len, 1, false, nullptr));
     const simx_dropout d1 = drop_of(c, l, 1), d2 = drop_of(c, l, 2), d3 = drop_of(c, l, 3);
+    if (pl) {
+      // fp32 engine on operand planes (see layer_fwd): gradients that feed a GEMM leave their producer as bf16 plane pairs --
+      // bufC = dz (x dropout mask) from the LayerNorm backward, du from the DGELU epilogue, dqkv from the attention backward;
+      // the activation operand of each wgrad GEMM is converted to a bf16 pair into xconv right before its use
+      const long psH = (long)Tp * H, psF = (long)Tp * F, ps3 = (long)Tp * 3 * H;
+      RUN(simx_ln_bwd_planes(stream, T, H, (const float*)a.z2, off(l, SIMX_P_LN2_G), c->eps, (const float*)bufB, (float*)bufA, bufC, psH,
+                             goff(l, SIMX_P_LN2_G), goff(l, SIMX_P_LN2_B), goff(l, SIMX_P_B2), &d2));
+      RUN(simx_gemm_nt_planes(stream, SIMX_BF16, SIMX_EPI_DGELU, Tp, F, H, bufC, H, psH, w.w2TP, H, (long)F * H, nullptr, F, nullptr,
+                              (const float*)a.u, F, du, F, psF, nullptr));
+      RUN(simx_planes_from(stream, SIMX_F16, SIMX_BF16, T, F, a.h, F, psF, xconv, F, psF));
+      RUN(simx_gemm_tn_planes(stream, H, F, T, bufC, H, psH, xconv, F, psF, goff(l, SIMX_P_W2), F, 1, tnws, tnws_bytes, nullptr));
+      RUN(simx_gemm_nt_planes(stream, SIMX_BF16, SIMX_EPI_NONE, Tp, H, F, du, F, psF, w.w1TP, F, (long)H * F, (float*)bufB, H, nullptr,
+                              (const float*)bufA, H, nullptr, 0, 0, nullptr));
+      RUN(simx_planes_from(stream, SIMX_F32, SIMX_BF16, T, H, a.x1, H, 0, xconv, H, psH));
+      RUN(simx_gemm_tn_planes(stream, F, H, T, du, F, psF, xconv, H, psH, goff(l, SIMX_P_W1), H, 1, tnws, tnws_bytes, goff(l, SIMX_P_B1)));
+      RUN(simx_ln_bwd_planes(stream, T, H, (const float*)a.z1, off(l, SIMX_P_LN1_G), c->eps, (const float*)bufB, (float*)bufA, bufC, psH,
+                             goff(l, SIMX_P_LN1_G), goff(l, SIMX_P_LN1_B), goff(l, SIMX_P_BO), &d1));
+      RUN(simx_gemm_nt_planes(stream, SIMX_BF16, SIMX_EPI_NONE, Tp, H, H, bufC, H, psH, w.woTP, H, (long)H * H, (float*)bufB, H, nullptr, nullptr, 0,
+                              nullptr, 0, 0, nullptr));
+      RUN(simx_planes_from(stream, SIMX_F16, SIMX_BF16, T, H, a.ctx, H, psH, xconv, H, psH));
+      RUN(simx_gemm_tn_planes(stream, H, H, T, bufC, H, psH, xconv, H, psH, goff(l, SIMX_P_WO), H, 1, tnws, tnws_bytes, nullptr));
+      RUN(simx_mha_bwd_planes(stream, nseq, c->heads, d, cu, max_len, T, (const float*)a.qkv, a.ctx, psH, a.lse, (const float*)bufB, dqkv, ps3, &d3));
+      RUN(simx_gemm_nt_planes(stream, SIMX_BF16, SIMX_EPI_NONE, Tp, H, 3 * H, dqkv, 3 * H, ps3, w.wqkvTP, 3 * H, 3L * H * H, (float*)bufB, H, nullptr,
+                              (const float*)bufA, H, nullptr, 0, 0, nullptr));
+      RUN(simx_planes_from(stream, SIMX_F32, SIMX_BF16, T, H, xin, H, 0, xconv, H, psH));
+      RUN(simx_gemm_tn_planes(stream, 3 * H, H, T, dqkv, 3 * H, ps3, xconv, H, psH, goff(l, SIMX_P_WQKV), H, 1, tnws, tnws_bytes,
+                              goff(l, SIMX_P_BQKV)));
+      continue;
+    }
     char* dzm = hd ? bufC : bufA;        // gradient of the (dropped) dense output; bufA = gradient of the residual branch
     // output LayerNorm : dz2, dgamma2, dbeta2, db2
     RUN(simx_ln_bwd_res(stream, dt, T, H, a.z2, sl ? a.x1 : nullptr, sl ? a.x1l : nullptr, off(l, SIMX_P_LN2_G), c->eps, bufB, bufA,

@@ -5,6 +5,7 @@
 // wave-level butterflies only (no LDS, no barriers) in the forward kernels.  Backward kernels keep
 // per-lane column partial sums (dgamma, dbeta, dbias / dtype0) across the rows a workgroup walks and
 // flush them once with f32 atomics.
+#include <type_traits>
 #include "common.h"
 #include "prof.h"
 
@@ -54,6 +55,16 @@ __device__ __forceinline__ void st4_residue(T* p, const float (&o)[4], float (&r
   }
 }
 
+// plane pair (csrc/gemm_xp.hip, simx.h "operand planes") of 4 consecutive f32 values: hi = rnd16(o), lo = rnd16(o - hi)
+template <typename F>
+__device__ __forceinline__ void st4_planes(bf16_t* p, long plane_stride, const float (&o)[4]) {
+  const uint32_t h0 = H16<F>::pack2(o[0], o[1]), h1 = H16<F>::pack2(o[2], o[3]);
+  const uint32_t l0 = H16<F>::pack2(o[0] - H16<F>::lo(h0), o[1] - H16<F>::hi(h0));
+  const uint32_t l1 = H16<F>::pack2(o[2] - H16<F>::lo(h1), o[3] - H16<F>::hi(h1));
+  *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+  *reinterpret_cast<uint2*>(p + plane_stride) = make_uint2(l0, l1);
+}
+
 // One wave per row, rows strided by 4 inside a block; the next row's loads are issued before this row's
 // reductions, and gamma/beta are read from LDS so the row body never queues behind those loads on vmcnt.
 // RES ("f32-grade residual stream" of the 16-bit engines, simx.h stream_lo): the input row is  z = d + r_hi + r_lo  -- the
@@ -66,7 +77,9 @@ template <typename T, int VPL, bool RES>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int H, int rows_per_block, const T* __restrict__ z,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float eps, T* __restrict__ y, const T* __restrict__ rh,
-                                                     const uint8_t* __restrict__ rl, uint8_t* __restrict__ ylo) {
+                                                     const uint8_t* __restrict__ rl, uint8_t* __restrict__ ylo,
+                                                     bf16_t* __restrict__ yp = nullptr, long yps = 0) {
+  // yp (f32 engine, "operand planes"): y also leaves as the fp16 plane pair the next GEMM stages
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sgam = reinterpret_cast<float*>(smem);
   float* sbet = sgam + H;
@@ -138,6 +151,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int H, int rows_p
           *reinterpret_cast<uint32_t*>(ylo + (long)row * H + c) = lo8_encode4<T>(w0, w1, rr);
         } else {
           st4(yr + c, o);
+          if constexpr (std::is_same<T, float>::value) { if (yp) st4_planes<f16_t>(yp + (long)row * H + c, yps, o); }
         }
       }
     }
@@ -149,7 +163,8 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(int rows, int H, cons
                                                            const int* __restrict__ pos, const float* __restrict__ word,
                                                            const float* __restrict__ posw, const float* __restrict__ typew,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           float eps, T* __restrict__ y, DropCtx drop, uint8_t* __restrict__ ylo) {
+                                                           float eps, T* __restrict__ y, DropCtx drop, uint8_t* __restrict__ ylo,
+                                                           bf16_t* __restrict__ yp = nullptr, long yps = 0) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + w;
   if (row >= rows) return;
@@ -197,6 +212,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(int rows, int H, cons
         *reinterpret_cast<uint32_t*>(ylo + (long)row * H + c) = lo8_encode4<T>(w0, w1, rr);
       } else {
         st4(yr + c, o);
+        if constexpr (std::is_same<T, float>::value) { if (yp) st4_planes<f16_t>(yp + (long)row * H + c, yps, o); }
       }
     }
   }
@@ -275,7 +291,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int H, int rows_p
                                                      float* __restrict__ dbeta, float* __restrict__ dbias,
                                                      T* __restrict__ dzm, DropCtx drop, const int* __restrict__ row_keys,
                                                      const float* __restrict__ gs, const T* __restrict__ rh,
-                                                     const uint8_t* __restrict__ rl, float* __restrict__ det_part) {
+                                                     const uint8_t* __restrict__ rl, float* __restrict__ det_part,
+                                                     bf16_t* __restrict__ dzpl = nullptr, long dzps = 0) {
+  // dzpl (f32 engine, "operand planes"): the gradient of the (dropped) dense output leaves as the bf16 plane pair the dgrad /
+  // wgrad GEMMs stage -- with or without dropout -- and the f32 masked copy dzm is not written
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sred = reinterpret_cast<float*>(smem);          // [4][H] flush scratch
   float* sgam = sred + 4 * H;                            // [H]
@@ -344,8 +363,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int H, int rows_p
           drop_mult4(drop, (uint32_t)(row_keys ? row_keys[row] : row), (uint32_t)c, m4);   // keys: rows gathered from a larger tensor
 #pragma unroll
           for (int e = 0; e < 4; ++e) dz[v][e] *= m4[e];
-          st4(dzm + (long)row * H + c, dz[v]);
+          if (!dzpl) st4(dzm + (long)row * H + c, dz[v]);
         }
+        if constexpr (std::is_same<T, float>::value) { if (dzpl) st4_planes<bf16_t>(dzpl + (long)row * H + c, dzps, dz[v]); }
 #pragma unroll
         for (int e = 0; e < 4; ++e) pz[v][e] += dz[v][e];
       }
@@ -664,6 +684,24 @@ extern "C" int simx_ln_fwd_res(simx_stream_t stream, int dtype, int T, int H, co
   return SIMX_OK;
 }
 
+// f32 engine with operand planes: y (f32) and its fp16 plane pair (y_planes, lo at + plane_stride elements; leading dimension H)
+extern "C" int simx_ln_fwd_planes(simx_stream_t stream, int T, int H, const float* z, const float* gamma, const float* beta, float eps,
+                                  float* y, void* y_planes, long plane_stride) {
+  SIMX_PROF(SIMX_K_LN_FWD, stream, (double)T * H * 12);
+  int rc = ln_check(SIMX_F32, T, H, "ln_fwd_planes");
+  if (rc) return rc;
+  SIMX_REQUIRE(y_planes && plane_stride % 4 == 0 && (((uintptr_t)y_planes) & 7) == 0, SIMX_ERR_BAD_SHAPE, "ln_fwd_planes: bad plane buffer");
+  hipStream_t s = (hipStream_t)stream;
+  const int rpb = ln_rows_per_block(T, "SIMX_LN_FWD_BLOCKS", 1 << 30);
+  const size_t lds = (size_t)2 * H * sizeof(float);
+#define LFP(TT, V) hipLaunchKernelGGL((ln_fwd_kernel<float, V, false>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, z, gamma, beta, eps, y, \
+                                      (const float*)nullptr, (const uint8_t*)nullptr, (uint8_t*)nullptr, (bf16_t*)y_planes, plane_stride)
+  LN_BY_H(float, LFP);
+#undef LFP
+  SIMX_CHECK_LAUNCH("ln_fwd_planes");
+  return SIMX_OK;
+}
+
 extern "C" int simx_ln_bwd(simx_stream_t stream, int dtype, int T, int H, const void* z, const float* gamma, float eps,
                            const void* dy, void* dz, float* dgamma, float* dbeta, float* dbias) {
   return simx_ln_bwd_gs(stream, dtype, T, H, z, gamma, eps, dy, dz, nullptr, dgamma, dbeta, dbias, nullptr, nullptr, nullptr);
@@ -714,6 +752,48 @@ extern "C" int simx_ln_bwd_res(simx_stream_t stream, int dtype, int T, int H, co
 #undef LB
   SIMX_CHECK_LAUNCH("ln_bwd");
   if (det) return simx_det_reduce(s, det, 3L * H, nblk, H, dgamma, dbeta, dbias, gs);
+  return SIMX_OK;
+}
+
+// f32 engine with operand planes: dz (f32, the residual branch's gradient) and the bf16 plane pair of the dropped dense
+// output's gradient (dz x mask when dropout is on, dz otherwise) for the dgrad / wgrad GEMMs
+extern "C" int simx_ln_bwd_planes(simx_stream_t stream, int T, int H, const float* z, const float* gamma, float eps, const float* dy, float* dz,
+                                  void* dzm_planes, long plane_stride, float* dgamma, float* dbeta, float* dbias, const simx_dropout* dropd) {
+  SIMX_PROF(SIMX_K_LN_BWD, stream, (double)T * H * 16);
+  int rc = ln_check(SIMX_F32, T, H, "ln_bwd_planes");
+  if (rc) return rc;
+  SIMX_REQUIRE(dzm_planes && plane_stride % 4 == 0 && (((uintptr_t)dzm_planes) & 7) == 0, SIMX_ERR_BAD_SHAPE, "ln_bwd_planes: bad plane buffer");
+  const DropCtx drop = make_drop(dropd);
+  hipStream_t s = (hipStream_t)stream;
+  const int rpb = bwd_rows_per_block(T);
+  const size_t lds = (size_t)5 * H * sizeof(float);
+  const int nblk = cdiv(T, rpb);
+  float* det = nullptr;
+  if (simx_det()) {
+    det = simx_det_ws(s, (size_t)nblk * 3 * H * sizeof(float));
+    if (!det) return SIMX_ERR_WORKSPACE;
+  }
+#define LBP(TT, V) hipLaunchKernelGGL((ln_bwd_kernel<float, V, false>), dim3(cdiv(T, rpb)), dim3(256), lds, s, T, H, rpb, z, gamma, eps, dy, dz, dgamma, dbeta, \
+                                      dbias, (float*)nullptr, drop, (const int*)nullptr, (const float*)nullptr, (const float*)nullptr,                     \
+                                      (const uint8_t*)nullptr, det, (bf16_t*)dzm_planes, plane_stride)
+  LN_BY_H(float, LBP);
+#undef LBP
+  SIMX_CHECK_LAUNCH("ln_bwd_planes");
+  if (det) return simx_det_reduce(s, det, 3L * H, nblk, H, dgamma, dbeta, dbias, nullptr);
+  return SIMX_OK;
+}
+
+extern "C" int simx_embed_ln_fwd_planes(simx_stream_t stream, int T, int H, const int32_t* ids, const int32_t* pos_ids, const float* word,
+                                        const float* posw, const float* typew, const float* gamma, const float* beta, float eps, float* out,
+                                        void* out_planes, long plane_stride, const simx_dropout* dropd) {
+  const DropCtx drop = make_drop(dropd);
+  SIMX_PROF(SIMX_K_EMBED_FWD, stream, (double)T * H * 12);
+  int rc = ln_check(SIMX_F32, T, H, "embed_ln_fwd_planes");
+  if (rc) return rc;
+  SIMX_REQUIRE(out_planes && plane_stride % 4 == 0 && (((uintptr_t)out_planes) & 7) == 0, SIMX_ERR_BAD_SHAPE, "embed_ln_fwd_planes: bad plane buffer");
+  hipLaunchKernelGGL((embed_ln_fwd_kernel<float>), dim3(cdiv(T, 4)), dim3(256), 0, (hipStream_t)stream, T, H, ids, pos_ids, word, posw, typew, gamma,
+                     beta, eps, out, drop, (uint8_t*)nullptr, (bf16_t*)out_planes, plane_stride);
+  SIMX_CHECK_LAUNCH("embed_ln_fwd_planes");
   return SIMX_OK;
 }
 

@@ -516,6 +516,212 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_xp_kernel(
 #undef XS_FULL
 }
 
+// ------------------------------------------------------------------------------------------ TN (wgrad), four-plane stages
+// The same product with HALF-DEPTH, FOUR-PLANE stages: a 64 KB stage holds 32 tokens of Ahi | Alo | Bhi | Blo (16 KB each;
+// token-major rows are 512 B whatever the depth, so the LDS-DMA still moves whole lines) and feeds three k-steps,
+// Ahi.Blo, Alo.Bhi, Ahi.Bhi: 96 MFMAs per wave and barrier instead of 64, and 64 KB of operand traffic per 96 MFMAs where the
+// tripled-K form above stages 96 KB (every hi plane twice).  The Bhi fragments of the second k-step serve the third.
+// LDS image of a stage: A region (32 KB) rows 0-31 = Ahi, 32-63 = Alo; B region (32 KB) rows 0-31 = Bhi, 32-63 = Blo;
+// row kr at kr * 512 B, 32-B chunk q at q ^ (kr & 7).  Waves 0-3 stage the hi planes, waves 4-7 the lo planes.
+// No fused bias gradient here: with the per-row `do_bias` branches and their conversions in the loop the kernel needs 40 more
+// VGPRs than the 256 a wave of a 512-thread workgroup has and spills into scratch inside the loop (2.3x slower, measured);
+// without them it fits.  The wgrad GEMMs that also produce a bias gradient (W1, Wqkv) stay on gemm_tn_xp_kernel.
+template <typename F>
+__global__ __launch_bounds__(512, 2) void gemm_tn_xq_kernel(
+    int M, int N, int K, const bf16_t* __restrict__ A, int lda, long a_ps, const bf16_t* __restrict__ B, int ldb, long b_ps,
+    float* __restrict__ out, long slab_stride, int ldo, int tiles_n, int tiles_mn, int k_per_split, int accumulate,
+    float* __restrict__ dbias, int dbias_parts) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int vb = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = vb / tiles_mn;
+  const int tile = vb % tiles_mn;
+  const int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int kb = split * k_per_split;
+  const int ke = min(K, kb + k_per_split);
+  const int fs = lane & 15, fg = lane >> 4;
+  const int bias_slot = (tile % tiles_n) * 4 + wc, bias_mod = tiles_n * 4;
+  bool do_bias = false;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  const int nst = (ke - kb + 31) / 32;             // 32-token stages
+  const int last_valid = (ke - kb) - (nst - 1) * 32;               // rows of the last stage (32 = not ragged)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const int r_lo = 4 * fg + (fs >> 2);
+  const int x_lo = r_lo & 7, x_hi = (r_lo + 16) & 7;
+  const uint32_t row_lo = (uint32_t)(r_lo * 512 + (fs & 3) * 8), row_hi = (uint32_t)((r_lo + 16) * 512 + (fs & 3) * 8);
+  // this wave's share of a stage: plane (hi: waves 0-3, lo: 4-7), token rows (wave & 3) * 8 + 2 j + (lane >> 5)
+  const bf16_t* Aw = A + (wave >= 4 ? a_ps : 0L);
+  const bf16_t* Bw = B + (wave >= 4 ? b_ps : 0L);
+  const int trow = (wave & 3) * 8;
+  uint32_t oa[4], ob[4];
+  tn2_lane_offsets(lda, m0, M, ldb, n0, N, lane, oa, ob, 0);
+  // piece j of stage ST's operand (full stages): SGPR base carries the token row, the lane offset the column swizzle
+#define XQ_ONE_A(ST, J) P_DMA16(oa[J], reinterpret_cast<const char*>(Aw + (long)(kb + (ST) * 32 + trow + 2 * (J)) * lda), \
+                                lds0 + (uint32_t)(((ST) & 1) * TN2_STAGE + (wave * 4 + (J)) * 1024))
+#define XQ_ONE_B(ST, J) P_DMA16(ob[J], reinterpret_cast<const char*>(Bw + (long)(kb + (ST) * 32 + trow + 2 * (J)) * ldb), \
+                                lds0 + 32768u + (uint32_t)(((ST) & 1) * TN2_STAGE + (wave * 4 + (J)) * 1024))
+  // a (possibly ragged) stage at once, token rows clamped into [0, valid): rows >= valid are zeroed after landing
+#define XQ_CLAMPED_ONE(ST, VALID, J)                                                                            \
+  do {                                                                                                          \
+    int t__ = trow + 2 * (J) + (lane >> 5);                                                                     \
+    t__ = t__ < (VALID) ? t__ : (VALID) - 1;                                                                    \
+    const uint32_t ca__ = oa[J] - (uint32_t)((lane >> 5) * lda) * 2, cb__ = ob[J] - (uint32_t)((lane >> 5) * ldb) * 2; \
+    P_DMA16(ca__ + (uint32_t)(t__ * lda) * 2, reinterpret_cast<const char*>(Aw + (long)(kb + (ST) * 32) * lda),  \
+            lds0 + (uint32_t)(((ST) & 1) * TN2_STAGE + (wave * 4 + (J)) * 1024));                               \
+    P_DMA16(cb__ + (uint32_t)(t__ * ldb) * 2, reinterpret_cast<const char*>(Bw + (long)(kb + (ST) * 32) * ldb),  \
+            lds0 + 32768u + (uint32_t)(((ST) & 1) * TN2_STAGE + (wave * 4 + (J)) * 1024));                      \
+  } while (0)
+#define stage_clamped(ST, VALID) do { XQ_CLAMPED_ONE(ST, VALID, 0); XQ_CLAMPED_ONE(ST, VALID, 1); XQ_CLAMPED_ONE(ST, VALID, 2); XQ_CLAMPED_ONE(ST, VALID, 3); } while (0)
+#define XQ_ZERO_TAIL(BUF)                                                                                       \
+  do {                                                                                                          \
+    char* sp__ = smem + (BUF) * TN2_STAGE;                                                                      \
+    for (int idx = tid; idx < 128 * 32; idx += 512) {           /* 128 rows (4 planes x 32) x 32 16-B pieces */ \
+      const int row = idx >> 5, c16 = idx & 31;                                                                 \
+      if ((row & 31) >= last_valid) *reinterpret_cast<uint4*>(sp__ + row * 512 + c16 * 16) = make_uint4(0, 0, 0, 0); \
+    }                                                                                                           \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                             \
+  } while (0)
+#define XQ_VALID(ST) ((ST) == nst - 1 ? last_valid : 32)
+
+  stage_clamped(0, XQ_VALID(0));
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  if (nst > 1) stage_clamped(1, XQ_VALID(1));
+  if (nst == 1 && last_valid < 32) XQ_ZERO_TAIL(0);
+
+  bf16x4 al_lo[4], al_hi[4], ah_lo[4], ah_hi[4], bx_lo[4], bx_hi[4], by_lo[4], by_hi[4];
+#define XQ_ADDR_LO(TILE, CT) ((TILE) + row_lo + (uint32_t)((((CT)) ^ x_lo) << 5))
+#define XQ_ADDR_HI(TILE, CT) ((TILE) + row_hi + (uint32_t)((((CT)) ^ x_hi) << 5))
+#define TN2_FRAG(LO, HI) ((bf16x8){LO[0], LO[1], LO[2], LO[3], HI[0], HI[1], HI[2], HI[3]})
+#define XQ_MFMA_ROW(I, ALO, AHI, BLO, BHI, BIAS)                                                                \
+  do {                                                                                                          \
+    const bf16x8 af__ = TN2_FRAG(ALO, AHI);                                                                     \
+    acc[I][0] = H16<F>::mfma(TN2_FRAG(BLO[0], BHI[0]), af__, acc[I][0]);    \
+    acc[I][1] = H16<F>::mfma(TN2_FRAG(BLO[1], BHI[1]), af__, acc[I][1]);    \
+    acc[I][2] = H16<F>::mfma(TN2_FRAG(BLO[2], BHI[2]), af__, acc[I][2]);    \
+    acc[I][3] = H16<F>::mfma(TN2_FRAG(BLO[3], BHI[3]), af__, acc[I][3]);    \
+    if (false && (BIAS) && do_bias) {                                                                                    \
+      _Pragma("unroll") for (int e__ = 0; e__ < 4; ++e__)                                                       \
+          bsum[I] += H16<F>::one(ALO[e__]) + H16<F>::one(AHI[e__]);                                           \
+    }                                                                                                           \
+  } while (0)
+#define XQ_SB __builtin_amdgcn_sched_barrier(0)
+  {   // fragments of k-step 0 of stage 0: A rows 0-3 of Ahi, B = Blo
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      TN2_RD(al_lo[i], al_hi[i], XQ_ADDR_LO(lds0, wr * 8 + i), XQ_ADDR_HI(lds0, wr * 8 + i));
+      TN2_RD(bx_lo[i], bx_hi[i], XQ_ADDR_LO(lds0 + 49152u, wc * 4 + i), XQ_ADDR_HI(lds0 + 49152u, wc * 4 + i));
+    }
+  }
+  // one k-step (32 tokens of one term).  CURA: this k-step's A tile (its row fragments 4-7 are read here), NXTA / NXTB: the
+  // next k-step's A and B tiles (A row fragments 0-3 and the B fragments are read here; RDB = 0: the next k-step keeps this
+  // one's B fragments).  SYNC: the stage boundary sits in the middle of this k-step (every fragment of the stage's tiles
+  // that is still needed has been issued before it).  PIECES: 1 = first half of the next-next stage's DMA pieces, 2 = second.
+#define XQ_STEP(CURA, NXTA, NXTB, BCL, BCH, BNL, BNH, RDB, BIAS, SYNC, ST)                                      \
+  do {                                                                                                          \
+    const uint32_t cur__ = (CURA), nxa__ = (NXTA), nxb__ = (NXTB);                                              \
+    bool spread__ = false;                                                                                      \
+    const bool tail__ = !(SYNC) && pend && (BIAS) == 0;       /* second half of the previous boundary's stage (k-step 0 only) */ \
+    XQ_SB; XQ_MFMA_ROW(0, al_lo[0], al_hi[0], BCL, BCH, BIAS); XQ_SB;                                           \
+    TN2_RD(ah_lo[0], ah_hi[0], XQ_ADDR_LO(cur__, wr * 8 + 4), XQ_ADDR_HI(cur__, wr * 8 + 4));                   \
+    TN2_RD(ah_lo[1], ah_hi[1], XQ_ADDR_LO(cur__, wr * 8 + 5), XQ_ADDR_HI(cur__, wr * 8 + 5));                   \
+    if (tail__) XQ_ONE_A((ST) + 1, 2);                                                                          \
+    XQ_SB; XQ_MFMA_ROW(1, al_lo[1], al_hi[1], BCL, BCH, BIAS); XQ_SB;                                           \
+    TN2_RD(ah_lo[2], ah_hi[2], XQ_ADDR_LO(cur__, wr * 8 + 6), XQ_ADDR_HI(cur__, wr * 8 + 6));                   \
+    TN2_RD(ah_lo[3], ah_hi[3], XQ_ADDR_LO(cur__, wr * 8 + 7), XQ_ADDR_HI(cur__, wr * 8 + 7));                   \
+    if (tail__) XQ_ONE_B((ST) + 1, 2);                                                                          \
+    XQ_SB; XQ_MFMA_ROW(2, al_lo[2], al_hi[2], BCL, BCH, BIAS);                                                  \
+    if (tail__) XQ_ONE_A((ST) + 1, 3);                                                                          \
+    XQ_SB; XQ_MFMA_ROW(3, al_lo[3], al_hi[3], BCL, BCH, BIAS);                                                  \
+    if (tail__) { XQ_ONE_B((ST) + 1, 3); pend = false; }                                                        \
+    XQ_SB;                                                                                                      \
+    if (SYNC) {                                                                                                 \
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                                             \
+      const int s2__ = (ST) + 2;                                                                                \
+      spread__ = s2__ < nst && XQ_VALID(s2__) == 32;                                                            \
+      if (spread__) { XQ_ONE_A(s2__, 0); pend = true; }                                                         \
+      else if (s2__ < nst) stage_clamped(s2__, XQ_VALID(s2__));                                                 \
+      if ((ST) + 1 == nst - 1 && last_valid < 32) XQ_ZERO_TAIL(((ST) + 1) & 1);                                 \
+    }                                                                                                           \
+    XQ_SB; XQ_MFMA_ROW(4, ah_lo[0], ah_hi[0], BCL, BCH, BIAS); XQ_SB;                                           \
+    TN2_RD(al_lo[0], al_hi[0], XQ_ADDR_LO(nxa__, wr * 8 + 0), XQ_ADDR_HI(nxa__, wr * 8 + 0));                   \
+    if (RDB) TN2_RD(BNL[0], BNH[0], XQ_ADDR_LO(nxb__, wc * 4 + 0), XQ_ADDR_HI(nxb__, wc * 4 + 0));              \
+    TN2_RD(al_lo[1], al_hi[1], XQ_ADDR_LO(nxa__, wr * 8 + 1), XQ_ADDR_HI(nxa__, wr * 8 + 1));                   \
+    if (SYNC && spread__) XQ_ONE_B((ST) + 2, 0);                                                                \
+    XQ_SB; XQ_MFMA_ROW(5, ah_lo[1], ah_hi[1], BCL, BCH, BIAS); XQ_SB;                                           \
+    if (RDB) TN2_RD(BNL[1], BNH[1], XQ_ADDR_LO(nxb__, wc * 4 + 1), XQ_ADDR_HI(nxb__, wc * 4 + 1));              \
+    TN2_RD(al_lo[2], al_hi[2], XQ_ADDR_LO(nxa__, wr * 8 + 2), XQ_ADDR_HI(nxa__, wr * 8 + 2));                   \
+    if (RDB) TN2_RD(BNL[2], BNH[2], XQ_ADDR_LO(nxb__, wc * 4 + 2), XQ_ADDR_HI(nxb__, wc * 4 + 2));              \
+    if (SYNC && spread__) XQ_ONE_A((ST) + 2, 1);                                                                \
+    XQ_SB; XQ_MFMA_ROW(6, ah_lo[2], ah_hi[2], BCL, BCH, BIAS); XQ_SB;                                           \
+    TN2_RD(al_lo[3], al_hi[3], XQ_ADDR_LO(nxa__, wr * 8 + 3), XQ_ADDR_HI(nxa__, wr * 8 + 3));                   \
+    if (RDB) TN2_RD(BNL[3], BNH[3], XQ_ADDR_LO(nxb__, wc * 4 + 3), XQ_ADDR_HI(nxb__, wc * 4 + 3));              \
+    if (SYNC && spread__) XQ_ONE_B((ST) + 2, 1);                                                                \
+    XQ_SB; XQ_MFMA_ROW(7, ah_lo[3], ah_hi[3], BCL, BCH, BIAS);                                                  \
+    XQ_SB;                                                                                                      \
+  } while (0)
+
+  bool pend = false;
+  for (int st = 0; st < nst; ++st) {
+    const uint32_t sc = lds0 + (uint32_t)((st & 1) * TN2_STAGE), sn = lds0 + (uint32_t)(((st + 1) & 1) * TN2_STAGE);
+    do_bias = dbias != nullptr && (st % bias_mod) == bias_slot;
+    // Ahi.Blo (bx) ; Alo.Bhi (by) ; Ahi.Bhi (by, kept) -- the last k-step reads the next stage's Ahi rows 0-3 and Blo
+    XQ_STEP(sc, sc + 16384u, sc + 32768u, bx_lo, bx_hi, by_lo, by_hi, 1, 0, false, st);
+    XQ_STEP(sc + 16384u, sc, sc + 32768u, by_lo, by_hi, by_lo, by_hi, 0, 1, false, st);
+    XQ_STEP(sc, sn, sn + 49152u, by_lo, by_hi, bx_lo, bx_hi, 1, 2, true, st);
+  }
+#undef XQ_STEP
+
+  float* o = out + (long)split * slab_stride;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + wr * 128 + i * 16 + fs;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wc * 64 + j * 16 + fg * 4;
+      if (n >= N) continue;
+      float4* dst = reinterpret_cast<float4*>(o + (long)m * ldo + n);
+      float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      if (accumulate) { float4 c = *dst; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
+      *dst = v;
+    }
+  }
+  if (false && dbias != nullptr) {              // (this kernel carries no fused bias gradient: see the header comment)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float t = bsum[i];
+      t += __shfl_xor(t, 16, 64);
+      t += __shfl_xor(t, 32, 64);
+      const int m = m0 + wr * 128 + i * 16 + fs;
+      if (fg == 0 && m < M) {
+        if (dbias_parts) dbias[(long)(split * bias_mod + bias_slot) * M + m] = t;
+        else atomicAdd(dbias + m, t);
+      }
+    }
+  }
+#undef XQ_ZERO_TAIL
+#undef stage_clamped
+#undef XQ_CLAMPED_ONE
+#undef XQ_VALID
+#undef XQ_ONE_A
+#undef XQ_ONE_B
+#undef XQ_SB
+#undef XQ_MFMA_ROW
+#undef TN2_FRAG
+#undef XQ_ADDR_LO
+#undef XQ_ADDR_HI
+}
+
 __global__ __launch_bounds__(256) void xp_slab_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int splits, int M, int N,
                                                              float* __restrict__ C, int ldc, int accumulate) {
   const long total4 = (long)M * N / 4;
@@ -656,6 +862,7 @@ static const XpDevice* xp_device() {
     XP_ATTR((gemm_nt_xp_kernel<bf16_t, SIMX_EPI_NONE, true, false>), P_LDS);
     XP_ATTR((gemm_nt_xp_kernel<bf16_t, SIMX_EPI_DGELU, true, false>), P_LDS);
     XP_ATTR(gemm_tn_xp_kernel<bf16_t>, TN2_LDS);
+    XP_ATTR(gemm_tn_xq_kernel<bf16_t>, TN2_LDS);
 #undef XP_ATTR
     g.ok = ok;
   });
@@ -751,8 +958,11 @@ extern "C" int simx_gemm_tn_planes(simx_stream_t stream, int M, int N, int K, co
     if (!dbias) return SIMX_ERR_WORKSPACE;
   }
   const int dparts = dbias != dbias_out;
+  // SIMX_TN_XP=k3 pins the tripled-K kernel (A/B measurements); default: four-plane stages
+  static const bool k3 = [] { const char* e = getenv("SIMX_TN_XP"); return e && e[0] == 'k'; }();
+  auto kern = (k3 || dbias) ? gemm_tn_xp_kernel<bf16_t> : gemm_tn_xq_kernel<bf16_t>;
   if (sp == 1) {
-    hipLaunchKernelGGL(gemm_tn_xp_kernel<bf16_t>, dim3(t_mn), dim3(512), TN2_LDS, s, M, N, K, (const bf16_t*)A, lda, a_ps, (const bf16_t*)B, ldb, b_ps,
+    hipLaunchKernelGGL(kern, dim3(t_mn), dim3(512), TN2_LDS, s, M, N, K, (const bf16_t*)A, lda, a_ps, (const bf16_t*)B, ldb, b_ps,
                        C, 0L, ldc, t_n, t_mn, kps, accumulate, dbias, dparts);
     SIMX_CHECK_LAUNCH("gemm_tn_xp");
     if (dparts) return simx_det_reduce(s, dbias, (long)M, nbp, M, dbias_out, nullptr, nullptr, nullptr);
@@ -760,7 +970,7 @@ extern "C" int simx_gemm_tn_planes(simx_stream_t stream, int M, int N, int K, co
   }
   const size_t need = (size_t)sp * M * N * sizeof(float);
   SIMX_REQUIRE(ws && ws_bytes >= need && xal16(ws), SIMX_ERR_WORKSPACE, "gemm_tn_planes: workspace %zu < %zu (or not 16-B aligned)", ws_bytes, need);
-  hipLaunchKernelGGL(gemm_tn_xp_kernel<bf16_t>, dim3(t_mn * sp), dim3(512), TN2_LDS, s, M, N, K, (const bf16_t*)A, lda, a_ps, (const bf16_t*)B, ldb, b_ps,
+  hipLaunchKernelGGL(kern, dim3(t_mn * sp), dim3(512), TN2_LDS, s, M, N, K, (const bf16_t*)A, lda, a_ps, (const bf16_t*)B, ldb, b_ps,
                      (float*)ws, (long)M * N, N, t_n, t_mn, kps, 0, dbias, dparts);
   SIMX_CHECK_LAUNCH("gemm_tn_xp");
   if (dparts) { int rcd = simx_det_reduce(s, dbias, (long)M, nbp, M, dbias_out, nullptr, nullptr, nullptr); if (rcd) return rcd; }

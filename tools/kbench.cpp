@@ -66,6 +66,13 @@ int main(int argc, char** argv) {
       printf("xp gemm_tn+bias %-31s %8.3f ms  %7.1f TF/s\n", s.name, ms, fl / ms / 1e9);
     }
     printf("xp gemm_tn total %.2f ms  avg %.1f TF/s\n", tot, totf / tot / 1e9);
+    tot = 0; totf = 0;
+    for (auto& s : tn) {
+      double ms = timeit([&] { SX(simx_gemm_tn_planes(0, s.M, s.N, T, Ab, s.M, (long)T * s.M, Xb, s.N, (long)T * s.N, G, s.N, 1, ws, wsb, nullptr)); }, 5);
+      double fl = 2.0 * T * s.M * s.N; tot += ms; totf += fl;
+      printf("xp gemm_tn (no bias) %-26s %8.3f ms  %7.1f TF/s\n", s.name, ms, fl / ms / 1e9);
+    }
+    printf("xp gemm_tn (no bias) total %.2f ms  avg %.1f TF/s\n", tot, totf / tot / 1e9);
     double ms = timeit([&] { SX(simx_planes_from(0, SIMX_F16, SIMX_BF16, T, F, Ah, F, (long)T * F, Xb, F, (long)T * F)); }, 5);
     printf("xp planes f16->bf16 [T,%d] %8.3f ms  %6.2f TB/s\n", F, ms, 8.0 * T * F / ms / 1e9);
     ms = timeit([&] { SX(simx_planes_from(0, SIMX_F32, SIMX_BF16, T, H, C, H, 0, Xb, H, (long)T * H)); }, 5);

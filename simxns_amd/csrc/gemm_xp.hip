@@ -51,7 +51,7 @@ __device__ __forceinline__ void xp_gelu_both(float u, float& g, float& dg) {
 // The main loop is gemm_nt_p3_kernel's (csrc/gemm.hip; comments there), with stage -> (k block, term) addressing.  The
 // epilogue differs: inputs (`in`) arrive by direct 16-B global loads in the accumulator layout, one 16-row chunk ahead, all
 // waits counted; results pass through the wave's 4 KB of the A slot the tile's last stage freed and leave as full lines.
-template <typename F, int EPI, bool HAS_IN, bool DROP>
+template <typename F, int EPI, bool HAS_IN, bool DROP, bool RING>
 __global__ __launch_bounds__(512, 2) void gemm_nt_xp_kernel(
     int M, int N, int K, const bf16_t* __restrict__ A, int lda, long a_ps, const bf16_t* __restrict__ B, int ldb, long b_ps,
     float* __restrict__ C, int ldc, const float* __restrict__ bias, const float* __restrict__ in, int ldin,
@@ -81,12 +81,32 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_xp_kernel(
   int v = blockIdx.x;
   int tile = xcd_remap(v, ntiles);
   int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
-  p3_half(B, ldb, n0, XP_BK(0), ldsB, wave, offB0, offB1);
-  p3_half(A, lda, m0, XP_AK(0), lds0, wave, offA0, offA1);
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-  p3_half(B, ldb, n0, XP_BK(1), ldsB + 32768u, wave, offB0, offB1);
-  p3_half(A, lda, m0, XP_AK(1), lds0 + 32768u, wave, offA0, offA1);
-  p3_half(A, lda, m0, XP_AK(2), lds0 + 65536u, wave, offA0, offA1);
+  // RING (needs lda == ldb): FOUR loads per k block instead of six.  The three terms of a k block run as sub-stages
+  //   S0 = Ahi.Blo, S1 = Ahi.Bhi, S2 = Alo.Bhi  -- S0 / S1 share the staged Ahi tile, S1 / S2 the Bhi tile --
+  // from five 32 KB tile slots: Blo always in slot L, the other four a ring with roles H (Ahi of this k block), G (Bhi), M (Alo)
+  // and Hn (Ahi of the next k block), rotating by one per k block.  Load order ... Ahi(k) Blo(k) Bhi(k) Alo(k) Ahi(k+1) ...; at
+  // the boundary inside S0 the freed L takes Blo(k+1), inside S1 the freed H takes Bhi(k+1), inside S2 the freed G and M take
+  // Alo(k+1) and Ahi(k+2): three tile loads (96 KB) stay in flight behind the two being consumed, as in the p3 ring, and the
+  // counted waits are vmcnt(8), vmcnt(8), vmcnt(4).
+  const int nks = K / 64;
+  const uint32_t ldsL = lds0 + 131072u;
+#define R_SLOT(J) (lds0 + (uint32_t)(((J) & 3) * 32768))
+  int rr = 0;                                      // ring position of H
+  if constexpr (RING) {
+    p3_half(A, lda, m0, 0, R_SLOT(0), wave, offA0, offA1);
+    p3_half(B + b_ps, ldb, n0, 0, ldsL, wave, offB0, offB1);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    p3_half(B, ldb, n0, 0, R_SLOT(1), wave, offB0, offB1);
+    p3_half(A + a_ps, lda, m0, 0, R_SLOT(2), wave, offA0, offA1);
+    p3_half(A, lda, m0, 64, R_SLOT(3), wave, offA0, offA1);
+  } else {
+    p3_half(B, ldb, n0, XP_BK(0), ldsB, wave, offB0, offB1);
+    p3_half(A, lda, m0, XP_AK(0), lds0, wave, offA0, offA1);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    p3_half(B, ldb, n0, XP_BK(1), ldsB + 32768u, wave, offB0, offB1);
+    p3_half(A, lda, m0, XP_AK(1), lds0 + 32768u, wave, offA0, offA1);
+    p3_half(A, lda, m0, XP_AK(2), lds0 + 65536u, wave, offA0, offA1);
+  }
   int a0 = 0, b0 = 0;
   f32x4 bq0, bq1, bq2, bq3;
   {
@@ -158,6 +178,41 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_xp_kernel(
     P_DMA16(offB0, pb_g, pb_slot);                                                             \
   } while (0)
 
+  // ---- RING boundaries.  Source of k block KB of the running stream: this tile while KB < nks, else the next tile's KB - nks.
+#define R_SRC(PTR, LD, ROW_CUR, ROW_NXT, KB) \
+  reinterpret_cast<const char*>((PTR) + (long)(((KB) < nks ? (ROW_CUR) : (ROW_NXT)) + wave * 32) * (LD) + (long)((KB) < nks ? (KB) : (KB) - nks) * 64)
+#define R_ISSUE_X(SRC, SLOT) do { pb_g = (SRC); pb_slot = (SLOT) + (uint32_t)(wave * 4096); pb_pend = true; P_DMA16(offB0, pb_g, pb_slot); } while (0)
+#define R_BND0() do { asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory"); R_ISSUE_X(R_SRC(B + b_ps, ldb, n0, n0n, kb + 1), ldsL); } while (0)
+#define R_BND1() do { asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory"); R_ISSUE_X(R_SRC(B, ldb, n0, n0n, kb + 1), sH); } while (0)
+#define R_BND2()                                                                               \
+  do {                                                                                         \
+    asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");                              \
+    R_ISSUE_X(R_SRC(A + a_ps, lda, m0, m0n, kb + 1), sG);                                      \
+    pa_g = R_SRC(A, lda, m0, m0n, kb + 2); pa_slot = sM + (uint32_t)(wave * 4096); pa_pend = true; \
+  } while (0)
+#define R_BND_LAST()                                                                           \
+  do {                                                                                         \
+    asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");                              \
+    P_LANE(lb__);                                                                              \
+    const uint32_t boff__ = (uint32_t)((lb__ >> 4) * 16);                                      \
+    P_GLD4(bq0, boff__, bptr, 0); P_GLD4(bq1, boff__, bptr, 64); P_GLD4(bq2, boff__, bptr, 128); P_GLD4(bq3, boff__, bptr, 192); \
+    if (HAS_IN) {                                                                              \
+      const uint32_t io__ = (uint32_t)((lb__ & 15) * ldin + (lb__ >> 4) * 4) * 4;              \
+      P_GLD4(rin[0][0], io__, ibase, 0); P_GLD4(rin[0][1], io__, ibase, 64); P_GLD4(rin[0][2], io__, ibase, 128); P_GLD4(rin[0][3], io__, ibase, 192); \
+    }                                                                                          \
+    R_ISSUE_X(R_SRC(A + a_ps, lda, m0, m0n, kb + 1), sG);       /* (Ahi(kb + 2) goes into the slot the epilogue borrows: after it) */ \
+  } while (0)
+  // one k block: three sub-stages of two k-steps; BND2 = R_BND2 (inside a tile) or R_BND_LAST
+#define R_KBLOCK(BND2)                                                                         \
+  do {                                                                                         \
+    P_STEP(sH + oA0, sH + oA1, ldsL + oB1, bx0, bx1, bx2, bx3, by0, by1, by2, by3, P_BND_NONE, 1); \
+    P_STEP(sH + oA1, sH + oA0, sG + oB0, by0, by1, by2, by3, bx0, bx1, bx2, bx3, R_BND0, 0);   \
+    P_STEP(sH + oA0, sH + oA1, sG + oB1, bx0, bx1, bx2, bx3, by0, by1, by2, by3, P_BND_NONE, 1); \
+    P_STEP(sH + oA1, sM + oA0, sG + oB0, by0, by1, by2, by3, bx0, bx1, bx2, bx3, R_BND1, 0);   \
+    P_STEP(sM + oA0, sM + oA1, sG + oB1, bx0, bx1, bx2, bx3, by0, by1, by2, by3, P_BND_NONE, 1); \
+    P_STEP(sM + oA1, sHn + oA0, ldsL + oB0, by0, by1, by2, by3, bx0, bx1, bx2, bx3, BND2, 0);  \
+  } while (0)
+
   for (;;) {
     const int vn = v + (int)gridDim.x;
     const bool has_next = vn < ntiles;
@@ -182,27 +237,44 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_xp_kernel(
     bf16x8 al0, al1, al2, al3, ah0, ah1, ah2, ah3, bx0, bx1, bx2, bx3, by0, by1, by2, by3;
     f32x4 rin[2][4];                              // the epilogue's input chunks (accumulator layout), ping-pong
     {
-      const uint32_t aa = lds0 + (uint32_t)(a0 * 32768) + oA0, ab = ldsB + (uint32_t)(b0 * 32768) + oB0;
+      const uint32_t aa = RING ? R_SLOT(rr) + oA0 : lds0 + (uint32_t)(a0 * 32768) + oA0;
+      const uint32_t ab = RING ? ldsL + oB0 : ldsB + (uint32_t)(b0 * 32768) + oB0;
       V3_READ4(al0, al1, al2, al3, aa, 0, 2048, 4096, 6144);
       V3_READ4(bx0, bx1, bx2, bx3, ab, 0, 2048, 4096, 6144);
       V3_PIN8("s_waitcnt lgkmcnt(0)", al0, al1, al2, al3, bx0, bx1, bx2, bx3);
     }
     int ac = a0, bc = b0;
-    for (int st = 0; st < nst - 1; ++st) {
-      const int an = ac == 2 ? 0 : ac + 1, bn = bc ^ 1;
-      const uint32_t sa = lds0 + (uint32_t)(ac * 32768), sb = ldsB + (uint32_t)(bc * 32768);
-      const uint32_t na = lds0 + (uint32_t)(an * 32768), nb = ldsB + (uint32_t)(bn * 32768);
-      P_STEP(sa + oA0, sa + oA1, sb + oB1, bx0, bx1, bx2, bx3, by0, by1, by2, by3, P_BND_NONE, 1);
-      P_STEP(sa + oA1, na + oA0, nb + oB0, by0, by1, by2, by3, bx0, bx1, bx2, bx3, P_BND_MID, 0);
-      ac = an; bc = bn;
-    }
-    const uint32_t ereg = lds0 + (uint32_t)(ac * 32768 + wave * 4096);     // this wave's slice of the last stage's A slot
-    {
-      const int an = ac == 2 ? 0 : ac + 1, bn = bc ^ 1;
-      const uint32_t sa = lds0 + (uint32_t)(ac * 32768), sb = ldsB + (uint32_t)(bc * 32768);
-      const uint32_t na = lds0 + (uint32_t)(an * 32768), nb = ldsB + (uint32_t)(bn * 32768);
-      P_STEP(sa + oA0, sa + oA1, sb + oB1, bx0, bx1, bx2, bx3, by0, by1, by2, by3, P_BND_NONE, 1);
-      P_STEP(sa + oA1, na + oA0, nb + oB0, by0, by1, by2, by3, bx0, bx1, bx2, bx3, P_BND_LAST, 0);
+    uint32_t ereg;                                 // this wave's slice of the A slot the tile's last (sub-)stage frees
+    if constexpr (RING) {
+      int kb = 0;
+      for (; kb < nks - 1; ++kb) {
+        const uint32_t sH = R_SLOT(rr), sG = R_SLOT(rr + 1), sM = R_SLOT(rr + 2), sHn = R_SLOT(rr + 3);
+        R_KBLOCK(R_BND2);
+        rr = (rr + 3) & 3;
+      }
+      {
+        const uint32_t sH = R_SLOT(rr), sG = R_SLOT(rr + 1), sM = R_SLOT(rr + 2), sHn = R_SLOT(rr + 3);
+        ereg = sM + (uint32_t)(wave * 4096);
+        R_KBLOCK(R_BND_LAST);
+        rr = (rr + 3) & 3;
+      }
+    } else {
+      for (int st = 0; st < nst - 1; ++st) {
+        const int an = ac == 2 ? 0 : ac + 1, bn = bc ^ 1;
+        const uint32_t sa = lds0 + (uint32_t)(ac * 32768), sb = ldsB + (uint32_t)(bc * 32768);
+        const uint32_t na = lds0 + (uint32_t)(an * 32768), nb = ldsB + (uint32_t)(bn * 32768);
+        P_STEP(sa + oA0, sa + oA1, sb + oB1, bx0, bx1, bx2, bx3, by0, by1, by2, by3, P_BND_NONE, 1);
+        P_STEP(sa + oA1, na + oA0, nb + oB0, by0, by1, by2, by3, bx0, bx1, bx2, bx3, P_BND_MID, 0);
+        ac = an; bc = bn;
+      }
+      ereg = lds0 + (uint32_t)(ac * 32768 + wave * 4096);
+      {
+        const int an = ac == 2 ? 0 : ac + 1, bn = bc ^ 1;
+        const uint32_t sa = lds0 + (uint32_t)(ac * 32768), sb = ldsB + (uint32_t)(bc * 32768);
+        const uint32_t na = lds0 + (uint32_t)(an * 32768), nb = ldsB + (uint32_t)(bn * 32768);
+        P_STEP(sa + oA0, sa + oA1, sb + oB1, bx0, bx1, bx2, bx3, by0, by1, by2, by3, P_BND_NONE, 1);
+        P_STEP(sa + oA1, na + oA0, nb + oB0, by0, by1, by2, by3, bx0, bx1, bx2, bx3, P_BND_LAST, 0);
+      }
     }
 
     // ---- epilogue: 8 chunks of 16 rows (= accumulator row block i) per wave, straight-line, no barrier.
@@ -301,7 +373,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_xp_kernel(
         }
       }
     }
-    if (has_next) {
+    if constexpr (RING) {                          // Ahi of the next tile's k block 1 -> the slot the epilogue borrowed
+      if (has_next) {
+        pa_g = reinterpret_cast<const char*>(A + (long)(m0n + wave * 32) * lda + 64);
+        pa_slot = ereg;
+        pa_pend = true;
+      } else {
+        p3_half(A, lda, m0n, 64, ereg - (uint32_t)(wave * 4096), wave, offA0, offA1);
+      }
+    } else if (has_next) {
       pa_g = reinterpret_cast<const char*>(A + (long)(m0n + wave * 32) * lda + XP_AK(2));
       pa_slot = lds0 + (uint32_t)(ac * 32768 + wave * 4096);
       pa_pend = true;
@@ -318,6 +398,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_xp_kernel(
 #undef P3_HB
 #undef XP_AK
 #undef XP_BK
+#undef R_KBLOCK
+#undef R_BND_LAST
+#undef R_BND2
+#undef R_BND1
+#undef R_BND0
+#undef R_ISSUE_X
+#undef R_SRC
+#undef R_SLOT
 #undef P_BND_LAST
 #undef P_BND_MID
 #undef P_BND_NONE
@@ -854,13 +942,13 @@ static const XpDevice* xp_device() {
     bool ok = true;
 #define XP_ATTR(KERNEL, BYTES) \
     ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)) == hipSuccess
-    XP_ATTR((gemm_nt_xp_kernel<f16_t, SIMX_EPI_NONE, false, false>), P_LDS);
-    XP_ATTR((gemm_nt_xp_kernel<f16_t, SIMX_EPI_NONE, true, false>), P_LDS);
-    XP_ATTR((gemm_nt_xp_kernel<f16_t, SIMX_EPI_NONE, true, true>), P_LDS);
-    XP_ATTR((gemm_nt_xp_kernel<f16_t, SIMX_EPI_GELU, false, false>), P_LDS);
-    XP_ATTR((gemm_nt_xp_kernel<bf16_t, SIMX_EPI_NONE, false, false>), P_LDS);
-    XP_ATTR((gemm_nt_xp_kernel<bf16_t, SIMX_EPI_NONE, true, false>), P_LDS);
-    XP_ATTR((gemm_nt_xp_kernel<bf16_t, SIMX_EPI_DGELU, true, false>), P_LDS);
+    XP_ATTR((gemm_nt_xp_kernel<f16_t, SIMX_EPI_NONE, false, false, false>), P_LDS); XP_ATTR((gemm_nt_xp_kernel<f16_t, SIMX_EPI_NONE, false, false, true>), P_LDS);
+    XP_ATTR((gemm_nt_xp_kernel<f16_t, SIMX_EPI_NONE, true, false, false>), P_LDS); XP_ATTR((gemm_nt_xp_kernel<f16_t, SIMX_EPI_NONE, true, false, true>), P_LDS);
+    XP_ATTR((gemm_nt_xp_kernel<f16_t, SIMX_EPI_NONE, true, true, false>), P_LDS); XP_ATTR((gemm_nt_xp_kernel<f16_t, SIMX_EPI_NONE, true, true, true>), P_LDS);
+    XP_ATTR((gemm_nt_xp_kernel<f16_t, SIMX_EPI_GELU, false, false, false>), P_LDS); XP_ATTR((gemm_nt_xp_kernel<f16_t, SIMX_EPI_GELU, false, false, true>), P_LDS);
+    XP_ATTR((gemm_nt_xp_kernel<bf16_t, SIMX_EPI_NONE, false, false, false>), P_LDS); XP_ATTR((gemm_nt_xp_kernel<bf16_t, SIMX_EPI_NONE, false, false, true>), P_LDS);
+    XP_ATTR((gemm_nt_xp_kernel<bf16_t, SIMX_EPI_NONE, true, false, false>), P_LDS); XP_ATTR((gemm_nt_xp_kernel<bf16_t, SIMX_EPI_NONE, true, false, true>), P_LDS);
+    XP_ATTR((gemm_nt_xp_kernel<bf16_t, SIMX_EPI_DGELU, true, false, false>), P_LDS); XP_ATTR((gemm_nt_xp_kernel<bf16_t, SIMX_EPI_DGELU, true, false, true>), P_LDS);
     XP_ATTR(gemm_tn_xp_kernel<bf16_t>, TN2_LDS);
     XP_ATTR(gemm_tn_xq_kernel<bf16_t>, TN2_LDS);
 #undef XP_ATTR
@@ -893,8 +981,13 @@ extern "C" int simx_gemm_nt_planes(simx_stream_t stream, int fmt, int epilogue, 
   const int tn = N / 256, nt = (M / 256) * tn;
   const int grid = nt < gd->ncu ? nt : gd->ncu;
   const DropCtx drop = make_drop(epilogue == SIMX_EPI_NONE ? dropd : nullptr);
-#define LXP(FF, E, HI, DR) hipLaunchKernelGGL((gemm_nt_xp_kernel<FF, E, HI, DR>), dim3(grid), dim3(512), P_LDS, s, M, N, K, (const bf16_t*)A, lda, a_ps, \
-                                              (const bf16_t*)B, ldb, b_ps, C, ldc, bias, in, ldin, (bf16_t*)Cp, ldcp, cp_ps, tn, nt, drop)
+  // SIMX_NT_XP=k3 pins the tripled-K stream (six tile loads per k block; A/B measurements); the ring form needs lda == ldb
+  static const bool k3 = [] { const char* e = getenv("SIMX_NT_XP"); return e && e[0] == 'k'; }();
+  const bool ring = !k3 && lda == ldb;
+#define LXP(FF, E, HI, DR) do { if (ring) hipLaunchKernelGGL((gemm_nt_xp_kernel<FF, E, HI, DR, true>), dim3(grid), dim3(512), P_LDS, s, M, N, K, (const bf16_t*)A, lda, a_ps, \
+                                              (const bf16_t*)B, ldb, b_ps, C, ldc, bias, in, ldin, (bf16_t*)Cp, ldcp, cp_ps, tn, nt, drop);    \
+                                else hipLaunchKernelGGL((gemm_nt_xp_kernel<FF, E, HI, DR, false>), dim3(grid), dim3(512), P_LDS, s, M, N, K, (const bf16_t*)A, lda, a_ps, \
+                                              (const bf16_t*)B, ldb, b_ps, C, ldc, bias, in, ldin, (bf16_t*)Cp, ldcp, cp_ps, tn, nt, drop); } while (0)
   if (epilogue == SIMX_EPI_NONE) {
     SIMX_REQUIRE(c_ok, SIMX_ERR_BAD_SHAPE, "gemm_nt_planes: C must be a 16-B aligned f32 matrix");
     if (fmt == SIMX_F16) {

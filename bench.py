@@ -81,6 +81,16 @@ def main():
     ap.add_argument("--teacher-arch", default="base", choices=["base", "large"],
                     help="large: the recipe's ernie-2.0-large-en cross-encoder geometry (24 layers, H=1024, F=4096)")
     ap.add_argument("--grad-ckpt", action="store_true", help="gradient checkpointing (every train_*_AR2.sh passes it)")
+    ap.add_argument("--student-arch", default="base", choices=["base", "large"],
+                    help="large: BERT-large towers (24 layers, H=1024, F=4096: BASELINE configs[4], coCondenser-large)")
+    ap.add_argument("--student-layers", type=int, default=0, help="override the towers' depth (PROD: 6-layer student, configs[3])")
+    ap.add_argument("--qlen", type=int, default=32)
+    ap.add_argument("--plen", type=int, default=128)
+    ap.add_argument("--celen", type=int, default=160, help="cross-encoder row length (q + ctx[1:-1], padded)")
+    ap.add_argument("--loss", default="kl", choices=["kl", "cekd"],
+                    help="cekd: PROD's CrossBERTKDLoss (CE + T=4 KD against the cross-encoder, PROD/ProD_KD/model/models.py:668-781)")
+    ap.add_argument("--teacher-step", action="store_true",
+                    help="time the RERANKER phase instead (co_training_marco_train.py:225-262): cross-encoder fwd + bwd + CE, clip + AdamW")
     ap.add_argument("--side", action="store_true", help="(internal) this run IS a side line: no side lines of its own")
     ap.add_argument("--varlen", action="store_true", help="realistic sequence lengths instead of all-max")
     ap.add_argument("--inbatch", action="store_true", help="config 3: all-gather embeddings + in-batch NLL term")
@@ -127,15 +137,34 @@ def main():
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=dev)
+    forced = world == 1 and os.environ.get("SIMX_FORCE_COLLECTIVES") == "1"
+    if forced:
+        # one-rank RCCL group: the cfg3_inbatch side line drives all_gather_into_tensor of the embeddings through RCCL on one GPU
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(port))
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
     L.load()
 
     B, N, Cn = args.batch, args.negs, args.cands
     P = B * (1 + N)
-    QL, PL, CL = 32, 128, 160
+    QL, PL, CL = args.qlen, args.plen, args.celen
     pdrop = 0.0 if args.no_dropout else 0.1
-    cfg = BertConfigLite(hidden_dropout_prob=pdrop, attention_probs_dropout_prob=pdrop, gradient_checkpointing=args.grad_ckpt)
-    tkw = dict(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096) if args.teacher_arch == "large" else {}
-    tcfg = BertConfigLite(hidden_dropout_prob=pdrop, attention_probs_dropout_prob=pdrop, **tkw)
+    LARGE = dict(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096)
+    skw = dict(LARGE) if args.student_arch == "large" else {}
+    if args.student_layers:
+        skw["num_hidden_layers"] = args.student_layers
+    mp = max(512, PL + 2, CL + 2)
+    cfg = BertConfigLite(hidden_dropout_prob=pdrop, attention_probs_dropout_prob=pdrop, gradient_checkpointing=args.grad_ckpt,
+                         max_position_embeddings=mp, **skw)
+    tkw = dict(LARGE) if args.teacher_arch == "large" else {}
+    # (the reranker phase trains the cross-encoder: its gradient checkpointing flag is the recipe's, like the towers')
+    tcfg = BertConfigLite(hidden_dropout_prob=pdrop, attention_probs_dropout_prob=pdrop, max_position_embeddings=mp,
+                          gradient_checkpointing=args.grad_ckpt and args.teacher_step, **tkw)
+    SL_, SH_, SF_ = cfg.num_hidden_layers, cfg.hidden_size, cfg.intermediate_size
     torch.manual_seed(1234 + rank)
 
     def tower(c=cfg):
@@ -151,7 +180,10 @@ def main():
             m.init_weights()
     bi.to(dev).train()              # retriever step: model.train(), teacher_model.eval() (co_training_marco_train.py:196-197)
     teacher.to(dev).eval()
-    opt = FusedAdamW(bi, lr=5e-6, eps=1e-8)
+    if args.teacher_step:           # reranker phase: teacher_model.train(), model.eval() (:226-227)
+        bi.eval()
+        teacher.train()
+    opt = FusedAdamW(teacher if args.teacher_step else bi, lr=1e-6 if args.teacher_step else 5e-6, eps=1e-8)
     sch = LinearWarmupSchedule(opt, 5400, 54000, last_step=1)     # (step 0 of the schedule has lr = 0: start one in)
     if world > 1:
         # gradient slices are all-reduced on a communication stream while the rest of the backward runs
@@ -192,6 +224,11 @@ def main():
         sel = torch.cat([zero_col, neg.long() + 1], dim=1)                         # [B,1+N] rows of the query's pool
         batch = ops.assemble_batch(pool["q"], pool["p"], q_rows, (row_base + sel).to(torch.int32), 1 + N, pad_id=0, sep_id=102, ce_len=CL)
         q_ids, q_mask, c_ids, c_mask, _ = batch["student"]
+        if args.teacher_step:
+            z = teacher(batch["teacher"][0], batch["teacher"][1])
+            loss, _ = ops.teacher_ce_loss(z, args.accum)
+            loss.backward()
+            return loss
         if args.no_teacher:
             q, c = bi(q_ids, q_mask, c_ids, c_mask)
             z = fixed_z
@@ -209,7 +246,11 @@ def main():
             q, c = bi(q_ids, q_mask, c_ids, c_mask)
             with torch.no_grad():
                 z = teacher(batch["teacher"][0], batch["teacher"][1])
-        loss, distill, sim = ops.kl_distill_loss(q, c, z, 1.0, False, args.accum)
+        if args.loss == "cekd":
+            loss = ops.cross_kd_loss(q, c, z.view(B, 1 + N), 4.0, 0.1, 0.9)
+            loss = loss[0] if isinstance(loss, (tuple, list)) else loss
+        else:
+            loss, distill, sim = ops.kl_distill_loss(q, c, z, 1.0, False, args.accum)
         if args.inbatch:
             from simxns_amd import parallel
             loss = loss + 0.2 * parallel.inbatch_nll_allgather(q, c, 1 + N)
@@ -308,8 +349,8 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             df = float(tt.item())
         full_rows = {"value": round(world * P * args.accum * 3 / df, 1), "ms_per_step": round(df / 3 * 1e3, 2), "steps": 3,
-                     "step_mfma_util": round(args.accum * (3 * (B * fwd_flops_seq(QL) + P * fwd_flops_seq(PL)) +
-                                                           (0 if args.no_teacher else P * fwd_flops_seq(ce_tokens, tcfg.num_hidden_layers, tcfg.hidden_size, tcfg.intermediate_size)))
+                     "step_mfma_util": round(args.accum * ((0 if args.teacher_step else 3 * (B * fwd_flops_seq(QL, SL_, SH_, SF_) + P * fwd_flops_seq(PL, SL_, SH_, SF_))) +
+                                                           (0 if args.no_teacher else (3 if args.teacher_step else 1) * P * fwd_flops_seq(ce_tokens, tcfg.num_hidden_layers, tcfg.hidden_size, tcfg.intermediate_size)))
                                              / (df / 3) / 2.5e15, 4) if is16 else None}
     if rank != 0:
         if world > 1:
@@ -320,17 +361,18 @@ def main():
     PP = P * args.accum                                   # scored pairs per optimiser step and GPU
     pairs_per_s = world * PP * args.steps / dt
     TL, TH, TF = tcfg.num_hidden_layers, tcfg.hidden_size, tcfg.intermediate_size
-    stu = args.accum * 3 * (B * fwd_flops_seq(QL) + P * fwd_flops_seq(PL))
-    tea = 0 if args.no_teacher else args.accum * P * fwd_flops_seq(ce_tokens, TL, TH, TF)
+    stu = 0 if args.teacher_step else args.accum * 3 * (B * fwd_flops_seq(QL, SL_, SH_, SF_) + P * fwd_flops_seq(PL, SL_, SH_, SF_))
+    tea = 0 if args.no_teacher else args.accum * (3 if args.teacher_step else 1) * P * fwd_flops_seq(ce_tokens, TL, TH, TF)
     # FLOPs actually issued: the towers read sequence_output[:, 0, :] only (models.py:81), so in the last layer the
     # engine projects K and V for every token but runs the Q projection, the attention core, the attention-output and
     # the FFN blocks for the [CLS] row alone -- for the other S-1 rows of a sequence 4H^2 + 4HF + 4SH FLOPs are dead
     # code on this path and are skipped (forward, dgrad and wgrad).  SIMX_FULL_LAST_LAYER=1 computes them anyway.
     full_last = os.environ.get("SIMX_FULL_LAST_LAYER", "0") == "1"
-    dead = (lambda S, H=H_, F=F_: 0) if full_last else (lambda S, H=H_, F=F_: (S - 1) * (4 * H * H + 4 * H * F + 4 * S * H))
-    ckpt_extra = args.accum * (B * fwd_flops_seq(QL) + P * fwd_flops_seq(PL)) if args.grad_ckpt else 0     # the recomputed forward
-    stu_issued = stu - args.accum * 3 * (B * dead(QL) + P * dead(PL)) + ckpt_extra
-    tea_issued = 0 if args.no_teacher else tea - args.accum * P * dead(ce_tokens, TH, TF)
+    dead = (lambda S, H=SH_, F=SF_: 0) if full_last else (lambda S, H=SH_, F=SF_: (S - 1) * (4 * H * H + 4 * H * F + 4 * S * H))
+    ckpt_extra = args.accum * (B * fwd_flops_seq(QL, SL_, SH_, SF_) + P * fwd_flops_seq(PL, SL_, SH_, SF_)) if args.grad_ckpt and not args.teacher_step else 0     # the recomputed forward
+    stu_issued = 0 if args.teacher_step else stu - args.accum * 3 * (B * dead(QL) + P * dead(PL)) + ckpt_extra
+    tea_issued = 0 if args.no_teacher else tea - args.accum * (3 if args.teacher_step else 1) * P * dead(ce_tokens, TH, TF) + \
+        (args.accum * P * fwd_flops_seq(ce_tokens, TL, TH, TF) if args.teacher_step and args.grad_ckpt else 0)
     util_ok = is16 and not args.varlen
     arith = {"fp16": "IEEE-half GEMM / attention operands (the operand width of apex O1, the reference's --fp16 mode), f32 accumulation, "
                      "f32 LayerNorm / softmax, f32-grade residual stream (16-bit value + one correction byte per element: 19 significand bits), f32 master weights, dynamic "
@@ -344,13 +386,21 @@ def main():
            "unit": "query+passage pairs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(ms_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": args.dtype, "arithmetic": arith, "data": "synthetic",
-           "config": {"workload": "SimANS MS-MARCO Passage retriever step (BASELINE configs[%d]): BERT-base x2 towers + "
-                                  "%s cross-encoder teacher fwd, B=%d/GPU%s, %d hard negs from %d candidates (SimANS "
-                                  "sampler + batch assembly on GPU), q%d/p%d/ce%d (= q + ctx[1:-1], padded to %d), %s lengths, KL-distill%s "
+           "config": {"workload": "%s (BASELINE configs[%d]): %s x2 towers + "
+                                  "%s cross-encoder teacher %s, B=%d/GPU%s, %d hard negs from %d candidates (SimANS "
+                                  "sampler + batch assembly on GPU), q%d/p%d/ce%d (= q + ctx[1:-1], padded to %d), %s lengths, %s%s "
                                   "loss, clip 2.0 + AdamW%s"
-                                  % (2 if args.inbatch else 1, "BERT-base" if args.teacher_arch == "base" else "ernie-2.0-large-geometry (24L, H=1024)",
+                                  % ("SimANS reranker (cross-encoder teacher) TRAIN step, co_training_marco_train.py:225-262" if args.teacher_step else
+                                     "PROD cross-encoder -> dual-encoder distillation step" if args.loss == "cekd" else
+                                     "SimANS MS-MARCO Document retriever step" if PL >= 512 else "SimANS MS-MARCO Passage retriever step",
+                                     3 if args.loss == "cekd" else 4 if PL >= 512 else 2 if args.inbatch else 1,
+                                     "%d-layer H=%d" % (SL_, SH_) if (SL_, SH_) != (12, 768) else "BERT-base",
+                                     "BERT-base" if args.teacher_arch == "base" else "ernie-2.0-large-geometry (24L, H=1024)",
+                                     "fwd + bwd + CE" if args.teacher_step else "fwd",
                                      B, " x %d accumulated micro-steps" % args.accum if args.accum > 1 else "", N, Cn, QL, PL, ce_tokens, CL,
-                                     "realistic" if args.varlen else "all-max", " + 0.2*in-batch NLL (all-gather)" if args.inbatch else "",
+                                     "realistic" if args.varlen else "all-max",
+                                     "teacher cross-entropy" if args.teacher_step else "CE + KD (T=4, 0.1/0.9)" if args.loss == "cekd" else "KL-distill",
+                                     " + 0.2*in-batch NLL (all-gather)" if args.inbatch else "",
                                      ", gradient checkpointing" if args.grad_ckpt else ""),
                       "global_batch": world * B * args.accum, "pairs_per_step_per_gpu": PP, "parallelism": "dp%d" % world,
                       "teacher_in_step": not args.no_teacher, "dropout": pdrop,
@@ -382,7 +432,8 @@ def main():
     def alg_bytes_per_launch(launches_per_step):
         tot, cnt = p3_algorithmic_bytes(B, P, QL, PL, ce_tokens, not args.no_teacher, full_last)
         # (the enumeration must describe the launches that were measured; otherwise report nothing rather than a guess)
-        plain = args.accum == 1 and args.teacher_arch == "base" and not args.grad_ckpt and not args.varlen
+        plain = (args.accum == 1 and args.teacher_arch == "base" and not args.grad_ckpt and not args.varlen and not args.teacher_step and
+                 (SL_, SH_, QL, PL) == (12, 768, 32, 128))
         return round(tot / cnt) if cnt and cnt == launches_per_step and plain else None
 
     # 16-bit: the persistent kernel's launches ("gemm_nt" = the small-shape kernels); fp32: every NT GEMM of the step (the split
@@ -447,13 +498,35 @@ def main():
                                             "accumulation 2, ernie-2.0-large cross-encoder teacher")
         out["teacher_large"] = side_line(args, ["--dtype", args.dtype, "--teacher-arch", "large", "--steps", "5", "--warmup", "2"],
                                          "headline batch with the recipe's cross-encoder geometry (24 layers, H = 1024, F = 4096, S = 160)")
+        # the other BASELINE configs and the reranker phase on one GPU (never `value`; each with its own roofline block)
+        out["cfg3_inbatch"] = side_line(args, ["--dtype", args.dtype, "--inbatch", "--steps", "5", "--warmup", "2"],
+                                        "BASELINE configs[2] on one rank: + all_gather_into_tensor of the [CLS] embeddings through RCCL (world 1, "
+                                        "collectives forced) and the in-batch NLL over the gathered score matrix (KL + 0.2 NLL)",
+                                        env={"SIMX_FORCE_COLLECTIVES": "1"})
+        out["cfg4_prod"] = {
+            "B8": side_line(args, ["--dtype", args.dtype, "--student-layers", "6", "--loss", "cekd", "--batch", "8", "--steps", "20", "--warmup", "5"],
+                            "BASELINE configs[3] at the reference's shape (PROD/README.md:216-224): 6-layer dual-encoder student, 12-layer "
+                            "cross-encoder teacher, CE + KD loss, per-GPU batch 8 x 16"),
+            "B128": side_line(args, ["--dtype", args.dtype, "--student-layers", "6", "--loss", "cekd", "--steps", "5", "--warmup", "2"],
+                              "the same step at the headline batch (128 x 16)")}
+        out["cfg5_doc"] = {
+            "fp16": side_line(args, ["--dtype", "fp16", "--student-arch", "large", "--qlen", "128", "--plen", "512", "--celen", "512", "--negs", "7",
+                                     "--batch", "16", "--grad-ckpt", "--steps", "4", "--warmup", "1"],
+                              "BASELINE configs[4]: BERT-large towers (coCondenser-large geometry), q128 / p512, 7 hard negatives, gradient "
+                              "checkpointing + fp16 (train_MS_Doc_AR2.sh:9-26), 16 queries x 8 documents per GPU", timeout_s=420),
+            "fp32": side_line(args, ["--dtype", "fp32", "--student-arch", "large", "--qlen", "128", "--plen", "512", "--celen", "512", "--negs", "7",
+                                     "--batch", "16", "--grad-ckpt", "--steps", "3", "--warmup", "1"],
+                              "the same in the fp32 arithmetic the shipped MS-Doc recipe selects", timeout_s=420)}
+        out["teacher_train_step"] = side_line(args, ["--dtype", args.dtype, "--teacher-step", "--teacher-arch", "large", "--steps", "5", "--warmup", "2"],
+                                              "the RERANKER phase (co_training_marco_train.py:225-262; 10 % of every AR2 iteration): ernie-2.0-large "
+                                              "geometry cross-encoder forward + backward + CE on 2048 x 160 tokens, clip + AdamW")
     if not args.no_cpu_baseline and world == 1:
         try:
             out["cpu_baseline"] = cpu_baseline()
         except Exception as e:            # the baseline must never take the GPU number down with it
             out["cpu_baseline"] = {"value": None, "error": repr(e)}
     print(json.dumps(out))
-    if world > 1:
+    if world > 1 or forced:
         dist.destroy_process_group()
 
 
@@ -481,15 +554,18 @@ def p3_algorithmic_bytes(B, P, QL, PL, CE, teacher, full_last, L=L_, H=H_, F=F_)
     return tot, cnt
 
 
-def side_line(args, argv, what, timeout_s=300):
+def side_line(args, argv, what, timeout_s=300, env=None):
     """`python bench.py <argv> --side` on the same GPU in a child process; returns its headline numbers (never `value`)."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--side", "--negs", str(args.negs), "--cands", str(args.cands)] + argv
+    cmd = [sys.executable, os.path.abspath(__file__), "--side", "--cands", str(args.cands)] + argv
+    if "--negs" not in argv:
+        cmd += ["--negs", str(args.negs)]
     if "--batch" not in argv:
         cmd += ["--batch", str(args.batch)]
-    cmd += (["--no-teacher"] if args.no_teacher else []) + (["--no-dropout"] if args.no_dropout else []) + (["--inbatch"] if args.inbatch else [])
+    cmd += (["--no-teacher"] if args.no_teacher else []) + (["--no-dropout"] if args.no_dropout else []) + (["--inbatch"] if args.inbatch and "--inbatch" not in argv else [])
     try:
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s, text=True)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s, text=True,
+                           env=dict(os.environ, **env) if env else None)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or not line:
             return {"value": None, "error": (r.stderr or "no output")[-400:]}

@@ -108,36 +108,43 @@ def train(args, model, teacher_model, tokenizer, global_step=0, dataset_cls=Rock
     scheduler = LinearWarmupSchedule(optimizer, 0.1 * student_max_step, student_max_step)
     teacher_scheduler = LinearWarmupSchedule(teacher_optimizer, 0.1 * teacher_max_step, teacher_max_step)
     if global_step != 0:
-        train_data_path = os.path.join(args.ann_dir, 'train_ce_' + str(global_step) + '.tsv')
         _load_saved_state(model, optimizer, scheduler,
                           load_states_from_checkpoint(os.path.join(args.output_dir, 'checkpoint-' + str(global_step))))
         _load_saved_state(teacher_model, teacher_optimizer, teacher_scheduler,
                           load_states_from_checkpoint(os.path.join(args.output_dir, 'checkpoint-reranker' + str(global_step))))
-    else:
-        train_data_path = args.origin_data_dir
-    train_dataset = dataset_cls(train_data_path, tokenizer, num_hard_negatives=args.number_neg,
-                                trainer_id=max(args.local_rank, 0), trainer_num=world,
-                                corpus_path=args.passage_path, rand_pool=100, **(dataset_kwargs or {}))
-    gpu_sampler = getattr(args, "sampler", "host") == "gpu" and hasattr(train_dataset, "build_device_pool")
-    if gpu_sampler:
-        # --sampler gpu: the SimANS draw and the collate run on the device from tables tokenised once per iteration
-        # (Rocketqa_v2Dataset.build_device_pool / device_batch); the host only deals out row numbers
-        pool = train_dataset.build_device_pool(args.device)
-        logger.info("device pool: %d queries, %d passages, %d candidates per query resident in HBM", pool["q_tok"].shape[0],
-                    pool["p_tok"].shape[0], pool["cand_rows"].shape[1])
 
-        class _DeviceBatches(object):
-            def __iter__(self_):
-                order = list(RandomSampler(train_dataset))
-                for lo in range(0, len(order), args.train_batch_size):
-                    self_.n = getattr(self_, "n", 0) + 1
-                    yield train_dataset.device_batch(order[lo:lo + args.train_batch_size], seed=args.seed + max(args.local_rank, 0),
-                                                     step=self_.n)
-        train_dataloader = _DeviceBatches()
-    else:
-        train_dataloader = DataLoader(train_dataset, sampler=RandomSampler(train_dataset),
-                                      collate_fn=dataset_cls.get_collate_fn(args),
-                                      batch_size=args.train_batch_size, num_workers=args.num_workers)
+    def iteration_loader(gstep):
+        """Dataset + batch iterator of the shell-loop iteration that starts at optimiser step `gstep` (train_ce_<gstep>.tsv)."""
+        train_data_path = os.path.join(args.ann_dir, 'train_ce_' + str(gstep) + '.tsv') if gstep != 0 else args.origin_data_dir
+        train_dataset = dataset_cls(train_data_path, tokenizer, num_hard_negatives=args.number_neg,
+                                    trainer_id=max(args.local_rank, 0), trainer_num=world,
+                                    corpus_path=args.passage_path, rand_pool=100, **(dataset_kwargs or {}))
+        gpu_sampler = getattr(args, "sampler", "host") == "gpu" and hasattr(train_dataset, "build_device_pool")
+        if gpu_sampler:
+            # --sampler gpu: the SimANS draw and the collate run on the device from tables tokenised once per iteration
+            # (Rocketqa_v2Dataset.build_device_pool / device_batch); the host only deals out row numbers
+            pool = train_dataset.build_device_pool(args.device)
+            logger.info("device pool: %d queries, %d passages, %d candidates per query resident in HBM", pool["q_tok"].shape[0],
+                        pool["p_tok"].shape[0], pool["cand_rows"].shape[1])
+
+            class _DeviceBatches(object):
+                # the Philox draw is keyed by (seed, rank, micro-step OF THE WHOLE RUN): a relaunch at optimiser step gstep
+                # continues the counter instead of replaying the first iteration's picks
+                n = gstep * args.gradient_accumulation_steps
+
+                def __iter__(self_):
+                    order = list(RandomSampler(train_dataset))
+                    for lo in range(0, len(order), args.train_batch_size):
+                        self_.n += 1
+                        yield train_dataset.device_batch(order[lo:lo + args.train_batch_size], seed=args.seed + max(args.local_rank, 0),
+                                                         step=self_.n)
+            loader = _DeviceBatches()
+        else:
+            loader = DataLoader(train_dataset, sampler=RandomSampler(train_dataset),
+                                collate_fn=dataset_cls.get_collate_fn(args),
+                                batch_size=args.train_batch_size, num_workers=args.num_workers)
+        return train_dataset, loader
+    train_dataset, train_dataloader = iteration_loader(global_step)
     it = iter(train_dataloader)
     logger.info("***** Running training *****  max steps %d, per-GPU batch %d, accumulation %d, examples %d",
                 args.max_steps, args.per_gpu_train_batch_size, args.gradient_accumulation_steps, len(train_dataset))
@@ -219,6 +226,20 @@ def train(args, model, teacher_model, tokenizer, global_step=0, dataset_cls=Rock
                 if world > 1:
                     dist.barrier()
                 train_flag = 0
+                if os.environ.get("SIMX_CONTINUE_AT_BOUNDARY") == "1" and global_step < args.max_steps:
+                    # test hook (tests/test_train_script_gpu.py): run the next shell-loop iteration IN THIS PROCESS exactly as
+                    # a relaunch with --global_step would start it -- reseed, re-read the mined file, restart the counters a
+                    # fresh process starts at zero -- but on the live model / optimiser / scheduler objects, i.e. WITHOUT the
+                    # checkpoint round trip: the uninterrupted reference a resumed job is compared with
+                    set_seed(args)
+                    for mod in list(model.modules()) + list(teacher_model.modules()):
+                        if getattr(mod, "engine", None) is not None:
+                            mod.engine._drop_calls = 0
+                    train_dataset, train_dataloader = iteration_loader(global_step)
+                    it = iter(train_dataloader)
+                    step = 0
+                    tr_loss = tr_distll_loss = tr_contr_loss = 0.0
+                    continue
                 break
             if args.save_steps > 0 and global_step % args.save_steps == 0 and is_first_worker():
                 _save_checkpoint(args, model, optimizer, scheduler, global_step)

@@ -28,7 +28,8 @@ def _fixed_seed(enc, seed, full_last_layer=False):
 
 @pytest.mark.parametrize("full_last_layer", [False, True])     # False: the [CLS]-only last layer (what the towers run); True: every row
 @pytest.mark.parametrize("dtype,heads,hidden,p_len", [("fp32", 4, 64, 128), ("bf16", 1, 64, 128), ("fp32", 1, 64, 128),
-                                                    ("bf16", 2, 128, 600)])     # 600: chunked long-sequence attention backward
+                                                    ("bf16", 2, 128, 600),      # 600: chunked long-sequence attention backward
+                                                    ("fp16", 1, 64, 128), ("fp16", 2, 128, 600)])   # the benchmarked engine (apex-O1 form)
 def test_step_with_dropout_matches_oracle(dev, dtype, heads, hidden, p_len, full_last_layer):
     from simxns_amd import ops
     from simxns_amd.engine import BertConfigLite
@@ -63,10 +64,14 @@ def test_step_with_dropout_matches_oracle(dev, dtype, heads, hidden, p_len, full
     assert np.abs(oq0 - oq).max() > 1e-2
     osim = ol.sim_block(oq, oc)
     ol_, _, ods = ol.kl_distill(osim, z.astype(np.float64))
-    tol = 2e-5 if dtype == "fp32" else 8e-2
+    # (NOTE: "matches the oracle" here is a consistency check of the mask plumbing -- the oracle restates the product's own
+    # stateless hash; what is pinned to the REFERENCE's dropout semantics is the keep rate and the 1/(1-p) scaling)
+    tol = 2e-5 if dtype == "fp32" else 1.5e-3 if dtype == "fp16" else 8e-2       # fp16 measured on MI355X: embeddings 0.9-1.8e-3, loss 0.4-1.4e-3
+    print("dropout step %s: q err %.2e c err %.2e loss err %.2e" % (dtype, np.abs(q.detach().cpu().numpy() - oq).max(),
+                                                                   np.abs(c.detach().cpu().numpy() - oc).max(), abs(loss.item() - ol_)))
     assert np.abs(q.detach().cpu().numpy() - oq).max() <= tol * 4
     assert np.abs(c.detach().cpu().numpy() - oc).max() <= tol * 4
-    assert abs(loss.item() - ol_) <= (1e-4 if dtype == "fp32" else 8e-2)
+    assert abs(loss.item() - ol_) <= (1e-4 if dtype == "fp32" else 5e-3 if dtype == "fp16" else 8e-2)
     dq, dc = ol.sim_block_bwd(oq, oc, ods)
     Gq = ob.bert_backward(Pq, q_ids, q_mask, heads, cq, dq)
     Gc = ob.bert_backward(Pc, c_ids, c_mask, heads, cc, dc)
@@ -79,7 +84,7 @@ def test_step_with_dropout_matches_oracle(dev, dtype, heads, hidden, p_len, full
                 assert np.abs(got - g).max() <= 2e-4 * np.abs(g).max() + 1e-5 * gmax, (pre, k)
             elif k.endswith("dense.weight") and "pooler" not in k:
                 cos = float(got.ravel() @ g.ravel() / (np.linalg.norm(got) * np.linalg.norm(g) + 1e-30))
-                assert cos > 0.97, (pre, k, cos)
+                assert cos > (0.999 if dtype == "fp16" else 0.97), (pre, k, cos)
     # eval() switches dropout off again
     bi.eval()
     q2, _ = bi(t(q_ids), t(q_mask), t(c_ids), t(c_mask))

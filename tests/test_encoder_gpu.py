@@ -374,6 +374,31 @@ def test_tiny_teacher_step_bf16(dev, golden_dir):
         assert cos >= 0.98, "teacher grad %s cosine %.4f" % (k, cos)
 
 
+def _teacher_step_16bit_errors(G, grads, loss):
+    names = [k[len("tgrad."):] for k in G.files if k.startswith("tgrad.")]
+    cos, rel = [], []
+    for k in names:
+        ref = G["tgrad." + k].ravel().astype(np.float64)
+        g = grads[k].ravel()
+        if np.linalg.norm(ref) <= 1e-9 * max(np.linalg.norm(G["tgrad." + n]) for n in names):
+            continue
+        rel.append(abs(np.linalg.norm(g) - np.linalg.norm(ref)) / np.linalg.norm(ref))
+        if k.endswith("dense.weight") or k.endswith("query.weight") or k.endswith("key.weight") or k.endswith("value.weight") or k == "qa_classifier.weight":
+            cos.append(float(g @ ref / (np.linalg.norm(g) * np.linalg.norm(ref) + 1e-30)))
+    return dict(loss_abs=abs(loss - float(G["teacher_ce_loss"])), cos_min=min(cos), gnorm_rel_med=float(np.median(rel)), gnorm_rel_max=float(max(rel)))
+
+
+def test_tiny_teacher_step_fp16(dev, golden_dir):
+    """The reranker TRAIN step (co_training_marco_train.py:225-245) on the benchmarked engine (fp16, apex-O1 form) against the
+    reference golden.  Measured on MI355X: loss error 1e-6..3e-5, slice cosine min 0.99988, gradient norms 0.05-0.06 % median /
+    0.7-1.1 % max; bounds = 3x."""
+    G = np.load(os.path.join(golden_dir, "step_tiny.npz"))
+    loss, grads = run_teacher_step(G, dev, "fp16")
+    e = _teacher_step_16bit_errors(G, grads, loss)
+    print("teacher step fp16 errors:", json.dumps(e))
+    assert e["loss_abs"] <= 1e-4 and e["cos_min"] >= 0.9996 and e["gnorm_rel_med"] <= 2e-3 and e["gnorm_rel_max"] <= 3.5e-2, e
+
+
 # ------------------------------------------------------------------------------------------ BERT-large geometry (configs 4 / 5)
 def test_large_hidden_geometry_against_oracle(dev):
     """H=1024, 16 heads, F=4096 (ernie-large / BERT-large layer geometry, two layers), passages of 512 tokens and

@@ -75,6 +75,22 @@ def test_roberta_dot_bf16(dev, golden_dir):
         assert cos >= 0.97, "grad %s cosine %.4f" % (k, cos)
 
 
+@pytest.mark.parametrize("fixture", ["roberta_dot_tiny.npz", "roberta_dot_mean_tiny.npz"])
+def test_roberta_dot_fp16(dev, golden_dir, fixture):
+    """E4 on the benchmarked engine (fp16, apex-O1 form), [CLS] and masked-mean pooling.  Measured on MI355X: embeddings 6e-4..1e-3, loss
+    7e-5..1.1e-4, gradient cosines >= 0.99998; bounds = 3x."""
+    G = np.load(os.path.join(golden_dir, fixture))
+    q, d, loss, grads = _step(G, dev, "fp16")
+    eq, ed, el = np.abs(q - G["q_emb"]).max(), np.abs(d - G["d_emb"]).max(), abs(loss - float(G["loss"]))
+    cos = {}
+    for k in ("roberta.encoder.layer.1.output.dense.weight", "embeddingHead.weight", "roberta.embeddings.position_embeddings.weight"):
+        g, ref = grads[k].ravel(), G["grad." + k].ravel()
+        cos[k] = float(g @ ref / (np.linalg.norm(g) * np.linalg.norm(ref) + 1e-30))
+    print("roberta_dot fp16 %s: q %.2e d %.2e loss %.2e cos %s" % (fixture, eq, ed, el, {k.split(".")[-2]: round(v, 6) for k, v in cos.items()}))
+    assert eq <= 3e-3 and ed <= 3e-3 and el <= 4e-4
+    assert min(cos.values()) >= 0.99994, cos
+
+
 def test_roberta_dot_mean_pooling_fp32_vs_reference_golden(dev, golden_dir):
     """use_mean=True (EmbeddingMixin.masked_mean, models.py:296-305): the embedding is the mean of the last hidden state
     over the real tokens, so EVERY row of the hidden state carries gradient (simx_seq_mean_* + simx_bert_bwd_ex)."""

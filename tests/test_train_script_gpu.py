@@ -543,3 +543,68 @@ def test_ms_doc_iteration_train_generate_train(dev, tmp_path):
     kept = open(path).read().splitlines()
     assert 2 <= len(kept) <= n_q
     assert D.main(train + ["--global_step", "6"]) == 12 and os.path.exists(os.path.join(out, "checkpoint-12"))
+
+
+def test_ms_pas_recipe_defaults_job_and_resume_equals_uninterrupted(dev, tmp_path, caplog, monkeypatch, capsys):
+    """The job a drop-in user of train_MS_Pas_AR2.sh gets: `python -m simxns_amd.launch MS_Pas --dry-run` prints it, and its flags
+    of record -- fp32 (no --fp16), --gradient_checkpointing, --sampler=gpu, accumulation 2, --distill_loss
+    (SimANS/train_MS_Pas_AR2.sh:8-26) -- are run here through co_training_marco_train.py on a synthetic shard (paths, model size
+    and step counts are the only substitutions) across ONE iteration boundary:
+      * relaunched: job A stops at the boundary (checkpoint-4 / checkpoint-reranker4), job B resumes with --global_step 4 from the
+        checkpoint files and runs the next iteration (one student step, two reranker steps, one student step);
+      * uninterrupted: the same two iterations in one process on the live model / optimiser / scheduler objects, no save / load
+        round trip (SIMX_CONTINUE_AT_BOUNDARY=1).
+    The losses the two log for steps 5..8 must agree (f32 atomics' summation order aside) -- i.e. the checkpoint carries
+    everything a resumed job needs: weights, Adam moments, both schedulers, the sampler's counter."""
+    import logging
+    import re
+    from simxns_amd import launch
+    from simxns_amd.co_training import co_training_marco_train as T
+    launch.main(["MS_Pas", "--dry-run", "--nproc", "8", "--last-step", "0"])
+    line = [l for l in capsys.readouterr().out.splitlines() if "co_training_marco_train.py" in l][0]
+    assert "--gradient_checkpointing" in line and "--sampler=gpu" in line and "--gradient_accumulation_steps=2" in line
+    assert "--fp16" not in line and "--distill_loss" in line and "--per_gpu_train_batch_size=16" in line
+    flags = dict(launch.RECIPES["MS_Pas"]()["train"][1])
+    root = str(tmp_path / "data")
+    _write_corpus(root)
+    import shutil
+    shutil.copy(os.path.join(root, "train_ce_0.tsv"), os.path.join(root, "train_ce_4.tsv"))     # (the mined file of the next iteration)
+
+    def argv(out, global_step):
+        f = dict(flags, model_type=os.path.join(root, "student"), teacher_model_type=os.path.join(root, "teacher"), model_name_or_path="",
+                 teacher_model_path="", per_gpu_train_batch_size=4, number_neg=7, learning_rate=1e-3, teacher_learning_rate=1e-4,
+                 output_dir=out, log_dir=str(tmp_path / "tb"), origin_data_dir=os.path.join(root, "train_ce_0.tsv"),
+                 passage_path=root, ann_dir=root, logging_steps=1, save_steps=1000, max_steps=8, iteration_step=4,
+                 iteration_reranker_step=2, global_step=global_step, train_qa_path="", dev_qa_path="")
+        assert f["gradient_checkpointing"] is True and f["sampler"] == "gpu" and f["gradient_accumulation_steps"] == 2 and "fp16" not in f
+        a = ["--tokenizer_name", "hash", "--num_workers", "0"]
+        for k, v in f.items():
+            if v is True:
+                a.append("--" + k)
+            elif v not in (False, None, ""):
+                a += ["--" + k, str(v)]
+        return a
+
+    def losses(records):
+        out = {}
+        for r in records:
+            m = re.match(r"^\{.*\"step\": (\d+)\}$", r.getMessage())
+            if m:
+                out[int(m.group(1))] = json.loads(r.getMessage())["loss"]
+        return out
+
+    caplog.set_level(logging.INFO)
+    monkeypatch.delenv("SIMX_CONTINUE_AT_BOUNDARY", raising=False)
+    outA = str(tmp_path / "relaunched")
+    assert T.main(argv(outA, 0)) == 4 and os.path.exists(os.path.join(outA, "checkpoint-4"))
+    assert T.main(argv(outA, 4)) == 8 and os.path.exists(os.path.join(outA, "checkpoint-reranker8"))
+    rel = losses(caplog.records)
+    caplog.clear()
+    monkeypatch.setenv("SIMX_CONTINUE_AT_BOUNDARY", "1")
+    outB = str(tmp_path / "uninterrupted")
+    assert T.main(argv(outB, 0)) == 8
+    unint = losses(caplog.records)
+    assert sorted(rel) == sorted(unint) == list(range(1, 9)), (sorted(rel), sorted(unint))
+    for st in range(1, 9):
+        assert np.isfinite(rel[st]) and abs(rel[st] - unint[st]) <= 2e-5 * max(1.0, abs(unint[st])), (st, rel[st], unint[st])
+    assert len({round(v, 6) for v in rel.values()}) > 4                     # (the losses do move: not a degenerate comparison)

@@ -187,7 +187,7 @@ def main():
     sch = LinearWarmupSchedule(opt, 5400, 54000, last_step=1)     # (step 0 of the schedule has lr = 0: start one in)
     if world > 1:
         # gradient slices are all-reduced on a communication stream while the rest of the backward runs
-        opt.enable_overlap(world, parts=int(os.environ.get("SIMX_BWD_PARTS", "2")), payload=os.environ.get("SIMX_GRAD_PAYLOAD", "fp32"))
+        opt.enable_overlap(world, parts=int(os.environ.get("SIMX_BWD_PARTS", "2")), payload=os.environ.get("SIMX_GRAD_PAYLOAD") or None)      # default: bf16 slices at W > 1
         opt.profile_comm = True
 
     # ---- synthetic, PRE-TOKENISED candidate pool in HBM (per rank: B queries x (1 positive + Cn candidates)); the
@@ -271,8 +271,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_step()
+    for wi in range(args.warmup):
+        l0 = one_step()
+        if world > 1 and wi == 0:
+            # replica check: identical weights + identical reduced gradients => after the first optimiser step every rank must hold
+            # the same parameters.  (Losses differ per rank -- the queries are sharded -- so the check is on a parameter checksum.)
+            cks = torch.stack([m.engine.flat.double().abs().sum() for m in (bi.question_model, bi.ctx_model)]).to(dev)
+            hi_, lo_ = cks.clone(), cks.clone()
+            dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+            dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+            dev_max = float(((hi_ - lo_) / (hi_.abs() + 1e-30)).max())
+            if dev_max > 1e-6:
+                raise SystemExit("bench.py --gpus %d: replicas diverged after the first step (relative checksum deviation %.3e)" % (world, dev_max))
     sync()
     # the timed region carries no instrumentation (HIP events around ~1700 launches per step cost 1.1 % of the step)
     t0 = time.perf_counter()
@@ -422,6 +432,10 @@ def main():
                                       "fall in the warm-up when applied_steps - skipped_steps bookkeeping shows none later"}
     if world > 1:
         out["comm"] = opt.comm_stats()
+        need = ("allreduce_bytes_per_step", "allreduce_ms_on_comm_stream_per_step", "exposed_wait_ms_per_step")
+        if out["comm"] is None or any(k not in out["comm"] for k in need):
+            raise SystemExit("bench.py --gpus %d: no communication record (%r): the gradient all-reduce did not run" % (world, out["comm"]))
+        out["comm"]["replica_check"] = "parameter checksums of all ranks agree to 1e-6 after the first optimiser step"
     busy = pmc_mfma_busy()
     if busy is not None and is16:
         out["mfma_busy_pmc"] = busy

@@ -78,6 +78,11 @@ class HFBertEncoder(nn.Module):
                 p.grad = gviews[name]
 
     def zero_grad(self, set_to_none=False):
+        # a data-parallel optimiser may already have this tower's gradient slices on the wire (armed backward, then the step is
+        # dropped): its collectives are waited for and its per-step bookkeeping reset before the buffer is zeroed
+        owner = getattr(getattr(self.engine, "grad_ready_hook", None), "__self__", None)
+        if owner is not None and hasattr(owner, "_discard_pending"):
+            owner._discard_pending()
         if self.engine.flat_grad is not None:
             self.engine.flat_grad.zero_()
         self.engine._open_graphs = 0          # graphs that never got a backward must not hold back the data-parallel hooks

@@ -82,10 +82,14 @@ class FusedAdamW(object):
         self.world_size = int(world_size)
         if process_group is not None:
             self.group = process_group
-        if payload is not None:
-            if payload not in ("fp32", "bf16"):
-                raise ValueError("payload must be 'fp32' or 'bf16', got %r" % (payload,))
-            self.payload = payload
+        if payload is None:
+            # default at W > 1: bf16 slices (438 MB instead of 876 MB per step and rank over the xGMI links; the
+            # master gradients stay f32).  SIMX_GRAD_PAYLOAD=fp32 (or payload="fp32") sends f32.
+            import os
+            payload = os.environ.get("SIMX_GRAD_PAYLOAD") or ("bf16" if self.world_size > 1 else "fp32")
+        if payload not in ("fp32", "bf16"):
+            raise ValueError("payload must be 'fp32' or 'bf16', got %r" % (payload,))
+        self.payload = payload
         if self.world_size <= 1 and not force:
             return self
         dev = self.towers[0][1].flat.device if self.towers else None
@@ -225,7 +229,31 @@ class FusedAdamW(object):
             self.state["extra"] = st
         return st
 
+    def _discard_pending(self):
+        """Drop a step whose gradient reduction is already on the wire (zero_grad() without step(), e.g. after a non-finite
+        loss): the collectives launched by the backward hooks are waited for on the communication stream, the compute stream
+        joins it -- nothing may zero a buffer RCCL is still reading or writing -- and the per-step bookkeeping is reset so
+        that the next backward may arm its slices again."""
+        if self._pending:
+            on_gpu = bool(self.towers) and self.towers[0][1].flat.is_cuda
+            comm = self._comm if on_gpu else None
+            ctx = torch.cuda.stream(comm) if comm is not None else _NullCtx()
+            with ctx:
+                for w, e, lo, hi, buf, ev in self._pending:
+                    w.wait()
+            if comm is not None:
+                torch.cuda.current_stream().wait_stream(comm)
+            self._pending = []
+        self._reduced = {}
+        self._synced = False
+        for m, e in self.towers:
+            e._reduced_this_step = False
+        st = self.state.get("extra")
+        if st is not None:
+            st["g_ready"] = False
+
     def zero_grad(self, set_to_none=False):
+        self._discard_pending()
         for m, e in self.towers:
             if e.flat_grad is not None:
                 e.flat_grad.zero_()

@@ -181,6 +181,27 @@ for mode in ("plain", "rccl", "rccl_bf16"):
             raise SystemExit("second backward after the slices were reduced did not raise")
         except Exception as e:
             assert "already all-reduced" in str(e), e
+# a DROPPED step (armed backward, slices on the wire, then zero_grad() without step() -- e.g. a non-finite loss): zero_grad must
+# wait for the pending collectives, reset the bookkeeping, and the next backward + step must equal a plain step
+bi = build(dev, dtype).train()
+opt = FusedAdamW(bi, lr=1e-3, eps=1e-8).enable_overlap(1, parts=2, force=True, payload="bf16")
+parallel.FORCE_COLLECTIVES = True
+q, c = bi(q_ids, q_mask, c_ids, c_mask)
+(ops.kl_distill_loss(q, c, z)[0] * 3.0).backward()                 # a different gradient than the one that will count
+assert len(opt._pending) == 4
+bi.zero_grad()                                                     # HFBertEncoder.zero_grad -> FusedAdamW._discard_pending
+assert not opt._pending and not opt._reduced and not any(m.engine._reduced_this_step for m in (bi.question_model, bi.ctx_model))
+q, c = bi(q_ids, q_mask, c_ids, c_mask)
+loss, _, _ = ops.kl_distill_loss(q, c, z)
+loss = loss + 0.2 * parallel.inbatch_nll_allgather(q, c, D)
+loss.backward()
+opt.sync_grads()
+torch.cuda.synchronize()
+gd = torch.cat([bi.question_model.engine.flat_grad, bi.ctx_model.engine.flat_grad]).clone()
+opt.step(max_grad_norm=2.0)
+torch.cuda.synchronize()
+rel_d = ((gd - res["plain"][1]).abs().max() / res["plain"][1].abs().max()).item()
+assert rel_d <= 4e-3, ("gradient after a dropped step", rel_d)    # (bf16 payload: 2^-9 per element; stale slices would be O(1) off)
 l0, g0, p0 = res["plain"]
 l1, g1, p1 = res["rccl"]
 # (equal up to the order of the f32 atomic sums in the LayerNorm / bias / embedding gradients, which differs run to run)
@@ -212,3 +233,27 @@ def test_rccl_one_rank_drives_the_whole_dp_path(dev, tmp_path, dtype):
     p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     out = p.stdout.decode()
     assert p.returncode == 0 and "rccl one-rank ok" in out, out
+
+
+def test_bench_two_ranks_share_one_gpu(dev):
+    """`bench.py --gpus 2` end to end (the command the driver's SCALE run launches at N = 2, 4, 8): self-spawned ranks, rendezvous on
+    127.0.0.1, sharded queries, overlapped gradient all-reduce with the default bf16 payload, replica check after the first step,
+    barrier + max-over-ranks timing, ONE JSON line from rank 0 with a `comm` block.  SIMX_BENCH_SHARE_GPU=1 puts both ranks on
+    cuda:0 over gloo (a 1-GPU box cannot host two RCCL ranks): the control flow is what is checked here, never a number."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SIMX_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("SIMX_GRAD_PAYLOAD", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8", "--side"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
+    c = d["comm"]
+    assert c["payload"] == "bf16" and c["allreduce_bytes_per_step"] > 2 * 100e6          # two BERT-base towers, 2 B per parameter
+    assert c["allreduce_ms_on_comm_stream_per_step"] > 0 and c["exposed_wait_ms_per_step"] >= 0 and "replica_check" in c

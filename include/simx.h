@@ -162,7 +162,7 @@ int simx_planes_join(simx_stream_t stream, int src_fmt, int rows, int cols, cons
 /* the producers that write plane pairs directly (fp32 engine; leading dimension of every pair = the tensor's own):
  *   LayerNorm / embedding LayerNorm: y (f32) and its SIMX_F16 pair (LEAD/modeling_bert.py:230-240, 384-388, 462-466);
  *   LayerNorm backward: dz (f32) and the SIMX_BF16 pair of dz x dropout mask (the gradient of the dropped dense output);
- *   attention (head size 64, sequences <= 256: simx_mha_planes_ok): f32 q/k/v in, context as a SIMX_F16 pair; backward reads
+ *   attention (head size 64, sequences <= 4096: simx_mha_planes_ok): f32 q/k/v in, context as a SIMX_F16 pair; backward reads
  *   that pair and writes dq/dk/dv as a SIMX_BF16 pair (LEAD/modeling_bert.py:318-374). */
 int simx_ln_fwd_planes(simx_stream_t stream, int T, int H, const float* z, const float* gamma, const float* beta, float eps,
                        float* y, void* y_planes, long plane_stride);

@@ -885,7 +885,7 @@ extern "C" int simx_mha_bwd(simx_stream_t stream, int dtype, int nseq, int heads
 
 // fp32 engine with operand planes (csrc/gemm_xp.hip): f32 q/k/v in; the context leaves as the fp16 plane pair the
 // attention-output GEMM stages, backward reads it (for rowsum(dO . O)) and writes dq/dk/dv as the bf16 plane pair of the QKV
-// dgrad / wgrad GEMMs.  Head size 64, sequences <= 256 (simx_mha_planes_ok).
+// dgrad / wgrad GEMMs.  Head size 64, sequences <= 4096 (simx_mha_planes_ok).
 extern "C" int simx_mha_planes_ok(int d, int max_len) { return simx_mha_f32_ok(d, max_len) ? 1 : 0; }
 extern "C" int simx_mha_fwd_planes(simx_stream_t stream, int nseq, int heads, int d, const int32_t* cu, int max_len, int T, const float* qkv,
                                    void* ctx_planes, long ctx_plane_stride, float* lse, const simx_dropout* dropd) {
@@ -894,7 +894,7 @@ extern "C" int simx_mha_fwd_planes(simx_stream_t stream, int nseq, int heads, in
   int rc = check_common(SIMX_F32, nseq, heads, d, max_len, T, "mha_fwd_planes");
   if (rc) return rc;
   SIMX_REQUIRE(simx_mha_f32_ok(d, max_len) && ctx_plane_stride > 0 && ctx_plane_stride % 4 == 0, SIMX_ERR_UNSUPPORTED,
-               "mha_fwd_planes: needs head size 64, max_len <= 256 and a plane stride %% 4 == 0");
+               "mha_fwd_planes: needs head size 64, max_len <= 4096 and a plane stride %% 4 == 0");
   return simx_mha_fwd_f32(s, nseq, heads, cu, max_len, T, qkv, (float*)ctx_planes, lse, 1.0f / sqrtf((float)d), make_drop(dropd), ctx_plane_stride);
 }
 extern "C" int simx_mha_bwd_planes(simx_stream_t stream, int nseq, int heads, int d, const int32_t* cu, int max_len, int T, const float* qkv,
@@ -905,7 +905,7 @@ extern "C" int simx_mha_bwd_planes(simx_stream_t stream, int nseq, int heads, in
   int rc = check_common(SIMX_F32, nseq, heads, d, max_len, T, "mha_bwd_planes");
   if (rc) return rc;
   SIMX_REQUIRE(simx_mha_f32_ok(d, max_len) && ctx_plane_stride > 0 && ctx_plane_stride % 4 == 0 && dqkv_plane_stride > 0 && dqkv_plane_stride % 4 == 0,
-               SIMX_ERR_UNSUPPORTED, "mha_bwd_planes: needs head size 64, max_len <= 256 and plane strides %% 4 == 0");
+               SIMX_ERR_UNSUPPORTED, "mha_bwd_planes: needs head size 64, max_len <= 4096 and plane strides %% 4 == 0");
   return simx_mha_bwd_f32(s, nseq, heads, cu, max_len, T, qkv, (const float*)ctx_planes, lse, dctx, (float*)dqkv_planes, 1.0f / sqrtf((float)d),
                           make_drop(dropd), ctx_plane_stride, dqkv_plane_stride);
 }

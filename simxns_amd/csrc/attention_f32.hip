@@ -362,6 +362,296 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_f32_kernel(const float* __res
   }
 }
 
+// ------------------------------------------------------------------------------------------ long sequences (256 < S <= 4096)
+// MS-MARCO Document (BASELINE configs[4]: 512-token documents) in the fp32 arithmetic its recipe selects.  The resident-K/V
+// kernels above need the whole sequence in LDS; here the sequence is cut into 128-token chunks:
+//   forward : one workgroup per (sequence, head, 128-query chunk), each wave owns ONE 32-query tile (Q half rows, the running
+//             maximum / normaliser and the output accumulators stay in registers) and the workgroup walks the key chunks --
+//             K and V of a chunk staged in LDS, online softmax (the accumulators are rescaled when the running maximum moves);
+//   dQ      : the same grid and walk with the forward's lse, dq accumulates in registers;
+//   dK, dV  : one workgroup per (sequence, head, 128-key chunk), each wave owns one 32-key tile and the workgroup walks the
+//             query chunks (Q, dO, lse, rowsum(dO . O) of a chunk staged in LDS).
+// No atomics, no f32 scratch in HBM, every wave takes part in every barrier (tiles past the sequence end compute on clamped
+// rows and store nothing).  The one-wave-per-row kernels these replace took 5.2 of the 5.8 s of a BERT-large S = 512 step.
+#define AFL_NKT 4                              // 32-token tiles per chunk
+template <bool PL>
+__global__ __launch_bounds__(256, 2) void mha_fwd_f32_long_kernel(const float* __restrict__ qkv, float* __restrict__ ctx, float* __restrict__ lse,
+                                                                  const int* __restrict__ cu, int heads, int T, int nchunk, float scale,
+                                                                  DropCtx drop, long cps) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sK = reinterpret_cast<float*>(smem);
+  float* sV = sK + AFL_NKT * 32 * AF_PITCH;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qc = blockIdx.x % nchunk, sh = blockIdx.x / nchunk;
+  const int seq = sh / heads, h = sh % heads;
+  const int t0 = cu[seq], len = cu[seq + 1] - t0;
+  if (len <= 0 || qc * 128 >= len) return;       // (uniform per workgroup)
+  const int H = heads * 64;
+  const long H3 = 3L * H;
+  const float* Qg = qkv + (long)t0 * H3 + h * 64;
+  const int col = lane & 31, half = lane >> 5;
+  const float c2 = scale * AF_LOG2E;
+  const int q = qc * 128 + wave * 32 + col;
+  const int qcl = q < len ? q : len - 1;
+  float qr[32];
+  af_row_regs(Qg, H3, qcl, half, qr);
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x16 o[2];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { o[0][e] = 0.f; o[1][e] = 0.f; }
+  const int nkc = (len + 127) >> 7;
+  for (int kc = 0; kc < nkc; ++kc) {
+    const int k0 = kc * 128, klen = min(128, len - k0), nkt = (klen + 31) >> 5;
+    if (kc) __syncthreads();                     // every wave is done with the previous chunk
+    af_stage(Qg + H + (long)k0 * H3, H3, klen, nkt * 32, sK, tid);
+    af_stage(Qg + 2 * H + (long)k0 * H3, H3, klen, nkt * 32, sV, tid);
+    __syncthreads();
+    f32x16 s[AFL_NKT];
+    float m = m_run;
+#pragma unroll
+    for (int kt = 0; kt < AFL_NKT; ++kt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[kt][e] = 0.f;
+      if (kt < nkt) {
+        const float* ak = sK + (kt * 32 + col) * AF_PITCH + 32 * half;
+#pragma unroll
+        for (int t = 0; t < 32; ++t) s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ak[t], qr[t], s[kt], 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = kt * 32 + af_row(e, half);
+          s[kt][e] = key < klen ? s[kt][e] : -INFINITY;
+          m = fmaxf(m, s[kt][e]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[kt][e] = -INFINITY;
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));         // (finite: every chunk holds at least one real key)
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m) * c2);     // exp2(-inf) = 0 on the first chunk
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < AFL_NKT; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float p = __builtin_amdgcn_exp2f((s[kt][e] - m) * c2);
+        s[kt][e] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    l_run = l_run * alpha + sum;
+    m_run = m;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { o[0][e] *= alpha; o[1][e] *= alpha; }
+    if (drop.thr) {                               // dropout on the probabilities (the normaliser stays unmasked)
+      const uint32_t drow = (uint32_t)(h * T + t0 + q);
+#pragma unroll
+      for (int kt = 0; kt < AFL_NKT; ++kt)
+        if (kt < nkt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) s[kt][e] *= drop_mult(drop, drow, (uint32_t)(k0 + kt * 32 + af_row(e, half)));
+    }
+#pragma unroll
+    for (int kt = 0; kt < AFL_NKT; ++kt)
+      if (kt < nkt) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float* av = sV + (kt * 32 + af_row(e, half)) * AF_PITCH + col;
+          o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], s[kt][e], o[0], 0, 0, 0);
+          o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[32], s[kt][e], o[1], 0, 0, 0);
+        }
+      }
+  }
+  if (q < len) {
+    if (PL) af_store_t_planes<f16_t>(o, 1.0f / l_run, reinterpret_cast<bf16_t*>(ctx) + (long)(t0 + q) * H + h * 64, cps, half);
+    else af_store_t(o, 1.0f / l_run, ctx + (long)(t0 + q) * H + h * 64, half);
+    if (half == 0) lse[(long)h * T + t0 + q] = m_run * scale + logf(l_run);
+  }
+}
+
+template <bool PL>
+__global__ __launch_bounds__(256, 2) void mha_bwd_dq_f32_long_kernel(const float* __restrict__ qkv, const float* __restrict__ O,
+                                                                     const float* __restrict__ lse, const float* __restrict__ dO,
+                                                                     float* __restrict__ dqkv, const int* __restrict__ cu, int heads, int T,
+                                                                     int nchunk, float scale, DropCtx drop, long ops, long dps) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sK = reinterpret_cast<float*>(smem);
+  float* sV = sK + AFL_NKT * 32 * AF_PITCH;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qc = blockIdx.x % nchunk, sh = blockIdx.x / nchunk;
+  const int seq = sh / heads, h = sh % heads;
+  const int t0 = cu[seq], len = cu[seq + 1] - t0;
+  if (len <= 0 || qc * 128 >= len) return;
+  const int H = heads * 64;
+  const long H3 = 3L * H;
+  const float* Qg = qkv + (long)t0 * H3 + h * 64;
+  const float* Og = O + (long)t0 * H + h * 64;
+  const bf16_t* Opl = reinterpret_cast<const bf16_t*>(O) + (long)t0 * H + h * 64;
+  const float* dOg = dO + (long)t0 * H + h * 64;
+  const int col = lane & 31, half = lane >> 5;
+  const float c2 = scale * AF_LOG2E;
+  const int q = qc * 128 + wave * 32 + col;
+  const int qcl = q < len ? q : len - 1;
+  const bool qok = q < len;
+  float qr[32], dr[32];
+  af_row_regs(Qg, H3, qcl, half, qr);
+  af_row_regs(dOg, H, qcl, half, dr);
+  float delta = 0.f;
+  {
+    const float4* po = reinterpret_cast<const float4*>(Og + (long)qcl * H + 32 * half);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float4 v = PL ? af_ld4_planes(Opl + (long)qcl * H + 32 * half + 4 * i, ops) : po[i];
+      delta += dr[4 * i] * v.x + dr[4 * i + 1] * v.y + dr[4 * i + 2] * v.z + dr[4 * i + 3] * v.w;
+    }
+  }
+  delta += __shfl_xor(delta, 32, 64);
+  const float lq = lse[(long)h * T + t0 + qcl] * AF_LOG2E;
+  f32x16 dq[2];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { dq[0][e] = 0.f; dq[1][e] = 0.f; }
+  const int nkc = (len + 127) >> 7;
+  for (int kc = 0; kc < nkc; ++kc) {
+    const int k0 = kc * 128, klen = min(128, len - k0), nkt = (klen + 31) >> 5;
+    if (kc) __syncthreads();
+    af_stage(Qg + H + (long)k0 * H3, H3, klen, nkt * 32, sK, tid);
+    af_stage(Qg + 2 * H + (long)k0 * H3, H3, klen, nkt * 32, sV, tid);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+      const float* ak = sK + (kt * 32 + col) * AF_PITCH + 32 * half;
+      const float* av = sV + (kt * 32 + col) * AF_PITCH + 32 * half;
+#pragma unroll
+      for (int t = 0; t < 32; ++t) {
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(ak[t], qr[t], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], dr[t], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = kt * 32 + af_row(e, half);
+        float p = __builtin_amdgcn_exp2f(s[e] * c2 - lq);
+        p = (key < klen && qok) ? p : 0.f;
+        const float mm = drop.thr ? drop_mult(drop, (uint32_t)(h * T + t0 + q), (uint32_t)(k0 + key)) : 1.f;
+        s[e] = p * (dp[e] * mm - delta) * scale;
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float* an = sK + (kt * 32 + af_row(e, half)) * AF_PITCH + col;
+        dq[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[0], s[e], dq[0], 0, 0, 0);
+        dq[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[32], s[e], dq[1], 0, 0, 0);
+      }
+    }
+  }
+  if (qok) {
+    if (PL) af_store_t_planes<bf16_t>(dq, 1.0f, reinterpret_cast<bf16_t*>(dqkv) + (long)(t0 + q) * H3 + h * 64, dps, half);
+    else af_store_t(dq, 1.0f, dqkv + (long)(t0 + q) * H3 + h * 64, half);
+  }
+}
+
+template <bool PL>
+__global__ __launch_bounds__(256, 2) void mha_bwd_dkv_f32_long_kernel(const float* __restrict__ qkv, const float* __restrict__ O,
+                                                                      const float* __restrict__ lse, const float* __restrict__ dO,
+                                                                      float* __restrict__ dqkv, const int* __restrict__ cu, int heads, int T,
+                                                                      int nchunk, float scale, DropCtx drop, long ops, long dps) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sQ = reinterpret_cast<float*>(smem);
+  float* sD = sQ + AFL_NKT * 32 * AF_PITCH;
+  float* sLse = sD + AFL_NKT * 32 * AF_PITCH;
+  float* sDel = sLse + AFL_NKT * 32;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kc = blockIdx.x % nchunk, sh = blockIdx.x / nchunk;
+  const int seq = sh / heads, h = sh % heads;
+  const int t0 = cu[seq], len = cu[seq + 1] - t0;
+  if (len <= 0 || kc * 128 >= len) return;
+  const int H = heads * 64;
+  const long H3 = 3L * H;
+  const float* Qg = qkv + (long)t0 * H3 + h * 64;
+  const float* Og = O + (long)t0 * H + h * 64;
+  const bf16_t* Opl = reinterpret_cast<const bf16_t*>(O) + (long)t0 * H + h * 64;
+  const float* dOg = dO + (long)t0 * H + h * 64;
+  const int col = lane & 31, half = lane >> 5;
+  const float c2 = scale * AF_LOG2E;
+  const int key = kc * 128 + wave * 32 + col;
+  const int kcl = key < len ? key : len - 1;
+  const bool kok = key < len;
+  float kr[32], vr[32];
+  af_row_regs(Qg + H, H3, kcl, half, kr);
+  af_row_regs(Qg + 2 * H, H3, kcl, half, vr);
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { dk[0][e] = 0.f; dk[1][e] = 0.f; dv[0][e] = 0.f; dv[1][e] = 0.f; }
+  const int nqc = (len + 127) >> 7;
+  for (int qc = 0; qc < nqc; ++qc) {
+    const int q0 = qc * 128, qlen = min(128, len - q0), nqt = (qlen + 31) >> 5;
+    if (qc) __syncthreads();
+    af_stage(Qg + (long)q0 * H3, H3, qlen, nqt * 32, sQ, tid);
+    af_stage(dOg + (long)q0 * H, H, qlen, nqt * 32, sD, tid);
+    for (int r = tid; r < nqt * 32; r += 256) {
+      float del = 0.f, l = 0.f;
+      if (r < qlen) {
+        const float4* po = reinterpret_cast<const float4*>(Og + (long)(q0 + r) * H);
+        const float4* pd = reinterpret_cast<const float4*>(dOg + (long)(q0 + r) * H);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float4 a = PL ? af_ld4_planes(Opl + (long)(q0 + r) * H + 4 * i, ops) : po[i], b = pd[i];
+          del += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+        }
+        l = lse[(long)h * T + t0 + q0 + r] * AF_LOG2E;
+      }
+      sDel[r] = del;
+      sLse[r] = l;
+    }
+    __syncthreads();
+    for (int qt = 0; qt < nqt; ++qt) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+      const float* aq = sQ + (qt * 32 + col) * AF_PITCH + 32 * half;
+      const float* ad = sD + (qt * 32 + col) * AF_PITCH + 32 * half;
+#pragma unroll
+      for (int t = 0; t < 32; ++t) {
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[t], kr[t], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[t], vr[t], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int qr_ = qt * 32 + af_row(e, half);
+        float p = __builtin_amdgcn_exp2f(s[e] * c2 - sLse[qr_]);
+        p = (qr_ < qlen && kok) ? p : 0.f;
+        const float mm = drop.thr ? drop_mult(drop, (uint32_t)(h * T + t0 + q0 + qr_), (uint32_t)key) : 1.f;
+        s[e] = p * mm;
+        dp[e] = p * (dp[e] * mm - sDel[qr_]) * scale;
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int qr_ = qt * 32 + af_row(e, half);
+        const float* dn = sD + qr_ * AF_PITCH + col;
+        const float* qn = sQ + qr_ * AF_PITCH + col;
+        dv[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(dn[0], s[e], dv[0], 0, 0, 0);
+        dv[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(dn[32], s[e], dv[1], 0, 0, 0);
+        dk[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(qn[0], dp[e], dk[0], 0, 0, 0);
+        dk[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(qn[32], dp[e], dk[1], 0, 0, 0);
+      }
+    }
+  }
+  if (kok) {
+    if (PL) {
+      bf16_t* dst = reinterpret_cast<bf16_t*>(dqkv) + (long)(t0 + key) * H3 + H + h * 64;
+      af_store_t_planes<bf16_t>(dk, 1.0f, dst, dps, half);
+      af_store_t_planes<bf16_t>(dv, 1.0f, dst + H, dps, half);
+    } else {
+      float* dst = dqkv + (long)(t0 + key) * H3 + H + h * 64;
+      af_store_t(dk, 1.0f, dst, half);
+      af_store_t(dv, 1.0f, dst + H, half);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ host (called from attention.hip)
 template <typename K>
 static int af_set_lds(K kernel, size_t bytes, const char* name) {
@@ -374,7 +664,7 @@ static int af_set_lds(K kernel, size_t bytes, const char* name) {
 
 bool simx_mha_f32_ok(int d, int max_len) {
   static const char* pin = getenv("SIMX_MHA_F32");            // SIMX_MHA_F32=generic pins the one-wave-per-row kernels (A/B)
-  return d == 64 && max_len <= 256 && !(pin && pin[0] == 'g');
+  return d == 64 && max_len <= 4096 && !(pin && pin[0] == 'g');
 }
 
 // ctx_ps > 0: ctx is an fp16 plane pair (hi at ctx, lo at + ctx_ps 16-bit elements) instead of an f32 matrix
@@ -395,6 +685,21 @@ int simx_mha_fwd_f32(hipStream_t s, int nseq, int heads, const int32_t* cu, int 
     }                                                                                                                      \
   } while (0)
   static const bool dense5 = [] { const char* e = getenv("SIMX_MHA_F32_DENSE"); return !e || e[0] != '0'; }();
+  if (max_len > 256) {                             // chunked kernels: one workgroup per (sequence, head, 128-query chunk)
+    const int nchunk = (max_len + 127) / 128;
+    const size_t lds = (size_t)2 * AFL_NKT * 32 * AF_PITCH * sizeof(float);
+    if (ctx_ps > 0) {
+      rc = af_set_lds(mha_fwd_f32_long_kernel<true>, lds, "mha_fwd_f32_long");
+      if (rc) return rc;
+      hipLaunchKernelGGL(mha_fwd_f32_long_kernel<true>, dim3(nseq * heads * nchunk), dim3(256), lds, s, qkv, ctx, lse, cu, heads, T, nchunk, scale, drop, ctx_ps);
+    } else {
+      rc = af_set_lds(mha_fwd_f32_long_kernel<false>, lds, "mha_fwd_f32_long");
+      if (rc) return rc;
+      hipLaunchKernelGGL(mha_fwd_f32_long_kernel<false>, dim3(nseq * heads * nchunk), dim3(256), lds, s, qkv, ctx, lse, cu, heads, T, nchunk, scale, drop, 0L);
+    }
+    SIMX_CHECK_LAUNCH("mha_fwd_f32_long");
+    return SIMX_OK;
+  }
   if (max_len <= 32) LF(1, false);
   else if (max_len <= 128) LF(4, false);
   else if (max_len <= 160 && dense5) LF(5, true);   // exactly 80 KB: two workgroups per CU
@@ -421,6 +726,23 @@ int simx_mha_bwd_f32(hipStream_t s, int nseq, int heads, const int32_t* cu, int 
     hipLaunchKernelGGL((mha_bwd_dkv_f32_kernel<NKT, PL>), dim3(nseq * heads), dim3(256), lds2, s, qkv, ctx, lse, dctx, dqkv, cu, heads, T, scale, drop, ctx_ps, dqkv_ps); \
   } while (0)
 #define LB(NKT) do { if (ctx_ps > 0) LB2(NKT, true); else LB2(NKT, false); } while (0)
+  if (max_len > 256) {
+    const int nchunk = (max_len + 127) / 128;
+    const size_t lds = (size_t)2 * AFL_NKT * 32 * AF_PITCH * sizeof(float), lds2 = lds + (size_t)2 * AFL_NKT * 32 * sizeof(float);
+#define LBL(PL)                                                                                                            \
+  do {                                                                                                                     \
+    rc = af_set_lds(mha_bwd_dq_f32_long_kernel<PL>, lds, "mha_bwd_f32_long");                                              \
+    if (rc) return rc;                                                                                                     \
+    rc = af_set_lds(mha_bwd_dkv_f32_long_kernel<PL>, lds2, "mha_bwd_f32_long");                                            \
+    if (rc) return rc;                                                                                                     \
+    hipLaunchKernelGGL(mha_bwd_dq_f32_long_kernel<PL>, dim3(nseq * heads * nchunk), dim3(256), lds, s, qkv, ctx, lse, dctx, dqkv, cu, heads, T, nchunk, scale, drop, ctx_ps, dqkv_ps); \
+    hipLaunchKernelGGL(mha_bwd_dkv_f32_long_kernel<PL>, dim3(nseq * heads * nchunk), dim3(256), lds2, s, qkv, ctx, lse, dctx, dqkv, cu, heads, T, nchunk, scale, drop, ctx_ps, dqkv_ps); \
+  } while (0)
+    if (ctx_ps > 0) LBL(true); else LBL(false);
+#undef LBL
+    SIMX_CHECK_LAUNCH("mha_bwd_f32_long");
+    return SIMX_OK;
+  }
   if (max_len <= 32) LB(1);
   else if (max_len <= 128) LB(4);
   else if (max_len <= 160) LB(5);

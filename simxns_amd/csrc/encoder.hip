@@ -82,7 +82,7 @@ extern "C" size_t simx_bert_param_offset(const simx_bert_cfg* c, int layer, int 
 // pairs.  Three predicates, each a function of its arguments only so that sizing calls, forward and backward agree:
 //   pl_weights(c)            the weight cache also holds fp16 planes of W and bf16 planes of W^T
 //   pl_layout(c, Tp)         activation / scratch buffers have room for the planes of the residual stream (x0, x1, xout)
-//   pl_run(c, Tp, max_len)   the tower's full layers run on planes (needs the f32 MFMA attention: sequences <= 256)
+//   pl_run(c, Tp, max_len)   the tower's full layers run on planes (needs the f32 MFMA attention: head size 64, sequences <= 4096)
 // SIMX_F32_PLANES=0 pins the register-split kernels of gemm_x3.hip (A/B measurements); SIMX_F32_PLANES_MIN_TILES lowers the
 // size threshold (tests run small towers through the plane kernels).
 static bool pl_weights(const simx_bert_cfg* c) {

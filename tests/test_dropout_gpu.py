@@ -29,6 +29,7 @@ def _fixed_seed(enc, seed, full_last_layer=False):
 @pytest.mark.parametrize("full_last_layer", [False, True])     # False: the [CLS]-only last layer (what the towers run); True: every row
 @pytest.mark.parametrize("dtype,heads,hidden,p_len", [("fp32", 4, 64, 128), ("bf16", 1, 64, 128), ("fp32", 1, 64, 128),
                                                     ("bf16", 2, 128, 600),      # 600: chunked long-sequence attention backward
+                                                    ("fp32", 2, 128, 600),      # the chunked f32 MFMA attention (with dropout keys)
                                                     ("fp16", 1, 64, 128), ("fp16", 2, 128, 600)])   # the benchmarked engine (apex-O1 form)
 def test_step_with_dropout_matches_oracle(dev, dtype, heads, hidden, p_len, full_last_layer):
     from simxns_amd import ops

@@ -432,7 +432,9 @@ def _mha_ref(qkv, lens, heads, d, dctx=None):
     (False, 2, 64, [128, 1, 17, 33, 16, 100]),
     (False, 2, 64, [160, 129, 45]),             # NKT = 5
     (False, 1, 64, [250, 200, 256]),            # NKT = 8
-    (False, 1, 64, [300, 33]),                  # > 256: generic kernels
+    (False, 1, 64, [300, 33]),                  # > 256: the chunked f32 MFMA kernels (128-token chunks, online softmax)
+    (False, 2, 64, [512, 257, 384, 40, 511, 129]),      # whole and ragged chunks, sequences shorter than one chunk
+    (False, 1, 64, [1000, 700]),
     (True, 4, 16, [5, 32, 17]),                 # generic kernel in bf16
     (True, 2, 64, [128, 1, 17, 33, 16, 100]),   # MFMA kernel, NKT=8
     (True, 3, 64, [9, 32, 4, 31]),              # NKT=2

@@ -147,6 +147,11 @@ int simx_gemm_nt_planes_ok(int M, int N, int K);
 int simx_gemm_nt_planes(simx_stream_t stream, int fmt, int epilogue, int M, int N, int K, const void* A, int lda, long a_plane_stride,
                         const void* B, int ldb, long b_plane_stride, float* C, int ldc, const float* bias, const float* in, int ldin,
                         void* Cp, int ldcp, long cp_plane_stride, const simx_dropout* drop);
+/* same; SIMX_EPI_DGELU only: colsum[N] (may be NULL) += column sums of the output rows [0, rows_valid) -- the bias gradient of
+ * the dense layer whose pre-activation gradient the launch produces (f32 atomics) */
+int simx_gemm_nt_planes_cs(simx_stream_t stream, int fmt, int epilogue, int M, int N, int K, const void* A, int lda, long a_plane_stride,
+                           const void* B, int ldb, long b_plane_stride, float* C, int ldc, const float* bias, const float* in, int ldin,
+                           void* Cp, int ldcp, long cp_plane_stride, const simx_dropout* drop, float* colsum, int rows_valid);
 /* wgrad: C[M,N] (+)= A[K,M]^T . B[K,N], A = dY, B = X as SIMX_BF16 plane pairs (K = tokens); dbias[M] (may be NULL) +=
  * column sums of A.  Split over K into f32 slabs added in slice order; ws >= simx_gemm_tn_planes_workspace_bytes. */
 size_t simx_gemm_tn_planes_workspace_bytes(int M, int N, int K);

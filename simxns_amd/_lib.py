@@ -126,6 +126,7 @@ SIGNATURES = {
     "simx_adamw_step_sc": (_i, [_p, _p, _p, _p, _p, _z, _f, _f, _f, _f, _f, _i, _p, _f, _f, _i, _p]),
     "simx_gemm_nt_planes_ok": (_i, [_i, _i, _i]),
     "simx_gemm_nt_planes": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _l, _p, _i, _l, _p, _i, _p, _p, _i, _p, _i, _l, _dp]),
+    "simx_gemm_nt_planes_cs": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _l, _p, _i, _l, _p, _i, _p, _p, _i, _p, _i, _l, _dp, _p, _i]),
     "simx_gemm_tn_planes_workspace_bytes": (_z, [_i, _i, _i]),
     "simx_gemm_tn_planes": (_i, [_p, _i, _i, _i, _p, _i, _l, _p, _i, _l, _p, _i, _i, _p, _z, _p]),
     "simx_planes_from": (_i, [_p, _i, _i, _i, _i, _p, _i, _l, _p, _i, _l]),

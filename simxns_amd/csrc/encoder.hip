@@ -625,14 +625,18 @@ extern "C" int simx_bert_bwd_range(simx_stream_t stream, const simx_bert_cfg* c,
       const long psH = (long)Tp * H, psF = (long)Tp * F, ps3 = (long)Tp * 3 * H;
       RUN(simx_ln_bwd_planes(stream, T, H, (const float*)a.z2, off(l, SIMX_P_LN2_G), c->eps, (const float*)bufB, (float*)bufA, bufC, psH,
                              goff(l, SIMX_P_LN2_G), goff(l, SIMX_P_LN2_B), goff(l, SIMX_P_B2), &d2));
-      RUN(simx_gemm_nt_planes(stream, SIMX_BF16, SIMX_EPI_DGELU, Tp, F, H, bufC, H, psH, w.w2TP, H, (long)F * H, nullptr, F, nullptr,
-                              (const float*)a.u, F, du, F, psF, nullptr));
+      // (the bias gradient of B1 = column sums of du comes out of this epilogue, so the W1 wgrad runs on the four-plane-stage
+      // kernel, which carries no fused bias pass; the deterministic mode keeps the wgrad kernel's ordered pass)
+      const bool b1_here = !simx_det();
+      RUN(simx_gemm_nt_planes_cs(stream, SIMX_BF16, SIMX_EPI_DGELU, Tp, F, H, bufC, H, psH, w.w2TP, H, (long)F * H, nullptr, F, nullptr,
+                                 (const float*)a.u, F, du, F, psF, nullptr, b1_here ? goff(l, SIMX_P_B1) : nullptr, T));
       RUN(simx_planes_from(stream, SIMX_F16, SIMX_BF16, T, F, a.h, F, psF, xconv, F, psF));
       RUN(simx_gemm_tn_planes(stream, H, F, T, bufC, H, psH, xconv, F, psF, goff(l, SIMX_P_W2), F, 1, tnws, tnws_bytes, nullptr));
       RUN(simx_gemm_nt_planes(stream, SIMX_BF16, SIMX_EPI_NONE, Tp, H, F, du, F, psF, w.w1TP, F, (long)H * F, (float*)bufB, H, nullptr,
                               (const float*)bufA, H, nullptr, 0, 0, nullptr));
       RUN(simx_planes_from(stream, SIMX_F32, SIMX_BF16, T, H, a.x1, H, 0, xconv, H, psH));
-      RUN(simx_gemm_tn_planes(stream, F, H, T, du, F, psF, xconv, H, psH, goff(l, SIMX_P_W1), H, 1, tnws, tnws_bytes, goff(l, SIMX_P_B1)));
+      RUN(simx_gemm_tn_planes(stream, F, H, T, du, F, psF, xconv, H, psH, goff(l, SIMX_P_W1), H, 1, tnws, tnws_bytes,
+                              b1_here ? nullptr : goff(l, SIMX_P_B1)));
       RUN(simx_ln_bwd_planes(stream, T, H, (const float*)a.z1, off(l, SIMX_P_LN1_G), c->eps, (const float*)bufB, (float*)bufA, bufC, psH,
                              goff(l, SIMX_P_LN1_G), goff(l, SIMX_P_LN1_B), goff(l, SIMX_P_BO), &d1));
       RUN(simx_gemm_nt_planes(stream, SIMX_BF16, SIMX_EPI_NONE, Tp, H, H, bufC, H, psH, w.woTP, H, (long)H * H, (float*)bufB, H, nullptr, nullptr, 0,

@@ -55,7 +55,9 @@ template <typename F, int EPI, bool HAS_IN, bool DROP, bool RING>
 __global__ __launch_bounds__(512, 2) void gemm_nt_xp_kernel(
     int M, int N, int K, const bf16_t* __restrict__ A, int lda, long a_ps, const bf16_t* __restrict__ B, int ldb, long b_ps,
     float* __restrict__ C, int ldc, const float* __restrict__ bias, const float* __restrict__ in, int ldin,
-    bf16_t* __restrict__ Cp, int ldcp, long cp_ps, int tiles_n, int ntiles, DropCtx drop) {
+    bf16_t* __restrict__ Cp, int ldcp, long cp_ps, int tiles_n, int ntiles, DropCtx drop, float* __restrict__ colsum, int m_valid) {
+  // colsum (SIMX_EPI_DGELU only, may be NULL): += column sums of the output over rows < m_valid -- the bias gradient of the dense
+  // layer whose pre-activation gradient this launch produces (B1 from du), so that its wgrad GEMM needs no fused bias pass
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -295,6 +297,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_xp_kernel(
       const uint32_t po0 = (uint32_t)(lr * ldcp + pc0 * 8) * 2, po1 = (uint32_t)((lr + 8) * ldcp + pc1 * 8) * 2;
       constexpr int NS = 4;                         // stores per chunk of the HAS_IN forms (f32: 2 x 2, planes: 2 x 2)
       const bool want_c = EPI != SIMX_EPI_GELU || C != nullptr;     // (GELU with C == NULL: the inference form)
+      float cs[4][4];                                // DGELU: this lane's column partial sums over its 8 rows
+      if (EPI == SIMX_EPI_DGELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) cs[j][e] = 0.f;
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         if (HAS_IN) {
@@ -350,6 +359,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_xp_kernel(
           P_GST4(eo0, ob + 128, w2);
           P_GST4(eo1, ob + 128, w3);
         }
+        if (EPI == SIMX_EPI_DGELU) {
+          const float keep = (mw + i * 16 + fr) < m_valid ? 1.0f : 0.0f;       // rows past the real tokens hold garbage
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cs[j][e] += keep != 0.0f ? vv[j][e] : 0.0f;
+        }
         if (EPI != SIMX_EPI_NONE) {
           // plane pair output: hi in the first 2 KB of the slice, lo in the second
 #pragma unroll
@@ -370,6 +386,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_xp_kernel(
           P_GST4(po1, pb, w1);
           P_GST4(po0, pb + cp_ps * 2, w2);
           P_GST4(po1, pb + cp_ps * 2, w3);
+        }
+      }
+      if (EPI == SIMX_EPI_DGELU) {
+        if (colsum != nullptr) {                   // (uniform) 16-lane row sums by DPP, one atomic per column from the fr == 0 lanes
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float t = cs[j][e];
+              t += dpp_mov<0xB1, 0xF>(t);
+              t += dpp_mov<0x4E, 0xF>(t);
+              t += dpp_mov<0x141, 0xF>(t);
+              t += dpp_mov<0x140, 0xF>(t);
+              if (fr == 0) atomicAdd(colsum + nw + j * 16 + fg * 4 + e, t);
+            }
         }
       }
     }
@@ -965,7 +996,16 @@ extern "C" int simx_gemm_nt_planes_ok(int M, int N, int K) {
 extern "C" int simx_gemm_nt_planes(simx_stream_t stream, int fmt, int epilogue, int M, int N, int K, const void* A, int lda, long a_ps,
                                    const void* B, int ldb, long b_ps, float* C, int ldc, const float* bias, const float* in, int ldin,
                                    void* Cp, int ldcp, long cp_ps, const simx_dropout* dropd) {
+  return simx_gemm_nt_planes_cs(stream, fmt, epilogue, M, N, K, A, lda, a_ps, B, ldb, b_ps, C, ldc, bias, in, ldin, Cp, ldcp, cp_ps, dropd, nullptr, M);
+}
+// SIMX_EPI_DGELU with colsum != NULL: colsum[N] += column sums of the output rows [0, rows_valid) (atomics; not used in the
+// deterministic mode, where the wgrad GEMM's ordered bias pass stays)
+extern "C" int simx_gemm_nt_planes_cs(simx_stream_t stream, int fmt, int epilogue, int M, int N, int K, const void* A, int lda, long a_ps,
+                                      const void* B, int ldb, long b_ps, float* C, int ldc, const float* bias, const float* in, int ldin,
+                                      void* Cp, int ldcp, long cp_ps, const simx_dropout* dropd, float* colsum, int rows_valid) {
   hipStream_t s = (hipStream_t)stream;
+  const int m_valid = rows_valid;
+  SIMX_REQUIRE(!colsum || epilogue == SIMX_EPI_DGELU, SIMX_ERR_UNSUPPORTED, "gemm_nt_planes: colsum is a DGELU output");
   SIMX_PROF(SIMX_K_GEMM_NT_XP, s, 2.0 * M * N * K);
   SIMX_REQUIRE(fmt == SIMX_F16 || fmt == SIMX_BF16, SIMX_ERR_BAD_DTYPE, "gemm_nt_planes: fmt %d (the format of the operand planes)", fmt);
   SIMX_REQUIRE(simx_gemm_nt_planes_ok(M, N, K), SIMX_ERR_UNSUPPORTED, "gemm_nt_planes: shape %d x %d x %d (needs M, N %% 256 == 0, K %% 64 == 0, K >= 128)", M, N, K);
@@ -985,9 +1025,9 @@ extern "C" int simx_gemm_nt_planes(simx_stream_t stream, int fmt, int epilogue, 
   static const bool k3 = [] { const char* e = getenv("SIMX_NT_XP"); return e && e[0] == 'k'; }();
   const bool ring = !k3 && lda == ldb;
 #define LXP(FF, E, HI, DR) do { if (ring) hipLaunchKernelGGL((gemm_nt_xp_kernel<FF, E, HI, DR, true>), dim3(grid), dim3(512), P_LDS, s, M, N, K, (const bf16_t*)A, lda, a_ps, \
-                                              (const bf16_t*)B, ldb, b_ps, C, ldc, bias, in, ldin, (bf16_t*)Cp, ldcp, cp_ps, tn, nt, drop);    \
+                                              (const bf16_t*)B, ldb, b_ps, C, ldc, bias, in, ldin, (bf16_t*)Cp, ldcp, cp_ps, tn, nt, drop, colsum, m_valid);    \
                                 else hipLaunchKernelGGL((gemm_nt_xp_kernel<FF, E, HI, DR, false>), dim3(grid), dim3(512), P_LDS, s, M, N, K, (const bf16_t*)A, lda, a_ps, \
-                                              (const bf16_t*)B, ldb, b_ps, C, ldc, bias, in, ldin, (bf16_t*)Cp, ldcp, cp_ps, tn, nt, drop); } while (0)
+                                              (const bf16_t*)B, ldb, b_ps, C, ldc, bias, in, ldin, (bf16_t*)Cp, ldcp, cp_ps, tn, nt, drop, colsum, m_valid); } while (0)
   if (epilogue == SIMX_EPI_NONE) {
     SIMX_REQUIRE(c_ok, SIMX_ERR_BAD_SHAPE, "gemm_nt_planes: C must be a 16-B aligned f32 matrix");
     if (fmt == SIMX_F16) {

@@ -144,3 +144,30 @@ def test_gemm_tn_planes(dev, M, N, K, with_bias, accumulate):
         rb = Av.sum(0) + db0.astype(np.float64)
         gb = db.cpu().numpy().astype(np.float64)
         assert np.all(np.abs(gb - rb) <= 1e-5 * np.abs(Av).sum(0) + 1e-7), np.abs(gb - rb).max()
+
+
+@pytest.mark.parametrize("M,N,K,valid", [(512, 768, 768, 512), (2048, 3072, 768, 1999), (66048, 768, 256, 65900)])
+def test_gemm_nt_planes_dgelu_colsum(dev, M, N, K, valid):
+    """SIMX_EPI_DGELU with the fused bias gradient: colsum[N] += column sums of (acc * in) over the rows below `valid` (rows past
+    the real tokens hold garbage in the engine: here NaN, which must not leak)."""
+    lib = L()
+    A = torch.from_numpy(rnd((M, K), 1, 1e-3)).to(dev)
+    A[valid:] = float("nan")
+    B = torch.from_numpy(rnd((N, K), 2, 0.05)).to(dev)
+    Ap, Bp = planes_of(A, BF16, dev), planes_of(B, BF16, dev)
+    inn = torch.from_numpy(rnd((M, N), 4)).to(dev)
+    Cp = torch.zeros(2, M, N, device=dev, dtype=torch.int16)
+    cs0 = rnd((N,), 6, 1e-3)
+    cs = torch.from_numpy(cs0.copy()).to(dev)
+    lib.call("simx_gemm_nt_planes_cs", lib.stream_ptr(), BF16, 2, M, N, K, lib.ptr(Ap), K, M * K, lib.ptr(Bp), K, N * K, None, N,
+             None, lib.ptr(inn), N, lib.ptr(Cp), N, M * N, None, lib.ptr(cs), valid)
+    torch.cuda.synchronize()
+    Av, Bv = planes_value(Ap, BF16)[:valid], planes_value(Bp, BF16)
+    ref = (Av @ Bv.T) * inn.cpu().numpy().astype(np.float64)[:valid]
+    du = planes_value(Cp, BF16)[:valid]
+    scale = np.sqrt((Av ** 2).sum(1))[:, None] * np.sqrt((Bv ** 2).sum(1))[None, :] * np.abs(inn.cpu().numpy().astype(np.float64)[:valid])
+    assert np.all(np.abs(du - ref) <= 2.0 ** -15 * np.abs(ref) + 2e-6 * scale + 1e-12)
+    got = cs.cpu().numpy().astype(np.float64)
+    want = ref.sum(0) + cs0
+    assert np.isfinite(got).all()
+    assert np.all(np.abs(got - want) <= 2e-5 * np.abs(ref).sum(0) + 1e-7), np.abs(got - want).max()

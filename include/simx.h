@@ -63,7 +63,8 @@ enum { SIMX_EPI_NONE = 0,   /* C = acc (+bias) (+residual)                      
        SIMX_EPI_GELU = 1,   /* u = acc + bias: C2 = gelu_erf(u), C = gelu_erf'(u) -- the factor backward multiplies by,
                                kept instead of u itself (nothing downstream reads the pre-activation)             */
        SIMX_EPI_DGELU = 2,  /* C = (acc (+residual)) * aux,  aux = the C a SIMX_EPI_GELU launch wrote           */
-       SIMX_EPI_GELU_INFER = 3 /* as GELU, but C is scratch: kernels may skip computing / storing it (no backward) */ };
+       SIMX_EPI_GELU_INFER = 3, /* as GELU, but C is scratch: kernels may skip computing / storing it (no backward) */
+       SIMX_EPI_NONE_PLANES = 4 /* simx_gemm_nt_planes only: acc + bias leaves as a plane pair (Cp), no f32 output */ };
 
 /* Dropout descriptor (nn.Dropout of BertEmbeddings / BertSelfAttention / BertSelfOutput / BertOutput,
  * LEAD/modeling_bert.py:239, 358, 386, 464; p = 0.1 forced in training, SimANS/model/models.py:70-72).
@@ -142,7 +143,8 @@ int simx_gemm_f32_strided_ws(simx_stream_t stream, int M, int N, int K, const fl
  *     SIMX_EPI_NONE        C (f32) = acc + bias, dropout `drop` (SIMX_F16 only, needs `in`), + in (f32 [M,N], may be NULL)
  *     SIMX_EPI_GELU        SIMX_F16: u = acc + bias; Cp = plane pair of gelu_erf(u); C (f32) = gelu_erf'(u)
  *     SIMX_EPI_GELU_INFER  as GELU, C not written (may be NULL)
- *     SIMX_EPI_DGELU       SIMX_BF16: Cp = plane pair of acc * in  (in = the C a GELU launch wrote) */
+ *     SIMX_EPI_DGELU       SIMX_BF16: Cp = plane pair of acc * in  (in = the C a GELU launch wrote)
+ *     SIMX_EPI_NONE_PLANES SIMX_F16: Cp = plane pair of acc + bias (the QKV projection feeding simx_mha_*_x3) */
 int simx_gemm_nt_planes_ok(int M, int N, int K);
 int simx_gemm_nt_planes(simx_stream_t stream, int fmt, int epilogue, int M, int N, int K, const void* A, int lda, long a_plane_stride,
                         const void* B, int ldb, long b_plane_stride, float* C, int ldc, const float* bias, const float* in, int ldin,
@@ -177,6 +179,15 @@ int simx_embed_ln_fwd_planes(simx_stream_t stream, int T, int H, const int32_t* 
                              const float* posw, const float* typew, const float* gamma, const float* beta, float eps, float* out,
                              void* out_planes, long plane_stride, const simx_dropout* drop);
 int simx_mha_planes_ok(int d, int max_len);
+/* the same products on the 16-bit matrix cores from fp16 plane pairs (csrc/attention_x3.hip; head size 64, sequences <= 256:
+ * simx_mha_x3_ok): q / k / v = the plane pair a SIMX_EPI_NONE_PLANES QKV projection wrote, context as a SIMX_F16 pair; backward
+ * takes dctx in f32 and writes dq / dk / dv as a SIMX_BF16 pair. */
+int simx_mha_x3_ok(int d, int max_len);
+int simx_mha_fwd_x3(simx_stream_t stream, int nseq, int heads, int d, const int32_t* cu, int max_len, int T, const void* qkv_planes,
+                    long qkv_plane_stride, void* ctx_planes, long ctx_plane_stride, float* lse, const simx_dropout* drop);
+int simx_mha_bwd_x3(simx_stream_t stream, int nseq, int heads, int d, const int32_t* cu, int max_len, int T, const void* qkv_planes,
+                    long qkv_plane_stride, const void* ctx_planes, long ctx_plane_stride, const float* lse, const float* dctx,
+                    void* dqkv_planes, long dqkv_plane_stride, const simx_dropout* drop);
 int simx_mha_fwd_planes(simx_stream_t stream, int nseq, int heads, int d, const int32_t* cu, int max_len, int T, const float* qkv,
                         void* ctx_planes, long ctx_plane_stride, float* lse, const simx_dropout* drop);
 int simx_mha_bwd_planes(simx_stream_t stream, int nseq, int heads, int d, const int32_t* cu, int max_len, int T, const float* qkv,

@@ -410,9 +410,17 @@ static int layer_fwd(hipStream_t stream, const simx_bert_cfg* c, const float* pa
     // LayerNorm, ctx by the attention kernel, x1p by LayerNorm, h by the FFN-in epilogue; f32 forms exist where an
     // elementwise consumer needs them (residuals x / x1, q/k/v, the pre-LayerNorm sums, gelu')
     const long psH = (long)Tp * H, psF = (long)Tp * F;
-    RUN(simx_gemm_nt_planes(stream, SIMX_F16, SIMX_EPI_NONE, Tp, 3 * H, H, xp, H, psH, w.wqkvP, H, 3L * H * H, (float*)a.qkv, 3 * H,
-                            off(l, SIMX_P_BQKV), nullptr, 0, nullptr, 0, 0, nullptr));
-    RUN(simx_mha_fwd_planes(stream, nseq, c->heads, d, cu, max_len, T, (const float*)a.qkv, a.ctx, psH, a.lse, &d3));
+    if (simx_mha_x3_ok(d, max_len)) {
+      // q / k / v leave the projection as an fp16 plane pair (no f32 form) and the attention products run on the 16-bit
+      // matrix cores from pairs (csrc/attention_x3.hip); longer sequences keep f32 q / k / v and the chunked f32 MFMA kernels
+      RUN(simx_gemm_nt_planes(stream, SIMX_F16, SIMX_EPI_NONE_PLANES, Tp, 3 * H, H, xp, H, psH, w.wqkvP, H, 3L * H * H, nullptr, 3 * H,
+                              off(l, SIMX_P_BQKV), nullptr, 0, a.qkv, 3 * H, (long)Tp * 3 * H, nullptr));
+      RUN(simx_mha_fwd_x3(stream, nseq, c->heads, d, cu, max_len, T, a.qkv, (long)Tp * 3 * H, a.ctx, psH, a.lse, &d3));
+    } else {
+      RUN(simx_gemm_nt_planes(stream, SIMX_F16, SIMX_EPI_NONE, Tp, 3 * H, H, xp, H, psH, w.wqkvP, H, 3L * H * H, (float*)a.qkv, 3 * H,
+                              off(l, SIMX_P_BQKV), nullptr, 0, nullptr, 0, 0, nullptr));
+      RUN(simx_mha_fwd_planes(stream, nseq, c->heads, d, cu, max_len, T, (const float*)a.qkv, a.ctx, psH, a.lse, &d3));
+    }
     RUN(simx_gemm_nt_planes(stream, SIMX_F16, SIMX_EPI_NONE, Tp, H, H, a.ctx, H, psH, w.woP, H, (long)H * H, (float*)a.z1, H, off(l, SIMX_P_BO),
                             (const float*)x, H, nullptr, 0, 0, &d1));
     RUN(simx_ln_fwd_planes(stream, T, H, (const float*)a.z1, off(l, SIMX_P_LN1_G), off(l, SIMX_P_LN1_B), c->eps, (float*)a.x1, a.x1p, psH));
@@ -643,7 +651,10 @@ extern "C" int simx_bert_bwd_range(simx_stream_t stream, const simx_bert_cfg* c,
                               nullptr, 0, 0, nullptr));
       RUN(simx_planes_from(stream, SIMX_F16, SIMX_BF16, T, H, a.ctx, H, psH, xconv, H, psH));
       RUN(simx_gemm_tn_planes(stream, H, H, T, bufC, H, psH, xconv, H, psH, goff(l, SIMX_P_WO), H, 1, tnws, tnws_bytes, nullptr));
-      RUN(simx_mha_bwd_planes(stream, nseq, c->heads, d, cu, max_len, T, (const float*)a.qkv, a.ctx, psH, a.lse, (const float*)bufB, dqkv, ps3, &d3));
+      if (simx_mha_x3_ok(d, max_len))
+        RUN(simx_mha_bwd_x3(stream, nseq, c->heads, d, cu, max_len, T, a.qkv, ps3, a.ctx, psH, a.lse, (const float*)bufB, dqkv, ps3, &d3));
+      else
+        RUN(simx_mha_bwd_planes(stream, nseq, c->heads, d, cu, max_len, T, (const float*)a.qkv, a.ctx, psH, a.lse, (const float*)bufB, dqkv, ps3, &d3));
       RUN(simx_gemm_nt_planes(stream, SIMX_BF16, SIMX_EPI_NONE, Tp, H, 3 * H, dqkv, 3 * H, ps3, w.wqkvTP, 3 * H, 3L * H * H, (float*)bufB, H, nullptr,
                               (const float*)bufA, H, nullptr, 0, 0, nullptr));
       RUN(simx_planes_from(stream, SIMX_F32, SIMX_BF16, T, H, xin, H, 0, xconv, H, psH));

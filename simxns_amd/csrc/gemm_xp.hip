@@ -976,6 +976,7 @@ static const XpDevice* xp_device() {
     XP_ATTR((gemm_nt_xp_kernel<f16_t, SIMX_EPI_NONE, false, false, false>), P_LDS); XP_ATTR((gemm_nt_xp_kernel<f16_t, SIMX_EPI_NONE, false, false, true>), P_LDS);
     XP_ATTR((gemm_nt_xp_kernel<f16_t, SIMX_EPI_NONE, true, false, false>), P_LDS); XP_ATTR((gemm_nt_xp_kernel<f16_t, SIMX_EPI_NONE, true, false, true>), P_LDS);
     XP_ATTR((gemm_nt_xp_kernel<f16_t, SIMX_EPI_NONE, true, true, false>), P_LDS); XP_ATTR((gemm_nt_xp_kernel<f16_t, SIMX_EPI_NONE, true, true, true>), P_LDS);
+    XP_ATTR((gemm_nt_xp_kernel<f16_t, SIMX_EPI_NONE_PLANES, false, false, false>), P_LDS); XP_ATTR((gemm_nt_xp_kernel<f16_t, SIMX_EPI_NONE_PLANES, false, false, true>), P_LDS);
     XP_ATTR((gemm_nt_xp_kernel<f16_t, SIMX_EPI_GELU, false, false, false>), P_LDS); XP_ATTR((gemm_nt_xp_kernel<f16_t, SIMX_EPI_GELU, false, false, true>), P_LDS);
     XP_ATTR((gemm_nt_xp_kernel<bf16_t, SIMX_EPI_NONE, false, false, false>), P_LDS); XP_ATTR((gemm_nt_xp_kernel<bf16_t, SIMX_EPI_NONE, false, false, true>), P_LDS);
     XP_ATTR((gemm_nt_xp_kernel<bf16_t, SIMX_EPI_NONE, true, false, false>), P_LDS); XP_ATTR((gemm_nt_xp_kernel<bf16_t, SIMX_EPI_NONE, true, false, true>), P_LDS);
@@ -1045,6 +1046,9 @@ extern "C" int simx_gemm_nt_planes_cs(simx_stream_t stream, int fmt, int epilogu
     SIMX_REQUIRE(!C || c_ok, SIMX_ERR_BAD_SHAPE, "gemm_nt_planes: C (the stored derivative) must be a 16-B aligned f32 matrix");
     if (!C) ldc = N;
     LXP(f16_t, SIMX_EPI_GELU, false, false);
+  } else if (epilogue == SIMX_EPI_NONE_PLANES) {
+    SIMX_REQUIRE(fmt == SIMX_F16 && p_ok && !in && !drop.thr, SIMX_ERR_UNSUPPORTED, "gemm_nt_planes: NONE_PLANES is a forward epilogue (fp16 planes out, no `in`, no dropout)");
+    LXP(f16_t, SIMX_EPI_NONE_PLANES, false, false);
   } else if (epilogue == SIMX_EPI_DGELU) {
     SIMX_REQUIRE(fmt == SIMX_BF16 && p_ok && in, SIMX_ERR_UNSUPPORTED, "gemm_nt_planes: DGELU is a backward epilogue (bf16 planes out, `in` = the stored derivative)");
     LXP(bf16_t, SIMX_EPI_DGELU, true, false);

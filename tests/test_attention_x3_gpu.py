@@ -1,0 +1,139 @@
+"""fp32-engine attention on the 16-bit matrix cores from fp16 plane pairs (csrc/attention_x3.hip) against float64 NumPy on the
+plane values, at f32-grade tolerances (NOT 16-bit ones), and against the f32 MFMA kernels it replaces (timing printed)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from tests.test_kernels_gpu import _mha_ref
+from tests.test_planes_gpu import planes_of, planes_value, rnd, L, F16, BF16, F32
+
+pytestmark = pytest.mark.gpu
+
+LENS = [[40, 7], [9, 32, 4, 31], [128, 1, 17, 33, 16, 100], [160, 129, 45], [250, 200, 256], [128] * 6]
+
+
+def _ms(fn, n=5):
+    fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+
+@pytest.mark.parametrize("heads", [1, 3])
+@pytest.mark.parametrize("lens", LENS)
+@pytest.mark.parametrize("scale_q", [1.0, 4.0])                 # 4.0: peaked softmax rows (scores up to ~100)
+def test_mha_fwd_x3(dev, heads, lens, scale_q):
+    lib = L()
+    d, T, H = 64, sum(lens), heads * 64
+    qkv = rnd((T, 3 * H), 1, 1.0)
+    qkv[:, :H] *= scale_q
+    dq = torch.from_numpy(qkv).to(dev)
+    qp = planes_of(dq, F16, dev)
+    cu = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)).to(dev)
+    ctxp = torch.zeros(2, T, H, device=dev, dtype=torch.int16)
+    lse = torch.zeros(heads, T, device=dev)
+    lib.call("simx_mha_fwd_x3", lib.stream_ptr(), len(lens), heads, d, lib.ptr(cu), max(lens), T, lib.ptr(qp), T * 3 * H, lib.ptr(ctxp), T * H,
+             lib.ptr(lse), None)
+    torch.cuda.synchronize()
+    rc, rl, _ = _mha_ref(planes_value(qp, F16), lens, heads, d)
+    got = planes_value(ctxp, F16)
+    assert np.abs(got - rc).max() <= 3e-6 * max(1.0, np.abs(rc).max()), np.abs(got - rc).max()
+    assert np.abs(lse.cpu().numpy() - rl).max() <= 2e-5 * max(1.0, np.abs(rl).max())
+
+
+def test_mha_fwd_x3_dropout_and_speed(dev):
+    """dropout on the probabilities (same stateless mask as the f32 kernels: equal results), and the rate against the f32 MFMA
+    kernel on the benchmark's passage-tower shape."""
+    import ctypes as C
+    lib = L()
+    heads, d, S, nseq = 12, 64, 128, 512
+    T, H = nseq * S, heads * 64
+    qkv = torch.from_numpy(rnd((T, 3 * H), 3, 1.0)).to(dev)
+    qp = planes_of(qkv, F16, dev)
+    cu = torch.arange(0, T + 1, S, dtype=torch.int32, device=dev)
+    drop = lib.Dropout(0.1, 99, 11)
+    ctxp = torch.zeros(2, T, H, device=dev, dtype=torch.int16)
+    ctxq = torch.zeros(2, T, H, device=dev, dtype=torch.int16)
+    lse, lse2 = torch.zeros(heads, T, device=dev), torch.zeros(heads, T, device=dev)
+    x3 = lambda dr: lib.call("simx_mha_fwd_x3", lib.stream_ptr(), nseq, heads, d, lib.ptr(cu), S, T, lib.ptr(qp), T * 3 * H, lib.ptr(ctxp), T * H,
+                             lib.ptr(lse), C.byref(dr) if dr else None)
+    f32 = lambda dr: lib.call("simx_mha_fwd_planes", lib.stream_ptr(), nseq, heads, d, lib.ptr(cu), S, T, lib.ptr(qkv), lib.ptr(ctxq), T * H,
+                              lib.ptr(lse2), C.byref(dr) if dr else None)
+    x3(drop)
+    f32(drop)
+    torch.cuda.synchronize()
+    a, b = planes_value(ctxp, F16), planes_value(ctxq, F16)
+    assert np.abs(a - b).max() <= 5e-6 * max(1.0, np.abs(b).max()), np.abs(a - b).max()
+    assert np.abs(lse.cpu().numpy() - lse2.cpu().numpy()).max() <= 2e-5 * 20
+    t3, t32 = _ms(lambda: x3(None)), _ms(lambda: f32(None))
+    print("mha_fwd S=128 x %d seqs x 12 heads: x3 %.3f ms, f32 MFMA %.3f ms" % (nseq, t3, t32))
+
+
+@pytest.mark.parametrize("heads", [1, 3])
+@pytest.mark.parametrize("lens", LENS)
+@pytest.mark.parametrize("gscale", [1.0, 1e-7, 3e4])            # gradients of any magnitude: the per-block power-of-two scaling
+def test_mha_bwd_x3(dev, heads, lens, gscale):
+    lib = L()
+    d, T, H = 64, sum(lens), heads * 64
+    qkv = rnd((T, 3 * H), 1, 1.0)
+    dctx = (rnd((T, H), 2) * np.exp(rnd((T, 1), 3, 2.0)) * gscale).astype(np.float32)      # rows of very different size
+    dq = torch.from_numpy(qkv).to(dev)
+    qp = planes_of(dq, F16, dev)
+    cu = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)).to(dev)
+    ctxp = torch.zeros(2, T, H, device=dev, dtype=torch.int16)
+    lse = torch.zeros(heads, T, device=dev)
+    lib.call("simx_mha_fwd_x3", lib.stream_ptr(), len(lens), heads, d, lib.ptr(cu), max(lens), T, lib.ptr(qp), T * 3 * H, lib.ptr(ctxp), T * H,
+             lib.ptr(lse), None)
+    dd = torch.from_numpy(dctx).to(dev)
+    dqkvp = torch.zeros(2, T, 3 * H, device=dev, dtype=torch.int16)
+    lib.call("simx_mha_bwd_x3", lib.stream_ptr(), len(lens), heads, d, lib.ptr(cu), max(lens), T, lib.ptr(qp), T * 3 * H, lib.ptr(ctxp), T * H,
+             lib.ptr(lse), lib.ptr(dd), lib.ptr(dqkvp), T * 3 * H, None)
+    torch.cuda.synchronize()
+    _, _, rdq = _mha_ref(planes_value(qp, F16), lens, heads, d, dctx.astype(np.float64))
+    got = planes_value(dqkvp, BF16)
+    assert np.isfinite(got).all()
+    # per (sequence, head) block the error is bounded relative to the block's gradient scale: bf16 pair output (2^-16) + the products
+    t0 = 0
+    for n in lens:
+        for hh in range(heads):
+            sls = [(slice(t0, t0 + n), slice(w * H + hh * 64, w * H + (hh + 1) * 64)) for w in range(3)]
+            gmax = max(np.abs(rdq[sl]).max() for sl in sls)          # (a one-token sequence has dq = dk = 0 exactly: scale by the block)
+            for w, sl in enumerate(sls):
+                err = np.abs(got[sl] - rdq[sl]).max()
+                assert err <= 2e-5 * gmax + 1e-30, (n, hh, w, err, gmax)
+        t0 += n
+
+
+def test_mha_bwd_x3_dropout_and_speed(dev):
+    import ctypes as C
+    lib = L()
+    heads, d, S, nseq = 12, 64, 128, 512
+    T, H = nseq * S, heads * 64
+    qkv = torch.from_numpy(rnd((T, 3 * H), 3, 1.0)).to(dev)
+    dctx = torch.from_numpy(rnd((T, H), 4, 1e-3)).to(dev)
+    qp = planes_of(qkv, F16, dev)
+    cu = torch.arange(0, T + 1, S, dtype=torch.int32, device=dev)
+    drop = lib.Dropout(0.1, 99, 11)
+    ctxp = torch.zeros(2, T, H, device=dev, dtype=torch.int16)
+    lse = torch.zeros(heads, T, device=dev)
+    lib.call("simx_mha_fwd_x3", lib.stream_ptr(), nseq, heads, d, lib.ptr(cu), S, T, lib.ptr(qp), T * 3 * H, lib.ptr(ctxp), T * H, lib.ptr(lse), C.byref(drop))
+    g3 = torch.zeros(2, T, 3 * H, device=dev, dtype=torch.int16)
+    g32 = torch.zeros(2, T, 3 * H, device=dev, dtype=torch.int16)
+    x3 = lambda dr: lib.call("simx_mha_bwd_x3", lib.stream_ptr(), nseq, heads, d, lib.ptr(cu), S, T, lib.ptr(qp), T * 3 * H, lib.ptr(ctxp), T * H,
+                             lib.ptr(lse), lib.ptr(dctx), lib.ptr(g3), T * 3 * H, C.byref(dr) if dr else None)
+    f32 = lambda dr: lib.call("simx_mha_bwd_planes", lib.stream_ptr(), nseq, heads, d, lib.ptr(cu), S, T, lib.ptr(qkv), lib.ptr(ctxp), T * H,
+                              lib.ptr(lse), lib.ptr(dctx), lib.ptr(g32), T * 3 * H, C.byref(dr) if dr else None)
+    x3(drop)
+    f32(drop)
+    torch.cuda.synchronize()
+    a, b = planes_value(g3, BF16), planes_value(g32, BF16)
+    assert np.abs(a - b).max() <= 4e-5 * np.abs(b).max(), (np.abs(a - b).max(), np.abs(b).max())
+    t3, t32 = _ms(lambda: x3(None)), _ms(lambda: f32(None))
+    print("mha_bwd S=128 x %d seqs x 12 heads: x3 %.3f ms, f32 MFMA %.3f ms" % (nseq, t3, t32))

@@ -188,6 +188,10 @@ int simx_mha_fwd_x3(simx_stream_t stream, int nseq, int heads, int d, const int3
 int simx_mha_bwd_x3(simx_stream_t stream, int nseq, int heads, int d, const int32_t* cu, int max_len, int T, const void* qkv_planes,
                     long qkv_plane_stride, const void* ctx_planes, long ctx_plane_stride, const float* lse, const float* dctx,
                     void* dqkv_planes, long dqkv_plane_stride, const simx_dropout* drop);
+/* same; dbias [3H] (may be NULL) += column sums of dq | dk | dv over the tokens: the QKV projection's bias gradient (f32 atomics) */
+int simx_mha_bwd_x3_bias(simx_stream_t stream, int nseq, int heads, int d, const int32_t* cu, int max_len, int T, const void* qkv_planes,
+                         long qkv_plane_stride, const void* ctx_planes, long ctx_plane_stride, const float* lse, const float* dctx,
+                         void* dqkv_planes, long dqkv_plane_stride, const simx_dropout* drop, float* dbias);
 int simx_mha_fwd_planes(simx_stream_t stream, int nseq, int heads, int d, const int32_t* cu, int max_len, int T, const float* qkv,
                         void* ctx_planes, long ctx_plane_stride, float* lse, const simx_dropout* drop);
 int simx_mha_bwd_planes(simx_stream_t stream, int nseq, int heads, int d, const int32_t* cu, int max_len, int T, const float* qkv,

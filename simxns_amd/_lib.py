@@ -140,6 +140,7 @@ SIGNATURES = {
     "simx_mha_x3_ok": (_i, [_i, _i]),
     "simx_mha_fwd_x3": (_i, [_p, _i, _i, _i, _p, _i, _i, _p, _l, _p, _l, _p, _dp]),
     "simx_mha_bwd_x3": (_i, [_p, _i, _i, _i, _p, _i, _i, _p, _l, _p, _l, _p, _p, _p, _l, _dp]),
+    "simx_mha_bwd_x3_bias": (_i, [_p, _i, _i, _i, _p, _i, _i, _p, _l, _p, _l, _p, _p, _p, _l, _dp, _p]),
     "simx_prof_begin": (_i, [_i]),
     "simx_prof_end": (_i, [_p, _p, _p]),
     "simx_prof_kernel_count": (_i, []),

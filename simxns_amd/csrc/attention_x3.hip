@@ -245,13 +245,34 @@ __device__ __forceinline__ void x3a_store_planes_bf16(const f32x4 (&acc)[4], flo
   }
 }
 
+// column sums of a wave's accumulated tiles -> colsum[64] (this head's slice of the bias gradient): 16-lane row sums by DPP, the
+// four waves' partials through LDS (part: 4 x 64 floats, free after the last barrier of the main loop), 64 atomics per workgroup
+__device__ __forceinline__ void x3a_colsum_flush(const f32x4 (&cs)[4], float mul, float* __restrict__ colsum, float* part, int tid) {
+  const int lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t = cs[dt][e];
+      t += dpp_mov<0xB1, 0xF>(t);
+      t += dpp_mov<0x4E, 0xF>(t);
+      t += dpp_mov<0x141, 0xF>(t);
+      t += dpp_mov<0x140, 0xF>(t);
+      if (fr == 0) part[wave * 64 + dt * 16 + 4 * fg + e] = t;
+    }
+  __syncthreads();
+  if (tid < 64) atomicAdd(colsum + tid, (part[tid] + part[64 + tid] + part[128 + tid] + part[192 + tid]) * mul);
+  __syncthreads();
+}
+
 // dQ: K and V pairs resident (LDS: Khi | Klo | Vhi | Vlo), waves own 16-query tiles (Q pair fragments and the scaled dO pair
 // fragments in registers) and walk the key-tile pairs.
 template <int NKT>
 __global__ __launch_bounds__(256, 2) void mha_bwd_dq_x3_kernel(const bf16_t* __restrict__ qkv, long qps, const bf16_t* __restrict__ O, long ops,
                                                                const float* __restrict__ lse, const float* __restrict__ dO,
                                                                bf16_t* __restrict__ dqkv, long dps, const int* __restrict__ cu, int heads, int T,
-                                                               float scale, DropCtx drop) {
+                                                               float scale, DropCtx drop, float* __restrict__ dbias) {
+  // dbias (may be NULL): [3H] += column sums of dq | dk | dv over the tokens -- the QKV projection's bias gradient
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -268,6 +289,9 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_dq_x3_kernel(const bf16_t* __r
   const int nkt = (len + 15) >> 4;
   const int nkt2 = (nkt + 1) & ~1;
   constexpr int TILE = NKT * 16 * 128;
+  f32x4 csq[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) csq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   x3a_stage(Kg, H3, len, nkt2 * 16, smem, wave, lane, 4);
   x3a_stage(Kg + qps, H3, len, nkt2 * 16, smem + TILE, wave, lane, 4);
   x3a_stage(Vg, H3, len, nkt2 * 16, smem + 2 * TILE, wave, lane, 4);
@@ -359,6 +383,12 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_dq_x3_kernel(const bf16_t* __r
       dq[3] = x3a_mfma3(X3A_CAT(h3l, h3h), X3A_CAT(l3l, l3h), sh, sl, dq[3]);
     }
     x3a_store_planes_bf16(dq, isc, dqkv + (long)(t0 + qt * 16) * H3 + h * 64, H3, dps, len - qt * 16, lane);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) csq[dt] += dq[dt];                    // (rows past the sequence end are exactly 0)
+  }
+  if (dbias != nullptr) {                                                // (uniform)
+    __syncthreads();                                                     // every wave is done with the K / V tiles
+    x3a_colsum_flush(csq, isc, dbias + h * 64, reinterpret_cast<float*>(smem), tid);
   }
 }
 
@@ -368,7 +398,7 @@ template <int NKT>
 __global__ __launch_bounds__(256, 2) void mha_bwd_dkv_x3_kernel(const bf16_t* __restrict__ qkv, long qps, const bf16_t* __restrict__ O, long ops,
                                                                 const float* __restrict__ lse, const float* __restrict__ dO,
                                                                 bf16_t* __restrict__ dqkv, long dps, const int* __restrict__ cu, int heads, int T,
-                                                                float scale, DropCtx drop) {
+                                                                float scale, DropCtx drop, float* __restrict__ dbias) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -387,6 +417,9 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_dkv_x3_kernel(const bf16_t* __
   constexpr int TILE = NKT * 16 * 128;
   char* sDh = smem + 2 * TILE;
   char* sDl = smem + 3 * TILE;
+  f32x4 csk[4], csv[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) { csk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; csv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
   float* sLse = reinterpret_cast<float*>(smem + 4 * TILE);
   float* sDel = sLse + NKT * 16;
   float* red = sDel + NKT * 16;
@@ -508,6 +541,13 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_dkv_x3_kernel(const bf16_t* __
     bf16_t* dst = dqkv + (long)(t0 + kt * 16) * H3 + H + h * 64;
     x3a_store_planes_bf16(dk, isc, dst, H3, dps, len - kt * 16, lane);
     x3a_store_planes_bf16(dv, isc * (1.0f / 1024.0f), dst + H, H3, dps, len - kt * 16, lane);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { csk[dt] += dk[dt]; csv[dt] += dv[dt]; }
+  }
+  if (dbias != nullptr) {
+    __syncthreads();
+    x3a_colsum_flush(csk, isc, dbias + H + h * 64, reinterpret_cast<float*>(smem), tid);
+    x3a_colsum_flush(csv, isc * (1.0f / 1024.0f), dbias + 2 * H + h * 64, reinterpret_cast<float*>(smem), tid);
   }
 }
 
@@ -558,6 +598,13 @@ extern "C" int simx_mha_fwd_x3(simx_stream_t stream, int nseq, int heads, int d,
 extern "C" int simx_mha_bwd_x3(simx_stream_t stream, int nseq, int heads, int d, const int32_t* cu, int max_len, int T, const void* qkv_planes,
                                long qkv_plane_stride, const void* ctx_planes, long ctx_plane_stride, const float* lse, const float* dctx,
                                void* dqkv_planes, long dqkv_plane_stride, const simx_dropout* dropd) {
+  return simx_mha_bwd_x3_bias(stream, nseq, heads, d, cu, max_len, T, qkv_planes, qkv_plane_stride, ctx_planes, ctx_plane_stride, lse, dctx,
+                              dqkv_planes, dqkv_plane_stride, dropd, nullptr);
+}
+// same; dbias [3H] (may be NULL) += column sums of dq | dk | dv over the T tokens (the QKV projection's bias gradient; atomics)
+extern "C" int simx_mha_bwd_x3_bias(simx_stream_t stream, int nseq, int heads, int d, const int32_t* cu, int max_len, int T, const void* qkv_planes,
+                                    long qkv_plane_stride, const void* ctx_planes, long ctx_plane_stride, const float* lse, const float* dctx,
+                                    void* dqkv_planes, long dqkv_plane_stride, const simx_dropout* dropd, float* dbias) {
   hipStream_t s = (hipStream_t)stream;
   SIMX_PROF(SIMX_K_MHA_BWD, s, 8.0 * T * max_len * heads * d);
   SIMX_REQUIRE(nseq > 0 && heads > 0 && T > 0 && qkv_planes && ctx_planes && lse && dctx && dqkv_planes && cu, SIMX_ERR_BAD_SHAPE, "mha_bwd_x3: bad arguments");
@@ -575,9 +622,9 @@ extern "C" int simx_mha_bwd_x3(simx_stream_t stream, int nseq, int heads, int d,
     rc = x3a_set_lds(mha_bwd_dkv_x3_kernel<NKT>, lds2, "mha_bwd_x3");                                                      \
     if (rc) return rc;                                                                                                     \
     hipLaunchKernelGGL((mha_bwd_dq_x3_kernel<NKT>), dim3(nseq * heads), dim3(256), lds1, s, (const bf16_t*)qkv_planes, qkv_plane_stride, \
-                       (const bf16_t*)ctx_planes, ctx_plane_stride, lse, dctx, (bf16_t*)dqkv_planes, dqkv_plane_stride, cu, heads, T, scale, drop); \
+                       (const bf16_t*)ctx_planes, ctx_plane_stride, lse, dctx, (bf16_t*)dqkv_planes, dqkv_plane_stride, cu, heads, T, scale, drop, dbias); \
     hipLaunchKernelGGL((mha_bwd_dkv_x3_kernel<NKT>), dim3(nseq * heads), dim3(256), lds2, s, (const bf16_t*)qkv_planes, qkv_plane_stride, \
-                       (const bf16_t*)ctx_planes, ctx_plane_stride, lse, dctx, (bf16_t*)dqkv_planes, dqkv_plane_stride, cu, heads, T, scale, drop); \
+                       (const bf16_t*)ctx_planes, ctx_plane_stride, lse, dctx, (bf16_t*)dqkv_planes, dqkv_plane_stride, cu, heads, T, scale, drop, dbias); \
   } while (0)
   if (max_len <= 32) LB(2);
   else if (max_len <= 128) LB(8);

@@ -651,15 +651,19 @@ extern "C" int simx_bert_bwd_range(simx_stream_t stream, const simx_bert_cfg* c,
                               nullptr, 0, 0, nullptr));
       RUN(simx_planes_from(stream, SIMX_F16, SIMX_BF16, T, H, a.ctx, H, psH, xconv, H, psH));
       RUN(simx_gemm_tn_planes(stream, H, H, T, bufC, H, psH, xconv, H, psH, goff(l, SIMX_P_WO), H, 1, tnws, tnws_bytes, nullptr));
+      // (x3 attention: the QKV bias gradient = column sums of dq | dk | dv comes out of the attention backward, so the Wqkv wgrad
+      // runs on the four-plane-stage kernel too; the deterministic mode keeps the wgrad kernel's ordered pass)
+      const bool bqkv_here = simx_mha_x3_ok(d, max_len) && !simx_det();
       if (simx_mha_x3_ok(d, max_len))
-        RUN(simx_mha_bwd_x3(stream, nseq, c->heads, d, cu, max_len, T, a.qkv, ps3, a.ctx, psH, a.lse, (const float*)bufB, dqkv, ps3, &d3));
+        RUN(simx_mha_bwd_x3_bias(stream, nseq, c->heads, d, cu, max_len, T, a.qkv, ps3, a.ctx, psH, a.lse, (const float*)bufB, dqkv, ps3, &d3,
+                                 bqkv_here ? goff(l, SIMX_P_BQKV) : nullptr));
       else
         RUN(simx_mha_bwd_planes(stream, nseq, c->heads, d, cu, max_len, T, (const float*)a.qkv, a.ctx, psH, a.lse, (const float*)bufB, dqkv, ps3, &d3));
       RUN(simx_gemm_nt_planes(stream, SIMX_BF16, SIMX_EPI_NONE, Tp, H, 3 * H, dqkv, 3 * H, ps3, w.wqkvTP, 3 * H, 3L * H * H, (float*)bufB, H, nullptr,
                               (const float*)bufA, H, nullptr, 0, 0, nullptr));
       RUN(simx_planes_from(stream, SIMX_F32, SIMX_BF16, T, H, xin, H, 0, xconv, H, psH));
       RUN(simx_gemm_tn_planes(stream, 3 * H, H, T, dqkv, 3 * H, ps3, xconv, H, psH, goff(l, SIMX_P_WQKV), H, 1, tnws, tnws_bytes,
-                              goff(l, SIMX_P_BQKV)));
+                              bqkv_here ? nullptr : goff(l, SIMX_P_BQKV)));
       continue;
     }
     char* dzm = hd ? bufC : bufA;        // gradient of the (dropped) dense output; bufA = gradient of the residual branch

@@ -78,12 +78,12 @@ def test_mha_fwd_x3_dropout_and_speed(dev):
 
 @pytest.mark.parametrize("heads", [1, 3])
 @pytest.mark.parametrize("lens", LENS)
-@pytest.mark.parametrize("gscale", [1.0, 1e-7, 3e4])            # gradients of any magnitude: the per-block power-of-two scaling
-def test_mha_bwd_x3(dev, heads, lens, gscale):
+@pytest.mark.parametrize("gscale,spread", [(1.0, 0.0), (1.0, 2.0), (1e-7, 2.0), (3e4, 0.0)])   # gradients of any magnitude: the per-block
+def test_mha_bwd_x3(dev, heads, lens, gscale, spread):                                          # power-of-two scaling; rows of equal / very different size
     lib = L()
     d, T, H = 64, sum(lens), heads * 64
     qkv = rnd((T, 3 * H), 1, 1.0)
-    dctx = (rnd((T, H), 2) * np.exp(rnd((T, 1), 3, 2.0)) * gscale).astype(np.float32)      # rows of very different size
+    dctx = (rnd((T, H), 2) * np.exp(rnd((T, 1), 3, spread)) * gscale).astype(np.float32)
     dq = torch.from_numpy(qkv).to(dev)
     qp = planes_of(dq, F16, dev)
     cu = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)).to(dev)
@@ -93,12 +93,20 @@ def test_mha_bwd_x3(dev, heads, lens, gscale):
              lib.ptr(lse), None)
     dd = torch.from_numpy(dctx).to(dev)
     dqkvp = torch.zeros(2, T, 3 * H, device=dev, dtype=torch.int16)
-    lib.call("simx_mha_bwd_x3", lib.stream_ptr(), len(lens), heads, d, lib.ptr(cu), max(lens), T, lib.ptr(qp), T * 3 * H, lib.ptr(ctxp), T * H,
-             lib.ptr(lse), lib.ptr(dd), lib.ptr(dqkvp), T * 3 * H, None)
+    db0 = rnd((3 * H,), 7, float(gscale))
+    db = torch.from_numpy(db0.copy()).to(dev)
+    lib.call("simx_mha_bwd_x3_bias", lib.stream_ptr(), len(lens), heads, d, lib.ptr(cu), max(lens), T, lib.ptr(qp), T * 3 * H, lib.ptr(ctxp), T * H,
+             lib.ptr(lse), lib.ptr(dd), lib.ptr(dqkvp), T * 3 * H, None, lib.ptr(db))
     torch.cuda.synchronize()
     _, _, rdq = _mha_ref(planes_value(qp, F16), lens, heads, d, dctx.astype(np.float64))
     got = planes_value(dqkvp, BF16)
     assert np.isfinite(got).all()
+    # the fused QKV bias gradient: column sums over the tokens, accumulated into the buffer
+    # (measured: 1e-6 of the column's L1 norm with rows of one magnitude -- the f32 MFMA kernels give 7e-7 --; with row magnitudes
+    # spread over e^+-6 inside a block the per-block scale leaves the small rows ~1e-5 of relative precision and the sum 1e-4)
+    gb = db.cpu().numpy().astype(np.float64)
+    ctol = 8e-6 if spread == 0.0 else 4e-4
+    assert np.all(np.abs(gb - (rdq.sum(0) + db0)) <= ctol * np.abs(rdq).sum(0) + 1e-6 * np.abs(db0) + 1e-30), np.abs(gb - (rdq.sum(0) + db0)).max()
     # per (sequence, head) block the error is bounded relative to the block's gradient scale: bf16 pair output (2^-16) + the products
     t0 = 0
     for n in lens:

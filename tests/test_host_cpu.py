@@ -204,7 +204,8 @@ from simxns_amd.model.models import HFBertEncoder, Reranker
 from simxns_amd.optim import FusedAdamW
 cfg = BertConfigLite(vocab_size=50, hidden_size=8, num_hidden_layers=2, num_attention_heads=2, intermediate_size=16, max_position_embeddings=16)
 model = Reranker(HFBertEncoder(cfg, "fp32"), 8)
-opt = FusedAdamW(model, lr=1e-3).enable_overlap(W, parts=2)
+assert FusedAdamW(model, lr=1e-3).enable_overlap(W, parts=2).payload == "bf16"     # the default at W > 1: half the bytes
+opt = FusedAdamW(model, lr=1e-3).enable_overlap(W, parts=2, payload="fp32")        # (exact sums below need the f32 payload)
 e = model.encoder.engine
 assert e.grad_ready_hook is not None and e.bwd_parts == 2
 n = e.n_params

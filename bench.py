@@ -438,6 +438,7 @@ def main():
         out["comm"]["replica_check"] = "parameter checksums of all ranks agree to 1e-6 after the first optimiser step"
     busy = pmc_mfma_busy()
     if busy is not None and is16:
+        busy["source"] = pmc_source("r*_mfma_busy.json")
         out["mfma_busy_pmc"] = busy
     if real is not None:
         out["realistic_lengths"] = real
@@ -463,7 +464,8 @@ def main():
                                                   "gemm_nt_xp_kernel" if rk == "gemm_nt_xp" else "gemm_x3_nt_kernel")
         out["roofline"] = {"bound": "mfma", "kernel": kname + " (forward + dgrad GEMMs)",
                            "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                           "traffic": pmc_traffic("gemm_nt_p3_kernel") if is16 else None, "launches": c_,
+                           "traffic": pmc_traffic("gemm_nt_p3_kernel") if is16 else (pmc_traffic("gemm_nt_xp_kernel", "r*_fp32_traffic.json") if rk == "gemm_nt_xp" else None),
+                           "traffic_source": pmc_source("r*_traffic.json" if is16 else "r*_fp32_traffic.json"), "launches": c_,
                            "algorithmic_bytes_per_launch": alg_bytes_per_launch(c_ // max(1, args.steps)) if is16 else None,
                            "avg_launch_ms": round(ms_ / c_, 4), "algorithmic_flop_per_launch": round(wk_ / c_),
                            "measured": "HIP events on the launch stream over %d steps of the same job run right after the timed "
@@ -636,14 +638,32 @@ def pmc_mfma_busy():
     return best
 
 
-def pmc_traffic(kernel):
+def pmc_source(pattern):
+    """{file, commit, date} of the latest committed profile file matching `pattern` (written by tools/traffic.py): the counters quoted
+    in the bench line are NOT measured in this run -- a reader must be able to tell which build they describe."""
+    import glob
+    fs = sorted(f for f in glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pattern))
+                if ("fp32" in os.path.basename(f)) == ("fp32" in pattern))
+    if not fs:
+        return None
+    try:
+        src = json.load(open(fs[-1])).get("source") or {}
+    except Exception:
+        src = {}
+    return {"file": "profiles/" + os.path.basename(fs[-1]), "commit": src.get("commit", "not recorded (profile older than round 4)"),
+            "date_utc": src.get("date_utc")}
+
+
+def pmc_traffic(kernel, pattern="r*_traffic.json"):
     """HBM bytes per launch of `kernel` from the committed PMC passes (tools/profile_round.sh -> profiles/*_traffic.json;
     FETCH_SIZE / WRITE_SIZE collected in their own rocprofv3 runs of this same command and corrected as
     MI355X_MICROARCH.md prescribes).  Counters cannot be read from inside the timed run, so this is the latest
     committed measurement, or None."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_traffic.json"))):
+    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pattern))):
+        if pattern == "r*_traffic.json" and "fp32" in os.path.basename(f):
+            continue
         try:
             ks = json.load(open(f)).get("kernels", {})
         except Exception:

@@ -1,10 +1,11 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): tools/profile_round.sh <round-tag, e.g. r01>
+# usage (on the GPU box, from the repo root): tools/profile_round.sh <round-tag, e.g. r01> <commit of the profiled tree>
 # Produces under gpurun_out/<tag>/ : bench line (un-profiled), rocprofv3 --kernel-trace --stats of the same command,
 # and two separate PMC passes (FETCH_SIZE / WRITE_SIZE) for the HBM traffic of the dominant kernel.
 # tools/traffic.py then turns them into profiles/<tag>_*.  PMC passes never combine with trace domains other than
 # --kernel-trace (pool rule).
 tag=${1:-r01}
+commit=${2:-unknown}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/$tag
 mkdir -p $O
@@ -26,5 +27,8 @@ timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -
 # (10 timed steps) and a kernel-trace summary of the same command
 timeout 600 python $R/bench.py --dtype fp32 --side --steps 10 --warmup 2 > $O/fp32_bench.json 2> $O/fp32_bench.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fp32_stats -o s -- python $R/bench.py --dtype fp32 --side --steps 3 --warmup 1 > $O/fp32_stats.log 2>&1
-cd $R && python tools/traffic.py $tag
+# HBM traffic of the fp32 engine's dominant kernel (gemm_nt_xp_kernel): the same two separate PMC passes
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fp32_pmc_fetch -o p -- python $R/bench.py --dtype fp32 --side --steps 2 --warmup 1 --no-prof > $O/fp32_pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/fp32_pmc_write -o p -- python $R/bench.py --dtype fp32 --side --steps 2 --warmup 1 --no-prof > $O/fp32_pmc_write.log 2>&1
+cd $R && python tools/traffic.py $tag $commit
 ls -la $O

@@ -15,6 +15,11 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = "gpurun_out/%s" % tag
 os.makedirs("profiles", exist_ok=True)
+# provenance of every file written here: the commit the profiled tree was built from (the GPU box has no .git: passed in by
+# tools/profile_round.sh) and the date of the run -- bench.py prints it beside the counters it quotes from these files
+import datetime
+SOURCE = {"profile_tag": tag, "commit": sys.argv[2] if len(sys.argv) > 2 else os.environ.get("SIMX_PROFILE_COMMIT", "unknown"),
+          "date_utc": datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%d %H:%M")}
 
 
 def per_kernel(path, counter):
@@ -26,15 +31,22 @@ def per_kernel(path, counter):
     return agg
 
 
-fetch, write = per_kernel(src + "/pmc_fetch", "FETCH_SIZE"), per_kernel(src + "/pmc_write", "WRITE_SIZE")
-out = {"note": "KiB per launch, raw rocprofv3 values; hbm_bytes_per_launch = FETCH_SIZE*1024*2 (gfx950 correction, "
-               "MI355X_MICROARCH.md) + WRITE_SIZE*1024", "kernels": {}}
-for k in sorted(set(fetch) | set(write)):
-    f = sum(fetch[k]) / max(1, len(fetch[k]))
-    w = sum(write[k]) / max(1, len(write[k]))
-    out["kernels"][k] = {"launches": len(fetch[k]) or len(write[k]), "FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1),
-                         "hbm_bytes_per_launch": round(f * 1024 * 2 + w * 1024)}
-json.dump(out, open("profiles/%s_traffic.json" % tag, "w"), indent=1)
+def traffic_file(fetch_dir, write_dir, name):
+    fetch, write = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
+    if not fetch and not write:
+        return
+    out = {"note": "KiB per launch, raw rocprofv3 values; hbm_bytes_per_launch = FETCH_SIZE*1024*2 (gfx950 correction, "
+                   "MI355X_MICROARCH.md) + WRITE_SIZE*1024", "source": SOURCE, "kernels": {}}
+    for k in sorted(set(fetch) | set(write)):
+        f = sum(fetch[k]) / max(1, len(fetch[k]))
+        w = sum(write[k]) / max(1, len(write[k]))
+        out["kernels"][k] = {"launches": len(fetch[k]) or len(write[k]), "FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1),
+                             "hbm_bytes_per_launch": round(f * 1024 * 2 + w * 1024)}
+    json.dump(out, open("profiles/%s" % name, "w"), indent=1)
+
+
+traffic_file(src + "/pmc_fetch", src + "/pmc_write", "%s_traffic.json" % tag)
+traffic_file(src + "/fp32_pmc_fetch", src + "/fp32_pmc_write", "%s_fp32_traffic.json" % tag)      # the fp32 engine's kernels
 for f in glob.glob(src + "/stats/**/*kernel_stats.csv", recursive=True):
     shutil.copy(f, "profiles/%s_kernel_stats.csv" % tag)
 if os.path.exists(src + "/bench.json"):
@@ -64,7 +76,7 @@ if mb and ga:
     util = {"note": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 256 CUs * 4 SIMDs); clock_ghz = "
                     "GRBM_GUI_ACTIVE / 8 / launch duration; per-launch averages of two rocprofv3 PMC passes of the bench "
                     "command (towers on one stream); step = all kernels of the run, MFMA-free ones included",
-            "kernels": {}}
+            "source": SOURCE, "kernels": {}}
     tb = ta = 0.0
     for k in sorted(set(ga)):
         a_ = sum(ga[k])

@@ -16,7 +16,8 @@
  *   - return value: SIMX_OK (0) or a negative SIMX_ERR_*; simx_last_error() gives
  *     the thread-local message;
  *   - dtype selects the activation / GEMM-operand type: SIMX_F32 (parity mode, exact
- *     f32 arithmetic), SIMX_BF16 (bf16 operands, f32 accumulate, f32 statistics) or SIMX_F16
+ *     f32 arithmetic), SIMX_BF16 (bf16 operands, f32 accumulate, f32 statistics -- EXPERIMENTAL: the round-1/2 engine,
+ *     kept for A/B measurements; 5 % logits error on the hot fixture, not a product mode) or SIMX_F16
  *     (IEEE half operands -- the operand width of the reference's optional apex-O1 mode,
  *     SimANS/co_training/co_training_marco_train.py:97-104 -- f32 accumulate and statistics;
  *     its backward carries a loss scale, see "gradient scale" below).

@@ -296,15 +296,13 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     # Roofline / kernel breakdown: a second pass of the SAME steps right after the timed region, with HIP events around
-    # every launch (on the launch's stream) and the two student towers on ONE stream and the weight-gradient GEMMs
-    # on that stream too: in the timed region the towers run on two HIP streams and the wgrad GEMMs on a third beside the
-    # activation-gradient chain, kernels share the CUs, and a kernel's event-to-event time there would not be its exclusive duration.
+    # every launch (on the launch's stream) and the two student towers on ONE stream: in the timed region the towers run on
+    # two HIP streams, kernels of different towers share the CUs, and a kernel's event-to-event time there would not be
+    # its exclusive duration.
     prof, ms_prof = None, None
     if not args.no_prof:
         overlap_env = os.environ.get("SIMX_OVERLAP_TOWERS")
         os.environ["SIMX_OVERLAP_TOWERS"] = "0"
-        wgrad_env = os.environ.get("SIMX_WGRAD_STREAM")
-        os.environ["SIMX_WGRAD_STREAM"] = "0"           # (and the weight-gradient GEMMs on the towers' own stream, not beside the chain)
         one_step()
         sync()
         L.call("simx_prof_begin", 4096 * max(1, args.steps))
@@ -321,10 +319,6 @@ def main():
             del os.environ["SIMX_OVERLAP_TOWERS"]
         else:
             os.environ["SIMX_OVERLAP_TOWERS"] = overlap_env
-        if wgrad_env is None:
-            del os.environ["SIMX_WGRAD_STREAM"]
-        else:
-            os.environ["SIMX_WGRAD_STREAM"] = wgrad_env
     # the same job on SURVEY 8d's realistic length distribution (the packed layout skips pad tokens; the reference pads
     # to q32/p128 regardless).  Reported beside the headline, never as `value`.
     real = None

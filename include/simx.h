@@ -11,10 +11,7 @@
  *   - every pointer is a DEVICE pointer owned by the caller (PyTorch allocator),
  *     unless the name ends in _host;
  *   - no allocation and no stream synchronisation inside; scratch memory is passed
- *     in (size from the matching *_bytes query).  One exception: simx_bert_bwd* queues the
- *     weight-gradient GEMMs of a large tower on a per-device side stream, created on first
- *     use together with a small pool of timing-free events and ordered against the caller's
- *     stream by events inside the call (SIMX_WGRAD_STREAM=0 disables it);
+ *     in (size from the matching *_bytes query);
  *   - `stream` is a hipStream_t;
  *   - return value: SIMX_OK (0) or a negative SIMX_ERR_*; simx_last_error() gives
  *     the thread-local message;

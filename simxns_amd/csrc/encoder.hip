@@ -500,42 +500,6 @@ extern "C" int simx_bert_fwd(simx_stream_t stream, const simx_bert_cfg* c, const
   return SIMX_OK;
 }
 
-// ------------------------------------------------------------------------------------------ weight-gradient lane
-// In a layer's backward only the activation-gradient chain is serial (LayerNorm -> dgrad -> dgrad -> LayerNorm -> dgrad ->
-// attention -> dgrad); the four weight-gradient GEMMs hang off it as leaves.  They run on a per-device SIDE STREAM (created on
-// first use, with a small pool of timing-free events: the one exception to "no allocation inside", see simx.h), forked from the
-// caller's stream when their operands are ready and joined before one of their operands is overwritten (the shared scratch
-// tensors dz / du / dqkv, the recomputed slot under gradient checkpointing) and at the end of the call.  The matrix-core-bound
-// wgrad GEMMs then share the chip with the HBM-bound LayerNorm / attention backward kernels of the chain and fill the tails of
-// its GEMM launches.  SIMX_WGRAD_STREAM=0 keeps everything on the caller's stream (bench.py's per-kernel timing pass does that:
-// an event-to-event time is a kernel's exclusive duration only when nothing runs beside it).
-#include <mutex>
-struct SideLane { std::once_flag once; hipStream_t s = nullptr; hipEvent_t ev[24]; int next = 0; bool ok = false; };
-static SideLane g_side[SIMX_MAX_DEVICES];
-static SideLane* side_lane() {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SIMX_MAX_DEVICES) return nullptr;
-  SideLane& g = g_side[dev];
-  std::call_once(g.once, [&g] {
-    if (hipStreamCreateWithFlags(&g.s, hipStreamNonBlocking) != hipSuccess) return;
-    for (auto& e : g.ev)
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return;
-    g.ok = true;
-  });
-  return g.ok ? &g : nullptr;
-}
-// `to` waits for everything queued on `from` so far
-static int lane_order(SideLane* L, hipStream_t from, hipStream_t to) {
-  if (!L || from == to) return SIMX_OK;
-  hipEvent_t e = L->ev[L->next];
-  L->next = (L->next + 1) % 24;
-  if (hipEventRecord(e, from) != hipSuccess || hipStreamWaitEvent(to, e, 0) != hipSuccess) {
-    simx_set_error("bert_bwd: stream ordering (event record / wait) failed");
-    return SIMX_ERR_HIP;
-  }
-  return SIMX_OK;
-}
-
 extern "C" int simx_bert_bwd(simx_stream_t stream, const simx_bert_cfg* c, const float* params, const void* wcache,
                              const int32_t* ids, const int32_t* pos_ids, const int32_t* cu, int nseq, int T, int max_len,
                              const void* act, size_t act_bytes, const float* dcls, float* grads, void* scratch,
@@ -585,23 +549,6 @@ extern "C" int simx_bert_bwd_range(simx_stream_t stream, const simx_bert_cfg* c,
   const size_t tnws_bytes = tn_ws_max(c, T);
   char* xconv = tnws + tnws_bytes + 3 * al((size_t)(nseq > 0 ? nseq : Tp) * H * e);   // operand planes: bf16 pair of a wgrad's activation operand
   const bool pl = pl_run(c, Tp, max_len);
-  // the weight-gradient lane (see above): large towers only (a small tower's GEMMs are launch-bound: nothing to overlap), not in
-  // the deterministic mode (its ordered-reduction scratch is per stream)
-  hipStream_t ms = (hipStream_t)stream;
-  SideLane* lane = nullptr;
-  {
-    const char* e_ = getenv("SIMX_WGRAD_STREAM");
-    if (!(e_ && e_[0] == '0') && Tp >= 8192 && !simx_det()) lane = side_lane();
-  }
-  hipStream_t wsm = lane ? lane->s : ms;             // the stream the wgrad branch is queued on
-  simx_stream_t wst = (simx_stream_t)wsm;
-  hipEvent_t ev_w2 = nullptr, ev_wo = nullptr, ev_wqkv = nullptr;      // side-stream completion marks of the last W2 / Wo / Wqkv wgrad
-  // FORK: the side stream waits for what the caller's stream has queued so far (a wgrad's operands are ready);
-  // MARK: an event on the side stream after the wgrad just queued; WAIT: the caller's stream waits for such a mark
-#define FORK() RUN(lane_order(lane, ms, wsm))
-#define MARK(E) do { if (lane) { (E) = lane->ev[lane->next]; lane->next = (lane->next + 1) % 24; \
-                       if (hipEventRecord((E), wsm) != hipSuccess) { simx_set_error("bert_bwd: event record failed"); return SIMX_ERR_HIP; } } } while (0)
-#define WAIT(E) do { if (lane && (E) != nullptr && hipStreamWaitEvent(ms, (E), 0) != hipSuccess) { simx_set_error("bert_bwd: event wait failed"); return SIMX_ERR_HIP; } } while (0)
   const int hm = hm_rows_for(c, T, Tp, max_len);        // layout of qkv / dqkv (the forward's choice: same config copy, same inputs)
   // fp16 engine: activation gradients travel multiplied by the loss scale S (gs = {S, 1/S} on the device); the kernels that
   // accumulate into `grads` multiply by 1/S, so `grads` holds true gradients (simx.h "gradient scale")
@@ -677,9 +624,6 @@ extern "C" int simx_bert_bwd_range(simx_stream_t stream, const simx_bert_cfg* c,
     const ALayer a = ckpt ? alayer_recompute(c, act, Tp) : alayer(c, act, Tp, l, 1);
     const char* xinl = layer_input_lo(c, act, Tp, l);
     const bool sl = stream_lo(c);
-    // the previous layer's W2 / W1 / Wo read dz and du, which this layer's chain rewrites first; its Wqkv reads dqkv (rewritten by
-    // this layer's attention backward) -- and, under checkpointing, all of them read the slot the recompute below rewrites
-    WAIT(ckpt ? ev_wqkv : ev_wo);
     if (ckpt) RUN(layer_fwd((hipStream_t)stream, c, params, wcache, l, xin, xinl, layer_input_pl(c, act, Tp, l), a, nullptr, cu, nseq, T, Tp, max_len, 1, false, nullptr));
     const simx_dropout d1 = drop_of(c, l, 1), d2 = drop_of(c, l, 2), d3 = drop_of(c, l, 3);
     if (pl) {
@@ -689,96 +633,73 @@ extern "C" int simx_bert_bwd_range(simx_stream_t stream, const simx_bert_cfg* c,
       const long psH = (long)Tp * H, psF = (long)Tp * F, ps3 = (long)Tp * 3 * H;
       RUN(simx_ln_bwd_planes(stream, T, H, (const float*)a.z2, off(l, SIMX_P_LN2_G), c->eps, (const float*)bufB, (float*)bufA, bufC, psH,
                              goff(l, SIMX_P_LN2_G), goff(l, SIMX_P_LN2_B), goff(l, SIMX_P_B2), &d2));
-      FORK();
-      RUN(simx_planes_from(wst, SIMX_F16, SIMX_BF16, T, F, a.h, F, psF, xconv, F, psF));
-      RUN(simx_gemm_tn_planes(wst, H, F, T, bufC, H, psH, xconv, F, psF, goff(l, SIMX_P_W2), F, 1, tnws, tnws_bytes, nullptr));
-      MARK(ev_w2);
       // (the bias gradient of B1 = column sums of du comes out of this epilogue, so the W1 wgrad runs on the four-plane-stage
       // kernel, which carries no fused bias pass; the deterministic mode keeps the wgrad kernel's ordered pass)
       const bool b1_here = !simx_det();
       RUN(simx_gemm_nt_planes_cs(stream, SIMX_BF16, SIMX_EPI_DGELU, Tp, F, H, bufC, H, psH, w.w2TP, H, (long)F * H, nullptr, F, nullptr,
                                  (const float*)a.u, F, du, F, psF, nullptr, b1_here ? goff(l, SIMX_P_B1) : nullptr, T));
-      FORK();
-      RUN(simx_planes_from(wst, SIMX_F32, SIMX_BF16, T, H, a.x1, H, 0, xconv, H, psH));
-      RUN(simx_gemm_tn_planes(wst, F, H, T, du, F, psF, xconv, H, psH, goff(l, SIMX_P_W1), H, 1, tnws, tnws_bytes,
-                              b1_here ? nullptr : goff(l, SIMX_P_B1)));
+      RUN(simx_planes_from(stream, SIMX_F16, SIMX_BF16, T, F, a.h, F, psF, xconv, F, psF));
+      RUN(simx_gemm_tn_planes(stream, H, F, T, bufC, H, psH, xconv, F, psF, goff(l, SIMX_P_W2), F, 1, tnws, tnws_bytes, nullptr));
       RUN(simx_gemm_nt_planes(stream, SIMX_BF16, SIMX_EPI_NONE, Tp, H, F, du, F, psF, w.w1TP, F, (long)H * F, (float*)bufB, H, nullptr,
                               (const float*)bufA, H, nullptr, 0, 0, nullptr));
-      WAIT(ev_w2);                                 // W2 reads bufC, which the next LayerNorm backward rewrites
+      RUN(simx_planes_from(stream, SIMX_F32, SIMX_BF16, T, H, a.x1, H, 0, xconv, H, psH));
+      RUN(simx_gemm_tn_planes(stream, F, H, T, du, F, psF, xconv, H, psH, goff(l, SIMX_P_W1), H, 1, tnws, tnws_bytes,
+                              b1_here ? nullptr : goff(l, SIMX_P_B1)));
       RUN(simx_ln_bwd_planes(stream, T, H, (const float*)a.z1, off(l, SIMX_P_LN1_G), c->eps, (const float*)bufB, (float*)bufA, bufC, psH,
                              goff(l, SIMX_P_LN1_G), goff(l, SIMX_P_LN1_B), goff(l, SIMX_P_BO), &d1));
-      FORK();
-      RUN(simx_planes_from(wst, SIMX_F16, SIMX_BF16, T, H, a.ctx, H, psH, xconv, H, psH));
-      RUN(simx_gemm_tn_planes(wst, H, H, T, bufC, H, psH, xconv, H, psH, goff(l, SIMX_P_WO), H, 1, tnws, tnws_bytes, nullptr));
-      MARK(ev_wo);
       RUN(simx_gemm_nt_planes(stream, SIMX_BF16, SIMX_EPI_NONE, Tp, H, H, bufC, H, psH, w.woTP, H, (long)H * H, (float*)bufB, H, nullptr, nullptr, 0,
                               nullptr, 0, 0, nullptr));
+      RUN(simx_planes_from(stream, SIMX_F16, SIMX_BF16, T, H, a.ctx, H, psH, xconv, H, psH));
+      RUN(simx_gemm_tn_planes(stream, H, H, T, bufC, H, psH, xconv, H, psH, goff(l, SIMX_P_WO), H, 1, tnws, tnws_bytes, nullptr));
       // (x3 attention: the QKV bias gradient = column sums of dq | dk | dv comes out of the attention backward, so the Wqkv wgrad
       // runs on the four-plane-stage kernel too; the deterministic mode keeps the wgrad kernel's ordered pass)
       const bool bqkv_here = simx_mha_x3_ok(d, max_len) && !simx_det();
-      WAIT(ev_wqkv);                               // the previous layer's Wqkv wgrad reads dqkv
       if (simx_mha_x3_ok(d, max_len))
         RUN(simx_mha_bwd_x3_bias(stream, nseq, c->heads, d, cu, max_len, T, a.qkv, ps3, a.ctx, psH, a.lse, (const float*)bufB, dqkv, ps3, &d3,
                                  bqkv_here ? goff(l, SIMX_P_BQKV) : nullptr));
       else
         RUN(simx_mha_bwd_planes(stream, nseq, c->heads, d, cu, max_len, T, (const float*)a.qkv, a.ctx, psH, a.lse, (const float*)bufB, dqkv, ps3, &d3));
-      FORK();
-      RUN(simx_planes_from(wst, SIMX_F32, SIMX_BF16, T, H, xin, H, 0, xconv, H, psH));
-      RUN(simx_gemm_tn_planes(wst, 3 * H, H, T, dqkv, 3 * H, ps3, xconv, H, psH, goff(l, SIMX_P_WQKV), H, 1, tnws, tnws_bytes,
-                              bqkv_here ? nullptr : goff(l, SIMX_P_BQKV)));
-      MARK(ev_wqkv);
       RUN(simx_gemm_nt_planes(stream, SIMX_BF16, SIMX_EPI_NONE, Tp, H, 3 * H, dqkv, 3 * H, ps3, w.wqkvTP, 3 * H, 3L * H * H, (float*)bufB, H, nullptr,
                               (const float*)bufA, H, nullptr, 0, 0, nullptr));
+      RUN(simx_planes_from(stream, SIMX_F32, SIMX_BF16, T, H, xin, H, 0, xconv, H, psH));
+      RUN(simx_gemm_tn_planes(stream, 3 * H, H, T, dqkv, 3 * H, ps3, xconv, H, psH, goff(l, SIMX_P_WQKV), H, 1, tnws, tnws_bytes,
+                              bqkv_here ? nullptr : goff(l, SIMX_P_BQKV)));
       continue;
     }
     char* dzm = hd ? bufC : bufA;        // gradient of the (dropped) dense output; bufA = gradient of the residual branch
     // output LayerNorm : dz2, dgamma2, dbeta2, db2
     RUN(simx_ln_bwd_res(stream, dt, T, H, a.z2, sl ? a.x1 : nullptr, sl ? a.x1l : nullptr, off(l, SIMX_P_LN2_G), c->eps, bufB, bufA,
                         hd ? bufC : nullptr, goff(l, SIMX_P_LN2_G), goff(l, SIMX_P_LN2_B), goff(l, SIMX_P_B2), &d2, nullptr, gs));
-    FORK();
-    RUN(simx_gemm_tn_gs(wst, gdb, H, F, T, dzm, H, a.h, F, goff(l, SIMX_P_W2), F, 1, tnws, tnws_bytes, nullptr, 0, gs));
-    MARK(ev_w2);
     // du = (dz2m . W2) * gelu'(u)
     RUN(simx_gemm_nt(stream, gdb, Tp, F, H, dzm, H, w.w2T, H, du, F, nullptr, nullptr, 0, SIMX_EPI_DGELU, a.u, F, nullptr, 0));
-    FORK();
-    RUN(simx_gemm_tn_gs(wst, gdb, F, H, T, du, F, a.x1, H, goff(l, SIMX_P_W1), H, 1, tnws, tnws_bytes, goff(l, SIMX_P_B1), 0, gs));
+    RUN(simx_gemm_tn_gs(stream, gdb, H, F, T, dzm, H, a.h, F, goff(l, SIMX_P_W2), F, 1, tnws, tnws_bytes, nullptr, 0, gs));
     // dx1 = du . W1 + dz2
     RUN(simx_gemm_nt(stream, gdb, Tp, H, F, du, F, w.w1T, F, bufB, H, nullptr, bufA, H, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
-    WAIT(ev_w2);                         // W2 reads dzm, which the next LayerNorm backward rewrites
+    RUN(simx_gemm_tn_gs(stream, gdb, F, H, T, du, F, a.x1, H, goff(l, SIMX_P_W1), H, 1, tnws, tnws_bytes, goff(l, SIMX_P_B1), 0, gs));
     // attention-output LayerNorm : dz1, dgamma1, dbeta1, dbo
     RUN(simx_ln_bwd_res(stream, dt, T, H, a.z1, sl ? xin : nullptr, sl ? xinl : nullptr, off(l, SIMX_P_LN1_G), c->eps, bufB, bufA,
                         hd ? bufC : nullptr, goff(l, SIMX_P_LN1_G), goff(l, SIMX_P_LN1_B), goff(l, SIMX_P_BO), &d1, nullptr, gs));
-    FORK();
-    RUN(simx_gemm_tn_gs(wst, gdb, H, H, T, dzm, H, a.ctx, H, goff(l, SIMX_P_WO), H, 1, tnws, tnws_bytes, nullptr, 0, gs));
-    MARK(ev_wo);
     // dctx = dz1m . Wo
     RUN(simx_gemm_nt(stream, gdb, Tp, H, H, dzm, H, w.woT, H, bufB, H, nullptr, nullptr, 0, SIMX_EPI_NONE, nullptr, 0, nullptr, 0));
-    WAIT(ev_wqkv);                       // the previous layer's Wqkv wgrad reads dqkv
+    RUN(simx_gemm_tn_gs(stream, gdb, H, H, T, dzm, H, a.ctx, H, goff(l, SIMX_P_WO), H, 1, tnws, tnws_bytes, nullptr, 0, gs));
     RUN(simx_mha_bwd_hm(stream, dt, nseq, c->heads, d, cu, max_len, T, a.qkv, a.ctx, a.lse, bufB, dqkv, &d3, hm));
-    FORK();
     // dx = dqkv . Wqkv + dz1
     if (hm) {
-      RUN(simx_gemm_tn_gs(wst, gdb, 3 * H, H, T, dqkv, 0, xin, H, goff(l, SIMX_P_WQKV), H, 1, tnws, tnws_bytes, goff(l, SIMX_P_BQKV), hm, gs));
-      MARK(ev_wqkv);
       RUN(simx_gemm_nt_hm(stream, dt, Tp, H, 3 * H, dqkv, 64, w.wqkvT, 3 * H, bufB, H, nullptr, bufA, H, nullptr, hm, 0));
+      RUN(simx_gemm_tn_gs(stream, gdb, 3 * H, H, T, dqkv, 0, xin, H, goff(l, SIMX_P_WQKV), H, 1, tnws, tnws_bytes, goff(l, SIMX_P_BQKV), hm, gs));
     } else {
-      RUN(simx_gemm_tn_gs(wst, gdb, 3 * H, H, T, dqkv, 3 * H, xin, H, goff(l, SIMX_P_WQKV), H, 1, tnws, tnws_bytes,
-                          goff(l, SIMX_P_BQKV), 0, gs));
-      MARK(ev_wqkv);
       RUN(simx_gemm_nt(stream, gdb, Tp, H, 3 * H, dqkv, 3 * H, w.wqkvT, 3 * H, bufB, H, nullptr, bufA, H, SIMX_EPI_NONE, nullptr, 0,
                        nullptr, 0));
+      RUN(simx_gemm_tn_gs(stream, gdb, 3 * H, H, T, dqkv, 3 * H, xin, H, goff(l, SIMX_P_WQKV), H, 1, tnws, tnws_bytes,
+                          goff(l, SIMX_P_BQKV), 0, gs));
     }
   }
-  WAIT(ev_wqkv);                         // every parameter gradient of this call is complete on the caller's stream
   if (layer_lo > 0) return SIMX_OK;               // the next part continues from bufB
   const simx_dropout d0 = drop_of(c, -1, 0);
   RUN(simx_embed_ln_bwd_seq_gs(stream, dt, nseq, max_len, T, H, cu, ids, pos_ids, off(-1, SIMX_P_WORD), off(-1, SIMX_P_POS),
                                off(-1, SIMX_P_TYPE), off(-1, SIMX_P_EMB_LN_G), c->eps, bufB, goff(-1, SIMX_P_WORD),
                                goff(-1, SIMX_P_POS), goff(-1, SIMX_P_TYPE), goff(-1, SIMX_P_EMB_LN_G), goff(-1, SIMX_P_EMB_LN_B), &d0, gs));
   return SIMX_OK;
-#undef FORK
-#undef MARK
-#undef WAIT
 }
 
 // ------------------------------------------------------------------------------------------ profiler

@@ -14,9 +14,8 @@ cd /tmp; export TMPDIR=/tmp
 # realistic-length side measurement, so that every launch of a kernel is the headline workload's and its duration is
 # exclusive -- the same conditions as bench.py's own roofline pass, which the averages must agree with.
 export SIMX_OVERLAP_TOWERS=0
-export SIMX_WGRAD_STREAM=0
 CMD="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-realistic --no-parity"
-SIMX_OVERLAP_TOWERS=1 SIMX_WGRAD_STREAM=1 timeout 900 python $R/bench.py --steps 5 --warmup 2 > $O/bench.json 2> $O/bench.err
+SIMX_OVERLAP_TOWERS=1 timeout 900 python $R/bench.py --steps 5 --warmup 2 > $O/bench.json 2> $O/bench.err
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- $CMD > $O/stats.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- $CMD > $O/pmc_fetch.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- $CMD > $O/pmc_write.log 2>&1
@@ -26,7 +25,7 @@ timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCL
 timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_active -o p -- $CMD > $O/pmc_active.log 2>&1
 # the fp32 engine (the arithmetic every shipped recipe selects) as a first-class measurement: its own un-profiled line
 # (10 timed steps) and a kernel-trace summary of the same command
-SIMX_OVERLAP_TOWERS=1 SIMX_WGRAD_STREAM=1 timeout 600 python $R/bench.py --dtype fp32 --side --steps 10 --warmup 2 > $O/fp32_bench.json 2> $O/fp32_bench.err
+timeout 600 python $R/bench.py --dtype fp32 --side --steps 10 --warmup 2 > $O/fp32_bench.json 2> $O/fp32_bench.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fp32_stats -o s -- python $R/bench.py --dtype fp32 --side --steps 3 --warmup 1 > $O/fp32_stats.log 2>&1
 # HBM traffic of the fp32 engine's dominant kernel (gemm_nt_xp_kernel): the same two separate PMC passes
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fp32_pmc_fetch -o p -- python $R/bench.py --dtype fp32 --side --steps 2 --warmup 1 --no-prof > $O/fp32_pmc_fetch.log 2>&1

@@ -241,7 +241,22 @@ __device__ __forceinline__ void a2_store_tile(const f32x4 (&acc)[4], char* patch
   }
 }
 
-template <typename F, int NKT>
+// What bounds it (tools/att_bench.py on the bench shape, fp16, 2048 x 12 blocks of S = 128, p = 0.1 / no dropout): 0.916 / 0.805 ms
+// as first written; 0.773 / 0.624 with every workgroup reading ONE block's operands (no HBM traffic: the instruction stream
+// alone); 0.605 with the two phases' loops removed (loads and stores only); the MFMAs alone would take 0.15.  So the kernel is
+// bound by its own VALU work (exp2, the softmax-gradient algebra, packing, and the dropout hash: 0.11 ms of it), not by HBM
+// and not by occupancy.  The mask is hashed ONCE per block, in the prologue: thread (query, key tile) draws the 16 bits of its
+// tile and files them in the LDS at [query][key tile]; phase A reads 32 bits per (query, key pair), phase B -- whose lanes hold
+// four different query ROWS and paid four hashes per four elements where phase A paid two -- four 16-bit words per query
+// tile.  One third fewer hashes: 0.916 -> 0.902 ms, the bit tests eat most of it.
+// (Also measured: the bits drawn by phase A and handed to phase B through wave ballots, which needs a workgroup barrier
+// between the phases -- 0.912; a three-tile form at THREE workgroups per CU instead of two -- 1.10 ms, and 1.13 at two; V
+// fragments from global memory +0.07..0.16 ms; 512-B store patches +0.04 ms.)
+// VG: the V tile is not staged.  Both phases only need V's ROW fragments (dP = dO V^T), which are exactly what a lane loads
+// from global memory with one 16-B access (phase A one key pair ahead: L1 / L2 hits after the first wave's).  Slower per
+// block, but S = 160 (the cross-encoder's 158 tokens) then needs 74 KB instead of 93 KB of LDS = two workgroups per CU
+// instead of one: 2.41 -> 1.58 ms on 2048 x 12 blocks.
+template <typename F, int NKT, bool VG>
 __global__ __launch_bounds__(256) void mha_bwd2_h16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ O,
                                                             const float* __restrict__ lse, const bf16_t* __restrict__ dO,
                                                             bf16_t* __restrict__ dqkv, const int* __restrict__ cu,
@@ -264,17 +279,18 @@ __global__ __launch_bounds__(256) void mha_bwd2_h16_kernel(const bf16_t* __restr
   const int nkt = (len + 15) >> 4;
   const int nkt2 = (nkt + 1) & ~1;
   constexpr int TILE = NKT * 16 * 128;
-  char* sQ = smem;
-  char* sK = smem + TILE;
-  char* sV = smem + 2 * TILE;
-  char* sD = smem + 3 * TILE;
-  float* sLse = reinterpret_cast<float*>(smem + 4 * TILE);
+  constexpr int OFF_Q = 0, OFF_K = TILE, OFF_D = 2 * TILE, OFF_V = 3 * TILE;      // (the V tile is last: absent with VG)
+  constexpr int VEC = (VG ? 3 : 4) * TILE;           // lse[NKT*16], delta[NKT*16] (f32)
+  constexpr int MSK = VEC + 2 * NKT * 16 * 4;        // dropout bits: one row of NKT * 2 bytes per query, 16 key bits per key tile
+  constexpr int MROW = NKT * 2;
+  constexpr int PATCH = MSK + NKT * 16 * MROW;
+  float* sLse = reinterpret_cast<float*>(smem + VEC);
   float* sDel = sLse + NKT * 16;
-  char* patch = smem + 4 * TILE + 2 * NKT * 16 * 4 + wave * 2048;
-  att_stage(Qg, H3, len, nkt2 * 16, sQ, wave, lane);
-  att_stage(Kg, H3, len, nkt2 * 16, sK, wave, lane);
-  att_stage(Vg, H3, len, nkt2 * 16, sV, wave, lane);
-  att_stage(dOg, H, len, nkt2 * 16, sD, wave, lane);
+  char* patch = smem + PATCH + wave * 2048;
+  att_stage(Qg, H3, len, nkt2 * 16, smem + OFF_Q, wave, lane);
+  att_stage(Kg, H3, len, nkt2 * 16, smem + OFF_K, wave, lane);
+  if (!VG) att_stage(Vg, H3, len, nkt2 * 16, smem + OFF_V, wave, lane);
+  att_stage(dOg, H, len, nkt2 * 16, smem + OFF_D, wave, lane);
   // delta_i = dO_i . O_i (two threads per row, 16-B loads) ; lse_i in log2 units
   for (int idx = tid; idx < nkt2 * 32; idx += 256) {
     const int r = idx >> 1, half = idx & 1;
@@ -297,12 +313,25 @@ __global__ __launch_bounds__(256) void mha_bwd2_h16_kernel(const bf16_t* __restr
       sLse[r] = r < len ? lse[(long)h * T + t0 + r] * LOG2E : 0.f;
     }
   }
+  if (drop.thr) {                                    // keep-bits of (query q, keys kt*16 .. +15): wave -> key tile, lane -> query
+    for (int kt = wave; kt < nkt2; kt += 4)
+      for (int q = lane; q < nkt * 16; q += 64) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const uint32_t hsh = drop_mix(drop.seed, drop.stream, (uint32_t)(h * T + t0 + q), (uint32_t)(kt * 8 + j));
+          w |= ((hsh & 0xFFFFu) >= drop.thr ? 1u : 0u) << (2 * j);
+          w |= ((hsh >> 16) >= drop.thr ? 2u : 0u) << (2 * j);
+        }
+        *reinterpret_cast<unsigned short*>(smem + MSK + q * MROW + kt * 2) = (unsigned short)w;
+      }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const int fr = lane & 15, fg = lane >> 4;
   const float c2 = scale * LOG2E;
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-  const uint32_t patch_addr = lds0 + (uint32_t)(4 * TILE + 2 * NKT * 16 * 4 + wave * 2048);
+  const uint32_t patch_addr = lds0 + (uint32_t)(PATCH + wave * 2048);
   // lane constants: row-fragment offsets (chunks fg and 4+fg of row fr) and transpose-fragment offsets per 16-column tile
   const int fsw = att_f(fr);
   const uint32_t rf_lo = (uint32_t)(fr * 128 + ((fg ^ fsw) << 4)), rf_hi = (uint32_t)(fr * 128 + (((4 + fg) ^ fsw) << 4));
@@ -311,13 +340,23 @@ __global__ __launch_bounds__(256) void mha_bwd2_h16_kernel(const bf16_t* __restr
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) tr[dt] = (uint32_t)(rr * 128 + (((dt * 2 + tx) ^ tsw) << 4) + (fr & 1) * 8);
   const bool full = (len == nkt2 * 16);             // no ragged tail: skip the per-element masks
+  const int npair = nkt2 >> 1;
+  // V row fragments of key pair KP from global memory (VG; rows past the end: copies of the last row)
+#define A2_VLOAD(KP, V00, V01, V10, V11)                                                                   \
+  do {                                                                                                     \
+    const int r0__ = (KP) * 32 + fr, r1__ = r0__ + 16;                                                     \
+    const bf16_t* p0__ = Vg + (long)(r0__ < len ? r0__ : len - 1) * H3 + fg * 8;                           \
+    const bf16_t* p1__ = Vg + (long)(r1__ < len ? r1__ : len - 1) * H3 + fg * 8;                           \
+    V00 = *reinterpret_cast<const bf16x8*>(p0__); V01 = *reinterpret_cast<const bf16x8*>(p0__ + 32);      \
+    V10 = *reinterpret_cast<const bf16x8*>(p1__); V11 = *reinterpret_cast<const bf16x8*>(p1__ + 32);      \
+  } while (0)
 
   // ---------------- phase A: dQ, waves own query tiles, loop over key-tile pairs
   for (int qt = wave; qt < nkt; qt += 4) {
     const int q = qt * 16 + fr;
     bf16x8 qf0, qf1, df0, df1;
     {
-      const uint32_t aq = lds0 + (uint32_t)(qt * 2048), ad = aq + 3 * TILE;
+      const uint32_t aq = lds0 + (uint32_t)(OFF_Q + qt * 2048), ad = lds0 + (uint32_t)(OFF_D + qt * 2048);
       A2_RD128(qf0, aq + rf_lo, 0); A2_RD128(qf1, aq + rf_hi, 0);
       A2_RD128(df0, ad + rf_lo, 0); A2_RD128(df1, ad + rf_hi, 0);
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qf0), "+v"(qf1), "+v"(df0), "+v"(df1)::"memory");
@@ -327,15 +366,26 @@ __global__ __launch_bounds__(256) void mha_bwd2_h16_kernel(const bf16_t* __restr
     f32x4 dq[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int kp = 0; kp < (nkt2 >> 1); ++kp) {
-      const uint32_t bk = lds0 + (uint32_t)(TILE + kp * 4096), bv = bk + TILE;
+    bf16x8 vn00, vn01, vn10, vn11;
+    if (VG) A2_VLOAD(0, vn00, vn01, vn10, vn11);
+    for (int kp = 0; kp < npair; ++kp) {
+      const uint32_t bk = lds0 + (uint32_t)(OFF_K + kp * 4096), bv = lds0 + (uint32_t)(OFF_V + kp * 4096);
       bf16x8 k00, k01, k10, k11, v00, v01, v10, v11;
       bf16x4 t0l, t0h, t1l, t1h, t2l, t2h, t3l, t3h;
       A2_RD128(k00, bk + rf_lo, 0); A2_RD128(k01, bk + rf_hi, 0); A2_RD128(k10, bk + rf_lo, 2048); A2_RD128(k11, bk + rf_hi, 2048);
-      A2_RD128(v00, bv + rf_lo, 0); A2_RD128(v01, bv + rf_hi, 0); A2_RD128(v10, bv + rf_lo, 2048); A2_RD128(v11, bv + rf_hi, 2048);
+      if (VG) {
+        v00 = vn00; v01 = vn01; v10 = vn10; v11 = vn11;
+        A2_VLOAD(kp + 1 < npair ? kp + 1 : kp, vn00, vn01, vn10, vn11);
+      } else {
+        A2_RD128(v00, bv + rf_lo, 0); A2_RD128(v01, bv + rf_hi, 0); A2_RD128(v10, bv + rf_lo, 2048); A2_RD128(v11, bv + rf_hi, 2048);
+      }
       A2_RDTR(t0l, bk + tr[0], 0); A2_RDTR(t0h, bk + tr[0], 2048); A2_RDTR(t1l, bk + tr[1], 0); A2_RDTR(t1h, bk + tr[1], 2048);
       A2_RDTR(t2l, bk + tr[2], 0); A2_RDTR(t2h, bk + tr[2], 2048); A2_RDTR(t3l, bk + tr[3], 0); A2_RDTR(t3h, bk + tr[3], 2048);
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(k00), "+v"(k01), "+v"(k10), "+v"(k11), "+v"(v00), "+v"(v01), "+v"(v10), "+v"(v11)::"memory");
+      uint32_t mwa = 0xFFFFFFFFu;
+      if (drop.thr) asm volatile("ds_read_b32 %0, %1" : "=&v"(mwa) : "v"(lds0 + (uint32_t)(MSK + q * MROW + kp * 4)) : "memory");
+      if (VG) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(k00), "+v"(k01), "+v"(k10), "+v"(k11), "+v"(mwa)::"memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(k00), "+v"(k01), "+v"(k10), "+v"(k11), "+v"(v00), "+v"(v01), "+v"(v10), "+v"(v11), "+v"(mwa)::"memory");
+      const uint32_t mqa = mwa >> (4 * fg);          // bit r: key 4 fg + r of tile 2 kp ; bit 16 + r: of tile 2 kp + 1
       asm volatile("" : "+v"(t0l), "+v"(t0h), "+v"(t1l), "+v"(t1h), "+v"(t2l), "+v"(t2h), "+v"(t3l), "+v"(t3h)::"memory");
       f32x4 ds[2];
 #pragma unroll
@@ -347,7 +397,10 @@ __global__ __launch_bounds__(256) void mha_bwd2_h16_kernel(const bf16_t* __restr
         dp = H16<F>::mfma(hf ? v10 : v00, df0, dp);
         dp = H16<F>::mfma(hf ? v11 : v01, df1, dp);
         float m4[4] = {1.f, 1.f, 1.f, 1.f};
-        if (drop.thr) drop_mult4(drop, (uint32_t)(h * T + t0 + q), (uint32_t)(kt * 16 + 4 * fg), m4);
+        if (drop.thr) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) m4[r] = ((mqa >> (hf * 16 + r)) & 1u) ? drop.scale : 0.f;
+        }
         float p[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(s[r] * c2 - lq);      // raw v_exp_f32: argument <= ~0, underflow -> 0
@@ -367,37 +420,54 @@ __global__ __launch_bounds__(256) void mha_bwd2_h16_kernel(const bf16_t* __restr
     }
     a2_store_tile<F>(dq, patch, patch_addr, dQg + (long)(qt * 16) * H3, H3, len - qt * 16, lane);
   }
+#undef A2_VLOAD
 
   // ---------------- phase B: dK, dV, waves own key tiles, loop over query-tile pairs
   for (int kt = wave; kt < nkt; kt += 4) {
     const int key = kt * 16 + fr;
     bf16x8 kf0, kf1, vf0, vf1;
     {
-      const uint32_t ak = lds0 + (uint32_t)(TILE + kt * 2048), av = ak + TILE;
+      const uint32_t ak = lds0 + (uint32_t)(OFF_K + kt * 2048), av = lds0 + (uint32_t)(OFF_V + kt * 2048);
       A2_RD128(kf0, ak + rf_lo, 0); A2_RD128(kf1, ak + rf_hi, 0);
-      A2_RD128(vf0, av + rf_lo, 0); A2_RD128(vf1, av + rf_hi, 0);
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf0), "+v"(kf1), "+v"(vf0), "+v"(vf1)::"memory");
+      if (VG) {
+        const bf16_t* pv = Vg + (long)(key < len ? key : len - 1) * H3 + fg * 8;
+        vf0 = *reinterpret_cast<const bf16x8*>(pv); vf1 = *reinterpret_cast<const bf16x8*>(pv + 32);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf0), "+v"(kf1)::"memory");
+      } else {
+        A2_RD128(vf0, av + rf_lo, 0); A2_RD128(vf1, av + rf_hi, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf0), "+v"(kf1), "+v"(vf0), "+v"(vf1)::"memory");
+      }
     }
     const bool kok = key < len;
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    for (int qp = 0; qp < (nkt2 >> 1); ++qp) {
-      const uint32_t bq = lds0 + (uint32_t)(qp * 4096), bd = bq + 3 * TILE;
-      const uint32_t bl = lds0 + (uint32_t)(4 * TILE + (qp * 32 + 4 * fg) * 4);     // sLse[qp*32 + 4 fg ..], sDel = + NKT*64 B
+    for (int qp = 0; qp < npair; ++qp) {
+      const uint32_t bq = lds0 + (uint32_t)(OFF_Q + qp * 4096), bd = lds0 + (uint32_t)(OFF_D + qp * 4096);
+      const uint32_t bl = lds0 + (uint32_t)(VEC + (qp * 32 + 4 * fg) * 4);     // sLse[qp*32 + 4 fg ..], sDel = + NKT*64 B
       bf16x8 q00, q01, q10, q11, d00, d01, d10, d11;
       bf16x4 e0l, e0h, e1l, e1h, e2l, e2h, e3l, e3h, u0l, u0h, u1l, u1h, u2l, u2h, u3l, u3h;
       f32x4 ls0, ls1, de0, de1;
+      uint32_t mb[2][4] = {{~0u, ~0u, ~0u, ~0u}, {~0u, ~0u, ~0u, ~0u}};   // keep-bits of the lane's four query rows, per tile of the pair
       A2_RD128(q00, bq + rf_lo, 0); A2_RD128(q01, bq + rf_hi, 0); A2_RD128(q10, bq + rf_lo, 2048); A2_RD128(q11, bq + rf_hi, 2048);
       A2_RD128(d00, bd + rf_lo, 0); A2_RD128(d01, bd + rf_hi, 0); A2_RD128(d10, bd + rf_lo, 2048); A2_RD128(d11, bd + rf_hi, 2048);
       asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %5\n\tds_read_b128 %3, %5 offset:64"
                    : "=&v"(ls0), "=&v"(ls1), "=&v"(de0), "=&v"(de1) : "v"(bl), "v"(bl + (uint32_t)(NKT * 64)) : "memory");
+      if (drop.thr) {
+        const uint32_t ma = lds0 + (uint32_t)(MSK + (qp * 32 + 4 * fg) * MROW + kt * 2);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            asm volatile("ds_read_u16 %0, %1 offset:%2" : "=&v"(mb[hf][r]) : "v"(ma), "n"((hf * 16 + r) * MROW) : "memory");
+      }
       A2_RDTR(e0l, bd + tr[0], 0); A2_RDTR(e0h, bd + tr[0], 2048); A2_RDTR(e1l, bd + tr[1], 0); A2_RDTR(e1h, bd + tr[1], 2048);
       A2_RDTR(e2l, bd + tr[2], 0); A2_RDTR(e2h, bd + tr[2], 2048); A2_RDTR(e3l, bd + tr[3], 0); A2_RDTR(e3h, bd + tr[3], 2048);
       A2_RDTR(u0l, bq + tr[0], 0); A2_RDTR(u0h, bq + tr[0], 2048); A2_RDTR(u1l, bq + tr[1], 0); A2_RDTR(u1h, bq + tr[1], 2048);
       A2_RDTR(u2l, bq + tr[2], 0); A2_RDTR(u2h, bq + tr[2], 2048); A2_RDTR(u3l, bq + tr[3], 0); A2_RDTR(u3h, bq + tr[3], 2048);
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q00), "+v"(q01), "+v"(q10), "+v"(q11), "+v"(d00), "+v"(d01), "+v"(d10), "+v"(d11),
                    "+v"(ls0), "+v"(ls1), "+v"(de0), "+v"(de1)::"memory");
+      asm volatile("" : "+v"(mb[0][0]), "+v"(mb[0][1]), "+v"(mb[0][2]), "+v"(mb[0][3]), "+v"(mb[1][0]), "+v"(mb[1][1]), "+v"(mb[1][2]), "+v"(mb[1][3])::"memory");
       asm volatile("" : "+v"(e0l), "+v"(e0h), "+v"(e1l), "+v"(e1h), "+v"(e2l), "+v"(e2h), "+v"(e3l), "+v"(e3h)::"memory");
       asm volatile("" : "+v"(u0l), "+v"(u0h), "+v"(u1l), "+v"(u1h), "+v"(u2l), "+v"(u2h), "+v"(u3l), "+v"(u3h)::"memory");
       f32x4 pp[2], ds[2];
@@ -420,7 +490,7 @@ __global__ __launch_bounds__(256) void mha_bwd2_h16_kernel(const bf16_t* __restr
         }
         if (drop.thr) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) mm[r] = drop_mult(drop, (uint32_t)(h * T + t0 + qt * 16 + 4 * fg + r), (uint32_t)key);
+          for (int r = 0; r < 4; ++r) mm[r] = ((mb[hf][r] >> fr) & 1u) ? drop.scale : 0.f;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -981,20 +1051,20 @@ extern "C" int simx_mha_bwd_hm(simx_stream_t stream, int dtype, int nseq, int he
   if (rc) return rc;
   const float scale = 1.0f / sqrtf((float)d);
   if (simx_is16(dtype) && d == 64 && max_len <= 256) {
-#define LB(NKT)                                                                                                      \
+#define LB(NKT, VG)                                                                                                  \
   do {                                                                                                               \
-    const size_t lds = (size_t)4 * NKT * 16 * 128 + 2 * NKT * 16 * sizeof(float) + 4 * 2048;                         \
-    rc = set_lds(mha_bwd2_h16_kernel<FF, NKT>, lds, "mha_bwd");                                                      \
+    const size_t lds = (size_t)((VG) ? 3 : 4) * NKT * 16 * 128 + 2 * NKT * 16 * sizeof(float) + (size_t)NKT * 16 * NKT * 2 + 4 * 2048; \
+    rc = set_lds(mha_bwd2_h16_kernel<FF, NKT, VG>, lds, "mha_bwd");                                                  \
     if (rc) return rc;                                                                                               \
-    hipLaunchKernelGGL((mha_bwd2_h16_kernel<FF, NKT>), dim3(nseq * heads), dim3(256), lds, s, (const bf16_t*)qkv,    \
+    hipLaunchKernelGGL((mha_bwd2_h16_kernel<FF, NKT, VG>), dim3(nseq * heads), dim3(256), lds, s, (const bf16_t*)qkv, \
                        (const bf16_t*)ctx, lse, (const bf16_t*)dctx, (bf16_t*)dqkv, cu, heads, T, scale, drop, hm_rows); \
   } while (0)
 #define LB_ALL()                                                                                                     \
   do {                                                                                                               \
-    if (max_len <= 32) LB(2);                                                                                        \
-    else if (max_len <= 128) LB(8);                                                                                  \
-    else if (max_len <= 160) LB(10);                                                                                 \
-    else LB(16);                                                                                                     \
+    if (max_len <= 32) LB(2, false);                                                                                 \
+    else if (max_len <= 128) LB(8, false);                                                                           \
+    else if (max_len <= 160) LB(10, true);         /* 74 KB: two workgroups per CU (93 KB with the V tile: one) */   \
+    else LB(16, false);                                                                                              \
   } while (0)
     SIMX_DISPATCH16(dtype, FF, LB_ALL());
 #undef LB_ALL

@@ -11,6 +11,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from simxns_amd import _lib as L       # noqa: E402
 from simxns_amd._lib import Dropout    # noqa: E402
 
+if os.environ.get("ATT_LIB"):          # A/B against a variant build (tools/variants/<name>/libsimx_hip.so)
+    L.LIB_PATH = os.environ["ATT_LIB"]
+
 nseq = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 p = float(sys.argv[3]) if len(sys.argv) > 3 else 0.1

@@ -14,6 +14,7 @@
 //
 // Keys are restricted to the sequence's own real tokens, which equals the reference's additive
 // (1-mask)*finfo.min bias (exp underflows to exactly 0).
+#include <type_traits>
 #include "common.h"
 #include "prof.h"
 
@@ -248,7 +249,8 @@ __device__ __forceinline__ void a2_store_tile(const f32x4 (&acc)[4], char* patch
 // and not by occupancy.  The mask is hashed ONCE per block, in the prologue: thread (query, key tile) draws the 16 bits of its
 // tile and files them in the LDS at [query][key tile]; phase A reads 32 bits per (query, key pair), phase B -- whose lanes hold
 // four different query ROWS and paid four hashes per four elements where phase A paid two -- four 16-bit words per query
-// tile.  One third fewer hashes: 0.916 -> 0.902 ms, the bit tests eat most of it.
+// tile.  One third fewer hashes: 0.916 -> 0.902 ms, the bit tests eat most of it; with the three items below 0.891 (no
+// dropout 0.805 -> 0.761; ragged lengths 0.817 -> 0.751; S = 256: 4.66 -> 4.09).
 // (Also measured: the bits drawn by phase A and handed to phase B through wave ballots, which needs a workgroup barrier
 // between the phases -- 0.912; a three-tile form at THREE workgroups per CU instead of two -- 1.10 ms, and 1.13 at two; V
 // fragments from global memory +0.07..0.16 ms; 512-B store patches +0.04 ms.)
@@ -256,7 +258,16 @@ __device__ __forceinline__ void a2_store_tile(const f32x4 (&acc)[4], char* patch
 // from global memory with one 16-B access (phase A one key pair ahead: L1 / L2 hits after the first wave's).  Slower per
 // block, but S = 160 (the cross-encoder's 158 tokens) then needs 74 KB instead of 93 KB of LDS = two workgroups per CU
 // instead of one: 2.41 -> 1.58 ms on 2048 x 12 blocks.
-template <typename F, int NKT, bool VG>
+//   * the pair iteration is ONE basic block: dropout on/off is a template parameter and "no ragged tail" selects one of two
+//     copies of each phase, so the two key (query) tiles of a pair are scheduled together -- with the uniform branches inside,
+//     hipcc emitted tile 0's MFMAs, waited for them, did its VALU work, and only then issued tile 1's;
+//   * operands that are read with the same lane constant (K and V row fragments; Q and dO row and transpose fragments) sit in
+//     adjacent LDS tiles and share one address register (the second through the instruction's immediate offset): 8
+//     address additions per iteration instead of 20;
+//   * 1/sqrt(d) multiplies the finished dQ / dK tiles, not every dS element.
+#define A2_RD128O(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
+#define A2_RDTRO(DST, ADDR, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
+template <typename F, int NKT, bool VG, bool DROP>
 __global__ __launch_bounds__(256) void mha_bwd2_h16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ O,
                                                             const float* __restrict__ lse, const bf16_t* __restrict__ dO,
                                                             bf16_t* __restrict__ dqkv, const int* __restrict__ cu,
@@ -279,7 +290,7 @@ __global__ __launch_bounds__(256) void mha_bwd2_h16_kernel(const bf16_t* __restr
   const int nkt = (len + 15) >> 4;
   const int nkt2 = (nkt + 1) & ~1;
   constexpr int TILE = NKT * 16 * 128;
-  constexpr int OFF_Q = 0, OFF_K = TILE, OFF_D = 2 * TILE, OFF_V = 3 * TILE;      // (the V tile is last: absent with VG)
+  constexpr int OFF_Q = 0, OFF_D = TILE, OFF_K = 2 * TILE, OFF_V = 3 * TILE;      // (the V tile is last: absent with VG)
   constexpr int VEC = (VG ? 3 : 4) * TILE;           // lse[NKT*16], delta[NKT*16] (f32)
   constexpr int MSK = VEC + 2 * NKT * 16 * 4;        // dropout bits: one row of NKT * 2 bytes per query, 16 key bits per key tile
   constexpr int MROW = NKT * 2;
@@ -313,7 +324,7 @@ __global__ __launch_bounds__(256) void mha_bwd2_h16_kernel(const bf16_t* __restr
       sLse[r] = r < len ? lse[(long)h * T + t0 + r] * LOG2E : 0.f;
     }
   }
-  if (drop.thr) {                                    // keep-bits of (query q, keys kt*16 .. +15): wave -> key tile, lane -> query
+  if (DROP) {                                        // keep-bits of (query q, keys kt*16 .. +15): wave -> key tile, lane -> query
     for (int kt = wave; kt < nkt2; kt += 4)
       for (int q = lane; q < nkt * 16; q += 64) {
         uint32_t w = 0;
@@ -339,7 +350,7 @@ __global__ __launch_bounds__(256) void mha_bwd2_h16_kernel(const bf16_t* __restr
   uint32_t tr[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) tr[dt] = (uint32_t)(rr * 128 + (((dt * 2 + tx) ^ tsw) << 4) + (fr & 1) * 8);
-  const bool full = (len == nkt2 * 16);             // no ragged tail: skip the per-element masks
+  const bool full = (len == nkt2 * 16);             // no ragged tail: the copies of the phases without per-element masks
   const int npair = nkt2 >> 1;
   // V row fragments of key pair KP from global memory (VG; rows past the end: copies of the last row)
 #define A2_VLOAD(KP, V00, V01, V10, V11)                                                                   \
@@ -352,167 +363,177 @@ __global__ __launch_bounds__(256) void mha_bwd2_h16_kernel(const bf16_t* __restr
   } while (0)
 
   // ---------------- phase A: dQ, waves own query tiles, loop over key-tile pairs
-  for (int qt = wave; qt < nkt; qt += 4) {
-    const int q = qt * 16 + fr;
-    bf16x8 qf0, qf1, df0, df1;
-    {
-      const uint32_t aq = lds0 + (uint32_t)(OFF_Q + qt * 2048), ad = lds0 + (uint32_t)(OFF_D + qt * 2048);
-      A2_RD128(qf0, aq + rf_lo, 0); A2_RD128(qf1, aq + rf_hi, 0);
-      A2_RD128(df0, ad + rf_lo, 0); A2_RD128(df1, ad + rf_hi, 0);
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qf0), "+v"(qf1), "+v"(df0), "+v"(df1)::"memory");
-    }
-    const float lq = sLse[q], dq_ = sDel[q];
-    const bool qok = q < len;
-    f32x4 dq[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bf16x8 vn00, vn01, vn10, vn11;
-    if (VG) A2_VLOAD(0, vn00, vn01, vn10, vn11);
-    for (int kp = 0; kp < npair; ++kp) {
-      const uint32_t bk = lds0 + (uint32_t)(OFF_K + kp * 4096), bv = lds0 + (uint32_t)(OFF_V + kp * 4096);
-      bf16x8 k00, k01, k10, k11, v00, v01, v10, v11;
-      bf16x4 t0l, t0h, t1l, t1h, t2l, t2h, t3l, t3h;
-      A2_RD128(k00, bk + rf_lo, 0); A2_RD128(k01, bk + rf_hi, 0); A2_RD128(k10, bk + rf_lo, 2048); A2_RD128(k11, bk + rf_hi, 2048);
-      if (VG) {
-        v00 = vn00; v01 = vn01; v10 = vn10; v11 = vn11;
-        A2_VLOAD(kp + 1 < npair ? kp + 1 : kp, vn00, vn01, vn10, vn11);
-      } else {
-        A2_RD128(v00, bv + rf_lo, 0); A2_RD128(v01, bv + rf_hi, 0); A2_RD128(v10, bv + rf_lo, 2048); A2_RD128(v11, bv + rf_hi, 2048);
+  auto phase_a = [&](auto full_c) {
+    constexpr bool FULL = decltype(full_c)::value;
+    for (int qt = wave; qt < nkt; qt += 4) {
+      const int q = qt * 16 + fr;
+      bf16x8 qf0, qf1, df0, df1;
+      {
+        const uint32_t aq = lds0 + (uint32_t)(OFF_Q + qt * 2048);
+        A2_RD128O(qf0, aq + rf_lo, 0); A2_RD128O(qf1, aq + rf_hi, 0);
+        A2_RD128O(df0, aq + rf_lo, OFF_D - OFF_Q); A2_RD128O(df1, aq + rf_hi, OFF_D - OFF_Q);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qf0), "+v"(qf1), "+v"(df0), "+v"(df1)::"memory");
       }
-      A2_RDTR(t0l, bk + tr[0], 0); A2_RDTR(t0h, bk + tr[0], 2048); A2_RDTR(t1l, bk + tr[1], 0); A2_RDTR(t1h, bk + tr[1], 2048);
-      A2_RDTR(t2l, bk + tr[2], 0); A2_RDTR(t2h, bk + tr[2], 2048); A2_RDTR(t3l, bk + tr[3], 0); A2_RDTR(t3h, bk + tr[3], 2048);
-      uint32_t mwa = 0xFFFFFFFFu;
-      if (drop.thr) asm volatile("ds_read_b32 %0, %1" : "=&v"(mwa) : "v"(lds0 + (uint32_t)(MSK + q * MROW + kp * 4)) : "memory");
-      if (VG) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(k00), "+v"(k01), "+v"(k10), "+v"(k11), "+v"(mwa)::"memory");
-      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(k00), "+v"(k01), "+v"(k10), "+v"(k11), "+v"(v00), "+v"(v01), "+v"(v10), "+v"(v11), "+v"(mwa)::"memory");
-      const uint32_t mqa = mwa >> (4 * fg);          // bit r: key 4 fg + r of tile 2 kp ; bit 16 + r: of tile 2 kp + 1
-      asm volatile("" : "+v"(t0l), "+v"(t0h), "+v"(t1l), "+v"(t1h), "+v"(t2l), "+v"(t2h), "+v"(t3l), "+v"(t3h)::"memory");
-      f32x4 ds[2];
+      const float lq = sLse[q], dq_ = sDel[q];
+      const bool qok = q < len;
+      f32x4 dq[4];
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const int kt = 2 * kp + hf;
-        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        s = H16<F>::mfma(hf ? k10 : k00, qf0, s);
-        s = H16<F>::mfma(hf ? k11 : k01, qf1, s);
-        dp = H16<F>::mfma(hf ? v10 : v00, df0, dp);
-        dp = H16<F>::mfma(hf ? v11 : v01, df1, dp);
-        float m4[4] = {1.f, 1.f, 1.f, 1.f};
-        if (drop.thr) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) m4[r] = ((mqa >> (hf * 16 + r)) & 1u) ? drop.scale : 0.f;
+      for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      bf16x8 vn00, vn01, vn10, vn11;
+      if (VG) A2_VLOAD(0, vn00, vn01, vn10, vn11);
+      for (int kp = 0; kp < npair; ++kp) {
+        const uint32_t po = (uint32_t)(OFF_K + kp * 4096);
+        const uint32_t a_lo = lds0 + rf_lo + po, a_hi = lds0 + rf_hi + po;
+        const uint32_t a_t0 = lds0 + tr[0] + po, a_t1 = lds0 + tr[1] + po, a_t2 = lds0 + tr[2] + po, a_t3 = lds0 + tr[3] + po;
+        bf16x8 k00, k01, k10, k11, v00, v01, v10, v11;
+        bf16x4 t0l, t0h, t1l, t1h, t2l, t2h, t3l, t3h;
+        A2_RD128O(k00, a_lo, 0); A2_RD128O(k01, a_hi, 0); A2_RD128O(k10, a_lo, 2048); A2_RD128O(k11, a_hi, 2048);
+        if (VG) {
+          v00 = vn00; v01 = vn01; v10 = vn10; v11 = vn11;
+          A2_VLOAD(kp + 1 < npair ? kp + 1 : kp, vn00, vn01, vn10, vn11);
+        } else {
+          A2_RD128O(v00, a_lo, OFF_V - OFF_K); A2_RD128O(v01, a_hi, OFF_V - OFF_K);
+          A2_RD128O(v10, a_lo, OFF_V - OFF_K + 2048); A2_RD128O(v11, a_hi, OFF_V - OFF_K + 2048);
         }
-        float p[4];
+        A2_RDTRO(t0l, a_t0, 0); A2_RDTRO(t0h, a_t0, 2048); A2_RDTRO(t1l, a_t1, 0); A2_RDTRO(t1h, a_t1, 2048);
+        A2_RDTRO(t2l, a_t2, 0); A2_RDTRO(t2h, a_t2, 2048); A2_RDTRO(t3l, a_t3, 0); A2_RDTRO(t3h, a_t3, 2048);
+        uint32_t mwa = 0xFFFFFFFFu;
+        if (DROP) asm volatile("ds_read_b32 %0, %1" : "=&v"(mwa) : "v"(lds0 + (uint32_t)(MSK + q * MROW + kp * 4)) : "memory");
+        if (VG) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(k00), "+v"(k01), "+v"(k10), "+v"(k11), "+v"(mwa)::"memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(k00), "+v"(k01), "+v"(k10), "+v"(k11), "+v"(v00), "+v"(v01), "+v"(v10), "+v"(v11), "+v"(mwa)::"memory");
+        asm volatile("" : "+v"(t0l), "+v"(t0h), "+v"(t1l), "+v"(t1h), "+v"(t2l), "+v"(t2h), "+v"(t3l), "+v"(t3h)::"memory");
+        const uint32_t mqa = mwa >> (4 * fg);        // bit r: key 4 fg + r of tile 2 kp ; bit 16 + r: of tile 2 kp + 1
+        f32x4 ds[2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(s[r] * c2 - lq);      // raw v_exp_f32: argument <= ~0, underflow -> 0
-        if (!full) {                                   // ragged tail only (uniform branch, kept a branch on purpose)
-          asm volatile("" ::: "memory");
+        for (int hf = 0; hf < 2; ++hf) {
+          const int kt = 2 * kp + hf;
+          f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+          s = H16<F>::mfma(hf ? k10 : k00, qf0, s);
+          s = H16<F>::mfma(hf ? k11 : k01, qf1, s);
+          dp = H16<F>::mfma(hf ? v10 : v00, df0, dp);
+          dp = H16<F>::mfma(hf ? v11 : v01, df1, dp);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) p[r] = (kt * 16 + 4 * fg + r < len && qok) ? p[r] : 0.f;
+          for (int r = 0; r < 4; ++r) {
+            float p = __builtin_amdgcn_exp2f(s[r] * c2 - lq);      // raw v_exp_f32: argument <= ~0, underflow -> 0
+            if (!FULL) p = (kt * 16 + 4 * fg + r < len && qok) ? p : 0.f;
+            float dpm = dp[r];
+            if (DROP) dpm = ((mqa >> (hf * 16 + r)) & 1u) ? dpm * drop.scale : 0.f;
+            ds[hf][r] = p * (dpm - dq_);
+          }
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ds[hf][r] = p[r] * (dp[r] * m4[r] - dq_) * scale;
+        const bf16x8 dsf = pack8<F>(ds[0], ds[1]);
+        dq[0] = H16<F>::mfma(A2_CAT(t0l, t0h), dsf, dq[0]);
+        dq[1] = H16<F>::mfma(A2_CAT(t1l, t1h), dsf, dq[1]);
+        dq[2] = H16<F>::mfma(A2_CAT(t2l, t2h), dsf, dq[2]);
+        dq[3] = H16<F>::mfma(A2_CAT(t3l, t3h), dsf, dq[3]);
       }
-      const bf16x8 dsf = pack8<F>(ds[0], ds[1]);
-      dq[0] = H16<F>::mfma(A2_CAT(t0l, t0h), dsf, dq[0]);
-      dq[1] = H16<F>::mfma(A2_CAT(t1l, t1h), dsf, dq[1]);
-      dq[2] = H16<F>::mfma(A2_CAT(t2l, t2h), dsf, dq[2]);
-      dq[3] = H16<F>::mfma(A2_CAT(t3l, t3h), dsf, dq[3]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dq[dt][e] *= scale;
+      a2_store_tile<F>(dq, patch, patch_addr, dQg + (long)(qt * 16) * H3, H3, len - qt * 16, lane);
     }
-    a2_store_tile<F>(dq, patch, patch_addr, dQg + (long)(qt * 16) * H3, H3, len - qt * 16, lane);
-  }
+  };
+  if (full) phase_a(std::true_type{}); else phase_a(std::false_type{});
 #undef A2_VLOAD
 
   // ---------------- phase B: dK, dV, waves own key tiles, loop over query-tile pairs
-  for (int kt = wave; kt < nkt; kt += 4) {
-    const int key = kt * 16 + fr;
-    bf16x8 kf0, kf1, vf0, vf1;
-    {
-      const uint32_t ak = lds0 + (uint32_t)(OFF_K + kt * 2048), av = lds0 + (uint32_t)(OFF_V + kt * 2048);
-      A2_RD128(kf0, ak + rf_lo, 0); A2_RD128(kf1, ak + rf_hi, 0);
-      if (VG) {
-        const bf16_t* pv = Vg + (long)(key < len ? key : len - 1) * H3 + fg * 8;
-        vf0 = *reinterpret_cast<const bf16x8*>(pv); vf1 = *reinterpret_cast<const bf16x8*>(pv + 32);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf0), "+v"(kf1)::"memory");
-      } else {
-        A2_RD128(vf0, av + rf_lo, 0); A2_RD128(vf1, av + rf_hi, 0);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf0), "+v"(kf1), "+v"(vf0), "+v"(vf1)::"memory");
+  auto phase_b = [&](auto full_c) {
+    constexpr bool FULL = decltype(full_c)::value;
+    for (int kt = wave; kt < nkt; kt += 4) {
+      const int key = kt * 16 + fr;
+      bf16x8 kf0, kf1, vf0, vf1;
+      {
+        const uint32_t ak = lds0 + (uint32_t)(OFF_K + kt * 2048);
+        A2_RD128O(kf0, ak + rf_lo, 0); A2_RD128O(kf1, ak + rf_hi, 0);
+        if (VG) {
+          const bf16_t* pv = Vg + (long)(key < len ? key : len - 1) * H3 + fg * 8;
+          vf0 = *reinterpret_cast<const bf16x8*>(pv); vf1 = *reinterpret_cast<const bf16x8*>(pv + 32);
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf0), "+v"(kf1)::"memory");
+        } else {
+          A2_RD128O(vf0, ak + rf_lo, OFF_V - OFF_K); A2_RD128O(vf1, ak + rf_hi, OFF_V - OFF_K);
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf0), "+v"(kf1), "+v"(vf0), "+v"(vf1)::"memory");
+        }
       }
+      const bool kok = key < len;
+      f32x4 dk[4], dv[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) { dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+      for (int qp = 0; qp < npair; ++qp) {
+        const uint32_t po = (uint32_t)(OFF_Q + qp * 4096);
+        const uint32_t a_lo = lds0 + rf_lo + po, a_hi = lds0 + rf_hi + po;
+        const uint32_t a_t0 = lds0 + tr[0] + po, a_t1 = lds0 + tr[1] + po, a_t2 = lds0 + tr[2] + po, a_t3 = lds0 + tr[3] + po;
+        const uint32_t bl = lds0 + (uint32_t)(VEC + (qp * 32 + 4 * fg) * 4);     // sLse[qp*32 + 4 fg ..], sDel = + NKT*64 B
+        bf16x8 q00, q01, q10, q11, d00, d01, d10, d11;
+        bf16x4 e0l, e0h, e1l, e1h, e2l, e2h, e3l, e3h, u0l, u0h, u1l, u1h, u2l, u2h, u3l, u3h;
+        f32x4 ls0, ls1, de0, de1;
+        uint32_t mb[2][4] = {{~0u, ~0u, ~0u, ~0u}, {~0u, ~0u, ~0u, ~0u}};   // keep-bits of the lane's four query rows, per tile of the pair
+        A2_RD128O(q00, a_lo, 0); A2_RD128O(q01, a_hi, 0); A2_RD128O(q10, a_lo, 2048); A2_RD128O(q11, a_hi, 2048);
+        A2_RD128O(d00, a_lo, OFF_D - OFF_Q); A2_RD128O(d01, a_hi, OFF_D - OFF_Q);
+        A2_RD128O(d10, a_lo, OFF_D - OFF_Q + 2048); A2_RD128O(d11, a_hi, OFF_D - OFF_Q + 2048);
+        A2_RD128O(ls0, bl, 0); A2_RD128O(ls1, bl, 64); A2_RD128O(de0, bl, NKT * 64); A2_RD128O(de1, bl, NKT * 64 + 64);
+        if (DROP) {
+          const uint32_t ma = lds0 + (uint32_t)(MSK + (qp * 32 + 4 * fg) * MROW + kt * 2);
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              asm volatile("ds_read_u16 %0, %1 offset:%2" : "=&v"(mb[hf][r]) : "v"(ma), "n"((hf * 16 + r) * MROW) : "memory");
+        }
+        A2_RDTRO(e0l, a_t0, OFF_D - OFF_Q); A2_RDTRO(e0h, a_t0, OFF_D - OFF_Q + 2048); A2_RDTRO(e1l, a_t1, OFF_D - OFF_Q); A2_RDTRO(e1h, a_t1, OFF_D - OFF_Q + 2048);
+        A2_RDTRO(e2l, a_t2, OFF_D - OFF_Q); A2_RDTRO(e2h, a_t2, OFF_D - OFF_Q + 2048); A2_RDTRO(e3l, a_t3, OFF_D - OFF_Q); A2_RDTRO(e3h, a_t3, OFF_D - OFF_Q + 2048);
+        A2_RDTRO(u0l, a_t0, 0); A2_RDTRO(u0h, a_t0, 2048); A2_RDTRO(u1l, a_t1, 0); A2_RDTRO(u1h, a_t1, 2048);
+        A2_RDTRO(u2l, a_t2, 0); A2_RDTRO(u2h, a_t2, 2048); A2_RDTRO(u3l, a_t3, 0); A2_RDTRO(u3h, a_t3, 2048);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q00), "+v"(q01), "+v"(q10), "+v"(q11), "+v"(d00), "+v"(d01), "+v"(d10), "+v"(d11),
+                     "+v"(ls0), "+v"(ls1), "+v"(de0), "+v"(de1)::"memory");
+        asm volatile("" : "+v"(mb[0][0]), "+v"(mb[0][1]), "+v"(mb[0][2]), "+v"(mb[0][3]), "+v"(mb[1][0]), "+v"(mb[1][1]), "+v"(mb[1][2]), "+v"(mb[1][3])::"memory");
+        asm volatile("" : "+v"(e0l), "+v"(e0h), "+v"(e1l), "+v"(e1h), "+v"(e2l), "+v"(e2h), "+v"(e3l), "+v"(e3h)::"memory");
+        asm volatile("" : "+v"(u0l), "+v"(u0h), "+v"(u1l), "+v"(u1h), "+v"(u2l), "+v"(u2h), "+v"(u3l), "+v"(u3h)::"memory");
+        f32x4 pp[2], ds[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const int qt = 2 * qp + hf;
+          f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+          s = H16<F>::mfma(hf ? q10 : q00, kf0, s);
+          s = H16<F>::mfma(hf ? q11 : q01, kf1, s);
+          dp = H16<F>::mfma(hf ? d10 : d00, vf0, dp);
+          dp = H16<F>::mfma(hf ? d11 : d01, vf1, dp);
+          const f32x4 lsv = hf ? ls1 : ls0, dev = hf ? de1 : de0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float p = __builtin_amdgcn_exp2f(s[r] * c2 - lsv[r]);
+            if (!FULL) p = (qt * 16 + 4 * fg + r < len && kok) ? p : 0.f;
+            float pm = p, dpm = dp[r];
+            if (DROP) {
+              const bool keep = ((mb[hf][r] >> fr) & 1u) != 0;
+              pm = keep ? p * drop.scale : 0.f;
+              dpm = keep ? dpm * drop.scale : 0.f;
+            }
+            pp[hf][r] = pm;
+            ds[hf][r] = p * (dpm - dev[r]);
+          }
+        }
+        const bf16x8 pf = pack8<F>(pp[0], pp[1]);
+        const bf16x8 dsf = pack8<F>(ds[0], ds[1]);
+        dv[0] = H16<F>::mfma(A2_CAT(e0l, e0h), pf, dv[0]);
+        dk[0] = H16<F>::mfma(A2_CAT(u0l, u0h), dsf, dk[0]);
+        dv[1] = H16<F>::mfma(A2_CAT(e1l, e1h), pf, dv[1]);
+        dk[1] = H16<F>::mfma(A2_CAT(u1l, u1h), dsf, dk[1]);
+        dv[2] = H16<F>::mfma(A2_CAT(e2l, e2h), pf, dv[2]);
+        dk[2] = H16<F>::mfma(A2_CAT(u2l, u2h), dsf, dk[2]);
+        dv[3] = H16<F>::mfma(A2_CAT(e3l, e3h), pf, dv[3]);
+        dk[3] = H16<F>::mfma(A2_CAT(u3l, u3h), dsf, dk[3]);
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dk[dt][e] *= scale;
+      bf16_t* dstk = dQg + lay.ws + (long)(kt * 16) * H3;
+      a2_store_tile<F>(dk, patch, patch_addr, dstk, H3, len - kt * 16, lane);
+      a2_store_tile<F>(dv, patch, patch_addr, dstk + lay.ws, H3, len - kt * 16, lane);
     }
-    const bool kok = key < len;
-    f32x4 dk[4], dv[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) { dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    for (int qp = 0; qp < npair; ++qp) {
-      const uint32_t bq = lds0 + (uint32_t)(OFF_Q + qp * 4096), bd = lds0 + (uint32_t)(OFF_D + qp * 4096);
-      const uint32_t bl = lds0 + (uint32_t)(VEC + (qp * 32 + 4 * fg) * 4);     // sLse[qp*32 + 4 fg ..], sDel = + NKT*64 B
-      bf16x8 q00, q01, q10, q11, d00, d01, d10, d11;
-      bf16x4 e0l, e0h, e1l, e1h, e2l, e2h, e3l, e3h, u0l, u0h, u1l, u1h, u2l, u2h, u3l, u3h;
-      f32x4 ls0, ls1, de0, de1;
-      uint32_t mb[2][4] = {{~0u, ~0u, ~0u, ~0u}, {~0u, ~0u, ~0u, ~0u}};   // keep-bits of the lane's four query rows, per tile of the pair
-      A2_RD128(q00, bq + rf_lo, 0); A2_RD128(q01, bq + rf_hi, 0); A2_RD128(q10, bq + rf_lo, 2048); A2_RD128(q11, bq + rf_hi, 2048);
-      A2_RD128(d00, bd + rf_lo, 0); A2_RD128(d01, bd + rf_hi, 0); A2_RD128(d10, bd + rf_lo, 2048); A2_RD128(d11, bd + rf_hi, 2048);
-      asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %5\n\tds_read_b128 %3, %5 offset:64"
-                   : "=&v"(ls0), "=&v"(ls1), "=&v"(de0), "=&v"(de1) : "v"(bl), "v"(bl + (uint32_t)(NKT * 64)) : "memory");
-      if (drop.thr) {
-        const uint32_t ma = lds0 + (uint32_t)(MSK + (qp * 32 + 4 * fg) * MROW + kt * 2);
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            asm volatile("ds_read_u16 %0, %1 offset:%2" : "=&v"(mb[hf][r]) : "v"(ma), "n"((hf * 16 + r) * MROW) : "memory");
-      }
-      A2_RDTR(e0l, bd + tr[0], 0); A2_RDTR(e0h, bd + tr[0], 2048); A2_RDTR(e1l, bd + tr[1], 0); A2_RDTR(e1h, bd + tr[1], 2048);
-      A2_RDTR(e2l, bd + tr[2], 0); A2_RDTR(e2h, bd + tr[2], 2048); A2_RDTR(e3l, bd + tr[3], 0); A2_RDTR(e3h, bd + tr[3], 2048);
-      A2_RDTR(u0l, bq + tr[0], 0); A2_RDTR(u0h, bq + tr[0], 2048); A2_RDTR(u1l, bq + tr[1], 0); A2_RDTR(u1h, bq + tr[1], 2048);
-      A2_RDTR(u2l, bq + tr[2], 0); A2_RDTR(u2h, bq + tr[2], 2048); A2_RDTR(u3l, bq + tr[3], 0); A2_RDTR(u3h, bq + tr[3], 2048);
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q00), "+v"(q01), "+v"(q10), "+v"(q11), "+v"(d00), "+v"(d01), "+v"(d10), "+v"(d11),
-                   "+v"(ls0), "+v"(ls1), "+v"(de0), "+v"(de1)::"memory");
-      asm volatile("" : "+v"(mb[0][0]), "+v"(mb[0][1]), "+v"(mb[0][2]), "+v"(mb[0][3]), "+v"(mb[1][0]), "+v"(mb[1][1]), "+v"(mb[1][2]), "+v"(mb[1][3])::"memory");
-      asm volatile("" : "+v"(e0l), "+v"(e0h), "+v"(e1l), "+v"(e1h), "+v"(e2l), "+v"(e2h), "+v"(e3l), "+v"(e3h)::"memory");
-      asm volatile("" : "+v"(u0l), "+v"(u0h), "+v"(u1l), "+v"(u1h), "+v"(u2l), "+v"(u2h), "+v"(u3l), "+v"(u3h)::"memory");
-      f32x4 pp[2], ds[2];
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const int qt = 2 * qp + hf;
-        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        s = H16<F>::mfma(hf ? q10 : q00, kf0, s);
-        s = H16<F>::mfma(hf ? q11 : q01, kf1, s);
-        dp = H16<F>::mfma(hf ? d10 : d00, vf0, dp);
-        dp = H16<F>::mfma(hf ? d11 : d01, vf1, dp);
-        const f32x4 lsv = hf ? ls1 : ls0, dev = hf ? de1 : de0;
-        float p[4], mm[4] = {1.f, 1.f, 1.f, 1.f};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(s[r] * c2 - lsv[r]);
-        if (!full) {
-          asm volatile("" ::: "memory");
-#pragma unroll
-          for (int r = 0; r < 4; ++r) p[r] = (qt * 16 + 4 * fg + r < len && kok) ? p[r] : 0.f;
-        }
-        if (drop.thr) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) mm[r] = ((mb[hf][r] >> fr) & 1u) ? drop.scale : 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          pp[hf][r] = p[r] * mm[r];
-          ds[hf][r] = p[r] * (dp[r] * mm[r] - dev[r]) * scale;
-        }
-      }
-      const bf16x8 pf = pack8<F>(pp[0], pp[1]);
-      const bf16x8 dsf = pack8<F>(ds[0], ds[1]);
-      dv[0] = H16<F>::mfma(A2_CAT(e0l, e0h), pf, dv[0]);
-      dk[0] = H16<F>::mfma(A2_CAT(u0l, u0h), dsf, dk[0]);
-      dv[1] = H16<F>::mfma(A2_CAT(e1l, e1h), pf, dv[1]);
-      dk[1] = H16<F>::mfma(A2_CAT(u1l, u1h), dsf, dk[1]);
-      dv[2] = H16<F>::mfma(A2_CAT(e2l, e2h), pf, dv[2]);
-      dk[2] = H16<F>::mfma(A2_CAT(u2l, u2h), dsf, dk[2]);
-      dv[3] = H16<F>::mfma(A2_CAT(e3l, e3h), pf, dv[3]);
-      dk[3] = H16<F>::mfma(A2_CAT(u3l, u3h), dsf, dk[3]);
-    }
-    bf16_t* dstk = dQg + lay.ws + (long)(kt * 16) * H3;
-    a2_store_tile<F>(dk, patch, patch_addr, dstk, H3, len - kt * 16, lane);
-    a2_store_tile<F>(dv, patch, patch_addr, dstk + lay.ws, H3, len - kt * 16, lane);
-  }
+  };
+  if (full) phase_b(std::true_type{}); else phase_b(std::false_type{});
 }
 
 // ------------------------------------------------------------------------------------------ backward, long sequences
@@ -1054,10 +1075,17 @@ extern "C" int simx_mha_bwd_hm(simx_stream_t stream, int dtype, int nseq, int he
 #define LB(NKT, VG)                                                                                                  \
   do {                                                                                                               \
     const size_t lds = (size_t)((VG) ? 3 : 4) * NKT * 16 * 128 + 2 * NKT * 16 * sizeof(float) + (size_t)NKT * 16 * NKT * 2 + 4 * 2048; \
-    rc = set_lds(mha_bwd2_h16_kernel<FF, NKT, VG>, lds, "mha_bwd");                                                  \
-    if (rc) return rc;                                                                                               \
-    hipLaunchKernelGGL((mha_bwd2_h16_kernel<FF, NKT, VG>), dim3(nseq * heads), dim3(256), lds, s, (const bf16_t*)qkv, \
-                       (const bf16_t*)ctx, lse, (const bf16_t*)dctx, (bf16_t*)dqkv, cu, heads, T, scale, drop, hm_rows); \
+    if (drop.thr) {                                                                                                  \
+      rc = set_lds(mha_bwd2_h16_kernel<FF, NKT, VG, true>, lds, "mha_bwd");                                          \
+      if (rc) return rc;                                                                                             \
+      hipLaunchKernelGGL((mha_bwd2_h16_kernel<FF, NKT, VG, true>), dim3(nseq * heads), dim3(256), lds, s, (const bf16_t*)qkv, \
+                         (const bf16_t*)ctx, lse, (const bf16_t*)dctx, (bf16_t*)dqkv, cu, heads, T, scale, drop, hm_rows); \
+    } else {                                                                                                         \
+      rc = set_lds(mha_bwd2_h16_kernel<FF, NKT, VG, false>, lds, "mha_bwd");                                         \
+      if (rc) return rc;                                                                                             \
+      hipLaunchKernelGGL((mha_bwd2_h16_kernel<FF, NKT, VG, false>), dim3(nseq * heads), dim3(256), lds, s, (const bf16_t*)qkv, \
+                         (const bf16_t*)ctx, lse, (const bf16_t*)dctx, (bf16_t*)dqkv, cu, heads, T, scale, drop, hm_rows); \
+    }                                                                                                                \
   } while (0)
 #define LB_ALL()                                                                                                     \
   do {                                                                                                               \

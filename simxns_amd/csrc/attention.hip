@@ -73,8 +73,12 @@ __device__ __forceinline__ P* qkv_head(P* base, int heads, int h, int t0, int hm
 }
 
 // ------------------------------------------------------------------------------------------ forward
-template <typename F, int NKT>
-__global__ __launch_bounds__(256) void mha_fwd_h16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+// (ALLT: every one of the NKT key tiles is present -- all-max batches and the cross-encoder's 158 of 160 -- is a copy of the
+// query-tile loop without uniform branches: with them hipcc emitted one key tile at a time, ds_read -> wait -> two MFMAs -> wait
+// -> its share of the row maximum; as ONE basic block the sixteen QK^T MFMAs of a query tile issue back to back.  Dropout on /
+// off is a template parameter for the same reason.)
+template <typename F, int NKT, bool DROP>
+__global__ __launch_bounds__(256, (NKT <= 8 ? 4 : NKT <= 10 ? 3 : NKT <= 16 ? 2 : 1)) void mha_fwd_h16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
                                                            float* __restrict__ lse, const int* __restrict__ cu,
                                                            int heads, int T, float scale, DropCtx drop, int hm_rows) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -109,6 +113,8 @@ __global__ __launch_bounds__(256) void mha_fwd_h16_kernel(const bf16_t* __restri
     for (int dt = 0; dt < 4; ++dt) vtr[dt] = (uint32_t)(rr * 128 + (((dt * 2 + tx) ^ tsw) << 4) + (fr & 1) * 8);
   }
 
+  auto tiles = [&](auto allt_c) {
+  constexpr bool ALLT = decltype(allt_c)::value;
   for (int qt = wave; qt < nkt; qt += 4) {
     const int q = qt * 16 + fr;
     const int qc = q < len ? q : len - 1;
@@ -119,14 +125,14 @@ __global__ __launch_bounds__(256) void mha_fwd_h16_kernel(const bf16_t* __restri
     float m = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-      if (kt < nkt) {
+      if (ALLT || kt < nkt) {
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
         a = H16<F>::mfma(lds_row_frag(sK, kt * 16 + fr, fg), qf[0], a);
         a = H16<F>::mfma(lds_row_frag(sK, kt * 16 + fr, 4 + fg), qf[1], a);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = kt * 16 + 4 * fg + r;
-          a[r] = key < len ? a[r] : -INFINITY;
+          if (!ALLT || kt == NKT - 1) a[r] = key < len ? a[r] : -INFINITY;      // (all tiles present: only the last can be ragged)
           m = fmaxf(m, a[r]);
         }
         s[kt] = a;
@@ -148,11 +154,11 @@ __global__ __launch_bounds__(256) void mha_fwd_h16_kernel(const bf16_t* __restri
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
-    if (drop.thr) {                              // dropout on the probabilities (the normaliser stays unmasked)
+    if (DROP) {                                  // dropout on the probabilities (the normaliser stays unmasked)
       const uint32_t drow = (uint32_t)(h * T + t0 + q);
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt)
-        if (kt < nkt) {
+        if (ALLT || kt < nkt) {
           float m4[4];
           drop_mult4(drop, drow, (uint32_t)(kt * 16 + 4 * fg), m4);
           s[kt][0] *= m4[0]; s[kt][1] *= m4[1]; s[kt][2] *= m4[2]; s[kt][3] *= m4[3];
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(256) void mha_fwd_h16_kernel(const bf16_t* __restri
     // first version left the wave parked ~40 % of its cycles); addresses = tile + pair*4096 + lane constant (+2048)
 #pragma unroll
     for (int kb = 0; kb < NKT / 2; kb += 2) {
-      if (2 * kb < nkt) {
+      if (ALLT || 2 * kb < nkt) {
         const uint32_t b0 = sV_addr + (uint32_t)(kb * 4096);
         bf16x4 a0l, a0h, a1l, a1h, a2l, a2h, a3l, a3h, c0l, c0h, c1l, c1h, c2l, c2h, c3l, c3h;
         F2_RDTR(a0l, b0 + vtr[0], 0); F2_RDTR(a0h, b0 + vtr[0], 2048); F2_RDTR(a1l, b0 + vtr[1], 0); F2_RDTR(a1h, b0 + vtr[1], 2048);
@@ -174,16 +180,20 @@ __global__ __launch_bounds__(256) void mha_fwd_h16_kernel(const bf16_t* __restri
         if (kb + 1 < NKT / 2) {                       // compile-time: the second pair's slots exist in the LDS tile
           F2_RDTR(c0l, b0 + vtr[0], 4096); F2_RDTR(c0h, b0 + vtr[0], 6144); F2_RDTR(c1l, b0 + vtr[1], 4096); F2_RDTR(c1h, b0 + vtr[1], 6144);
           F2_RDTR(c2l, b0 + vtr[2], 4096); F2_RDTR(c2h, b0 + vtr[2], 6144); F2_RDTR(c3l, b0 + vtr[3], 4096); F2_RDTR(c3h, b0 + vtr[3], 6144);
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c0l), "+v"(c0h), "+v"(c1l), "+v"(c1h), "+v"(c2l), "+v"(c2h), "+v"(c3l), "+v"(c3h)::"memory");
+          // (ONE wait names every register an asm read above is still filling: a register the wait does not name may be copied
+          // by the compiler before it)
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0l), "+v"(a0h), "+v"(a1l), "+v"(a1h), "+v"(a2l), "+v"(a2h), "+v"(a3l), "+v"(a3h),
+                       "+v"(c0l), "+v"(c0h), "+v"(c1l), "+v"(c1h), "+v"(c2l), "+v"(c2h), "+v"(c3l), "+v"(c3h)::"memory");
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0l), "+v"(a0h), "+v"(a1l), "+v"(a1h), "+v"(a2l), "+v"(a2h), "+v"(a3l), "+v"(a3h)::"memory");
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0l), "+v"(a0h), "+v"(a1l), "+v"(a1h), "+v"(a2l), "+v"(a2h), "+v"(a3l), "+v"(a3h)::"memory");
         const bf16x8 pf = pack8<F>(s[2 * kb], s[2 * kb + 1]);
         o[0] = H16<F>::mfma(F2_CAT(a0l, a0h), pf, o[0]);
         o[1] = H16<F>::mfma(F2_CAT(a1l, a1h), pf, o[1]);
         o[2] = H16<F>::mfma(F2_CAT(a2l, a2h), pf, o[2]);
         o[3] = H16<F>::mfma(F2_CAT(a3l, a3h), pf, o[3]);
         if (kb + 1 < NKT / 2) {
-          if (2 * (kb + 1) < nkt) {                   // rows past the padded length are uninitialised LDS: skip, never multiply
+          if (ALLT || 2 * (kb + 1) < nkt) {           // rows past the padded length are uninitialised LDS: skip, never multiply
             const bf16x8 pg = pack8<F>(s[2 * kb + 2], s[2 * kb + 3]);
             o[0] = H16<F>::mfma(F2_CAT(c0l, c0h), pg, o[0]);
             o[1] = H16<F>::mfma(F2_CAT(c1l, c1h), pg, o[1]);
@@ -203,6 +213,8 @@ __global__ __launch_bounds__(256) void mha_fwd_h16_kernel(const bf16_t* __restri
       if (fg == 0) lse[(long)h * T + t0 + q] = m * scale + logf(sum);
     }
   }
+  };
+  if (nkt == NKT) tiles(std::true_type{}); else tiles(std::false_type{});
 }
 
 // ------------------------------------------------------------------------------------------ backward
@@ -292,9 +304,8 @@ __global__ __launch_bounds__(256) void mha_bwd2_h16_kernel(const bf16_t* __restr
   constexpr int TILE = NKT * 16 * 128;
   constexpr int OFF_Q = 0, OFF_D = TILE, OFF_K = 2 * TILE, OFF_V = 3 * TILE;      // (the V tile is last: absent with VG)
   constexpr int VEC = (VG ? 3 : 4) * TILE;           // lse[NKT*16], delta[NKT*16] (f32)
-  constexpr int MSK = VEC + 2 * NKT * 16 * 4;        // dropout bits: one row of NKT * 2 bytes per query, 16 key bits per key tile
-  constexpr int MROW = NKT * 2;
-  constexpr int PATCH = MSK + NKT * 16 * MROW;
+  constexpr int MSK = VEC + 2 * NKT * 16 * 4;        // dropout bits [key tile][query]: 16 bits = the keys of the tile
+  constexpr int PATCH = MSK + NKT * 16 * NKT * 2;
   float* sLse = reinterpret_cast<float*>(smem + VEC);
   float* sDel = sLse + NKT * 16;
   char* patch = smem + PATCH + wave * 2048;
@@ -334,7 +345,7 @@ __global__ __launch_bounds__(256) void mha_bwd2_h16_kernel(const bf16_t* __restr
           w |= ((hsh & 0xFFFFu) >= drop.thr ? 1u : 0u) << (2 * j);
           w |= ((hsh >> 16) >= drop.thr ? 2u : 0u) << (2 * j);
         }
-        *reinterpret_cast<unsigned short*>(smem + MSK + q * MROW + kt * 2) = (unsigned short)w;
+        *reinterpret_cast<unsigned short*>(smem + MSK + (kt * NKT * 16 + q) * 2) = (unsigned short)w;
       }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -397,12 +408,16 @@ __global__ __launch_bounds__(256) void mha_bwd2_h16_kernel(const bf16_t* __restr
         }
         A2_RDTRO(t0l, a_t0, 0); A2_RDTRO(t0h, a_t0, 2048); A2_RDTRO(t1l, a_t1, 0); A2_RDTRO(t1h, a_t1, 2048);
         A2_RDTRO(t2l, a_t2, 0); A2_RDTRO(t2h, a_t2, 2048); A2_RDTRO(t3l, a_t3, 0); A2_RDTRO(t3h, a_t3, 2048);
-        uint32_t mwa = 0xFFFFFFFFu;
-        if (DROP) asm volatile("ds_read_b32 %0, %1" : "=&v"(mwa) : "v"(lds0 + (uint32_t)(MSK + q * MROW + kp * 4)) : "memory");
-        if (VG) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(k00), "+v"(k01), "+v"(k10), "+v"(k11), "+v"(mwa)::"memory");
-        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(k00), "+v"(k01), "+v"(k10), "+v"(k11), "+v"(v00), "+v"(v01), "+v"(v10), "+v"(v11), "+v"(mwa)::"memory");
-        asm volatile("" : "+v"(t0l), "+v"(t0h), "+v"(t1l), "+v"(t1h), "+v"(t2l), "+v"(t2h), "+v"(t3l), "+v"(t3h)::"memory");
-        const uint32_t mqa = mwa >> (4 * fg);        // bit r: key 4 fg + r of tile 2 kp ; bit 16 + r: of tile 2 kp + 1
+        uint32_t mwa0 = 0xFFFFu, mwa1 = 0xFFFFu;
+        if (DROP) {
+          const uint32_t ma = lds0 + (uint32_t)(MSK + (kp * 2 * NKT * 16 + q) * 2);
+          asm volatile("ds_read_u16 %0, %2\n\tds_read_u16 %1, %2 offset:%3" : "=&v"(mwa0), "=&v"(mwa1) : "v"(ma), "n"(NKT * 16 * 2) : "memory");
+        }
+        // (ONE wait names every register an asm read above is still filling: one it does not name may be copied before it)
+        if (VG) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(k00), "+v"(k01), "+v"(k10), "+v"(k11), "+v"(mwa0), "+v"(mwa1), "+v"(t0l), "+v"(t0h), "+v"(t1l), "+v"(t1h), "+v"(t2l), "+v"(t2h), "+v"(t3l), "+v"(t3h)::"memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(k00), "+v"(k01), "+v"(k10), "+v"(k11), "+v"(v00), "+v"(v01), "+v"(v10), "+v"(v11), "+v"(mwa0), "+v"(mwa1),
+                          "+v"(t0l), "+v"(t0h), "+v"(t1l), "+v"(t1h), "+v"(t2l), "+v"(t2h), "+v"(t3l), "+v"(t3h)::"memory");
+        const uint32_t mqa = ((mwa0 & 0xFFFFu) | (mwa1 << 16)) >> (4 * fg);      // bit r: key 4 fg + r of tile 2 kp ; bit 16 + r: of tile 2 kp + 1
         f32x4 ds[2];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
@@ -467,28 +482,24 @@ __global__ __launch_bounds__(256) void mha_bwd2_h16_kernel(const bf16_t* __restr
         bf16x8 q00, q01, q10, q11, d00, d01, d10, d11;
         bf16x4 e0l, e0h, e1l, e1h, e2l, e2h, e3l, e3h, u0l, u0h, u1l, u1h, u2l, u2h, u3l, u3h;
         f32x4 ls0, ls1, de0, de1;
-        uint32_t mb[2][4] = {{~0u, ~0u, ~0u, ~0u}, {~0u, ~0u, ~0u, ~0u}};   // keep-bits of the lane's four query rows, per tile of the pair
+        uint2 mb[2] = {make_uint2(~0u, ~0u), make_uint2(~0u, ~0u)};          // keep-bits of the lane's four query rows (16 bits each), per tile of the pair
         A2_RD128O(q00, a_lo, 0); A2_RD128O(q01, a_hi, 0); A2_RD128O(q10, a_lo, 2048); A2_RD128O(q11, a_hi, 2048);
         A2_RD128O(d00, a_lo, OFF_D - OFF_Q); A2_RD128O(d01, a_hi, OFF_D - OFF_Q);
         A2_RD128O(d10, a_lo, OFF_D - OFF_Q + 2048); A2_RD128O(d11, a_hi, OFF_D - OFF_Q + 2048);
         A2_RD128O(ls0, bl, 0); A2_RD128O(ls1, bl, 64); A2_RD128O(de0, bl, NKT * 64); A2_RD128O(de1, bl, NKT * 64 + 64);
         if (DROP) {
-          const uint32_t ma = lds0 + (uint32_t)(MSK + (qp * 32 + 4 * fg) * MROW + kt * 2);
-#pragma unroll
-          for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              asm volatile("ds_read_u16 %0, %1 offset:%2" : "=&v"(mb[hf][r]) : "v"(ma), "n"((hf * 16 + r) * MROW) : "memory");
+          const uint32_t ma = lds0 + (uint32_t)(MSK + (kt * NKT * 16 + qp * 32 + 4 * fg) * 2);
+          asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:32" : "=&v"(mb[0]), "=&v"(mb[1]) : "v"(ma) : "memory");
         }
         A2_RDTRO(e0l, a_t0, OFF_D - OFF_Q); A2_RDTRO(e0h, a_t0, OFF_D - OFF_Q + 2048); A2_RDTRO(e1l, a_t1, OFF_D - OFF_Q); A2_RDTRO(e1h, a_t1, OFF_D - OFF_Q + 2048);
         A2_RDTRO(e2l, a_t2, OFF_D - OFF_Q); A2_RDTRO(e2h, a_t2, OFF_D - OFF_Q + 2048); A2_RDTRO(e3l, a_t3, OFF_D - OFF_Q); A2_RDTRO(e3h, a_t3, OFF_D - OFF_Q + 2048);
         A2_RDTRO(u0l, a_t0, 0); A2_RDTRO(u0h, a_t0, 2048); A2_RDTRO(u1l, a_t1, 0); A2_RDTRO(u1h, a_t1, 2048);
         A2_RDTRO(u2l, a_t2, 0); A2_RDTRO(u2h, a_t2, 2048); A2_RDTRO(u3l, a_t3, 0); A2_RDTRO(u3h, a_t3, 2048);
+        // (ONE wait names all 30 registers in flight -- the operand limit of an asm statement)
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q00), "+v"(q01), "+v"(q10), "+v"(q11), "+v"(d00), "+v"(d01), "+v"(d10), "+v"(d11),
-                     "+v"(ls0), "+v"(ls1), "+v"(de0), "+v"(de1)::"memory");
-        asm volatile("" : "+v"(mb[0][0]), "+v"(mb[0][1]), "+v"(mb[0][2]), "+v"(mb[0][3]), "+v"(mb[1][0]), "+v"(mb[1][1]), "+v"(mb[1][2]), "+v"(mb[1][3])::"memory");
-        asm volatile("" : "+v"(e0l), "+v"(e0h), "+v"(e1l), "+v"(e1h), "+v"(e2l), "+v"(e2h), "+v"(e3l), "+v"(e3h)::"memory");
-        asm volatile("" : "+v"(u0l), "+v"(u0h), "+v"(u1l), "+v"(u1h), "+v"(u2l), "+v"(u2h), "+v"(u3l), "+v"(u3h)::"memory");
+                     "+v"(ls0), "+v"(ls1), "+v"(de0), "+v"(de1), "+v"(mb[0]), "+v"(mb[1]),
+                     "+v"(e0l), "+v"(e0h), "+v"(e1l), "+v"(e1h), "+v"(e2l), "+v"(e2h), "+v"(e3l), "+v"(e3h),
+                     "+v"(u0l), "+v"(u0h), "+v"(u1l), "+v"(u1h), "+v"(u2l), "+v"(u2h), "+v"(u3l), "+v"(u3h)::"memory");
         f32x4 pp[2], ds[2];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
@@ -505,7 +516,8 @@ __global__ __launch_bounds__(256) void mha_bwd2_h16_kernel(const bf16_t* __restr
             if (!FULL) p = (qt * 16 + 4 * fg + r < len && kok) ? p : 0.f;
             float pm = p, dpm = dp[r];
             if (DROP) {
-              const bool keep = ((mb[hf][r] >> fr) & 1u) != 0;
+              const uint32_t mword = r < 2 ? mb[hf].x : mb[hf].y;
+              const bool keep = ((mword >> ((r & 1) * 16 + fr)) & 1u) != 0;
               pm = keep ? p * drop.scale : 0.f;
               dpm = keep ? dpm * drop.scale : 0.f;
             }
@@ -660,8 +672,8 @@ __global__ __launch_bounds__(256, 1) void mha_bwd_long_kernel(const bf16_t* __re
           A2_RD128(v00, bv + rf_lo, 0); A2_RD128(v01, bv + rf_hi, 0); A2_RD128(v10, bv + rf_lo, 2048); A2_RD128(v11, bv + rf_hi, 2048);
           A2_RDTR(t0l, bk + tr[0], 0); A2_RDTR(t0h, bk + tr[0], 2048); A2_RDTR(t1l, bk + tr[1], 0); A2_RDTR(t1h, bk + tr[1], 2048);
           A2_RDTR(t2l, bk + tr[2], 0); A2_RDTR(t2h, bk + tr[2], 2048); A2_RDTR(t3l, bk + tr[3], 0); A2_RDTR(t3h, bk + tr[3], 2048);
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(k00), "+v"(k01), "+v"(k10), "+v"(k11), "+v"(v00), "+v"(v01), "+v"(v10), "+v"(v11)::"memory");
-          asm volatile("" : "+v"(t0l), "+v"(t0h), "+v"(t1l), "+v"(t1h), "+v"(t2l), "+v"(t2h), "+v"(t3l), "+v"(t3h)::"memory");
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(k00), "+v"(k01), "+v"(k10), "+v"(k11), "+v"(v00), "+v"(v01), "+v"(v10), "+v"(v11),
+                       "+v"(t0l), "+v"(t0h), "+v"(t1l), "+v"(t1h), "+v"(t2l), "+v"(t2h), "+v"(t3l), "+v"(t3h)::"memory");
           f32x4 ds[2];
 #pragma unroll
           for (int hf = 0; hf < 2; ++hf) {
@@ -743,9 +755,9 @@ __global__ __launch_bounds__(256, 1) void mha_bwd_long_kernel(const bf16_t* __re
           A2_RDTR(u0l, bq + tr[0], 0); A2_RDTR(u0h, bq + tr[0], 2048); A2_RDTR(u1l, bq + tr[1], 0); A2_RDTR(u1h, bq + tr[1], 2048);
           A2_RDTR(u2l, bq + tr[2], 0); A2_RDTR(u2h, bq + tr[2], 2048); A2_RDTR(u3l, bq + tr[3], 0); A2_RDTR(u3h, bq + tr[3], 2048);
           asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q00), "+v"(q01), "+v"(q10), "+v"(q11), "+v"(d00), "+v"(d01), "+v"(d10), "+v"(d11),
-                       "+v"(ls0), "+v"(ls1), "+v"(de0), "+v"(de1)::"memory");
-          asm volatile("" : "+v"(e0l), "+v"(e0h), "+v"(e1l), "+v"(e1h), "+v"(e2l), "+v"(e2h), "+v"(e3l), "+v"(e3h)::"memory");
-          asm volatile("" : "+v"(u0l), "+v"(u0h), "+v"(u1l), "+v"(u1h), "+v"(u2l), "+v"(u2h), "+v"(u3l), "+v"(u3h)::"memory");
+                       "+v"(ls0), "+v"(ls1), "+v"(de0), "+v"(de1),
+                       "+v"(e0l), "+v"(e0h), "+v"(e1l), "+v"(e1h), "+v"(e2l), "+v"(e2h), "+v"(e3l), "+v"(e3h),
+                       "+v"(u0l), "+v"(u0h), "+v"(u1l), "+v"(u1h), "+v"(u2l), "+v"(u2h), "+v"(u3l), "+v"(u3h)::"memory");
           f32x4 pp[2], ds[2];
 #pragma unroll
           for (int hf = 0; hf < 2; ++hf) {
@@ -1019,10 +1031,17 @@ extern "C" int simx_mha_fwd_hm(simx_stream_t stream, int dtype, int nseq, int he
 #define LF(NKT)                                                                                                      \
   do {                                                                                                               \
     const size_t lds = (size_t)2 * NKT * 16 * 128;                                                                   \
-    rc = set_lds(mha_fwd_h16_kernel<FF, NKT>, lds, "mha_fwd");                                                       \
-    if (rc) return rc;                                                                                               \
-    hipLaunchKernelGGL((mha_fwd_h16_kernel<FF, NKT>), dim3(nseq * heads), dim3(256), lds, s, (const bf16_t*)qkv,     \
-                       (bf16_t*)ctx, lse, cu, heads, T, scale, drop, hm_rows);                                       \
+    if (drop.thr) {                                                                                                  \
+      rc = set_lds(mha_fwd_h16_kernel<FF, NKT, true>, lds, "mha_fwd");                                               \
+      if (rc) return rc;                                                                                             \
+      hipLaunchKernelGGL((mha_fwd_h16_kernel<FF, NKT, true>), dim3(nseq * heads), dim3(256), lds, s, (const bf16_t*)qkv, \
+                         (bf16_t*)ctx, lse, cu, heads, T, scale, drop, hm_rows);                                     \
+    } else {                                                                                                         \
+      rc = set_lds(mha_fwd_h16_kernel<FF, NKT, false>, lds, "mha_fwd");                                              \
+      if (rc) return rc;                                                                                             \
+      hipLaunchKernelGGL((mha_fwd_h16_kernel<FF, NKT, false>), dim3(nseq * heads), dim3(256), lds, s, (const bf16_t*)qkv, \
+                         (bf16_t*)ctx, lse, cu, heads, T, scale, drop, hm_rows);                                     \
+    }                                                                                                                \
   } while (0)
 #define LF_ALL()                                                                                                     \
   do {                                                                                                               \

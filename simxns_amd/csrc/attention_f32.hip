@@ -71,7 +71,7 @@ __device__ __forceinline__ void af_store_t_planes(const f32x16 (&o)[2], float mu
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const float a = o[dt][4 * g] * mul, b = o[dt][4 * g + 1] * mul, c = o[dt][4 * g + 2] * mul, d = o[dt][4 * g + 3] * mul;
+      const float a = f32_pin(o[dt][4 * g] * mul), b = f32_pin(o[dt][4 * g + 1] * mul), c = f32_pin(o[dt][4 * g + 2] * mul), d = f32_pin(o[dt][4 * g + 3] * mul);
       const uint32_t h0 = H16<F>::pack2(a, b), h1 = H16<F>::pack2(c, d);
       const uint32_t l0 = H16<F>::pack2(a - H16<F>::lo(h0), b - H16<F>::hi(h0)), l1 = H16<F>::pack2(c - H16<F>::lo(h1), d - H16<F>::hi(h1));
       bf16_t* q = dst + dt * 32 + 8 * g + 4 * half;

@@ -15,6 +15,7 @@
 //     stage.  No loss scale, no overflow: |dS| <= 64 max|v| after the scaling.
 // Kernel structure = attention.hip's (scores transposed so that a softmax row is a lane column, P / dS feed the second product
 // from registers, token-contracted operands by ds_read_b64_tr_b16), with hi / lo tiles and three MFMAs per product.
+#include <type_traits>
 #include "common.h"
 #include "prof.h"
 
@@ -50,11 +51,12 @@ __device__ __forceinline__ f32x4 x3a_mfma3(const bf16x8& ah, const bf16x8& al, c
 __device__ __forceinline__ void x3a_split8(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const f16_t ha = (f16_t)a[r], hb = (f16_t)b[r];
+    const float ar = f32_pin(a[r]), br = f32_pin(b[r]);
+    const f16_t ha = (f16_t)ar, hb = (f16_t)br;
     hi[r] = __builtin_bit_cast(short, ha);
     hi[4 + r] = __builtin_bit_cast(short, hb);
-    lo[r] = __builtin_bit_cast(short, (f16_t)(a[r] - (float)ha));
-    lo[4 + r] = __builtin_bit_cast(short, (f16_t)(b[r] - (float)hb));
+    lo[r] = __builtin_bit_cast(short, (f16_t)(ar - (float)ha));
+    lo[4 + r] = __builtin_bit_cast(short, (f16_t)(br - (float)hb));
   }
 }
 #define X3A_RDTR(DST, ADDR, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #OFF : "=&v"(DST) : "v"(ADDR) : "memory")
@@ -62,7 +64,9 @@ __device__ __forceinline__ void x3a_split8(const f32x4& a, const f32x4& b, bf16x
 
 // ------------------------------------------------------------------------------------------ forward
 // LDS: Khi | Klo | Vhi | Vlo, each NKT * 16 rows x 128 B.  One workgroup (4 waves) per (sequence, head).
-template <int NKT>
+// (DROP and ALLT -- every one of the NKT key tiles present -- are compile-time: the query-tile loop then has no uniform branch
+// inside and is scheduled as one block, see mha_fwd_h16_kernel)
+template <int NKT, bool DROP>
 __global__ __launch_bounds__(256, 2) void mha_fwd_x3_kernel(const bf16_t* __restrict__ qkv, long qps, bf16_t* __restrict__ ctx, long cps,
                                                          float* __restrict__ lse, const int* __restrict__ cu, int heads, int T, float scale,
                                                          DropCtx drop) {
@@ -98,6 +102,8 @@ __global__ __launch_bounds__(256, 2) void mha_fwd_x3_kernel(const bf16_t* __rest
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) vtr[dt] = (uint32_t)(rr * 128 + (((dt * 2 + tx) ^ tsw) << 4) + (fr & 1) * 8);
   }
+  auto tiles = [&](auto allt_c) {
+  constexpr bool ALLT = decltype(allt_c)::value;
   for (int qt = wave; qt < nkt; qt += 4) {
     const int q = qt * 16 + fr;
     const int qc = q < len ? q : len - 1;
@@ -110,14 +116,14 @@ __global__ __launch_bounds__(256, 2) void mha_fwd_x3_kernel(const bf16_t* __rest
     float m = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-      if (kt < nkt) {
+      if (ALLT || kt < nkt) {
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
         a = x3a_mfma3(x3a_row_frag(sKh, kt * 16 + fr, fg), x3a_row_frag(sKl, kt * 16 + fr, fg), qh[0], ql[0], a);
         a = x3a_mfma3(x3a_row_frag(sKh, kt * 16 + fr, 4 + fg), x3a_row_frag(sKl, kt * 16 + fr, 4 + fg), qh[1], ql[1], a);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = kt * 16 + 4 * fg + r;
-          a[r] = key < len ? a[r] : -INFINITY;
+          if (!ALLT || kt == NKT - 1) a[r] = key < len ? a[r] : -INFINITY;      // (all tiles present: only the last can be ragged)
           m = fmaxf(m, a[r]);
         }
         s[kt] = a;
@@ -139,11 +145,11 @@ __global__ __launch_bounds__(256, 2) void mha_fwd_x3_kernel(const bf16_t* __rest
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
-    if (drop.thr) {
+    if (DROP) {
       const uint32_t drow = (uint32_t)(h * T + t0 + q);
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt)
-        if (kt < nkt) {
+        if (ALLT || kt < nkt) {
           float m4[4];
           drop_mult4(drop, drow, (uint32_t)(kt * 16 + 4 * fg), m4);
           s[kt][0] *= m4[0]; s[kt][1] *= m4[1]; s[kt][2] *= m4[2]; s[kt][3] *= m4[3];
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void mha_fwd_x3_kernel(const bf16_t* __rest
     for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < NKT / 2; ++kb) {
-      if (2 * kb < nkt) {                            // (rows past the padded length are uninitialised LDS: never multiplied)
+      if (ALLT || 2 * kb < nkt) {                    // (rows past the padded length are uninitialised LDS: never multiplied)
         const uint32_t b0 = sV_addr + (uint32_t)(kb * 4096);
         bf16x4 h0l, h0h, h1l, h1h, h2l, h2h, h3l, h3h, l0l, l0h, l1l, l1h, l2l, l2h, l3l, l3h;
         X3A_RDTR(h0l, b0 + vtr[0], 0); X3A_RDTR(h0h, b0 + vtr[0], 2048); X3A_RDTR(h1l, b0 + vtr[1], 0); X3A_RDTR(h1h, b0 + vtr[1], 2048);
@@ -162,8 +168,8 @@ __global__ __launch_bounds__(256, 2) void mha_fwd_x3_kernel(const bf16_t* __rest
         const uint32_t b1 = b0 + (uint32_t)TILE;
         X3A_RDTR(l0l, b1 + vtr[0], 0); X3A_RDTR(l0h, b1 + vtr[0], 2048); X3A_RDTR(l1l, b1 + vtr[1], 0); X3A_RDTR(l1h, b1 + vtr[1], 2048);
         X3A_RDTR(l2l, b1 + vtr[2], 0); X3A_RDTR(l2h, b1 + vtr[2], 2048); X3A_RDTR(l3l, b1 + vtr[3], 0); X3A_RDTR(l3h, b1 + vtr[3], 2048);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0l), "+v"(h0h), "+v"(h1l), "+v"(h1h), "+v"(h2l), "+v"(h2h), "+v"(h3l), "+v"(h3h)::"memory");
-        asm volatile("" : "+v"(l0l), "+v"(l0h), "+v"(l1l), "+v"(l1h), "+v"(l2l), "+v"(l2h), "+v"(l3l), "+v"(l3h)::"memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0l), "+v"(h0h), "+v"(h1l), "+v"(h1h), "+v"(h2l), "+v"(h2h), "+v"(h3l), "+v"(h3h),
+                     "+v"(l0l), "+v"(l0h), "+v"(l1l), "+v"(l1h), "+v"(l2l), "+v"(l2h), "+v"(l3l), "+v"(l3h)::"memory");   // (one wait names every register in flight)
         bf16x8 ph, pl;
         x3a_split8(s[2 * kb], s[2 * kb + 1], ph, pl);
         o[0] = x3a_mfma3(X3A_CAT(h0l, h0h), X3A_CAT(l0l, l0h), ph, pl, o[0]);
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void mha_fwd_x3_kernel(const bf16_t* __rest
       bf16_t* dst = ctx + (long)(t0 + q) * H + h * 64 + 4 * fg;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const float v0 = o[dt][0] * inv, v1 = o[dt][1] * inv, v2 = o[dt][2] * inv, v3 = o[dt][3] * inv;
+        const float v0 = f32_pin(o[dt][0] * inv), v1 = f32_pin(o[dt][1] * inv), v2 = f32_pin(o[dt][2] * inv), v3 = f32_pin(o[dt][3] * inv);
         const uint32_t h0 = pack2h(v0, v1), h1 = pack2h(v2, v3);
         const uint32_t l0 = pack2h(v0 - H16<f16_t>::lo(h0), v1 - H16<f16_t>::hi(h0)), l1 = pack2h(v2 - H16<f16_t>::lo(h1), v3 - H16<f16_t>::hi(h1));
         *reinterpret_cast<uint2*>(dst + dt * 16) = make_uint2(h0, h1);
@@ -185,6 +191,8 @@ __global__ __launch_bounds__(256, 2) void mha_fwd_x3_kernel(const bf16_t* __rest
       if (fg == 0) lse[(long)h * T + t0 + q] = m * scale + (logf(sum) - 10.0f * 0.69314718055994531f);
     }
   }
+  };
+  if (nkt == NKT) tiles(std::true_type{}); else tiles(std::false_type{});
 }
 
 // ------------------------------------------------------------------------------------------ backward
@@ -225,9 +233,10 @@ __device__ __forceinline__ void x3a_ld8_planes(const bf16_t* __restrict__ p, lon
 __device__ __forceinline__ void x3a_split_frag(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const f16_t h = (f16_t)v[e];
+    const float ve = f32_pin(v[e]);
+    const f16_t h = (f16_t)ve;
     hi[e] = __builtin_bit_cast(short, h);
-    lo[e] = __builtin_bit_cast(short, (f16_t)(v[e] - (float)h));
+    lo[e] = __builtin_bit_cast(short, (f16_t)(ve - (float)h));
   }
 }
 // a wave's 16 x 64 accumulator tile (lane = row fr, 4 columns dt * 16 + 4 fg) x mul as a bf16 plane pair, rows < nrows
@@ -237,7 +246,7 @@ __device__ __forceinline__ void x3a_store_planes_bf16(const f32x4 (&acc)[4], flo
   bf16_t* d = dst + (long)fr * ld + 4 * fg;
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) {
-    const float v0 = acc[dt][0] * mul, v1 = acc[dt][1] * mul, v2 = acc[dt][2] * mul, v3 = acc[dt][3] * mul;
+    const float v0 = f32_pin(acc[dt][0] * mul), v1 = f32_pin(acc[dt][1] * mul), v2 = f32_pin(acc[dt][2] * mul), v3 = f32_pin(acc[dt][3] * mul);
     const uint32_t h0 = pack2bf(v0, v1), h1 = pack2bf(v2, v3);
     const uint32_t l0 = pack2bf(v0 - H16<bf16_t>::lo(h0), v1 - H16<bf16_t>::hi(h0)), l1 = pack2bf(v2 - H16<bf16_t>::lo(h1), v3 - H16<bf16_t>::hi(h1));
     *reinterpret_cast<uint2*>(d + dt * 16) = make_uint2(h0, h1);
@@ -267,7 +276,7 @@ __device__ __forceinline__ void x3a_colsum_flush(const f32x4 (&cs)[4], float mul
 
 // dQ: K and V pairs resident (LDS: Khi | Klo | Vhi | Vlo), waves own 16-query tiles (Q pair fragments and the scaled dO pair
 // fragments in registers) and walk the key-tile pairs.
-template <int NKT>
+template <int NKT, bool DROP>
 __global__ __launch_bounds__(256, 2) void mha_bwd_dq_x3_kernel(const bf16_t* __restrict__ qkv, long qps, const bf16_t* __restrict__ O, long ops,
                                                                const float* __restrict__ lse, const float* __restrict__ dO,
                                                                bf16_t* __restrict__ dqkv, long dps, const int* __restrict__ cu, int heads, int T,
@@ -342,25 +351,24 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_dq_x3_kernel(const bf16_t* __r
     for (int kp = 0; kp < (nkt2 >> 1); ++kp) {
       const uint32_t bkh = lds0 + (uint32_t)(kp * 4096), bkl = bkh + TILE, bvh = bkh + 2 * TILE, bvl = bkh + 3 * TILE;
       f32x4 ds[2];
+      // both key tiles' row fragments in flight, one wait (the pair iteration is one basic block: DROP is compile-time)
+      bf16x8 kh[2][2], kl[2][2], vh[2][2], vl[2][2];
+      X3A_RD128(kh[0][0], bkh + rf_lo, 0); X3A_RD128(kh[0][1], bkh + rf_hi, 0); X3A_RD128(kl[0][0], bkl + rf_lo, 0); X3A_RD128(kl[0][1], bkl + rf_hi, 0);
+      X3A_RD128(vh[0][0], bvh + rf_lo, 0); X3A_RD128(vh[0][1], bvh + rf_hi, 0); X3A_RD128(vl[0][0], bvl + rf_lo, 0); X3A_RD128(vl[0][1], bvl + rf_hi, 0);
+      X3A_RD128(kh[1][0], bkh + rf_lo, 2048); X3A_RD128(kh[1][1], bkh + rf_hi, 2048); X3A_RD128(kl[1][0], bkl + rf_lo, 2048); X3A_RD128(kl[1][1], bkl + rf_hi, 2048);
+      X3A_RD128(vh[1][0], bvh + rf_lo, 2048); X3A_RD128(vh[1][1], bvh + rf_hi, 2048); X3A_RD128(vl[1][0], bvl + rf_lo, 2048); X3A_RD128(vl[1][1], bvl + rf_hi, 2048);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kh[0][0]), "+v"(kh[0][1]), "+v"(kl[0][0]), "+v"(kl[0][1]), "+v"(vh[0][0]), "+v"(vh[0][1]), "+v"(vl[0][0]), "+v"(vl[0][1]),
+                   "+v"(kh[1][0]), "+v"(kh[1][1]), "+v"(kl[1][0]), "+v"(kl[1][1]), "+v"(vh[1][0]), "+v"(vh[1][1]), "+v"(vl[1][0]), "+v"(vl[1][1])::"memory");
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int kt = 2 * kp + hf;
-        bf16x8 kh0, kh1, kl0, kl1, vh0, vh1, vl0, vl1;
-        if (hf == 0) {
-          X3A_RD128(kh0, bkh + rf_lo, 0); X3A_RD128(kh1, bkh + rf_hi, 0); X3A_RD128(kl0, bkl + rf_lo, 0); X3A_RD128(kl1, bkl + rf_hi, 0);
-          X3A_RD128(vh0, bvh + rf_lo, 0); X3A_RD128(vh1, bvh + rf_hi, 0); X3A_RD128(vl0, bvl + rf_lo, 0); X3A_RD128(vl1, bvl + rf_hi, 0);
-        } else {
-          X3A_RD128(kh0, bkh + rf_lo, 2048); X3A_RD128(kh1, bkh + rf_hi, 2048); X3A_RD128(kl0, bkl + rf_lo, 2048); X3A_RD128(kl1, bkl + rf_hi, 2048);
-          X3A_RD128(vh0, bvh + rf_lo, 2048); X3A_RD128(vh1, bvh + rf_hi, 2048); X3A_RD128(vl0, bvl + rf_lo, 2048); X3A_RD128(vl1, bvl + rf_hi, 2048);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kh0), "+v"(kh1), "+v"(kl0), "+v"(kl1), "+v"(vh0), "+v"(vh1), "+v"(vl0), "+v"(vl1)::"memory");
         f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        s = x3a_mfma3(kh0, kl0, qh0, ql0, s);
-        s = x3a_mfma3(kh1, kl1, qh1, ql1, s);
-        dp = x3a_mfma3(vh0, vl0, dh0, dl0, dp);
-        dp = x3a_mfma3(vh1, vl1, dh1, dl1, dp);
+        s = x3a_mfma3(kh[hf][0], kl[hf][0], qh0, ql0, s);
+        s = x3a_mfma3(kh[hf][1], kl[hf][1], qh1, ql1, s);
+        dp = x3a_mfma3(vh[hf][0], vl[hf][0], dh0, dl0, dp);
+        dp = x3a_mfma3(vh[hf][1], vl[hf][1], dh1, dl1, dp);
         float m4[4] = {1.f, 1.f, 1.f, 1.f};
-        if (drop.thr) drop_mult4(drop, (uint32_t)(h * T + t0 + q), (uint32_t)(kt * 16 + 4 * fg), m4);
+        if (DROP) drop_mult4(drop, (uint32_t)(h * T + t0 + q), (uint32_t)(kt * 16 + 4 * fg), m4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float p = __builtin_amdgcn_exp2f(s[r] * c2 - lq);
@@ -373,8 +381,8 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_dq_x3_kernel(const bf16_t* __r
       X3A_RDTR(h2l, bkh + tr[2], 0); X3A_RDTR(h2h, bkh + tr[2], 2048); X3A_RDTR(h3l, bkh + tr[3], 0); X3A_RDTR(h3h, bkh + tr[3], 2048);
       X3A_RDTR(l0l, bkl + tr[0], 0); X3A_RDTR(l0h, bkl + tr[0], 2048); X3A_RDTR(l1l, bkl + tr[1], 0); X3A_RDTR(l1h, bkl + tr[1], 2048);
       X3A_RDTR(l2l, bkl + tr[2], 0); X3A_RDTR(l2h, bkl + tr[2], 2048); X3A_RDTR(l3l, bkl + tr[3], 0); X3A_RDTR(l3h, bkl + tr[3], 2048);
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0l), "+v"(h0h), "+v"(h1l), "+v"(h1h), "+v"(h2l), "+v"(h2h), "+v"(h3l), "+v"(h3h)::"memory");
-      asm volatile("" : "+v"(l0l), "+v"(l0h), "+v"(l1l), "+v"(l1h), "+v"(l2l), "+v"(l2h), "+v"(l3l), "+v"(l3h)::"memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0l), "+v"(h0h), "+v"(h1l), "+v"(h1h), "+v"(h2l), "+v"(h2h), "+v"(h3l), "+v"(h3h),
+                   "+v"(l0l), "+v"(l0h), "+v"(l1l), "+v"(l1h), "+v"(l2l), "+v"(l2h), "+v"(l3l), "+v"(l3h)::"memory");   // (one wait names every register in flight)
       bf16x8 sh, sl;
       x3a_split8(ds[0], ds[1], sh, sl);
       dq[0] = x3a_mfma3(X3A_CAT(h0l, h0h), X3A_CAT(l0l, l0h), sh, sl, dq[0]);
@@ -394,7 +402,9 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_dq_x3_kernel(const bf16_t* __r
 
 // dK, dV: Q pair and the scaled dO pair resident (LDS: Qhi | Qlo | Dhi | Dlo | lse | delta), waves own 16-key tiles (K and V
 // pair fragments in registers) and walk the query-tile pairs.
-template <int NKT>
+// (the dropout keep-bits are hashed once per block in the prologue, [query][key tile] in the LDS, as in mha_bwd2_h16_kernel:
+// this kernel's lanes hold four different query ROWS of the mask = four hashes per four elements otherwise)
+template <int NKT, bool DROP>
 __global__ __launch_bounds__(256, 2) void mha_bwd_dkv_x3_kernel(const bf16_t* __restrict__ qkv, long qps, const bf16_t* __restrict__ O, long ops,
                                                                 const float* __restrict__ lse, const float* __restrict__ dO,
                                                                 bf16_t* __restrict__ dqkv, long dps, const int* __restrict__ cu, int heads, int T,
@@ -423,6 +433,8 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_dkv_x3_kernel(const bf16_t* __
   float* sLse = reinterpret_cast<float*>(smem + 4 * TILE);
   float* sDel = sLse + NKT * 16;
   float* red = sDel + NKT * 16;
+  constexpr int VEC = 4 * TILE;
+  constexpr int MSK = VEC + 2 * NKT * 16 * 4 + 64;   // dropout bits [key tile][query]: 16 bits = the keys of the tile
   x3a_stage(Qg, H3, len, nkt2 * 16, smem, wave, lane, 4);
   x3a_stage(Qg + qps, H3, len, nkt2 * 16, smem + TILE, wave, lane, 4);
   float sc, isc;
@@ -450,6 +462,19 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_dkv_x3_kernel(const bf16_t* __
       sDel[r] = r < len ? del : 0.f;
       sLse[r] = r < len ? lse[(long)h * T + t0 + r] * X3_LOG2E : 0.f;
     }
+  }
+  if (DROP) {                                        // keep-bits of (query q, keys kt*16 .. +15): wave -> key tile, lane -> query
+    for (int kt = wave; kt < nkt2; kt += 4)
+      for (int q = lane; q < nkt2 * 16; q += 64) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const uint32_t hsh = drop_mix(drop.seed, drop.stream, (uint32_t)(h * T + t0 + q), (uint32_t)(kt * 8 + j));
+          w |= ((hsh & 0xFFFFu) >= drop.thr ? 1u : 0u) << (2 * j);
+          w |= ((hsh >> 16) >= drop.thr ? 2u : 0u) << (2 * j);
+        }
+        *reinterpret_cast<unsigned short*>(smem + MSK + (kt * NKT * 16 + q) * 2) = (unsigned short)w;
+      }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -481,31 +506,43 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_dkv_x3_kernel(const bf16_t* __
     for (int qp = 0; qp < (nkt2 >> 1); ++qp) {
       const uint32_t bqh = lds0 + (uint32_t)(qp * 4096), bql = bqh + TILE, bdh = bqh + 2 * TILE, bdl = bqh + 3 * TILE;
       f32x4 pp[2], ds[2];
+      bf16x8 qhf[2][2], qlf[2][2], dhf[2][2], dlf[2][2];
+      f32x4 lsv[2], dev[2];
+      uint2 mb[2] = {make_uint2(~0u, ~0u), make_uint2(~0u, ~0u)};              // keep-bits of the lane's four query rows (16 bits each), per tile
+      X3A_RD128(qhf[0][0], bqh + rf_lo, 0); X3A_RD128(qhf[0][1], bqh + rf_hi, 0); X3A_RD128(qlf[0][0], bql + rf_lo, 0); X3A_RD128(qlf[0][1], bql + rf_hi, 0);
+      X3A_RD128(dhf[0][0], bdh + rf_lo, 0); X3A_RD128(dhf[0][1], bdh + rf_hi, 0); X3A_RD128(dlf[0][0], bdl + rf_lo, 0); X3A_RD128(dlf[0][1], bdl + rf_hi, 0);
+      X3A_RD128(qhf[1][0], bqh + rf_lo, 2048); X3A_RD128(qhf[1][1], bqh + rf_hi, 2048); X3A_RD128(qlf[1][0], bql + rf_lo, 2048); X3A_RD128(qlf[1][1], bql + rf_hi, 2048);
+      X3A_RD128(dhf[1][0], bdh + rf_lo, 2048); X3A_RD128(dhf[1][1], bdh + rf_hi, 2048); X3A_RD128(dlf[1][0], bdl + rf_lo, 2048); X3A_RD128(dlf[1][1], bdl + rf_hi, 2048);
+      {
+        const uint32_t bl = lds0 + (uint32_t)(VEC + (qp * 32 + 4 * fg) * 4);       // sLse[qp*32 + 4 fg ..]; sDel = + NKT * 64 B
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %5\n\tds_read_b128 %3, %5 offset:64"
+                     : "=&v"(lsv[0]), "=&v"(lsv[1]), "=&v"(dev[0]), "=&v"(dev[1]) : "v"(bl), "v"(bl + (uint32_t)(NKT * 64)) : "memory");
+      }
+      if (DROP) {
+        const uint32_t ma = lds0 + (uint32_t)(MSK + (kt * NKT * 16 + qp * 32 + 4 * fg) * 2);
+        asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:32" : "=&v"(mb[0]), "=&v"(mb[1]) : "v"(ma) : "memory");
+      }
+      // (ONE wait names every register an asm read above is still filling: one it does not name may be copied before it)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qhf[0][0]), "+v"(qhf[0][1]), "+v"(qlf[0][0]), "+v"(qlf[0][1]), "+v"(dhf[0][0]), "+v"(dhf[0][1]), "+v"(dlf[0][0]), "+v"(dlf[0][1]),
+                   "+v"(qhf[1][0]), "+v"(qhf[1][1]), "+v"(qlf[1][0]), "+v"(qlf[1][1]), "+v"(dhf[1][0]), "+v"(dhf[1][1]), "+v"(dlf[1][0]), "+v"(dlf[1][1]),
+                   "+v"(lsv[0]), "+v"(lsv[1]), "+v"(dev[0]), "+v"(dev[1]), "+v"(mb[0]), "+v"(mb[1])::"memory");
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int qt = 2 * qp + hf;
-        bf16x8 q0h, q1h, q0l, q1l, d0h, d1h, d0l, d1l;
-        if (hf == 0) {
-          X3A_RD128(q0h, bqh + rf_lo, 0); X3A_RD128(q1h, bqh + rf_hi, 0); X3A_RD128(q0l, bql + rf_lo, 0); X3A_RD128(q1l, bql + rf_hi, 0);
-          X3A_RD128(d0h, bdh + rf_lo, 0); X3A_RD128(d1h, bdh + rf_hi, 0); X3A_RD128(d0l, bdl + rf_lo, 0); X3A_RD128(d1l, bdl + rf_hi, 0);
-        } else {
-          X3A_RD128(q0h, bqh + rf_lo, 2048); X3A_RD128(q1h, bqh + rf_hi, 2048); X3A_RD128(q0l, bql + rf_lo, 2048); X3A_RD128(q1l, bql + rf_hi, 2048);
-          X3A_RD128(d0h, bdh + rf_lo, 2048); X3A_RD128(d1h, bdh + rf_hi, 2048); X3A_RD128(d0l, bdl + rf_lo, 2048); X3A_RD128(d1l, bdl + rf_hi, 2048);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q0h), "+v"(q1h), "+v"(q0l), "+v"(q1l), "+v"(d0h), "+v"(d1h), "+v"(d0l), "+v"(d1l)::"memory");
         f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        s = x3a_mfma3(q0h, q0l, kh0, kl0, s);
-        s = x3a_mfma3(q1h, q1l, kh1, kl1, s);
-        dp = x3a_mfma3(d0h, d0l, vh0, vl0, dp);
-        dp = x3a_mfma3(d1h, d1l, vh1, vl1, dp);
+        s = x3a_mfma3(qhf[hf][0], qlf[hf][0], kh0, kl0, s);
+        s = x3a_mfma3(qhf[hf][1], qlf[hf][1], kh1, kl1, s);
+        dp = x3a_mfma3(dhf[hf][0], dlf[hf][0], vh0, vl0, dp);
+        dp = x3a_mfma3(dhf[hf][1], dlf[hf][1], vh1, vl1, dp);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int qrow = qt * 16 + 4 * fg + r;
-          float p = __builtin_amdgcn_exp2f(s[r] * c2 - sLse[qrow]);
+          float p = __builtin_amdgcn_exp2f(s[r] * c2 - lsv[hf][r]);
           p = (qrow < len && kok) ? p : 0.f;
-          const float mm = drop.thr ? drop_mult(drop, (uint32_t)(h * T + t0 + qrow), (uint32_t)key) : 1.f;
+          const uint32_t mword = r < 2 ? mb[hf].x : mb[hf].y;
+          const float mm = DROP ? (((mword >> ((r & 1) * 16 + fr)) & 1u) ? drop.scale : 0.f) : 1.f;
           pp[hf][r] = p * mm * 1024.0f;                  // 2^10 P~: see the file header
-          ds[hf][r] = p * (dp[r] * mm - sDel[qrow]) * scale;
+          ds[hf][r] = p * (dp[r] * mm - dev[hf][r]) * scale;
         }
       }
       bf16x8 ph, pl, sh, sl;
@@ -517,8 +554,8 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_dkv_x3_kernel(const bf16_t* __
         X3A_RDTR(h2l, bdh + tr[2], 0); X3A_RDTR(h2h, bdh + tr[2], 2048); X3A_RDTR(h3l, bdh + tr[3], 0); X3A_RDTR(h3h, bdh + tr[3], 2048);
         X3A_RDTR(l0l, bdl + tr[0], 0); X3A_RDTR(l0h, bdl + tr[0], 2048); X3A_RDTR(l1l, bdl + tr[1], 0); X3A_RDTR(l1h, bdl + tr[1], 2048);
         X3A_RDTR(l2l, bdl + tr[2], 0); X3A_RDTR(l2h, bdl + tr[2], 2048); X3A_RDTR(l3l, bdl + tr[3], 0); X3A_RDTR(l3h, bdl + tr[3], 2048);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0l), "+v"(h0h), "+v"(h1l), "+v"(h1h), "+v"(h2l), "+v"(h2h), "+v"(h3l), "+v"(h3h)::"memory");
-        asm volatile("" : "+v"(l0l), "+v"(l0h), "+v"(l1l), "+v"(l1h), "+v"(l2l), "+v"(l2h), "+v"(l3l), "+v"(l3h)::"memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0l), "+v"(h0h), "+v"(h1l), "+v"(h1h), "+v"(h2l), "+v"(h2h), "+v"(h3l), "+v"(h3h),
+                     "+v"(l0l), "+v"(l0h), "+v"(l1l), "+v"(l1h), "+v"(l2l), "+v"(l2h), "+v"(l3l), "+v"(l3h)::"memory");   // (one wait names every register in flight)
         dv[0] = x3a_mfma3(X3A_CAT(h0l, h0h), X3A_CAT(l0l, l0h), ph, pl, dv[0]);
         dv[1] = x3a_mfma3(X3A_CAT(h1l, h1h), X3A_CAT(l1l, l1h), ph, pl, dv[1]);
         dv[2] = x3a_mfma3(X3A_CAT(h2l, h2h), X3A_CAT(l2l, l2h), ph, pl, dv[2]);
@@ -530,8 +567,8 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_dkv_x3_kernel(const bf16_t* __
         X3A_RDTR(h2l, bqh + tr[2], 0); X3A_RDTR(h2h, bqh + tr[2], 2048); X3A_RDTR(h3l, bqh + tr[3], 0); X3A_RDTR(h3h, bqh + tr[3], 2048);
         X3A_RDTR(l0l, bql + tr[0], 0); X3A_RDTR(l0h, bql + tr[0], 2048); X3A_RDTR(l1l, bql + tr[1], 0); X3A_RDTR(l1h, bql + tr[1], 2048);
         X3A_RDTR(l2l, bql + tr[2], 0); X3A_RDTR(l2h, bql + tr[2], 2048); X3A_RDTR(l3l, bql + tr[3], 0); X3A_RDTR(l3h, bql + tr[3], 2048);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0l), "+v"(h0h), "+v"(h1l), "+v"(h1h), "+v"(h2l), "+v"(h2h), "+v"(h3l), "+v"(h3h)::"memory");
-        asm volatile("" : "+v"(l0l), "+v"(l0h), "+v"(l1l), "+v"(l1h), "+v"(l2l), "+v"(l2h), "+v"(l3l), "+v"(l3h)::"memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0l), "+v"(h0h), "+v"(h1l), "+v"(h1h), "+v"(h2l), "+v"(h2h), "+v"(h3l), "+v"(h3h),
+                     "+v"(l0l), "+v"(l0h), "+v"(l1l), "+v"(l1h), "+v"(l2l), "+v"(l2h), "+v"(l3l), "+v"(l3h)::"memory");   // (one wait names every register in flight)
         dk[0] = x3a_mfma3(X3A_CAT(h0l, h0h), X3A_CAT(l0l, l0h), sh, sl, dk[0]);
         dk[1] = x3a_mfma3(X3A_CAT(h1l, h1h), X3A_CAT(l1l, l1h), sh, sl, dk[1]);
         dk[2] = x3a_mfma3(X3A_CAT(h2l, h2h), X3A_CAT(l2l, l2h), sh, sl, dk[2]);
@@ -580,10 +617,17 @@ extern "C" int simx_mha_fwd_x3(simx_stream_t stream, int nseq, int heads, int d,
 #define LF(NKT)                                                                                                            \
   do {                                                                                                                     \
     const size_t lds = (size_t)4 * NKT * 16 * 128;                                                                         \
-    rc = x3a_set_lds(mha_fwd_x3_kernel<NKT>, lds, "mha_fwd_x3");                                                           \
-    if (rc) return rc;                                                                                                     \
-    hipLaunchKernelGGL((mha_fwd_x3_kernel<NKT>), dim3(nseq * heads), dim3(256), lds, s, (const bf16_t*)qkv_planes, qkv_plane_stride, \
-                       (bf16_t*)ctx_planes, ctx_plane_stride, lse, cu, heads, T, scale, drop);                             \
+    if (drop.thr) {                                                                                                        \
+      rc = x3a_set_lds(mha_fwd_x3_kernel<NKT, true>, lds, "mha_fwd_x3");                                                   \
+      if (rc) return rc;                                                                                                   \
+      hipLaunchKernelGGL((mha_fwd_x3_kernel<NKT, true>), dim3(nseq * heads), dim3(256), lds, s, (const bf16_t*)qkv_planes, qkv_plane_stride, \
+                         (bf16_t*)ctx_planes, ctx_plane_stride, lse, cu, heads, T, scale, drop);                           \
+    } else {                                                                                                               \
+      rc = x3a_set_lds(mha_fwd_x3_kernel<NKT, false>, lds, "mha_fwd_x3");                                                  \
+      if (rc) return rc;                                                                                                   \
+      hipLaunchKernelGGL((mha_fwd_x3_kernel<NKT, false>), dim3(nseq * heads), dim3(256), lds, s, (const bf16_t*)qkv_planes, qkv_plane_stride, \
+                         (bf16_t*)ctx_planes, ctx_plane_stride, lse, cu, heads, T, scale, drop);                           \
+    }                                                                                                                      \
   } while (0)
   if (max_len <= 32) LF(2);
   else if (max_len <= 128) LF(8);
@@ -614,23 +658,26 @@ extern "C" int simx_mha_bwd_x3_bias(simx_stream_t stream, int nseq, int heads, i
   const DropCtx drop = make_drop(dropd);
   const float scale = 1.0f / sqrtf((float)d);
   int rc = SIMX_OK;
-#define LB(NKT)                                                                                                            \
+#define LBD(NKT, DROP)                                                                                                     \
   do {                                                                                                                     \
-    const size_t lds1 = (size_t)4 * NKT * 16 * 128 + 64, lds2 = (size_t)4 * NKT * 16 * 128 + 2 * NKT * 16 * 4 + 64;        \
-    rc = x3a_set_lds(mha_bwd_dq_x3_kernel<NKT>, lds1, "mha_bwd_x3");                                                       \
+    const size_t lds1 = (size_t)4 * NKT * 16 * 128 + 64;                                                                   \
+    const size_t lds2 = (size_t)4 * NKT * 16 * 128 + 2 * NKT * 16 * 4 + 64 + ((DROP) ? (size_t)NKT * 16 * NKT * 2 : 0);    \
+    rc = x3a_set_lds(mha_bwd_dq_x3_kernel<NKT, DROP>, lds1, "mha_bwd_x3");                                                 \
     if (rc) return rc;                                                                                                     \
-    rc = x3a_set_lds(mha_bwd_dkv_x3_kernel<NKT>, lds2, "mha_bwd_x3");                                                      \
+    rc = x3a_set_lds(mha_bwd_dkv_x3_kernel<NKT, DROP>, lds2, "mha_bwd_x3");                                                \
     if (rc) return rc;                                                                                                     \
-    hipLaunchKernelGGL((mha_bwd_dq_x3_kernel<NKT>), dim3(nseq * heads), dim3(256), lds1, s, (const bf16_t*)qkv_planes, qkv_plane_stride, \
+    hipLaunchKernelGGL((mha_bwd_dq_x3_kernel<NKT, DROP>), dim3(nseq * heads), dim3(256), lds1, s, (const bf16_t*)qkv_planes, qkv_plane_stride, \
                        (const bf16_t*)ctx_planes, ctx_plane_stride, lse, dctx, (bf16_t*)dqkv_planes, dqkv_plane_stride, cu, heads, T, scale, drop, dbias); \
-    hipLaunchKernelGGL((mha_bwd_dkv_x3_kernel<NKT>), dim3(nseq * heads), dim3(256), lds2, s, (const bf16_t*)qkv_planes, qkv_plane_stride, \
+    hipLaunchKernelGGL((mha_bwd_dkv_x3_kernel<NKT, DROP>), dim3(nseq * heads), dim3(256), lds2, s, (const bf16_t*)qkv_planes, qkv_plane_stride, \
                        (const bf16_t*)ctx_planes, ctx_plane_stride, lse, dctx, (bf16_t*)dqkv_planes, dqkv_plane_stride, cu, heads, T, scale, drop, dbias); \
   } while (0)
+#define LB(NKT) do { if (drop.thr) LBD(NKT, true); else LBD(NKT, false); } while (0)
   if (max_len <= 32) LB(2);
   else if (max_len <= 128) LB(8);
   else if (max_len <= 160) LB(10);
   else LB(16);
 #undef LB
+#undef LBD
   SIMX_CHECK_LAUNCH("mha_bwd_x3");
   return SIMX_OK;
 }

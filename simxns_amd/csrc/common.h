@@ -87,6 +87,14 @@ template <> struct H16<f16_t> {
   }
 };
 
+// A value that is about to be split into a 16-bit pair (hi = rnd16(x), lo = rnd16(x - hi)) must exist as ONE f32 register
+// first.  Handed an unrounded product x = a * b, hipcc contracts the subtraction into v_fma_mix(a, b, -hi) and selects the
+// conversion (f16)x TWICE: as v_fma_mixlo(a, b, 0) -- rounded once -- for that subtraction, and as v_mul + v_cvt_pk -- rounded
+// twice -- for the hi that is stored or fed to the MFMA.  In double-rounding cases the two differ by one ulp of the 16-bit
+// format, and the pair is then off by 2^-11 instead of 2^-22 (found in mha_fwd_x3_kernel once its dropout multiply and the
+// split shared a basic block: three rows in 10^4 wrong at 5e-5).  Every split goes through this.
+__device__ __forceinline__ float f32_pin(float x) { asm("" : "+v"(x)); return x; }
+
 // ---- stream correction in ONE byte per element (simx.h stream_lo): x = hi + (b - 128) * ulp(hi) / 256, ulp(hi) = the
 // spacing of the 16-bit format at hi's exponent.  |x - hi| <= ulp / 2, so b lands in [0, 256]: clamped to [1, 255] (at most
 // 1/256 ulp lost at the two ends).  The stream then carries 11 + 8 = 19 significand bits in fp16 (8 + 8 = 16 in bf16) at 3 B

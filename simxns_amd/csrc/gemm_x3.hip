@@ -29,6 +29,7 @@
 
 template <typename F>
 __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  a = f32_pin(a); b = f32_pin(b);
   hi = H16<F>::pack2(a, b);
   lo = H16<F>::pack2(a - H16<F>::lo(hi), b - H16<F>::hi(hi));
 }

@@ -57,7 +57,8 @@ __device__ __forceinline__ void st4_residue(T* p, const float (&o)[4], float (&r
 
 // plane pair (csrc/gemm_xp.hip, simx.h "operand planes") of 4 consecutive f32 values: hi = rnd16(o), lo = rnd16(o - hi)
 template <typename F>
-__device__ __forceinline__ void st4_planes(bf16_t* p, long plane_stride, const float (&o)[4]) {
+__device__ __forceinline__ void st4_planes(bf16_t* p, long plane_stride, const float (&oo)[4]) {
+  const float o[4] = {f32_pin(oo[0]), f32_pin(oo[1]), f32_pin(oo[2]), f32_pin(oo[3])};
   const uint32_t h0 = H16<F>::pack2(o[0], o[1]), h1 = H16<F>::pack2(o[2], o[3]);
   const uint32_t l0 = H16<F>::pack2(o[0] - H16<F>::lo(h0), o[1] - H16<F>::hi(h0));
   const uint32_t l1 = H16<F>::pack2(o[2] - H16<F>::lo(h1), o[3] - H16<F>::hi(h1));

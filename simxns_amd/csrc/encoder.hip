@@ -490,7 +490,12 @@ extern "C" int simx_bert_fwd(simx_stream_t stream, const simx_bert_cfg* c, const
     xl = a.xoutl;
     xp = a.xoutp;
   }
-  if (cls_out) RUN(simx_cls_gather(stream, dt, nseq, H, cu, x, cls_out));
+  if (cls_out) {
+    // (a stream_lo tower: the embeddings are f32(hi + correction byte), as the [CLS]-only last layer returns them -- the same
+    // precision whichever form the last layer ran in)
+    if (stream_lo(c) && xl) RUN(simx_stream_rows(stream, dt, nseq, H, cu, x, xl, nullptr, nullptr, cls_out));
+    else RUN(simx_cls_gather(stream, dt, nseq, H, cu, x, cls_out));
+  }
   if (hidden_out) {
     if (hipMemcpyAsync(hidden_out, x, (size_t)T * H * esz(dt), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
       simx_set_error("bert_fwd: copy of last hidden state failed");

@@ -8,6 +8,7 @@ libsimx_hip.so; there is no eager fallback.
 """
 import ctypes as C
 import json
+import logging
 import os
 from collections import OrderedDict
 
@@ -276,6 +277,12 @@ class BertEngine(object):
                               float(c.layer_norm_eps), 0.0, 0.0, 0, 0, 1 if ckpt else 0, 0, 1 if exact else 0, self._stream_lo(name), None)
         self.wcache = None
         self._dirty = True
+        # (one line per engine: which arithmetic a tower actually runs is decided by three inputs -- the argument, SIMX_DTYPE,
+        # SIMX_GEMM_F32 / SIMX_STREAM_LO -- and a log is where a user can see the outcome)
+        logging.getLogger("simxns_amd").info(
+            "BertEngine: compute dtype %s (code %d), f32 GEMMs %s, residual stream %s, gradient checkpointing %s", name, self.dtype_code,
+            "exact" if exact else "16-bit hi+lo splits on the matrix cores", "16-bit + correction byte" if self.ccfg.stream_lo else "plain",
+            "on" if ckpt else "off")
 
     def _stream_lo(self, name):
         """fp16: the residual stream carries one correction byte beside every 16-bit value and the LayerNorm kernels add the

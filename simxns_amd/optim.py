@@ -473,6 +473,9 @@ class LinearWarmupSchedule(object):
         elif "t" in sd:                                 # round-1 format: written when the train loop still called
             # scheduler.step() BEFORE optimizer.step(), i.e. `t` had already been advanced for the update it was saved after;
             # under today's order (optimizer first, as the reference) the same next learning rate needs t + 1
+            import warnings
+            warnings.warn("LinearWarmupSchedule: loading a round-1-format scheduler state ('t'): it is read as written by the "
+                          "scheduler-before-optimizer train loop of that round (t + 1); checkpoints written since carry 'last_epoch'")
             self.t, self.warm, self.total, self.base = sd["t"] + 1, sd["warm"], sd["total"], sd["base"]
         else:
             raise ValueError("scheduler state has neither 'last_epoch' nor 't': keys %s" % sorted(sd.keys()))

@@ -512,6 +512,13 @@ def main():
                                                    "--steps", "5", "--warmup", "2"],
                                             "train_MS_Pas_AR2.sh exactly: fp32 arithmetic, --gradient_checkpointing, micro-batch 16 x 16, "
                                             "accumulation 2, ernie-2.0-large cross-encoder teacher")
+        out["recipe_of_record_folded"] = side_line(args, ["--dtype", "fp32", "--grad-ckpt", "--batch", "32", "--accum", "1", "--teacher-arch", "large",
+                                                          "--steps", "5", "--warmup", "2"],
+                                                   "the same optimizer step as recipe_of_record (32 queries x 16 passages per GPU, fp32, checkpointing, "
+                                                   "ernie-large teacher) with its two micro-batches of 16 run as ONE batch of 32 (`python -m simxns_amd.launch "
+                                                   "MS_Pas --fold-accumulation`): the recipe splits the step for 32-40 GB GPUs; its losses are per-query, so "
+                                                   "the summed gradient is the same up to rounding and dropout draws; 65536 passage tokens = 768 tiles for "
+                                                   "N = 768 = 3.0 waves of the chip.  Not the recipe to the letter: reported beside it")
         out["teacher_large"] = side_line(args, ["--dtype", args.dtype, "--teacher-arch", "large", "--steps", "5", "--warmup", "2"],
                                          "headline batch with the recipe's cross-encoder geometry (24 layers, H = 1024, F = 4096, S = 160)")
         # the other BASELINE configs and the reranker phase on one GPU (never `value`; each with its own roofline block)

@@ -99,9 +99,20 @@ def main(argv=None):
     ap.add_argument("--first-step", type=int, default=0)
     ap.add_argument("--last-step", type=int, default=None)
     ap.add_argument("--dry-run", action="store_true", help="print the job command lines instead of running them")
+    ap.add_argument("--fold-accumulation", action="store_true",
+                    help="run the gradient_accumulation_steps micro-batches of an optimizer step as ONE batch (MS_Pas: 2 x 16 queries -> "
+                         "32).  The recipes split the step for 32-40 GB GPUs; their losses are per-query (no in-batch negatives), so the "
+                         "summed gradient is the same up to rounding and dropout draws, and 65536 passage tokens fill the 256 CUs in "
+                         "whole waves of GEMM tiles where 32768 leave the last wave half empty.  Off by default: the recipe to the letter")
     args, extra = ap.parse_known_args(argv)
     extra = [e for e in extra if e != "--"]
     r = RECIPES[args.recipe]()
+    if args.fold_accumulation:
+        flags = r["train"][1]
+        if flags.get("inbatch") or flags.get("in_batch"):
+            ap.error("--fold-accumulation: this recipe scores in-batch negatives; a larger batch changes its loss")
+        flags["per_gpu_train_batch_size"] *= flags["gradient_accumulation_steps"]
+        flags["gradient_accumulation_steps"] = 1
     step, last = r["iteration_step"], r["max_steps"] if args.last_step is None else args.last_step
     for global_step in range(args.first_step, last + 1, step):
         loop = dict(max_steps=r["max_steps"], iteration_step=step, iteration_reranker_step=r["iteration_reranker_step"])

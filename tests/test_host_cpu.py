@@ -485,3 +485,16 @@ def test_wiki_generate_output_files(tmp_path):
     assert len(ds) == 2
     q_ids, ctx_ids, ce, answers, se = ds[0]
     assert len(ctx_ids) == 3 and len(ce) == 3
+
+
+def test_launch_fold_accumulation_dry_run(capsys):
+    """`launch.py --fold-accumulation`: the micro-batches of an optimizer step as one batch (per-query losses only)."""
+    from simxns_amd import launch
+    launch.main(["MS_Pas", "--dry-run", "--nproc", "8", "--last-step", "0"])
+    plain = capsys.readouterr().out.splitlines()[0]
+    launch.main(["MS_Pas", "--dry-run", "--nproc", "8", "--last-step", "0", "--fold-accumulation"])
+    folded = capsys.readouterr().out.splitlines()[0]
+    assert "--per_gpu_train_batch_size=16" in plain and "--gradient_accumulation_steps=2" in plain
+    assert "--per_gpu_train_batch_size=32" in folded and "--gradient_accumulation_steps=1" in folded
+    assert plain.replace("--per_gpu_train_batch_size=16", "").replace("--gradient_accumulation_steps=2", "") == \
+        folded.replace("--per_gpu_train_batch_size=32", "").replace("--gradient_accumulation_steps=1", "")

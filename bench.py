@@ -512,6 +512,10 @@ def main():
                                                    "--steps", "5", "--warmup", "2"],
                                             "train_MS_Pas_AR2.sh exactly: fp32 arithmetic, --gradient_checkpointing, micro-batch 16 x 16, "
                                             "accumulation 2, ernie-2.0-large cross-encoder teacher")
+        out["recipe_shapes_folded"] = side_line(args, ["--dtype", args.dtype, "--batch", "32", "--accum", "1", "--teacher-arch", "large",
+                                                       "--steps", "10", "--warmup", "3"],
+                                                "recipe_shapes with the two micro-batches of an optimizer step run as one batch of 32 queries "
+                                                "(see recipe_of_record_folded)")
         out["recipe_of_record_folded"] = side_line(args, ["--dtype", "fp32", "--grad-ckpt", "--batch", "32", "--accum", "1", "--teacher-arch", "large",
                                                           "--steps", "5", "--warmup", "2"],
                                                    "the same optimizer step as recipe_of_record (32 queries x 16 passages per GPU, fp32, checkpointing, "

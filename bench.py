@@ -523,6 +523,9 @@ def main():
                                                    "MS_Pas --fold-accumulation`): the recipe splits the step for 32-40 GB GPUs; its losses are per-query, so "
                                                    "the summed gradient is the same up to rounding and dropout draws; 65536 passage tokens = 768 tiles for "
                                                    "N = 768 = 3.0 waves of the chip.  Not the recipe to the letter: reported beside it")
+        out["deterministic_mode"] = side_line(args, ["--dtype", args.dtype, "--steps", "4", "--warmup", "2"],
+                                              "the headline job with SIMX_DETERMINISTIC=1 (run-to-run bit-identical gradients: ordered slab and "
+                                              "bias-gradient passes instead of atomics)", env={"SIMX_DETERMINISTIC": "1"})
         out["teacher_large"] = side_line(args, ["--dtype", args.dtype, "--teacher-arch", "large", "--steps", "5", "--warmup", "2"],
                                          "headline batch with the recipe's cross-encoder geometry (24 layers, H = 1024, F = 4096, S = 160)")
         # the other BASELINE configs and the reranker phase on one GPU (never `value`; each with its own roofline block)

@@ -7,7 +7,11 @@ Tolerances
                     (BASELINE.json north_star: "loss/logits within 1e-3 of reference"); measured errors
                     are ~1e-5.  Parameter gradients: 2e-4 of each tensor's largest entry + 1e-5 of the model's
                     largest gradient entry (absolute floor for analytically-zero gradients); measured 4e-5.
-  bf16 perf mode  : documented looser bound (bf16 has 8 mantissa bits): embeddings 6e-2 abs on O(1)
+  fp16 engine     : (the benchmarked engine: fp16 operands, f32 accumulation, 16-bit + correction-byte residual stream) the
+                    measured x3 bounds of simxns_amd/utils/parity.py FP16_HOT_TOL -- at the distance from the fp64 reference at
+                    which an emulation of the reference's own apex-O1 mode sits (profiles/r03_o1_emulation.json): logits
+                    ~2.4e-3 of their scale, loss ~1e-3, gradient cosine >= 0.999 on the dense weights.
+  bf16 (experimental): documented looser bound (bf16 has 8 mantissa bits): embeddings 6e-2 abs on O(1)
                     values, loss 5e-2, gradients checked by cosine similarity >= 0.98.
 """
 import json

@@ -561,7 +561,10 @@ __global__ __launch_bounds__(256) void mha_bwd2_h16_kernel(const bf16_t* __restr
 #define AL_CH 256
 #define AL_TILE (16 * 16 * 128)          // one staged operand chunk: 256 rows x 128 B
 
-template <typename F, bool DKV>
+// (dropout on / off is a template parameter and "both chunks complete" selects one of two copies of the tile loop, so that the pair
+// iteration is one basic block; dK / dV read the dropout keep-bits of the (key chunk, query chunk) pair from the LDS, hashed once
+// while the query chunk is staged: see mha_bwd2_h16_kernel)
+template <typename F, bool DKV, bool DROP>
 __global__ __launch_bounds__(256, 1) void mha_bwd_long_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ O,
                                                               const float* __restrict__ lse, const bf16_t* __restrict__ dO,
                                                               bf16_t* __restrict__ dqkv, const int* __restrict__ cu,
@@ -589,6 +592,7 @@ __global__ __launch_bounds__(256, 1) void mha_bwd_long_kernel(const bf16_t* __re
   float* sLse = reinterpret_cast<float*>(smem + 4 * AL_TILE);
   float* sDel = sLse + AL_CH;
   char* patch = smem + 4 * AL_TILE + 2 * AL_CH * 4 + wave * 2048;
+  constexpr int MSK = 4 * AL_TILE + 2 * AL_CH * 4 + 4 * 2048;   // dropout bits [key tile of the own chunk][query of the staged chunk]
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
   const uint32_t patch_addr = lds0 + (uint32_t)(4 * AL_TILE + 2 * AL_CH * 4 + wave * 2048);
   const int fr = lane & 15, fg = lane >> 4;
@@ -626,6 +630,19 @@ __global__ __launch_bounds__(256, 1) void mha_bwd_long_kernel(const bf16_t* __re
         sLse[r] = r < n ? lse[(long)h * T + t0 + r0 + r] * LOG2E : 0.f;
       }
     }
+    if (DKV && DROP) {                               // keep-bits of (query r0 + q, keys own0 + kt*16 .. +15): wave -> key tile, lane -> query
+      for (int kt = wave; kt < 16; kt += 4)
+        for (int q = lane; q < npad; q += 64) {
+          uint32_t w = 0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const uint32_t hsh = drop_mix(drop.seed, drop.stream, (uint32_t)(h * T + t0 + r0 + q), (uint32_t)((own0 >> 1) + kt * 8 + j));
+            w |= ((hsh & 0xFFFFu) >= drop.thr ? 1u : 0u) << (2 * j);
+            w |= ((hsh >> 16) >= drop.thr ? 2u : 0u) << (2 * j);
+          }
+          *reinterpret_cast<unsigned short*>(smem + MSK + (kt * AL_CH + q) * 2) = (unsigned short)w;
+        }
+    }
   };
   auto stage_k = [&](int r0, int n) {
     const int npad = ((n + 31) >> 5) << 5;
@@ -650,6 +667,8 @@ __global__ __launch_bounds__(256, 1) void mha_bwd_long_kernel(const bf16_t* __re
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       const bool full = (ownlen == AL_CH) && (klen == AL_CH);
+      auto tiles = [&](auto full_c) {
+      constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int qt = wave + 4 * t;
@@ -684,17 +703,13 @@ __global__ __launch_bounds__(256, 1) void mha_bwd_long_kernel(const bf16_t* __re
             dp = H16<F>::mfma(hf ? v10 : v00, df0, dp);
             dp = H16<F>::mfma(hf ? v11 : v01, df1, dp);
             float m4[4] = {1.f, 1.f, 1.f, 1.f};
-            if (drop.thr) drop_mult4(drop, (uint32_t)(h * T + t0 + own0 + q), (uint32_t)(k0 + kt * 16 + 4 * fg), m4);
-            float p[4];
+            if (DROP) drop_mult4(drop, (uint32_t)(h * T + t0 + own0 + q), (uint32_t)(k0 + kt * 16 + 4 * fg), m4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(s[r] * c2 - lq);
-            if (!full) {
-              asm volatile("" ::: "memory");
-#pragma unroll
-              for (int r = 0; r < 4; ++r) p[r] = (kt * 16 + 4 * fg + r < klen && qok) ? p[r] : 0.f;
+            for (int r = 0; r < 4; ++r) {
+              float p = __builtin_amdgcn_exp2f(s[r] * c2 - lq);
+              if (!FULL) p = (kt * 16 + 4 * fg + r < klen && qok) ? p : 0.f;
+              ds[hf][r] = p * (dp[r] * m4[r] - dq_) * scale;
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ds[hf][r] = p[r] * (dp[r] * m4[r] - dq_) * scale;
           }
           const bf16x8 dsf = pack8<F>(ds[0], ds[1]);
           dq[t][0] = H16<F>::mfma(A2_CAT(t0l, t0h), dsf, dq[t][0]);
@@ -703,6 +718,8 @@ __global__ __launch_bounds__(256, 1) void mha_bwd_long_kernel(const bf16_t* __re
           dq[t][3] = H16<F>::mfma(A2_CAT(t3l, t3h), dsf, dq[t][3]);
         }
       }
+      };
+      if (full) tiles(std::true_type{}); else tiles(std::false_type{});
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -727,6 +744,8 @@ __global__ __launch_bounds__(256, 1) void mha_bwd_long_kernel(const bf16_t* __re
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       const bool full = (ownlen == AL_CH) && (qlen == AL_CH);
+      auto tiles = [&](auto full_c) {
+      constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int kt = wave + 4 * t;
@@ -746,16 +765,21 @@ __global__ __launch_bounds__(256, 1) void mha_bwd_long_kernel(const bf16_t* __re
           bf16x8 q00, q01, q10, q11, d00, d01, d10, d11;
           bf16x4 e0l, e0h, e1l, e1h, e2l, e2h, e3l, e3h, u0l, u0h, u1l, u1h, u2l, u2h, u3l, u3h;
           f32x4 ls0, ls1, de0, de1;
+          uint2 mb[2] = {make_uint2(~0u, ~0u), make_uint2(~0u, ~0u)};          // keep-bits of the lane's four query rows (16 bits each), per tile of the pair
           A2_RD128(q00, bq + rf_lo, 0); A2_RD128(q01, bq + rf_hi, 0); A2_RD128(q10, bq + rf_lo, 2048); A2_RD128(q11, bq + rf_hi, 2048);
           A2_RD128(d00, bd + rf_lo, 0); A2_RD128(d01, bd + rf_hi, 0); A2_RD128(d10, bd + rf_lo, 2048); A2_RD128(d11, bd + rf_hi, 2048);
           asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %5\n\tds_read_b128 %3, %5 offset:64"
                        : "=&v"(ls0), "=&v"(ls1), "=&v"(de0), "=&v"(de1) : "v"(bl), "v"(bl + (uint32_t)(AL_CH * 4)) : "memory");
+          if (DROP) {
+            const uint32_t ma = lds0 + (uint32_t)(MSK + (kt * AL_CH + qp * 32 + 4 * fg) * 2);
+            asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:32" : "=&v"(mb[0]), "=&v"(mb[1]) : "v"(ma) : "memory");
+          }
           A2_RDTR(e0l, bd + tr[0], 0); A2_RDTR(e0h, bd + tr[0], 2048); A2_RDTR(e1l, bd + tr[1], 0); A2_RDTR(e1h, bd + tr[1], 2048);
           A2_RDTR(e2l, bd + tr[2], 0); A2_RDTR(e2h, bd + tr[2], 2048); A2_RDTR(e3l, bd + tr[3], 0); A2_RDTR(e3h, bd + tr[3], 2048);
           A2_RDTR(u0l, bq + tr[0], 0); A2_RDTR(u0h, bq + tr[0], 2048); A2_RDTR(u1l, bq + tr[1], 0); A2_RDTR(u1h, bq + tr[1], 2048);
           A2_RDTR(u2l, bq + tr[2], 0); A2_RDTR(u2h, bq + tr[2], 2048); A2_RDTR(u3l, bq + tr[3], 0); A2_RDTR(u3h, bq + tr[3], 2048);
           asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q00), "+v"(q01), "+v"(q10), "+v"(q11), "+v"(d00), "+v"(d01), "+v"(d10), "+v"(d11),
-                       "+v"(ls0), "+v"(ls1), "+v"(de0), "+v"(de1),
+                       "+v"(ls0), "+v"(ls1), "+v"(de0), "+v"(de1), "+v"(mb[0]), "+v"(mb[1]),
                        "+v"(e0l), "+v"(e0h), "+v"(e1l), "+v"(e1h), "+v"(e2l), "+v"(e2h), "+v"(e3l), "+v"(e3h),
                        "+v"(u0l), "+v"(u0h), "+v"(u1l), "+v"(u1h), "+v"(u2l), "+v"(u2h), "+v"(u3l), "+v"(u3h)::"memory");
           f32x4 pp[2], ds[2];
@@ -768,23 +792,17 @@ __global__ __launch_bounds__(256, 1) void mha_bwd_long_kernel(const bf16_t* __re
             dp = H16<F>::mfma(hf ? d10 : d00, vf0, dp);
             dp = H16<F>::mfma(hf ? d11 : d01, vf1, dp);
             const f32x4 lsv = hf ? ls1 : ls0, dev = hf ? de1 : de0;
-            float p[4], mm[4] = {1.f, 1.f, 1.f, 1.f};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(s[r] * c2 - lsv[r]);
-            if (!full) {
-              asm volatile("" ::: "memory");
-#pragma unroll
-              for (int r = 0; r < 4; ++r) p[r] = (qt * 16 + 4 * fg + r < qlen && kok) ? p[r] : 0.f;
-            }
-            if (drop.thr) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r)
-                mm[r] = drop_mult(drop, (uint32_t)(h * T + t0 + q0 + qt * 16 + 4 * fg + r), (uint32_t)(own0 + key));
-            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              pp[hf][r] = p[r] * mm[r];
-              ds[hf][r] = p[r] * (dp[r] * mm[r] - dev[r]) * scale;
+              float p = __builtin_amdgcn_exp2f(s[r] * c2 - lsv[r]);
+              if (!FULL) p = (qt * 16 + 4 * fg + r < qlen && kok) ? p : 0.f;
+              float mm = 1.f;
+              if (DROP) {
+                const uint32_t mword = r < 2 ? mb[hf].x : mb[hf].y;
+                mm = ((mword >> ((r & 1) * 16 + fr)) & 1u) ? drop.scale : 0.f;
+              }
+              pp[hf][r] = p * mm;
+              ds[hf][r] = p * (dp[r] * mm - dev[r]) * scale;
             }
           }
           const bf16x8 pf = pack8<F>(pp[0], pp[1]);
@@ -799,6 +817,8 @@ __global__ __launch_bounds__(256, 1) void mha_bwd_long_kernel(const bf16_t* __re
           dk[t][3] = H16<F>::mfma(A2_CAT(u3l, u3h), dsf, dk[t][3]);
         }
       }
+      };
+      if (full) tiles(std::true_type{}); else tiles(std::false_type{});
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -1121,16 +1141,18 @@ extern "C" int simx_mha_bwd_hm(simx_stream_t stream, int dtype, int nseq, int he
   }
   if (simx_is16(dtype) && d == 64) {                            // 256 < max_len <= 4096: chunked MFMA kernels
     const int nchunk = cdiv(max_len, AL_CH);
-    const size_t ldsl = (size_t)4 * AL_TILE + 2 * AL_CH * sizeof(float) + 4 * 2048;
-#define LL(DKV)                                                                                                      \
+    const size_t ldsl = (size_t)4 * AL_TILE + 2 * AL_CH * sizeof(float) + 4 * 2048 + (size_t)16 * AL_CH * 2;   // (+ the dropout bits of dK / dV)
+#define LLD(DKV, DROP)                                                                                               \
   do {                                                                                                               \
-    rc = set_lds(mha_bwd_long_kernel<FF, DKV>, ldsl, "mha_bwd");                                                     \
+    rc = set_lds(mha_bwd_long_kernel<FF, DKV, DROP>, ldsl, "mha_bwd");                                               \
     if (rc) return rc;                                                                                               \
-    hipLaunchKernelGGL((mha_bwd_long_kernel<FF, DKV>), dim3(nseq * heads * nchunk), dim3(256), ldsl, s, (const bf16_t*)qkv, \
+    hipLaunchKernelGGL((mha_bwd_long_kernel<FF, DKV, DROP>), dim3(nseq * heads * nchunk), dim3(256), ldsl, s, (const bf16_t*)qkv, \
                        (const bf16_t*)ctx, lse, (const bf16_t*)dctx, (bf16_t*)dqkv, cu, heads, T, nchunk, scale, drop); \
   } while (0)
+#define LL(DKV) do { if (drop.thr) LLD(DKV, true); else LLD(DKV, false); } while (0)
     SIMX_DISPATCH16(dtype, FF, LL(false); LL(true));
 #undef LL
+#undef LLD
     SIMX_CHECK_LAUNCH("mha_bwd_long");
     return SIMX_OK;
   }

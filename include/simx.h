@@ -180,7 +180,7 @@ int simx_embed_ln_fwd_planes(simx_stream_t stream, int T, int H, const int32_t* 
                              const float* posw, const float* typew, const float* gamma, const float* beta, float eps, float* out,
                              void* out_planes, long plane_stride, const simx_dropout* drop);
 int simx_mha_planes_ok(int d, int max_len);
-/* the same products on the 16-bit matrix cores from fp16 plane pairs (csrc/attention_x3.hip; head size 64, sequences <= 4096 -- K / V resident in LDS up to 256 tokens, 128-token chunks with an online softmax above:
+/* the same products on the 16-bit matrix cores from fp16 plane pairs (csrc/attention_x3.hip; head size 64, sequences <= 4096 -- K / V resident in LDS up to 160 tokens, 128-token chunks with an online softmax above:
  * simx_mha_x3_ok): q / k / v = the plane pair a SIMX_EPI_NONE_PLANES QKV projection wrote, context as a SIMX_F16 pair; backward
  * takes dctx in f32 and writes dq / dk / dv as a SIMX_BF16 pair. */
 int simx_mha_x3_ok(int d, int max_len);

@@ -1,6 +1,6 @@
 // Self-attention of the fp32 engine on the 16-bit matrix cores from fp16 plane pairs (BertSelfAttention core,
 // LEAD/modeling_bert.py:318-374, in the fp32 arithmetic every train_*_AR2.sh selects).  Head size 64, sequences <= 4096 (K / V of the
-// (sequence, head) resident in LDS up to 256 tokens, 128-token chunks above).
+// (sequence, head) resident in LDS up to 160 tokens, 128-token chunks above).
 //
 // attention_f32.hip runs these products on v_mfma_f32_32x32x2_f32 (157 TFLOP/s peak) and spends 100 of the fp32 step's 590 ms
 // there.  Here every product is taken as hi.lo + lo.hi + hi.hi of fp16 pairs (three v_mfma_f32_16x16x32_f16 per tile pair:
@@ -1135,8 +1135,7 @@ extern "C" int simx_mha_fwd_x3(simx_stream_t stream, int nseq, int heads, int d,
   if (max_len <= 32) LF(2);
   else if (max_len <= 128) LF(8);
   else if (max_len <= 160) LF(10);
-  else if (max_len <= 256) LF(16);
-  else {                                               // chunked: one workgroup per (sequence, head, 128-query chunk)
+  else {                                               // chunked (161..256 tokens too: 2048 x 12 blocks of 256, 2.54 ms resident, 2.30 chunked): one workgroup per (sequence, head, 128-query chunk)
     const int nchunk = (max_len + XL_CH - 1) / XL_CH;
     const size_t lds = (size_t)4 * XL_TILE;
     if (drop.thr)
@@ -1201,8 +1200,7 @@ extern "C" int simx_mha_bwd_x3_bias(simx_stream_t stream, int nseq, int heads, i
   if (max_len <= 32) LB(2);
   else if (max_len <= 128) LB(8);
   else if (max_len <= 160) LB(10);
-  else if (max_len <= 256) LB(16);
-  else if (drop.thr) LBL(true);
+  else if (drop.thr) LBL(true);          // (161..256 tokens too: 2048 x 12 blocks of 256, 9.58 ms resident -- one workgroup per CU -- 8.57 chunked)
   else LBL(false);
 #undef LBL
 #undef LB

@@ -2,7 +2,8 @@
 frozen cross-encoder teacher, SimANS draw, KL-distill loss, clip 2.0 + AdamW + warm-up, dropout 0.1 -- run for N optimiser
 steps in the fp16 (apex-O1 form, dynamic loss scale), bf16 and fp32 engines from identical weights, data and dropout masks.
 Prints the loss curves, their distances from the fp32 curve and the fp16 engine's scaler state; the committed outputs are
-profiles/r02_loss_curve.json (bf16 / fp32) and profiles/r03_loss_curve.json (all three).
+profiles/r02_loss_curve.json (bf16 / fp32), profiles/r03_loss_curve.json (all three) and profiles/r04_loss_curve.json (+ the exact-f32
+engine as the reference curve: the fp32 engine runs on 16-bit plane pairs since round 4).
 usage: python tools/loss_curve.py [steps=60] [B=32] [N=15]"""
 import json
 import sys
@@ -72,17 +73,18 @@ def run(dtype):
 
 
 curves, scalers = {}, {}
-for dt in ("fp16", "bf16", "fp32"):
+ENGINES = ("fp16", "bf16", "fp32", "fp32_exact")        # fp32_exact: exact f32 products everywhere -- the curve the others are measured against
+for dt in ENGINES:
     curves[dt], scalers[dt] = run(dt)
-ref = np.array(curves["fp32"])
+ref = np.array(curves["fp32_exact"])
 out = {"job": "retriever step x %d, B=%d, %d negatives of %d candidates, 4 batches revisited, lr 2e-5 (warm-up 10), dropout 0.1, "
               "clip 2.0; identical weights / data / dropout masks in all engines" % (steps, B, N, Cn),
        "fp16_loss_scaler": scalers["fp16"]}
-for dt in ("fp16", "bf16", "fp32"):
+for dt in ENGINES:
     c = np.array(curves[dt])
     d = np.abs(c - ref)
     out["loss_" + dt] = [round(float(x), 4) for x in c]
     out["summary_" + dt] = {"first": round(float(c[0]), 4), "last5_mean": round(float(c[-5:].mean()), 4),
-                            "max_abs_diff_vs_fp32": round(float(d.max()), 4), "mean_abs_diff_vs_fp32": round(float(d.mean()), 4),
-                            "rel_diff_of_last5_mean_vs_fp32": round(float(abs(c[-5:].mean() - ref[-5:].mean()) / abs(ref[-5:].mean())), 4)}
+                            "max_abs_diff_vs_fp32_exact": round(float(d.max()), 4), "mean_abs_diff_vs_fp32_exact": round(float(d.mean()), 4),
+                            "rel_diff_of_last5_mean_vs_fp32_exact": round(float(abs(c[-5:].mean() - ref[-5:].mean()) / abs(ref[-5:].mean())), 4)}
 print(json.dumps(out))

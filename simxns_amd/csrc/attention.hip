@@ -551,21 +551,20 @@ __global__ __launch_bounds__(256) void mha_bwd2_h16_kernel(const bf16_t* __restr
 // ------------------------------------------------------------------------------------------ backward, long sequences
 // 256 < S <= 4096 (MS-Doc documents and BASELINE config 5 run at S = 512; the generic kernel took 95 % of a
 // fwd+bwd step there).  Q, K, V, dO of a whole sequence no longer fit the LDS, so the sequence is cut into chunks of
-// 256 tokens and the two gradients are computed by two launches of one template:
+// CH tokens (128 as launched) and the two gradients are computed by two launches of one template:
 //   DKV = false: block (seq, head, query chunk) keeps Q, dO of its chunk resident, walks the key chunks (K, V
 //                restaged per chunk) and accumulates dQ of its four query tiles per wave in registers;
 //   DKV = true : block (seq, head, key chunk) keeps K, V resident, walks the query chunks (Q, dO, lse, delta restaged)
 //                and accumulates dK, dV of its four key tiles per wave in registers (one wave per SIMD: 128 KB of LDS per
 //                block anyway, so the 512-register budget is there).
 // No atomics, no f32 scratch; the inner pair iteration is the one of mha_bwd2_bf16_kernel.
-#define AL_CH 256
-#define AL_TILE (16 * 16 * 128)          // one staged operand chunk: 256 rows x 128 B
 
 // (dropout on / off is a template parameter and "both chunks complete" selects one of two copies of the tile loop, so that the pair
 // iteration is one basic block; dK / dV read the dropout keep-bits of the (key chunk, query chunk) pair from the LDS, hashed once
 // while the query chunk is staged: see mha_bwd2_h16_kernel)
-template <typename F, bool DKV, bool DROP>
-__global__ __launch_bounds__(256, 1) void mha_bwd_long_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ O,
+// CH: tokens per chunk.  256: one workgroup per CU (4 tiles of 32 KB), four tiles per wave; 128: two workgroups per CU, two tiles per wave.
+template <typename F, bool DKV, bool DROP, int CH>
+__global__ __launch_bounds__(256, (CH == 128 ? 2 : 1)) void mha_bwd_long_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ O,
                                                               const float* __restrict__ lse, const bf16_t* __restrict__ dO,
                                                               bf16_t* __restrict__ dqkv, const int* __restrict__ cu,
                                                               int heads, int T, int nchunk, float scale, DropCtx drop) {
@@ -576,9 +575,9 @@ __global__ __launch_bounds__(256, 1) void mha_bwd_long_kernel(const bf16_t* __re
   const int sh = blockIdx.x / nchunk;
   const int seq = sh / heads, h = sh % heads;
   const int t0 = cu[seq], len = cu[seq + 1] - t0;
-  const int own0 = mine * AL_CH;
+  const int own0 = mine * CH;
   if (own0 >= len) return;
-  const int ownlen = min(AL_CH, len - own0);
+  const int ownlen = min(CH, len - own0);
   const int H = heads * 64, H3 = 3 * H;
   const bf16_t* Qg = qkv + (long)t0 * H3 + h * 64;
   const bf16_t* Kg = Qg + H;
@@ -586,15 +585,15 @@ __global__ __launch_bounds__(256, 1) void mha_bwd_long_kernel(const bf16_t* __re
   const bf16_t* Og = O + (long)t0 * H + h * 64;
   const bf16_t* dOg = dO + (long)t0 * H + h * 64;
   char* sQ = smem;
-  char* sK = smem + AL_TILE;
-  char* sV = smem + 2 * AL_TILE;
-  char* sD = smem + 3 * AL_TILE;
-  float* sLse = reinterpret_cast<float*>(smem + 4 * AL_TILE);
-  float* sDel = sLse + AL_CH;
-  char* patch = smem + 4 * AL_TILE + 2 * AL_CH * 4 + wave * 2048;
-  constexpr int MSK = 4 * AL_TILE + 2 * AL_CH * 4 + 4 * 2048;   // dropout bits [key tile of the own chunk][query of the staged chunk]
+  char* sK = smem + (CH * 128);
+  char* sV = smem + 2 * (CH * 128);
+  char* sD = smem + 3 * (CH * 128);
+  float* sLse = reinterpret_cast<float*>(smem + 4 * (CH * 128));
+  float* sDel = sLse + CH;
+  char* patch = smem + 4 * (CH * 128) + 2 * CH * 4 + wave * 2048;
+  constexpr int MSK = 4 * (CH * 128) + 2 * CH * 4 + 4 * 2048;   // dropout bits [key tile of the own chunk][query of the staged chunk]
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-  const uint32_t patch_addr = lds0 + (uint32_t)(4 * AL_TILE + 2 * AL_CH * 4 + wave * 2048);
+  const uint32_t patch_addr = lds0 + (uint32_t)(4 * (CH * 128) + 2 * CH * 4 + wave * 2048);
   const int fr = lane & 15, fg = lane >> 4;
   const float c2 = scale * LOG2E;
   const int fsw = att_f(fr);
@@ -631,7 +630,7 @@ __global__ __launch_bounds__(256, 1) void mha_bwd_long_kernel(const bf16_t* __re
       }
     }
     if (DKV && DROP) {                               // keep-bits of (query r0 + q, keys own0 + kt*16 .. +15): wave -> key tile, lane -> query
-      for (int kt = wave; kt < 16; kt += 4)
+      for (int kt = wave; kt < CH / 16; kt += 4)
         for (int q = lane; q < npad; q += 64) {
           uint32_t w = 0;
 #pragma unroll
@@ -640,7 +639,7 @@ __global__ __launch_bounds__(256, 1) void mha_bwd_long_kernel(const bf16_t* __re
             w |= ((hsh & 0xFFFFu) >= drop.thr ? 1u : 0u) << (2 * j);
             w |= ((hsh >> 16) >= drop.thr ? 2u : 0u) << (2 * j);
           }
-          *reinterpret_cast<unsigned short*>(smem + MSK + (kt * AL_CH + q) * 2) = (unsigned short)w;
+          *reinterpret_cast<unsigned short*>(smem + MSK + (kt * CH + q) * 2) = (unsigned short)w;
         }
     }
   };
@@ -653,30 +652,30 @@ __global__ __launch_bounds__(256, 1) void mha_bwd_long_kernel(const bf16_t* __re
   if (!DKV) {
     // ------------------------------------------------ dQ of query chunk `mine`
     stage_q(own0, ownlen);
-    f32x4 dq[4][4];
+    f32x4 dq[CH / 64][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < CH / 64; ++t)
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) dq[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nqt = (ownlen + 15) >> 4;
-    for (int kc = 0; kc * AL_CH < len; ++kc) {
-      const int k0 = kc * AL_CH, klen = min(AL_CH, len - k0);
+    for (int kc = 0; kc * CH < len; ++kc) {
+      const int k0 = kc * CH, klen = min(CH, len - k0);
       const int nkp = (((klen + 15) >> 4) + 1) >> 1;
       __syncthreads();                                     // everyone is done with the previous K, V chunk
       stage_k(k0, klen);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      const bool full = (ownlen == AL_CH) && (klen == AL_CH);
+      const bool full = (ownlen == CH) && (klen == CH);
       auto tiles = [&](auto full_c) {
       constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < CH / 64; ++t) {
         const int qt = wave + 4 * t;
         if (qt >= nqt) continue;                           // wave-uniform
         const int q = qt * 16 + fr;
         bf16x8 qf0, qf1, df0, df1;
         {
-          const uint32_t aq = lds0 + (uint32_t)(qt * 2048), ad = aq + 3 * AL_TILE;
+          const uint32_t aq = lds0 + (uint32_t)(qt * 2048), ad = aq + 3 * (CH * 128);
           A2_RD128(qf0, aq + rf_lo, 0); A2_RD128(qf1, aq + rf_hi, 0);
           A2_RD128(df0, ad + rf_lo, 0); A2_RD128(df1, ad + rf_hi, 0);
           asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qf0), "+v"(qf1), "+v"(df0), "+v"(df1)::"memory");
@@ -684,7 +683,7 @@ __global__ __launch_bounds__(256, 1) void mha_bwd_long_kernel(const bf16_t* __re
         const float lq = sLse[q], dq_ = sDel[q];
         const bool qok = q < ownlen;
         for (int kp = 0; kp < nkp; ++kp) {
-          const uint32_t bk = lds0 + (uint32_t)(AL_TILE + kp * 4096), bv = bk + AL_TILE;
+          const uint32_t bk = lds0 + (uint32_t)((CH * 128) + kp * 4096), bv = bk + (CH * 128);
           bf16x8 k00, k01, k10, k11, v00, v01, v10, v11;
           bf16x4 t0l, t0h, t1l, t1h, t2l, t2h, t3l, t3h;
           A2_RD128(k00, bk + rf_lo, 0); A2_RD128(k01, bk + rf_hi, 0); A2_RD128(k10, bk + rf_lo, 2048); A2_RD128(k11, bk + rf_hi, 2048);
@@ -722,7 +721,7 @@ __global__ __launch_bounds__(256, 1) void mha_bwd_long_kernel(const bf16_t* __re
       if (full) tiles(std::true_type{}); else tiles(std::false_type{});
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < CH / 64; ++t) {
       const int qt = wave + 4 * t;
       if (qt < nqt)
         a2_store_tile<F>(dq[t], patch, patch_addr, dqkv + (long)(t0 + own0 + qt * 16) * H3 + h * 64, H3, ownlen - qt * 16, lane);
@@ -730,38 +729,38 @@ __global__ __launch_bounds__(256, 1) void mha_bwd_long_kernel(const bf16_t* __re
   } else {
     // ------------------------------------------------ dK, dV of key chunk `mine`
     stage_k(own0, ownlen);
-    f32x4 dk[4][4], dv[4][4];
+    f32x4 dk[CH / 64][4], dv[CH / 64][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < CH / 64; ++t)
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) { dk[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     const int nkt = (ownlen + 15) >> 4;
-    for (int qc = 0; qc * AL_CH < len; ++qc) {
-      const int q0 = qc * AL_CH, qlen = min(AL_CH, len - q0);
+    for (int qc = 0; qc * CH < len; ++qc) {
+      const int q0 = qc * CH, qlen = min(CH, len - q0);
       const int nqp = (((qlen + 15) >> 4) + 1) >> 1;
       __syncthreads();
       stage_q(q0, qlen);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      const bool full = (ownlen == AL_CH) && (qlen == AL_CH);
+      const bool full = (ownlen == CH) && (qlen == CH);
       auto tiles = [&](auto full_c) {
       constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < CH / 64; ++t) {
         const int kt = wave + 4 * t;
         if (kt >= nkt) continue;
         const int key = kt * 16 + fr;
         bf16x8 kf0, kf1, vf0, vf1;
         {
-          const uint32_t ak = lds0 + (uint32_t)(AL_TILE + kt * 2048), av = ak + AL_TILE;
+          const uint32_t ak = lds0 + (uint32_t)((CH * 128) + kt * 2048), av = ak + (CH * 128);
           A2_RD128(kf0, ak + rf_lo, 0); A2_RD128(kf1, ak + rf_hi, 0);
           A2_RD128(vf0, av + rf_lo, 0); A2_RD128(vf1, av + rf_hi, 0);
           asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf0), "+v"(kf1), "+v"(vf0), "+v"(vf1)::"memory");
         }
         const bool kok = key < ownlen;
         for (int qp = 0; qp < nqp; ++qp) {
-          const uint32_t bq = lds0 + (uint32_t)(qp * 4096), bd = bq + 3 * AL_TILE;
-          const uint32_t bl = lds0 + (uint32_t)(4 * AL_TILE + (qp * 32 + 4 * fg) * 4);
+          const uint32_t bq = lds0 + (uint32_t)(qp * 4096), bd = bq + 3 * (CH * 128);
+          const uint32_t bl = lds0 + (uint32_t)(4 * (CH * 128) + (qp * 32 + 4 * fg) * 4);
           bf16x8 q00, q01, q10, q11, d00, d01, d10, d11;
           bf16x4 e0l, e0h, e1l, e1h, e2l, e2h, e3l, e3h, u0l, u0h, u1l, u1h, u2l, u2h, u3l, u3h;
           f32x4 ls0, ls1, de0, de1;
@@ -769,9 +768,9 @@ __global__ __launch_bounds__(256, 1) void mha_bwd_long_kernel(const bf16_t* __re
           A2_RD128(q00, bq + rf_lo, 0); A2_RD128(q01, bq + rf_hi, 0); A2_RD128(q10, bq + rf_lo, 2048); A2_RD128(q11, bq + rf_hi, 2048);
           A2_RD128(d00, bd + rf_lo, 0); A2_RD128(d01, bd + rf_hi, 0); A2_RD128(d10, bd + rf_lo, 2048); A2_RD128(d11, bd + rf_hi, 2048);
           asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %5\n\tds_read_b128 %3, %5 offset:64"
-                       : "=&v"(ls0), "=&v"(ls1), "=&v"(de0), "=&v"(de1) : "v"(bl), "v"(bl + (uint32_t)(AL_CH * 4)) : "memory");
+                       : "=&v"(ls0), "=&v"(ls1), "=&v"(de0), "=&v"(de1) : "v"(bl), "v"(bl + (uint32_t)(CH * 4)) : "memory");
           if (DROP) {
-            const uint32_t ma = lds0 + (uint32_t)(MSK + (kt * AL_CH + qp * 32 + 4 * fg) * 2);
+            const uint32_t ma = lds0 + (uint32_t)(MSK + (kt * CH + qp * 32 + 4 * fg) * 2);
             asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:32" : "=&v"(mb[0]), "=&v"(mb[1]) : "v"(ma) : "memory");
           }
           A2_RDTR(e0l, bd + tr[0], 0); A2_RDTR(e0h, bd + tr[0], 2048); A2_RDTR(e1l, bd + tr[1], 0); A2_RDTR(e1h, bd + tr[1], 2048);
@@ -821,7 +820,7 @@ __global__ __launch_bounds__(256, 1) void mha_bwd_long_kernel(const bf16_t* __re
       if (full) tiles(std::true_type{}); else tiles(std::false_type{});
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < CH / 64; ++t) {
       const int kt = wave + 4 * t;
       if (kt < nkt) {
         bf16_t* dstk = dqkv + (long)(t0 + own0 + kt * 16) * H3 + H + h * 64;
@@ -1140,13 +1139,16 @@ extern "C" int simx_mha_bwd_hm(simx_stream_t stream, int dtype, int nseq, int he
     return SIMX_OK;
   }
   if (simx_is16(dtype) && d == 64) {                            // 256 < max_len <= 4096: chunked MFMA kernels
-    const int nchunk = cdiv(max_len, AL_CH);
-    const size_t ldsl = (size_t)4 * AL_TILE + 2 * AL_CH * sizeof(float) + 4 * 2048 + (size_t)16 * AL_CH * 2;   // (+ the dropout bits of dK / dV)
+    // 128-token chunks: two workgroups per CU, two tiles per wave (256-token chunks -- one workgroup per CU, four tiles per wave -- measured
+    // on the MS-Doc step, one box: attention backward 37.8 ms per step, 128-token chunks 30.5)
+    constexpr int ch = 128;
+    const int nchunk = cdiv(max_len, ch);
+    const size_t ldsl = (size_t)4 * ch * 128 + 2 * ch * sizeof(float) + 4 * 2048 + (size_t)(ch / 16) * ch * 2;   // (+ the dropout bits of dK / dV)
 #define LLD(DKV, DROP)                                                                                               \
   do {                                                                                                               \
-    rc = set_lds(mha_bwd_long_kernel<FF, DKV, DROP>, ldsl, "mha_bwd");                                               \
+    rc = set_lds(mha_bwd_long_kernel<FF, DKV, DROP, ch>, ldsl, "mha_bwd");                                           \
     if (rc) return rc;                                                                                               \
-    hipLaunchKernelGGL((mha_bwd_long_kernel<FF, DKV, DROP>), dim3(nseq * heads * nchunk), dim3(256), ldsl, s, (const bf16_t*)qkv, \
+    hipLaunchKernelGGL((mha_bwd_long_kernel<FF, DKV, DROP, ch>), dim3(nseq * heads * nchunk), dim3(256), ldsl, s, (const bf16_t*)qkv, \
                        (const bf16_t*)ctx, lse, (const bf16_t*)dctx, (bf16_t*)dqkv, cu, heads, T, nchunk, scale, drop); \
   } while (0)
 #define LL(DKV) do { if (drop.thr) LLD(DKV, true); else LLD(DKV, false); } while (0)

@@ -1109,7 +1109,7 @@ extern "C" int simx_mha_bwd_hm(simx_stream_t stream, int dtype, int nseq, int he
   int rc = check_common(dtype, nseq, heads, d, max_len, T, "mha_bwd");
   if (rc) return rc;
   const float scale = 1.0f / sqrtf((float)d);
-  if (simx_is16(dtype) && d == 64 && max_len <= 256) {
+  if (simx_is16(dtype) && d == 64 && max_len <= 256) {               // (161-256 tokens on the chunked kernels instead: 4.20 vs 4.02 ms at 256, 3.60 vs 3.78 at 200 -- not taken)
 #define LB(NKT, VG)                                                                                                  \
   do {                                                                                                               \
     const size_t lds = (size_t)((VG) ? 3 : 4) * NKT * 16 * 128 + 2 * NKT * 16 * sizeof(float) + (size_t)NKT * 16 * NKT * 2 + 4 * 2048; \

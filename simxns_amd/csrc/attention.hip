@@ -217,6 +217,154 @@ __global__ __launch_bounds__(256, (NKT <= 8 ? 4 : NKT <= 10 ? 3 : NKT <= 16 ? 2 
   if (nkt == NKT) tiles(std::true_type{}); else tiles(std::false_type{});
 }
 
+// ------------------------------------------------------------------------------------------ forward, long sequences
+// 256 < S <= 4096 (S > 512 used to run the one-wave-per-row kernel; the resident kernel above holds K and V of the whole sequence).
+// Here one workgroup takes a (sequence, head, 128-query chunk), a wave two 16-query tiles (Q fragments, running maximum / normaliser
+// and the output accumulators in registers), and the workgroup walks the 128-key chunks: K and V of a chunk in 32 KB of LDS, online
+// softmax (the accumulators are rescaled when the running maximum moves).  Either q/k/v layout.
+template <typename F, bool DROP>
+__global__ __launch_bounds__(256, 2) void mha_fwd_long_h16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, float* __restrict__ lse,
+                                                                 const int* __restrict__ cu, int heads, int T, int nchunk, float scale, DropCtx drop,
+                                                                 int hm_rows) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int blk = blockIdx.x / nchunk, qc = blockIdx.x % nchunk;
+  const int seq = blk / heads, h = blk % heads;
+  const int t0 = cu[seq], len = cu[seq + 1] - t0;
+  const int q0 = qc * 128;
+  if (len <= 0 || q0 >= len) return;
+  const int H = heads * 64;
+  const QkvLay lay = qkv_lay(heads, hm_rows);
+  const int H3 = lay.ld;
+  const bf16_t* Qg = qkv_head(qkv, heads, h, t0, hm_rows);
+  const bf16_t* Kg = Qg + lay.ws;
+  const bf16_t* Vg = Kg + lay.ws;
+  const int nkc = (len + 127) >> 7;
+  char* sK = smem;
+  char* sV = smem + 16384;
+  const uint32_t sV_addr = (uint32_t)(uintptr_t)sV;
+  const int fr = lane & 15, fg = lane >> 4;
+  const float c2 = scale * LOG2E;
+  uint32_t vtr[4];
+  {
+    const int rr = 4 * fg + (fr >> 2), tsw = att_f(rr), tx = (fr & 3) >> 1;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) vtr[dt] = (uint32_t)(rr * 128 + (((dt * 2 + tx) ^ tsw) << 4) + (fr & 1) * 8);
+  }
+  bf16x8 qf[2][2];
+  f32x4 o[2][4];
+  float mrun[2], lrun[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int q = q0 + (wave + 4 * j) * 16 + fr;
+    const int qcl = q < len ? q : len - 1;
+    qf[j][0] = *reinterpret_cast<const bf16x8*>(Qg + (long)qcl * H3 + fg * 8);
+    qf[j][1] = *reinterpret_cast<const bf16x8*>(Qg + (long)qcl * H3 + 32 + fg * 8);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[j][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mrun[j] = -INFINITY;
+    lrun[j] = 0.f;
+  }
+  for (int kc = 0; kc < nkc; ++kc) {
+    const int k0 = kc * 128;
+    const int nk = len - k0 < 128 ? len - k0 : 128;
+    const int nkt = (nk + 15) >> 4, nkt2 = (nkt + 1) & ~1;
+    __syncthreads();                                 // every wave is done with the previous chunk's tiles
+    att_stage(Kg + (long)k0 * H3, H3, nk, nkt2 * 16, sK, wave, lane);
+    att_stage(Vg + (long)k0 * H3, H3, nk, nkt2 * 16, sV, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    auto chunk = [&](auto allt_c) {
+      constexpr bool ALLT = decltype(allt_c)::value;   // all 128 keys of the chunk are real: no masks, no tile guards
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (q0 + (wave + 4 * j) * 16 >= len) continue;                       // (wave-uniform)
+        const int q = q0 + (wave + 4 * j) * 16 + fr;
+        f32x4 s[8];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) {
+          if (ALLT || kt < nkt) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            a = H16<F>::mfma(lds_row_frag(sK, kt * 16 + fr, fg), qf[j][0], a);
+            a = H16<F>::mfma(lds_row_frag(sK, kt * 16 + fr, 4 + fg), qf[j][1], a);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if (!ALLT) a[r] = k0 + kt * 16 + 4 * fg + r < len ? a[r] : -INFINITY;
+              mx = fmaxf(mx, a[r]);
+            }
+            s[kt] = a;
+          } else {
+            s[kt] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+          }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(mrun[j], mx);                               // finite: a chunk holds at least one real key
+        const float alpha = __builtin_amdgcn_exp2f((mrun[j] - mnew) * c2);   // first chunk: exp2(-inf) = 0
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = __builtin_amdgcn_exp2f((s[kt][r] - mnew) * c2);
+            s[kt][r] = p;
+            sum += p;
+          }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        lrun[j] = lrun[j] * alpha + sum;
+        mrun[j] = mnew;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[j][dt][e] *= alpha;
+        if (DROP) {
+          const uint32_t drow = (uint32_t)(h * T + t0 + q);
+#pragma unroll
+          for (int kt = 0; kt < 8; ++kt)
+            if (ALLT || kt < nkt) {
+              float m4[4];
+              drop_mult4(drop, drow, (uint32_t)(k0 + kt * 16 + 4 * fg), m4);
+              s[kt][0] *= m4[0]; s[kt][1] *= m4[1]; s[kt][2] *= m4[2]; s[kt][3] *= m4[3];
+            }
+        }
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          if (ALLT || 2 * kb < nkt) {                  // (rows past the padded length are uninitialised LDS: never multiplied)
+            const uint32_t b0 = sV_addr + (uint32_t)(kb * 4096);
+            bf16x4 a0l, a0h, a1l, a1h, a2l, a2h, a3l, a3h;
+            F2_RDTR(a0l, b0 + vtr[0], 0); F2_RDTR(a0h, b0 + vtr[0], 2048); F2_RDTR(a1l, b0 + vtr[1], 0); F2_RDTR(a1h, b0 + vtr[1], 2048);
+            F2_RDTR(a2l, b0 + vtr[2], 0); F2_RDTR(a2h, b0 + vtr[2], 2048); F2_RDTR(a3l, b0 + vtr[3], 0); F2_RDTR(a3h, b0 + vtr[3], 2048);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0l), "+v"(a0h), "+v"(a1l), "+v"(a1h), "+v"(a2l), "+v"(a2h), "+v"(a3l), "+v"(a3h)::"memory");
+            const bf16x8 pf = pack8<F>(s[2 * kb], s[2 * kb + 1]);
+            o[j][0] = H16<F>::mfma(F2_CAT(a0l, a0h), pf, o[j][0]);
+            o[j][1] = H16<F>::mfma(F2_CAT(a1l, a1h), pf, o[j][1]);
+            o[j][2] = H16<F>::mfma(F2_CAT(a2l, a2h), pf, o[j][2]);
+            o[j][3] = H16<F>::mfma(F2_CAT(a3l, a3h), pf, o[j][3]);
+          }
+        }
+      }
+    };
+    if (nk == 128) chunk(std::true_type{}); else chunk(std::false_type{});
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int q = q0 + (wave + 4 * j) * 16 + fr;
+    if (q < len) {
+      const float inv = 1.0f / lrun[j];
+      bf16_t* dst = ctx + (long)(t0 + q) * H + h * 64 + 4 * fg;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        float v[4] = {o[j][dt][0] * inv, o[j][dt][1] * inv, o[j][dt][2] * inv, o[j][dt][3] * inv};
+        st4h<F>(dst + dt * 16, v);
+      }
+      if (fg == 0) lse[(long)h * T + t0 + q] = mrun[j] * scale + logf(lrun[j]);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ backward
 // Q, K, V, dO of the (sequence, head) staged once in LDS; phase A: dQ (waves own query tiles), phase B: dK, dV (waves
 // own key tiles).  How the instruction stream is built matters more than the MFMA count here (PMC on the first version: 38 % of wave cycles issuing ~5000 non-MFMA instructions per wave, 43 % parked in s_waitcnt):
@@ -1039,14 +1187,14 @@ extern "C" int simx_mha_fwd_ex(simx_stream_t stream, int dtype, int nseq, int he
 extern "C" int simx_mha_fwd_hm(simx_stream_t stream, int dtype, int nseq, int heads, int d, const int32_t* cu, int max_len,
                                int T, const void* qkv, void* ctx, float* lse, const simx_dropout* dropd, int hm_rows) {
   hipStream_t s = (hipStream_t)stream;
-  SIMX_REQUIRE(hm_rows == 0 || (simx_is16(dtype) && d == 64 && max_len <= 512 && hm_rows >= T), SIMX_ERR_UNSUPPORTED,
-               "mha_fwd: the head-major qkv layout needs a 16-bit dtype, head size 64, max_len <= 512 and hm_rows >= T");
+  SIMX_REQUIRE(hm_rows == 0 || (simx_is16(dtype) && d == 64 && max_len <= 4096 && hm_rows >= T), SIMX_ERR_UNSUPPORTED,
+               "mha_fwd: the head-major qkv layout needs a 16-bit dtype, head size 64, max_len <= 4096 and hm_rows >= T");
   const DropCtx drop = make_drop(dropd);
   SIMX_PROF(SIMX_K_MHA_FWD, s, 4.0 * T * max_len * heads * d);
   int rc = check_common(dtype, nseq, heads, d, max_len, T, "mha_fwd");
   if (rc) return rc;
   const float scale = 1.0f / sqrtf((float)d);
-  if (simx_is16(dtype) && d == 64 && max_len <= 512) {
+  if (simx_is16(dtype) && d == 64 && max_len <= 256) {
 #define LF(NKT)                                                                                                      \
   do {                                                                                                               \
     const size_t lds = (size_t)2 * NKT * 16 * 128;                                                                   \
@@ -1067,13 +1215,22 @@ extern "C" int simx_mha_fwd_hm(simx_stream_t stream, int dtype, int nseq, int he
     if (max_len <= 32) LF(2);                                                                                        \
     else if (max_len <= 128) LF(8);                                                                                  \
     else if (max_len <= 160) LF(10);                                                                                 \
-    else if (max_len <= 256) LF(16);                                                                                 \
-    else LF(32);                                                                                                     \
+    else LF(16);                                                                                                     \
   } while (0)
     SIMX_DISPATCH16(dtype, FF, LF_ALL());
 #undef LF_ALL
 #undef LF
     SIMX_CHECK_LAUNCH("mha_fwd_h16");
+    return SIMX_OK;
+  }
+  if (simx_is16(dtype) && d == 64 && max_len <= 4096) {            // 256 < max_len: chunked (768 x 16 blocks of 512 tokens: 2.33 ms against 2.41
+                                                                    // with K / V resident in 128 KB of LDS; 300 tokens: 1.12 against 1.91)
+    const int nchunk = cdiv(max_len, 128);
+#define LFL(DR) hipLaunchKernelGGL((mha_fwd_long_h16_kernel<FF, DR>), dim3(nseq * heads * nchunk), dim3(256), 32768, s, (const bf16_t*)qkv, \
+                                   (bf16_t*)ctx, lse, cu, heads, T, nchunk, scale, drop, hm_rows)
+    SIMX_DISPATCH16(dtype, FF, if (drop.thr) LFL(true); else LFL(false));
+#undef LFL
+    SIMX_CHECK_LAUNCH("mha_fwd_long_h16");
     return SIMX_OK;
   }
   if (dtype == SIMX_F32 && simx_mha_f32_ok(d, max_len))

@@ -19,7 +19,8 @@ the worst case (every sequence at its maximum length); --varlen draws realistic 
 
 Launch:  python bench.py --gpus 1 --steps K --warmup W
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
-Prints ONE JSON line (rank 0).
+Prints ONE compact JSON line (rank 0) on stdout -- the headline, roofline, cpu_baseline and {value, ms_per_step, frac} per side
+line, < 6 KB; the full record (side-line kernel tables, prose) goes to stderr and gpurun_out/bench_full.json.
 """
 import argparse
 import ctypes as C
@@ -63,6 +64,8 @@ def cpu_baseline(timeout_s=420):
                       "configs[1] (B=8 x 16 passages, q32/p128/ce160, teacher fwd + student fwd/bwd) %.2f s/step over %d steps after "
                       "%d warm-up; configs[0] (B=4, N=1, student only) %.3f s/step = %.1f pairs/s over 10 steps after 3 warm-up; "
                       "%.0f s of CPU wall in total" % (thr, s2, d.get("cfg1r_steps", 2), d.get("cfg1r_warmup", 1), s1, p1 / s1, d["wall_s"]),
+            "sample_short": "torch-CPU fp32 port of the reference step, %d threads: B=8 x 16 passages (1/16 of the GPU batch), q32/p128/ce160, teacher fwd + "
+                            "student fwd/bwd, %d steps after %d warm-up, %.2f s/step" % (thr, d.get("cfg1r_steps", 2), d.get("cfg1r_warmup", 1), s2),
             "config0_pairs_per_s": round(p1 / s1, 2), "config0_s_per_step": round(s1, 4)}
 
 
@@ -439,6 +442,7 @@ def main():
     busy = pmc_mfma_busy()
     if busy is not None and is16:
         busy["source"] = pmc_source("r*_mfma_busy.json")
+        busy["stale"] = bool(busy["source"] and busy["source"]["stale"])
         out["mfma_busy_pmc"] = busy
     if real is not None:
         out["realistic_lengths"] = real
@@ -466,6 +470,7 @@ def main():
                            "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                            "traffic": pmc_traffic("gemm_nt_p3_kernel") if is16 else (pmc_traffic("gemm_nt_xp_kernel", "r*_fp32_traffic.json") if rk == "gemm_nt_xp" else None),
                            "traffic_source": pmc_source("r*_traffic.json" if is16 else "r*_fp32_traffic.json"), "launches": c_,
+                           "traffic_stale": bool((pmc_source("r*_traffic.json" if is16 else "r*_fp32_traffic.json") or {"stale": True})["stale"]),
                            "algorithmic_bytes_per_launch": alg_bytes_per_launch(c_ // max(1, args.steps)) if is16 else None,
                            "avg_launch_ms": round(ms_ / c_, 4), "algorithmic_flop_per_launch": round(wk_ / c_),
                            "measured": "HIP events on the launch stream over %d steps of the same job run right after the timed "
@@ -555,9 +560,116 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         except Exception as e:            # the baseline must never take the GPU number down with it
             out["cpu_baseline"] = {"value": None, "error": repr(e)}
-    print(json.dumps(out))
+    if args.side:
+        print(json.dumps(out))                  # a side run's parent reads the full block from the child's stdout
+    else:
+        emit(out)
     if world > 1 or forced:
         dist.destroy_process_group()
+
+
+SIDE_KEYS = ("fp32_mode", "recipe_fp32_gradckpt", "recipe_shapes", "recipe_of_record", "recipe_shapes_folded", "recipe_of_record_folded",
+             "deterministic_mode", "teacher_large", "cfg3_inbatch", "cfg4_prod", "cfg5_doc", "teacher_train_step", "realistic_lengths",
+             "all_rows_last_layer")
+LINE_LIMIT = 6000
+
+
+def csrc_digest():
+    """sha256[:16] over the kernel sources (simxns_amd/csrc/*.hip|*.h, names + contents): what a committed counter file must
+    have been taken at for bench.py to quote it as describing THIS build (there is no .git on the GPU box)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "simxns_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "simxns_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _stub(d):
+    """{value, ms_per_step, frac} of a side line (nested blocks such as cfg4_prod keep their keys)."""
+    if not isinstance(d, dict):
+        return d
+    if "value" not in d:
+        return {k: _stub(v) for k, v in d.items()}
+    s = {"value": d.get("value"), "ms_per_step": d.get("ms_per_step")}
+    if d.get("value") is None:
+        s["error"] = str(d.get("error", ""))[-120:]
+    if isinstance(d.get("roofline"), dict) and d["roofline"].get("frac") is not None:
+        s["frac"] = d["roofline"]["frac"]
+    if d.get("step_mfma_util") is not None:
+        s["step_mfma_util"] = d["step_mfma_util"]
+    return s
+
+
+def compact_line(out, full_path=None):
+    """The ONE stdout line the driver parses: the headline, its roofline and cpu_baseline, and a three-number stub per side
+    line.  Everything else (prose, kernel tables of the side lines) goes to the full record (stderr + gpurun_out/bench_full.json).
+    Round 4's line grew to 24 KB and the driver's parser did not take it: this stays under LINE_LIMIT bytes by construction
+    (tests/test_host_cpu.py::test_bench_line_is_compact)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: out[k] for k in keep if k in out}
+    cfg = dict(out.get("config", {}))
+    if len(cfg.get("workload", "")) > 360:
+        cfg["workload"] = cfg["workload"][:357] + "..."
+    line["config"] = {k: cfg[k] for k in ("workload", "global_batch", "pairs_per_step_per_gpu", "parallelism", "dropout") if k in cfg}
+    for k in ("step_mfma_util", "step_mfma_util_reference_flops", "final_loss"):
+        if k in out:
+            line[k] = out[k]
+    rf = out.get("roofline")
+    if rf:
+        line["roofline"] = {k: rf[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_stale", "algorithmic_bytes_per_launch",
+                                               "avg_launch_ms", "launches", "algorithmic_flop_per_launch") if k in rf}
+        src = rf.get("traffic_source") or {}
+        if src:
+            line["roofline"]["traffic_source"] = "%s @ %s" % (src.get("file"), src.get("commit"))
+    if "kernel_breakdown_ms_per_step" in out:
+        kb = sorted(out["kernel_breakdown_ms_per_step"].items(), key=lambda kv: -kv[1])[:8]
+        line["kernel_ms_per_step"] = {k: round(v, 2) for k, v in kb}
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "error") if k in cb}
+        if cb.get("sample"):
+            line["cpu_baseline"]["sample"] = cb.get("sample_short") or cb["sample"][:200]
+    p16 = out.get("parity_16bit")
+    if isinstance(p16, dict):
+        line["parity_16bit"] = {k: p16[k] for k in ("fixture", "logits_rel_err", "loss_abs_err", "embeddings_max_abs_err", "error") if k in p16}
+    if isinstance(out.get("mfma_busy_pmc"), dict):
+        b = out["mfma_busy_pmc"]
+        line["mfma_busy_pmc"] = {k: b[k] for k in ("step", "step_clock_ghz", "gemm_nt_p3_kernel", "stale") if k in b}
+    if isinstance(out.get("comm"), dict):
+        line["comm"] = {k: v for k, v in out["comm"].items() if isinstance(v, (int, float, bool)) or v is None}
+    sides = {k: _stub(out[k]) for k in SIDE_KEYS if out.get(k) is not None}
+    if sides:
+        line["sides"] = sides
+    if full_path:
+        line["full_record"] = full_path
+    s = json.dumps(line)
+    if len(s) > LINE_LIMIT:                      # never again an unparseable line: shed the optional blocks, largest first
+        for k in ("sides", "kernel_ms_per_step", "parity_16bit", "mfma_busy_pmc"):
+            if k in line:
+                line[k] = "see full_record"
+                s = json.dumps(line)
+                if len(s) <= LINE_LIMIT:
+                    break
+    return s
+
+
+def emit(out):
+    """Full record -> gpurun_out/bench_full.json (merged back by gpurun) and stderr; compact line -> stdout, last."""
+    full_path = None
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        name = "bench_full.json" if out.get("n_gpus", 1) == 1 else "bench_full_n%d.json" % out["n_gpus"]
+        json.dump(out, open(os.path.join(d, name), "w"), indent=1)
+        full_path = "gpurun_out/" + name
+    except OSError:
+        pass
+    sys.stderr.write("[bench.py full record]\n" + json.dumps(out, indent=1) + "\n")
+    sys.stderr.flush()
+    sys.stdout.write(compact_line(out, full_path) + "\n")
+    sys.stdout.flush()
 
 
 def p3_algorithmic_bytes(B, P, QL, PL, CE, teacher, full_last, L=L_, H=H_, F=F_):
@@ -639,7 +751,7 @@ def pmc_mfma_busy():
     at the clock they actually ran at.  Counters cannot be read inside the timed run: latest committed measurement, or None."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_mfma_busy.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mfma_busy.json"))):
         try:
             d = json.load(open(f))
         except Exception:
@@ -656,7 +768,7 @@ def pmc_source(pattern):
     """{file, commit, date} of the latest committed profile file matching `pattern` (written by tools/traffic.py): the counters quoted
     in the bench line are NOT measured in this run -- a reader must be able to tell which build they describe."""
     import glob
-    fs = sorted(f for f in glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pattern))
+    fs = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", pattern))
                 if ("fp32" in os.path.basename(f)) == ("fp32" in pattern))
     if not fs:
         return None
@@ -664,8 +776,11 @@ def pmc_source(pattern):
         src = json.load(open(fs[-1])).get("source") or {}
     except Exception:
         src = {}
+    dg = src.get("csrc_digest")
     return {"file": "profiles/" + os.path.basename(fs[-1]), "commit": src.get("commit", "not recorded (profile older than round 4)"),
-            "date_utc": src.get("date_utc")}
+            "date_utc": src.get("date_utc"), "csrc_digest": dg,
+            # counters describe THIS build only if the kernel sources they were taken at are the ones in the tree
+            "stale": dg is None or dg != csrc_digest()}
 
 
 def pmc_traffic(kernel, pattern="r*_traffic.json"):
@@ -675,7 +790,7 @@ def pmc_traffic(kernel, pattern="r*_traffic.json"):
     committed measurement, or None."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pattern))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern))):
         if pattern == "r*_traffic.json" and "fp32" in os.path.basename(f):
             continue
         try:

@@ -498,3 +498,48 @@ def test_launch_fold_accumulation_dry_run(capsys):
     assert "--per_gpu_train_batch_size=32" in folded and "--gradient_accumulation_steps=1" in folded
     assert plain.replace("--per_gpu_train_batch_size=16", "").replace("--gradient_accumulation_steps=2", "") == \
         folded.replace("--per_gpu_train_batch_size=32", "").replace("--gradient_accumulation_steps=1", "")
+
+
+def test_bench_line_is_compact(golden_dir):
+    """The driver parses bench.py's LAST stdout line; round 4's 24 KB line was not taken (BENCH_r04.parsed == null).  The
+    formatter must turn the largest record ever produced (profiles/r04_bench.json, every side line present) -- with an N > 1
+    `comm` block added -- into one line under bench.LINE_LIMIT that round-trips through json.loads and still carries the
+    headline, `roofline` and `cpu_baseline`."""
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench.json")))
+    assert len(json.dumps(full)) > 20000
+    full["comm"] = {"allreduce_bytes_per_step": 437928960, "allreduce_ms_on_comm_stream_per_step": 9.87, "exposed_wait_ms_per_step": 0.42,
+                    "payload": "f32", "parts": 2, "replica_check": "parameter checksums of all ranks agree to 1e-6 after the first optimiser step"}
+    line = bench.compact_line(full, "gpurun_out/bench_full.json")
+    assert "\n" not in line and len(line) < bench.LINE_LIMIT < 8000
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert d[k] == full[k], k
+    assert d["config"]["workload"].startswith("SimANS MS-MARCO Passage retriever step (BASELINE configs[1])")
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert d["roofline"][k] == full["roofline"][k]
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-3
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"])
+    assert d["comm"]["allreduce_bytes_per_step"] == 437928960 and "replica_check" not in d["comm"]
+    for name in ("fp32_mode", "recipe_of_record", "cfg3_inbatch", "teacher_train_step"):
+        assert set(d["sides"][name]) <= {"value", "ms_per_step", "frac", "step_mfma_util"} and d["sides"][name]["value"] == full[name]["value"]
+    assert d["sides"]["cfg4_prod"]["B8"]["value"] == full["cfg4_prod"]["B8"]["value"]
+    # a failed side line degrades to a short error stub, and an absurdly long record still yields a parseable line
+    full["fp32_mode"] = {"value": None, "error": "x" * 5000}
+    full["config"]["workload"] = "w" * 20000
+    d2 = json.loads(bench.compact_line(full))
+    assert len(json.dumps(d2)) < bench.LINE_LIMIT and len(d2["sides"]["fp32_mode"]["error"]) <= 120
+
+
+def test_bench_marks_foreign_counters_stale(tmp_path, monkeypatch):
+    """Counters quoted from profiles/ are marked stale unless they were taken at the kernel sources in the tree."""
+    import bench
+    dg = bench.csrc_digest()
+    assert re.fullmatch(r"[0-9a-f]{16}", dg)
+    (tmp_path / "profiles").mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "csrc_digest", lambda: dg)
+    json.dump({"source": {"commit": "abc", "csrc_digest": "0" * 16}, "kernels": {}}, open(tmp_path / "profiles" / "r09_traffic.json", "w"))
+    assert bench.pmc_source("r*_traffic.json")["stale"] is True
+    json.dump({"source": {"commit": "abc", "csrc_digest": dg}, "kernels": {}}, open(tmp_path / "profiles" / "r09_traffic.json", "w"))
+    assert bench.pmc_source("r*_traffic.json")["stale"] is False

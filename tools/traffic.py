@@ -20,6 +20,12 @@ os.makedirs("profiles", exist_ok=True)
 import datetime
 SOURCE = {"profile_tag": tag, "commit": sys.argv[2] if len(sys.argv) > 2 else os.environ.get("SIMX_PROFILE_COMMIT", "unknown"),
           "date_utc": datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%d %H:%M")}
+sys.path.insert(0, os.getcwd())
+try:                                        # the kernel sources the counters were taken at (bench.py marks older files stale)
+    import bench as _bench
+    SOURCE["csrc_digest"] = _bench.csrc_digest()
+except Exception:
+    pass
 
 
 def per_kernel(path, counter):
@@ -51,6 +57,8 @@ for f in glob.glob(src + "/stats/**/*kernel_stats.csv", recursive=True):
     shutil.copy(f, "profiles/%s_kernel_stats.csv" % tag)
 if os.path.exists(src + "/bench.json"):
     shutil.copy(src + "/bench.json", "profiles/%s_bench.json" % tag)
+if os.path.exists(src + "/bench_line.json"):
+    shutil.copy(src + "/bench_line.json", "profiles/%s_bench_line.json" % tag)
 for f in glob.glob(src + "/fp32_stats/**/*kernel_stats.csv", recursive=True):
     shutil.copy(f, "profiles/%s_fp32_kernel_stats.csv" % tag)
 if os.path.exists(src + "/fp32_bench.json"):

@@ -638,7 +638,7 @@ def compact_line(out, full_path=None):
         b = out["mfma_busy_pmc"]
         line["mfma_busy_pmc"] = {k: b[k] for k in ("step", "step_clock_ghz", "gemm_nt_p3_kernel", "stale") if k in b}
     if isinstance(out.get("comm"), dict):
-        line["comm"] = {k: v for k, v in out["comm"].items() if isinstance(v, (int, float, bool)) or v is None}
+        line["comm"] = {k: v for k, v in out["comm"].items() if isinstance(v, (int, float, bool)) or v is None or (isinstance(v, str) and len(v) <= 16)}
     sides = {k: _stub(out[k]) for k in SIDE_KEYS if out.get(k) is not None}
     if sides:
         line["sides"] = sides

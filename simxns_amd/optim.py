@@ -83,10 +83,13 @@ class FusedAdamW(object):
         if process_group is not None:
             self.group = process_group
         if payload is None:
-            # default at W > 1: bf16 slices (438 MB instead of 876 MB per step and rank over the xGMI links; the
-            # master gradients stay f32).  SIMX_GRAD_PAYLOAD=fp32 (or payload="fp32") sends f32.
+            # default: the payload follows the engine's arithmetic.  f32 engines (every shipped recipe; the mode held to
+            # north_star's 1e-3) all-reduce f32 like the reference's DDP (co_training_marco_train.py:107-114); only when EVERY
+            # tower computes in 16 bits do the slices cross the links as bf16 (438 MB instead of 876 MB per step and
+            # rank; the sum is taken in bf16 by RCCL, the master gradients stay f32).  SIMX_GRAD_PAYLOAD=bf16|fp32 overrides.
             import os
-            payload = os.environ.get("SIMX_GRAD_PAYLOAD") or ("bf16" if self.world_size > 1 else "fp32")
+            all16 = bool(self.towers) and all(getattr(e, "dtype_code", None) in (L.SIMX_BF16, L.SIMX_F16) for _, e in self.towers)
+            payload = os.environ.get("SIMX_GRAD_PAYLOAD") or ("bf16" if self.world_size > 1 and all16 else "fp32")
         if payload not in ("fp32", "bf16"):
             raise ValueError("payload must be 'fp32' or 'bf16', got %r" % (payload,))
         self.payload = payload

@@ -204,8 +204,30 @@ from simxns_amd.model.models import HFBertEncoder, Reranker
 from simxns_amd.optim import FusedAdamW
 cfg = BertConfigLite(vocab_size=50, hidden_size=8, num_hidden_layers=2, num_attention_heads=2, intermediate_size=16, max_position_embeddings=16)
 model = Reranker(HFBertEncoder(cfg, "fp32"), 8)
-assert FusedAdamW(model, lr=1e-3).enable_overlap(W, parts=2).payload == "bf16"     # the default at W > 1: half the bytes
-opt = FusedAdamW(model, lr=1e-3).enable_overlap(W, parts=2, payload="fp32")        # (exact sums below need the f32 payload)
+# default payload follows the engine arithmetic: f32 engines reduce in f32 (the reference's DDP), all-16-bit engines send bf16
+assert FusedAdamW(model, lr=1e-3).enable_overlap(W, parts=2).payload == "fp32"
+m16 = Reranker(HFBertEncoder(cfg, "fp16"), 8)
+assert FusedAdamW(m16, lr=1e-3).enable_overlap(W, parts=2).payload == "bf16"
+os.environ["SIMX_GRAD_PAYLOAD"] = "bf16"
+assert FusedAdamW(model, lr=1e-3).enable_overlap(W, parts=2).payload == "bf16"     # opt-in for an f32 engine
+del os.environ["SIMX_GRAD_PAYLOAD"]
+# what the bf16 payload costs: each rank's slice rounded to 8 significand bits, summed in bf16 by the backend -> |err| <= 2^-7 * sum|g_r| per element
+# (2^-9 per rank for the rounding of its slice + the backend's bf16 add, which need not round to nearest)
+ob = FusedAdamW(m16, lr=1e-3).enable_overlap(W, parts=2)
+eb = m16.encoder.engine
+gen = torch.Generator().manual_seed(5)
+gr = [torch.randn(eb.n_params, generator=gen) * 10 ** torch.randint(-6, 2, (eb.n_params,), generator=gen).float() for _ in range(W)]
+eb.ensure_grad().copy_(gr[rank])
+for p_ in m16.qa_classifier.parameters():
+    p_.grad = torch.zeros_like(p_)
+eb.grad_ready_hook(eb, 0, eb.n_params)
+assert ob.sync_grads() == 1.0 / W
+exact = sum(g.double() for g in gr)
+bound = 2.0 ** -7 * sum(g.abs().double() for g in gr)
+errb = (eb.flat_grad.double() - exact).abs()
+assert bool((errb <= bound + 1e-30).all()) and float(errb.max() / exact.abs().max()) < 8e-3, float((errb / bound.clamp_min(1e-30)).max())
+opt = FusedAdamW(model, lr=1e-3).enable_overlap(W, parts=2)                         # f32 engine -> f32 payload: exact sums below
+assert opt.payload == "fp32"
 e = model.encoder.engine
 assert e.grad_ready_hook is not None and e.bwd_parts == 2
 n = e.n_params

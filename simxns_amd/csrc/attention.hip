@@ -377,6 +377,8 @@ __global__ __launch_bounds__(256, 2) void mha_fwd_long_h16_kernel(const bf16_t* 
 //     instead of 8-B stores (32-B segments).
 #define A2_RD128(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=&v"(DST) : "v"(ADDR) : "memory")
 #define A2_RDTR(DST, ADDR, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #OFF : "=&v"(DST) : "v"(ADDR) : "memory")
+#define A2_RD128O(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
+#define A2_RDTRO(DST, ADDR, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
 #define A2_CAT(LO, HI) ((bf16x8){LO[0], LO[1], LO[2], LO[3], HI[0], HI[1], HI[2], HI[3]})
 
 // stage a wave's 16x64 tile (MFMA layout: lane = row fr, 4 columns dt*16 + 4*fg) through its 2 KB LDS patch and store it
@@ -425,8 +427,6 @@ __device__ __forceinline__ void a2_store_tile(const f32x4 (&acc)[4], char* patch
 //     adjacent LDS tiles and share one address register (the second through the instruction's immediate offset): 8
 //     address additions per iteration instead of 20;
 //   * 1/sqrt(d) multiplies the finished dQ / dK tiles, not every dS element.
-#define A2_RD128O(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
-#define A2_RDTRO(DST, ADDR, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
 template <typename F, int NKT, bool VG, bool DROP>
 __global__ __launch_bounds__(256) void mha_bwd2_h16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ O,
                                                             const float* __restrict__ lse, const bf16_t* __restrict__ dO,
@@ -907,37 +907,49 @@ __global__ __launch_bounds__(256, (CH == 128 ? 2 : 1)) void mha_bwd_long_kernel(
         }
         const bool kok = key < ownlen;
         for (int qp = 0; qp < nqp; ++qp) {
-          const uint32_t bq = lds0 + (uint32_t)(qp * 4096), bd = bq + 3 * (CH * 128);
+          // (dO tile = Q tile + 3 * CH * 128 bytes: as an instruction offset where it encodes -- 16 bits, the 128-token chunks -- so
+          // that Q and dO requests share their address registers)
+          constexpr int DOFF = CH == 128 ? 3 * (CH * 128) : 0;
+          const uint32_t bq = lds0 + (uint32_t)(qp * 4096), bd = bq + (uint32_t)(3 * (CH * 128) - DOFF);
           const uint32_t bl = lds0 + (uint32_t)(4 * (CH * 128) + (qp * 32 + 4 * fg) * 4);
           bf16x8 q00, q01, q10, q11, d00, d01, d10, d11;
           bf16x4 e0l, e0h, e1l, e1h, e2l, e2h, e3l, e3h, u0l, u0h, u1l, u1h, u2l, u2h, u3l, u3h;
           f32x4 ls0, ls1, de0, de1;
           uint2 mb[2] = {make_uint2(~0u, ~0u), make_uint2(~0u, ~0u)};          // keep-bits of the lane's four query rows (16 bits each), per tile of the pair
           A2_RD128(q00, bq + rf_lo, 0); A2_RD128(q01, bq + rf_hi, 0); A2_RD128(q10, bq + rf_lo, 2048); A2_RD128(q11, bq + rf_hi, 2048);
-          A2_RD128(d00, bd + rf_lo, 0); A2_RD128(d01, bd + rf_hi, 0); A2_RD128(d10, bd + rf_lo, 2048); A2_RD128(d11, bd + rf_hi, 2048);
+          A2_RD128O(d00, bd + rf_lo, DOFF); A2_RD128O(d01, bd + rf_hi, DOFF); A2_RD128O(d10, bd + rf_lo, DOFF + 2048); A2_RD128O(d11, bd + rf_hi, DOFF + 2048);
           asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %5\n\tds_read_b128 %3, %5 offset:64"
                        : "=&v"(ls0), "=&v"(ls1), "=&v"(de0), "=&v"(de1) : "v"(bl), "v"(bl + (uint32_t)(CH * 4)) : "memory");
           if (DROP) {
             const uint32_t ma = lds0 + (uint32_t)(MSK + (kt * CH + qp * 32 + 4 * fg) * 2);
             asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:32" : "=&v"(mb[0]), "=&v"(mb[1]) : "v"(ma) : "memory");
           }
-          A2_RDTR(e0l, bd + tr[0], 0); A2_RDTR(e0h, bd + tr[0], 2048); A2_RDTR(e1l, bd + tr[1], 0); A2_RDTR(e1h, bd + tr[1], 2048);
-          A2_RDTR(e2l, bd + tr[2], 0); A2_RDTR(e2h, bd + tr[2], 2048); A2_RDTR(e3l, bd + tr[3], 0); A2_RDTR(e3h, bd + tr[3], 2048);
-          A2_RDTR(u0l, bq + tr[0], 0); A2_RDTR(u0h, bq + tr[0], 2048); A2_RDTR(u1l, bq + tr[1], 0); A2_RDTR(u1h, bq + tr[1], 2048);
-          A2_RDTR(u2l, bq + tr[2], 0); A2_RDTR(u2h, bq + tr[2], 2048); A2_RDTR(u3l, bq + tr[3], 0); A2_RDTR(u3h, bq + tr[3], 2048);
+          // two LDS phases (register budget: 256 per wave at two workgroups per CU): the Q / dO fragments are consumed by the
+          // S and dP MFMAs before the transposed tiles of the same pair are requested, so the two sets never live together;
+          // the transposed reads are in flight under the exp2 / dS arithmetic
           asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q00), "+v"(q01), "+v"(q10), "+v"(q11), "+v"(d00), "+v"(d01), "+v"(d10), "+v"(d11),
-                       "+v"(ls0), "+v"(ls1), "+v"(de0), "+v"(de1), "+v"(mb[0]), "+v"(mb[1]),
-                       "+v"(e0l), "+v"(e0h), "+v"(e1l), "+v"(e1h), "+v"(e2l), "+v"(e2h), "+v"(e3l), "+v"(e3h),
-                       "+v"(u0l), "+v"(u0h), "+v"(u1l), "+v"(u1h), "+v"(u2l), "+v"(u2h), "+v"(u3l), "+v"(u3h)::"memory");
-          f32x4 pp[2], ds[2];
+                       "+v"(ls0), "+v"(ls1), "+v"(de0), "+v"(de1), "+v"(mb[0]), "+v"(mb[1])::"memory");
+          f32x4 sv[2], dpv[2];
 #pragma unroll
           for (int hf = 0; hf < 2; ++hf) {
-            const int qt = 2 * qp + hf;
             f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
             s = H16<F>::mfma(hf ? q10 : q00, kf0, s);
             s = H16<F>::mfma(hf ? q11 : q01, kf1, s);
             dp = H16<F>::mfma(hf ? d10 : d00, vf0, dp);
             dp = H16<F>::mfma(hf ? d11 : d01, vf1, dp);
+            sv[hf] = s; dpv[hf] = dp;
+          }
+          // (the empty asm orders the requests after the MFMA issue: it names the accumulators, it does not read them)
+          asm volatile("" : "+v"(sv[0]), "+v"(sv[1]), "+v"(dpv[0]), "+v"(dpv[1]));
+          A2_RDTRO(e0l, bd + tr[0], DOFF); A2_RDTRO(e0h, bd + tr[0], DOFF + 2048); A2_RDTRO(e1l, bd + tr[1], DOFF); A2_RDTRO(e1h, bd + tr[1], DOFF + 2048);
+          A2_RDTRO(e2l, bd + tr[2], DOFF); A2_RDTRO(e2h, bd + tr[2], DOFF + 2048); A2_RDTRO(e3l, bd + tr[3], DOFF); A2_RDTRO(e3h, bd + tr[3], DOFF + 2048);
+          A2_RDTR(u0l, bq + tr[0], 0); A2_RDTR(u0h, bq + tr[0], 2048); A2_RDTR(u1l, bq + tr[1], 0); A2_RDTR(u1h, bq + tr[1], 2048);
+          A2_RDTR(u2l, bq + tr[2], 0); A2_RDTR(u2h, bq + tr[2], 2048); A2_RDTR(u3l, bq + tr[3], 0); A2_RDTR(u3h, bq + tr[3], 2048);
+          f32x4 pp[2], ds[2];
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const int qt = 2 * qp + hf;
+            const f32x4 s = sv[hf], dp = dpv[hf];
             const f32x4 lsv = hf ? ls1 : ls0, dev = hf ? de1 : de0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -952,8 +964,10 @@ __global__ __launch_bounds__(256, (CH == 128 ? 2 : 1)) void mha_bwd_long_kernel(
               ds[hf][r] = p * (dp[r] * mm - dev[r]) * scale;
             }
           }
-          const bf16x8 pf = pack8<F>(pp[0], pp[1]);
-          const bf16x8 dsf = pack8<F>(ds[0], ds[1]);
+          bf16x8 pf = pack8<F>(pp[0], pp[1]);
+          bf16x8 dsf = pack8<F>(ds[0], ds[1]);
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e0l), "+v"(e0h), "+v"(e1l), "+v"(e1h), "+v"(e2l), "+v"(e2h), "+v"(e3l), "+v"(e3h),
+                       "+v"(u0l), "+v"(u0h), "+v"(u1l), "+v"(u1h), "+v"(u2l), "+v"(u2h), "+v"(u3l), "+v"(u3h), "+v"(pf), "+v"(dsf)::"memory");
           dv[t][0] = H16<F>::mfma(A2_CAT(e0l, e0h), pf, dv[t][0]);
           dk[t][0] = H16<F>::mfma(A2_CAT(u0l, u0h), dsf, dk[t][0]);
           dv[t][1] = H16<F>::mfma(A2_CAT(e1l, e1h), pf, dv[t][1]);
@@ -967,13 +981,17 @@ __global__ __launch_bounds__(256, (CH == 128 ? 2 : 1)) void mha_bwd_long_kernel(
       };
       if (full) tiles(std::true_type{}); else tiles(std::false_type{});
     }
+    // (the store addresses are derived from a laundered copy of the lane id: computed here, not kept in registers across the
+    // chunk loop -- the dK/dV copy with dropout has no register to spare at two workgroups per CU)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
 #pragma unroll
     for (int t = 0; t < CH / 64; ++t) {
       const int kt = wave + 4 * t;
       if (kt < nkt) {
         bf16_t* dstk = dqkv + (long)(t0 + own0 + kt * 16) * H3 + H + h * 64;
-        a2_store_tile<F>(dk[t], patch, patch_addr, dstk, H3, ownlen - kt * 16, lane);
-        a2_store_tile<F>(dv[t], patch, patch_addr, dstk + H, H3, ownlen - kt * 16, lane);
+        a2_store_tile<F>(dk[t], patch, patch_addr, dstk, H3, ownlen - kt * 16, lane_e);
+        a2_store_tile<F>(dv[t], patch, patch_addr, dstk + H, H3, ownlen - kt * 16, lane_e);
       }
     }
   }

@@ -705,7 +705,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_xq_kernel(
 #define XQ_ZERO_TAIL(BUF)                                                                                       \
   do {                                                                                                          \
     char* sp__ = smem + (BUF) * TN2_STAGE;                                                                      \
-    for (int idx = tid; idx < 128 * 32; idx += 512) {           /* 128 rows (4 planes x 32) x 32 16-B pieces */ \
+    int tz__ = tid;                    /* laundered: the (rare) tail's addresses are computed here, not hoisted over the k loop */ \
+    asm volatile("" : "+v"(tz__));                                                                              \
+    for (int idx = tz__; idx < 128 * 32; idx += 512) {          /* 128 rows (4 planes x 32) x 32 16-B pieces */ \
       const int row = idx >> 5, c16 = idx & 31;                                                                 \
       if ((row & 31) >= last_valid) *reinterpret_cast<uint4*>(sp__ + row * 512 + c16 * 16) = make_uint4(0, 0, 0, 0); \
     }                                                                                                           \

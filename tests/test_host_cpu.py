@@ -565,3 +565,22 @@ def test_bench_marks_foreign_counters_stale(tmp_path, monkeypatch):
     assert bench.pmc_source("r*_traffic.json")["stale"] is True
     json.dump({"source": {"commit": "abc", "csrc_digest": dg}, "kernels": {}}, open(tmp_path / "profiles" / "r09_traffic.json", "w"))
     assert bench.pmc_source("r*_traffic.json")["stale"] is False
+
+
+def test_no_spills_on_the_hot_path():
+    """ISA gate (tools/check_isa.py): the compiler's resource report of every gfx950 kernel in libsimx_hip.so shows no VGPR
+    spill and no scratch.  Round 4 shipped mha_bwd_long_kernel<.., DKV, DROP, 128> with 12-23 spilled VGPRs and
+    gemm_tn_xq_kernel<bf16> with one; nothing failed."""
+    _lib()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_isa
+    if not check_isa.collect():                     # objects built before build.sh wrote resource reports: rebuild once
+        for f in os.listdir(os.path.join(ROOT, "simxns_amd", "csrc")):
+            if f.endswith(".o"):
+                os.remove(os.path.join(ROOT, "simxns_amd", "csrc", f))
+        subprocess.check_call(["bash", os.path.join(ROOT, "simxns_amd", "csrc", "build.sh")])
+    ks = check_isa.collect()
+    names = " ".join(k["name"] for k in ks)
+    assert len(ks) > 250 and "gemm_nt_p3_kernel" in names and "mha_bwd_long_kernel" in names and "gemm_tn_xq_kernel" in names
+    assert check_isa.offenders(ks) == []
+    assert not check_isa.ALLOW                      # nothing is exempt today; an entry needs a reason next to it

@@ -182,7 +182,8 @@ int simx_embed_ln_fwd_planes(simx_stream_t stream, int T, int H, const int32_t* 
 int simx_mha_planes_ok(int d, int max_len);
 /* the same products on the 16-bit matrix cores from fp16 plane pairs (csrc/attention_x3.hip; head size 64, sequences <= 4096 -- K / V resident in LDS up to 160 tokens, 128-token chunks with an online softmax above:
  * simx_mha_x3_ok): q / k / v = the plane pair a SIMX_EPI_NONE_PLANES QKV projection wrote, context as a SIMX_F16 pair; backward
- * takes dctx in f32 and writes dq / dk / dv as a SIMX_BF16 pair. */
+ * takes dctx in f32 and writes dq / dk / dv as a SIMX_BF16 pair.  Attention dropout p <= 0.9 (probabilities travel as
+ * 2^10 p / (1 - p_drop) in fp16 halves); above that the calls return SIMX_ERR_UNSUPPORTED. */
 int simx_mha_x3_ok(int d, int max_len);
 int simx_mha_fwd_x3(simx_stream_t stream, int nseq, int heads, int d, const int32_t* cu, int max_len, int T, const void* qkv_planes,
                     long qkv_plane_stride, void* ctx_planes, long ctx_plane_stride, float* lse, const simx_dropout* drop);
@@ -324,6 +325,8 @@ int simx_mha_cls_bwd(simx_stream_t stream, int dtype, int nseq, int heads, int h
  * the token-major form of the plain calls), the dgrad GEMM reads dq/dk/dv as its A operand (simx_gemm_nt_hm, a_hm_rows)
  * and the wgrad GEMM as its token-contracted operand (simx_gemm_tn_hm).  For the [CLS]-only last layer the K / V planes
  * are planes [heads, 3*heads).  Values are identical to the token-major path; only addresses change.
+ * simx_mha_fwd_hm / simx_mha_bwd_hm accept hm_rows != 0 for max_len <= 256 only (the chunked kernels for longer sequences
+ * are token-major; both calls return SIMX_ERR_UNSUPPORTED above that, so a forward that is accepted has a backward).
  * simx_gemm_hm_ok(rows, H, tokens) != 0 when the three GEMM forms exist for a tower of `rows` padded token rows (they
  * run on the persistent full-tile kernels only: rows % 256 == 0, H % 256 == 0, >= 192 output tiles at N = H). */
 int simx_gemm_hm_ok(int rows, int H, int tokens);

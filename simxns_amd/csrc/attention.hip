@@ -1205,8 +1205,9 @@ extern "C" int simx_mha_fwd_ex(simx_stream_t stream, int dtype, int nseq, int he
 extern "C" int simx_mha_fwd_hm(simx_stream_t stream, int dtype, int nseq, int heads, int d, const int32_t* cu, int max_len,
                                int T, const void* qkv, void* ctx, float* lse, const simx_dropout* dropd, int hm_rows) {
   hipStream_t s = (hipStream_t)stream;
-  SIMX_REQUIRE(hm_rows == 0 || (simx_is16(dtype) && d == 64 && max_len <= 4096 && hm_rows >= T), SIMX_ERR_UNSUPPORTED,
-               "mha_fwd: the head-major qkv layout needs a 16-bit dtype, head size 64, max_len <= 4096 and hm_rows >= T");
+  // (the same limit as simx_mha_bwd_hm: a forward the library accepts must have a backward it accepts)
+  SIMX_REQUIRE(hm_rows == 0 || (simx_is16(dtype) && d == 64 && max_len <= 256 && hm_rows >= T), SIMX_ERR_UNSUPPORTED,
+               "mha_fwd: the head-major qkv layout needs a 16-bit dtype, head size 64, max_len <= 256 and hm_rows >= T");
   const DropCtx drop = make_drop(dropd);
   SIMX_PROF(SIMX_K_MHA_FWD, s, 4.0 * T * max_len * heads * d);
   int rc = check_common(dtype, nseq, heads, d, max_len, T, "mha_fwd");

@@ -1114,6 +1114,8 @@ extern "C" int simx_mha_fwd_x3(simx_stream_t stream, int nseq, int heads, int d,
   SIMX_REQUIRE(nseq > 0 && heads > 0 && T > 0 && qkv_planes && ctx_planes && lse && cu, SIMX_ERR_BAD_SHAPE, "mha_fwd_x3: bad arguments");
   SIMX_REQUIRE(simx_mha_x3_ok(d, max_len) && qkv_plane_stride % 8 == 0 && ctx_plane_stride % 4 == 0, SIMX_ERR_UNSUPPORTED,
                "mha_fwd_x3: needs head size 64, max_len <= 4096, plane strides %% 8 / %% 4 == 0");
+  // (probabilities travel as 2^10 p / (1 - p_drop) in fp16 halves: finite only while 1 / (1 - p_drop) stays small)
+  SIMX_REQUIRE(!dropd || dropd->p <= 0.9f, SIMX_ERR_UNSUPPORTED, "mha_x3: attention dropout above 0.9 is not supported by the plane-pair kernels");
   const DropCtx drop = make_drop(dropd);
   const float scale = 1.0f / sqrtf((float)d);
   int rc = SIMX_OK;
@@ -1167,6 +1169,8 @@ extern "C" int simx_mha_bwd_x3_bias(simx_stream_t stream, int nseq, int heads, i
   SIMX_REQUIRE(simx_mha_x3_ok(d, max_len) && qkv_plane_stride % 8 == 0 && ctx_plane_stride % 8 == 0 && dqkv_plane_stride % 4 == 0 &&
                    (heads * 64) % 8 == 0 && (((uintptr_t)dctx) & 15) == 0, SIMX_ERR_UNSUPPORTED,
                "mha_bwd_x3: needs head size 64, max_len <= 4096, aligned plane strides");
+  // (probabilities travel as 2^10 p / (1 - p_drop) in fp16 halves: finite only while 1 / (1 - p_drop) stays small)
+  SIMX_REQUIRE(!dropd || dropd->p <= 0.9f, SIMX_ERR_UNSUPPORTED, "mha_x3: attention dropout above 0.9 is not supported by the plane-pair kernels");
   const DropCtx drop = make_drop(dropd);
   const float scale = 1.0f / sqrtf((float)d);
   int rc = SIMX_OK;

@@ -75,6 +75,14 @@ def test_mha_fwd_x3_dropout_and_speed(dev):
     assert np.abs(lse.cpu().numpy() - lse2.cpu().numpy()).max() <= 2e-5 * 20
     t3, t32 = _ms(lambda: x3(None)), _ms(lambda: f32(None))
     print("mha_fwd S=128 x %d seqs x 12 heads: x3 %.3f ms, f32 MFMA %.3f ms" % (nseq, t3, t32))
+    # probabilities travel as 2^10 p / (1 - p_drop) in fp16 halves: p_drop = 0.9 is finite, above it the call refuses (it used to
+    # return inf / NaN silently from p_drop ~ 0.984 on)
+    from simxns_amd._lib import SimxError
+    x3(lib.Dropout(0.9, 99, 11))
+    torch.cuda.synchronize()
+    assert np.isfinite(planes_value(ctxp, F16)).all()
+    with pytest.raises(SimxError):
+        x3(lib.Dropout(0.95, 99, 11))
 
 
 @pytest.mark.parametrize("heads", [1, 3])

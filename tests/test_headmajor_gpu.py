@@ -184,3 +184,22 @@ def test_plane_blocked_entry_rejects_what_is_not_built(dev):
     with pytest.raises(SimxError):                     # fp32 has no plane-blocked form
         lib.call("simx_gemm_nt_pb", lib.stream_ptr(), 0, M, N, K, lib.ptr(A), K, lib.ptr(B), K, lib.ptr(C), 64, None, None, 0, 0,
                  None, 0, None, 2, M)
+
+
+def test_head_major_attention_limit_is_the_same_forward_and_backward(dev):
+    """simx_mha_fwd_hm must not accept a head-major layout its backward rejects (sequences above 256 tokens run on the
+    token-major chunked kernels)."""
+    lib = L()
+    from simxns_amd._lib import SimxError
+    heads, d, S, n = 2, 64, 320, 2
+    T = n * S
+    R = 768
+    qkv = torch.zeros(3 * heads * R * 64, dtype=torch.bfloat16, device=dev)
+    ctx = torch.zeros(T, heads * 64, dtype=torch.bfloat16, device=dev)
+    lse = torch.zeros(heads, T, device=dev)
+    cu = torch.arange(0, T + 1, S, dtype=torch.int32, device=dev)
+    with pytest.raises(SimxError):
+        lib.call("simx_mha_fwd_hm", lib.stream_ptr(), 1, n, heads, d, lib.ptr(cu), S, T, lib.ptr(qkv), lib.ptr(ctx), lib.ptr(lse), None, R)
+    with pytest.raises(SimxError):
+        lib.call("simx_mha_bwd_hm", lib.stream_ptr(), 1, n, heads, d, lib.ptr(cu), S, T, lib.ptr(qkv), lib.ptr(ctx), lib.ptr(lse),
+                 lib.ptr(ctx), lib.ptr(qkv), None, R)

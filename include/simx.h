@@ -166,6 +166,11 @@ int simx_planes_from(simx_stream_t stream, int src_fmt, int dst_fmt, int rows, i
                      void* dst, int ld_dst, long dst_plane_stride);
 int simx_planes_join(simx_stream_t stream, int src_fmt, int rows, int cols, const void* src, int ld_src, long src_plane_stride, float* dst,
                      int ld_dst);
+/* operand forms of ONE dense weight W [rows, cols] f32 (an nn.Linear.weight, LEAD/modeling_bert.py:285-310, 385, 450, 463), as
+ * simx_bert_cast_weights produces them for every weight of an fp32-engine tower once per optimiser step: the SIMX_F16 plane pair
+ * of W (forward operand; lo plane at + rows * cols elements), the SIMX_BF16 plane pair of W^T [cols, rows] (dgrad operand) and
+ * W^T in f32.  Any output may be NULL.  rows, cols multiples of 64 run on 64 x 64 tiles with 16-byte accesses. */
+int simx_split_weight(simx_stream_t stream, const float* W, int rows, int cols, void* planes_f16, void* planesT_bf16, float* WT);
 
 /* the producers that write plane pairs directly (fp32 engine; leading dimension of every pair = the tensor's own):
  *   LayerNorm / embedding LayerNorm: y (f32) and its SIMX_F16 pair (LEAD/modeling_bert.py:230-240, 384-388, 462-466);

@@ -130,6 +130,7 @@ SIGNATURES = {
     "simx_gemm_tn_planes_workspace_bytes": (_z, [_i, _i, _i]),
     "simx_gemm_tn_planes": (_i, [_p, _i, _i, _i, _p, _i, _l, _p, _i, _l, _p, _i, _i, _p, _z, _p]),
     "simx_planes_from": (_i, [_p, _i, _i, _i, _i, _p, _i, _l, _p, _i, _l]),
+    "simx_split_weight": (_i, [_p, _p, _i, _i, _p, _p, _p]),
     "simx_planes_join": (_i, [_p, _i, _i, _i, _p, _i, _l, _p, _i]),
     "simx_ln_fwd_planes": (_i, [_p, _i, _i, _p, _p, _p, _f, _p, _p, _l]),
     "simx_ln_bwd_planes": (_i, [_p, _i, _i, _p, _p, _f, _p, _p, _p, _l, _p, _p, _p, _dp]),

@@ -171,3 +171,34 @@ def test_gemm_nt_planes_dgelu_colsum(dev, M, N, K, valid):
     want = ref.sum(0) + cs0
     assert np.isfinite(got).all()
     assert np.all(np.abs(got - want) <= 2e-5 * np.abs(ref).sum(0) + 1e-7), np.abs(got - want).max()
+
+
+@pytest.mark.parametrize("rows,cols", [(768, 3072), (2304, 768), (64, 64), (96, 40), (33, 7)])
+def test_split_weight_forms(dev, rows, cols):
+    """simx_split_weight (what simx_bert_cast_weights runs per dense weight of an fp32 tower): the fp16 plane pair of W, the bf16
+    plane pair of W^T and W^T in f32 are BIT-identical to the elementwise definition hi = rnd16(w), lo = rnd16(w - hi) -- on the
+    64 x 64-tile kernel (rows, cols multiples of 64) and on the 32 x 32 kernel for every other shape; and the rate of the former."""
+    lib = L()
+    w = torch.from_numpy(rnd((rows, cols), 7, 0.05) * np.exp(rnd((rows, cols), 8) * 1.5)).to(dev)
+    ph = torch.full((2, rows, cols), -1, device=dev, dtype=torch.int16)
+    pt = torch.full((2, cols, rows), -1, device=dev, dtype=torch.int16)
+    wT = torch.full((cols, rows), float("nan"), device=dev)
+    run = lambda: lib.call("simx_split_weight", lib.stream_ptr(), lib.ptr(w), rows, cols, lib.ptr(ph), lib.ptr(pt), lib.ptr(wT))
+    run()
+    torch.cuda.synchronize()
+    assert torch.equal(wT, w.t().contiguous())
+    for planes, src, t in ((ph, w, torch.float16), (pt, w.t().contiguous(), torch.bfloat16)):
+        hi = src.to(t)
+        lo = (src - hi.float()).to(t)
+        assert torch.equal(planes[0].view(t), hi) and torch.equal(planes[1].view(t), lo)
+    # any output may be absent
+    ph.fill_(-1)
+    lib.call("simx_split_weight", lib.stream_ptr(), lib.ptr(w), rows, cols, lib.ptr(ph), None, None)
+    torch.cuda.synchronize()
+    assert torch.equal(ph[0].view(torch.float16), w.to(torch.float16))
+    if rows * cols >= 768 * 3072:
+        from tests.test_attention_x3_gpu import _ms
+        ms = _ms(run, 20)
+        gbs = rows * cols * 16 / ms / 1e6
+        print("split_weight %d x %d: %.3f ms = %.0f GB/s" % (rows, cols, ms, gbs))
+        assert gbs > 1000, gbs                       # (the 32 x 32 scalar-store kernel ran at 220 GB/s)

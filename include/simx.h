@@ -69,9 +69,11 @@ enum { SIMX_EPI_NONE = 0,   /* C = acc (+bias) (+residual)                      
 
 /* Dropout descriptor (nn.Dropout of BertEmbeddings / BertSelfAttention / BertSelfOutput / BertOutput,
  * LEAD/modeling_bert.py:239, 358, 386, 464; p = 0.1 forced in training, SimANS/model/models.py:70-72).
- * The keep-mask is a stateless hash of (seed, stream, row, column): element (row, col) is kept iff the 16-bit lane
- * (col & 1) of mix32(seed, stream, row, col >> 1) is >= round(p * 65536); kept values are scaled by 1/(1-p).  Nothing is
- * stored: backward kernels recompute the mask from the same descriptor.  p == 0 (or a NULL descriptor) = no dropout. */
+ * The keep-mask is a stateless hash of (seed, stream, row, column): element (row, col) is kept iff byte (col & 3) of
+ * mix32(seed, stream, row, col >> 2) is >= thr = round(256 p) (one hash per four columns: the drop probability is realised
+ * in steps of 1/256, 26/256 = 0.1016 for p = 0.1); kept values are scaled by 256 / (256 - thr), the reciprocal of the
+ * realised keep rate, so the mask has mean 1 exactly.  0 < p < 1/512 rounds up to 1/256, p > 255/256 down to 255/256.  Nothing
+ * is stored: backward kernels recompute the mask from the same descriptor.  p == 0 (or a NULL descriptor) = no dropout. */
 typedef struct simx_dropout {
   float p;
   uint32_t seed;

@@ -50,12 +50,12 @@ def gelu_grad(u):
     return 0.5 * (1.0 + erf(u * SQRT1_2)) + u * np.exp(-0.5 * u * u) * INV_SQRT_2PI
 
 
-def _mix32(seed, stream, row, colpair):
+def _mix32(seed, stream, row, colquad):
     """uint32 hash of the product's dropout mask (simxns_amd/csrc/common.h drop_mix), vectorised."""
     M = np.uint64(0xFFFFFFFF)
     row = np.asarray(row, dtype=np.uint64)
-    cp = np.asarray(colpair, dtype=np.uint64)
-    h = ((row * np.uint64(0x9E3779B1)) & M) ^ ((((cp + np.uint64((stream * 0x632BE5AB) & 0xFFFFFFFF)) & M) * np.uint64(0x85EBCA77)) & M) ^ np.uint64(seed & 0xFFFFFFFF)
+    cq = np.asarray(colquad, dtype=np.uint64)
+    h = ((row * np.uint64(0x9E3779B1)) & M) ^ ((((cq + np.uint64((stream * 0x632BE5AB) & 0xFFFFFFFF)) & M) * np.uint64(0x85EBCA77)) & M) ^ np.uint64(seed & 0xFFFFFFFF)
     h ^= h >> np.uint64(16)
     h = (h * np.uint64(0x7FEB352D)) & M
     h ^= h >> np.uint64(15)
@@ -64,16 +64,26 @@ def _mix32(seed, stream, row, colpair):
     return h
 
 
+def drop_threshold(p):
+    """-> (thr, scale) of the stateless mask: one hash serves four columns (its bytes against an 8-bit threshold), so the drop
+    probability is realised in steps of 1/256 -- thr = round(256 p), 26/256 for p = 0.1 -- and kept values are scaled by the
+    reciprocal of the REALISED keep rate, 256 / (256 - thr): E[multiplier] = 1 exactly (common.h make_drop)."""
+    thr = int(np.float32(p) * np.float32(256.0) + np.float32(0.5))
+    thr = min(255, max(1, thr))
+    return thr, float(np.float32(256.0) / np.float32(256 - thr))
+
+
 def drop_multipliers(p, seed, stream, rows, cols):
-    """[len(rows), len(cols)] multipliers (0 or 1/(1-p)) of the stateless dropout mask (include/simx.h simx_dropout)."""
+    """[len(rows), len(cols)] multipliers (0 or 256/(256-thr)) of the stateless dropout mask (include/simx.h simx_dropout):
+    element (row, col) is kept iff byte (col & 3) of mix32(seed, stream, row, col >> 2) is >= thr."""
     rows = np.asarray(rows, dtype=np.uint64)[:, None]
     cols = np.asarray(cols, dtype=np.uint64)[None, :]
     if p <= 0:
         return np.ones((rows.shape[0], cols.shape[1]))
-    thr = int(np.float32(p) * np.float32(65536.0) + np.float32(0.5))
-    h = _mix32(seed, stream, rows, cols >> np.uint64(1))
-    lane = np.where((cols & np.uint64(1)) == 1, h >> np.uint64(16), h & np.uint64(0xFFFF))
-    return np.where(lane >= thr, 1.0 / (1.0 - float(np.float32(p))), 0.0)
+    thr, scale = drop_threshold(p)
+    h = _mix32(seed, stream, rows, cols >> np.uint64(2))
+    lane = (h >> ((cols & np.uint64(3)) * np.uint64(8))) & np.uint64(0xFF)
+    return np.where(lane >= thr, scale, 0.0)
 
 
 def _drop_masks(drop, ids, mask, heads, layers):

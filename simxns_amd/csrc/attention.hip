@@ -488,10 +488,9 @@ __global__ __launch_bounds__(256) void mha_bwd2_h16_kernel(const bf16_t* __restr
       for (int q = lane; q < nkt * 16; q += 64) {
         uint32_t w = 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const uint32_t hsh = drop_mix(drop.seed, drop.stream, (uint32_t)(h * T + t0 + q), (uint32_t)(kt * 8 + j));
-          w |= ((hsh & 0xFFFFu) >= drop.thr ? 1u : 0u) << (2 * j);
-          w |= ((hsh >> 16) >= drop.thr ? 2u : 0u) << (2 * j);
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t hsh = drop_mix(drop.seed, drop.stream, (uint32_t)(h * T + t0 + q), (uint32_t)(kt * 4 + j));
+          w |= drop_keep4(hsh, drop.thr) << (4 * j);
         }
         *reinterpret_cast<unsigned short*>(smem + MSK + (kt * NKT * 16 + q) * 2) = (unsigned short)w;
       }
@@ -782,10 +781,9 @@ __global__ __launch_bounds__(256, (CH == 128 ? 2 : 1)) void mha_bwd_long_kernel(
         for (int q = lane; q < npad; q += 64) {
           uint32_t w = 0;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const uint32_t hsh = drop_mix(drop.seed, drop.stream, (uint32_t)(h * T + t0 + r0 + q), (uint32_t)((own0 >> 1) + kt * 8 + j));
-            w |= ((hsh & 0xFFFFu) >= drop.thr ? 1u : 0u) << (2 * j);
-            w |= ((hsh >> 16) >= drop.thr ? 2u : 0u) << (2 * j);
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t hsh = drop_mix(drop.seed, drop.stream, (uint32_t)(h * T + t0 + r0 + q), (uint32_t)((own0 >> 2) + kt * 4 + j));
+            w |= drop_keep4(hsh, drop.thr) << (4 * j);
           }
           *reinterpret_cast<unsigned short*>(smem + MSK + (kt * CH + q) * 2) = (unsigned short)w;
         }

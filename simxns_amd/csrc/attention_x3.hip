@@ -469,10 +469,9 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_dkv_x3_kernel(const bf16_t* __
       for (int q = lane; q < nkt2 * 16; q += 64) {
         uint32_t w = 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const uint32_t hsh = drop_mix(drop.seed, drop.stream, (uint32_t)(h * T + t0 + q), (uint32_t)(kt * 8 + j));
-          w |= ((hsh & 0xFFFFu) >= drop.thr ? 1u : 0u) << (2 * j);
-          w |= ((hsh >> 16) >= drop.thr ? 2u : 0u) << (2 * j);
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t hsh = drop_mix(drop.seed, drop.stream, (uint32_t)(h * T + t0 + q), (uint32_t)(kt * 4 + j));
+          w |= drop_keep4(hsh, drop.thr) << (4 * j);
         }
         *reinterpret_cast<unsigned short*>(smem + MSK + (kt * NKT * 16 + q) * 2) = (unsigned short)w;
       }
@@ -975,10 +974,9 @@ __global__ __launch_bounds__(256, 2) void mha_bwd_dkv_x3_long_kernel(const bf16_
         for (int q = lane; q < nqt2 * 16; q += 64) {
           uint32_t w = 0;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const uint32_t hsh = drop_mix(drop.seed, drop.stream, (uint32_t)(h * T + t0 + q0 + q), (uint32_t)((k0 >> 1) + ktl * 8 + j));
-            w |= ((hsh & 0xFFFFu) >= drop.thr ? 1u : 0u) << (2 * j);
-            w |= ((hsh >> 16) >= drop.thr ? 2u : 0u) << (2 * j);
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t hsh = drop_mix(drop.seed, drop.stream, (uint32_t)(h * T + t0 + q0 + q), (uint32_t)((k0 >> 2) + ktl * 4 + j));
+            w |= drop_keep4(hsh, drop.thr) << (4 * j);
           }
           *reinterpret_cast<unsigned short*>(smem + MSK + (ktl * XL_CH + q) * 2) = (unsigned short)w;
         }

@@ -187,34 +187,47 @@ __device__ __forceinline__ void st4(bf16_t* p, const float (&v)[4]) {
 }
 
 // ---- stateless dropout mask (see simx_dropout in include/simx.h) ---------------------------------------------
+// One 32-bit hash serves FOUR consecutive columns (its four bytes against an 8-bit threshold): the 32-bit integer multiplies of
+// the mix are the cost of a mask (v_mul_lo_u32 issues at a quarter of the VALU rate), and until round 5 a hash served two
+// columns (16-bit lanes).  The drop probability is therefore realised in steps of 1/256 -- thr = round(256 p), 26/256 =
+// 0.1016 for the reference's p = 0.1 -- and kept values are scaled by 256 / (256 - thr), the reciprocal of the REALISED keep
+// rate, so that E[mask] = 1 exactly.  The reference fixes p only (SimANS/model/models.py:70-72); its RNG stream cannot be
+// replayed on a GPU kernel in any case (oracle/bert.py restates THIS definition).
 struct DropCtx { uint32_t thr; float scale; uint32_t seed; uint32_t stream; };   // thr == 0: disabled
 static inline DropCtx make_drop(const simx_dropout* d) {
   DropCtx c = {0u, 1.0f, 0u, 0u};
   if (d && d->p > 0.f) {
-    c.thr = (uint32_t)(d->p * 65536.0f + 0.5f);
-    c.scale = 1.0f / (1.0f - d->p);
+    uint32_t t = (uint32_t)(d->p * 256.0f + 0.5f);
+    t = t < 1u ? 1u : (t > 255u ? 255u : t);
+    c.thr = t;
+    c.scale = 256.0f / (float)(256u - t);
     c.seed = d->seed;
     c.stream = d->stream;
   }
   return c;
 }
-__device__ __forceinline__ uint32_t drop_mix(uint32_t seed, uint32_t stream, uint32_t row, uint32_t colpair) {
-  uint32_t h = (row * 0x9E3779B1u) ^ ((colpair + stream * 0x632BE5ABu) * 0x85EBCA77u) ^ seed;
+__device__ __forceinline__ uint32_t drop_mix(uint32_t seed, uint32_t stream, uint32_t row, uint32_t colquad) {
+  uint32_t h = (row * 0x9E3779B1u) ^ ((colquad + stream * 0x632BE5ABu) * 0x85EBCA77u) ^ seed;
   h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
   return h;
 }
-// multiplier (0 or 1/(1-p)) for element (row, col)
-__device__ __forceinline__ float drop_mult(const DropCtx& d, uint32_t row, uint32_t col) {
-  const uint32_t h = drop_mix(d.seed, d.stream, row, col >> 1);
-  return (((col & 1u) ? (h >> 16) : (h & 0xFFFFu)) >= d.thr) ? d.scale : 0.f;
+// keep flags of the four columns of a hash: bit e = byte e >= thr
+__device__ __forceinline__ uint32_t drop_keep4(uint32_t h, uint32_t thr) {
+  return ((h & 0xFFu) >= thr ? 1u : 0u) | (((h >> 8) & 0xFFu) >= thr ? 2u : 0u) | (((h >> 16) & 0xFFu) >= thr ? 4u : 0u) |
+         ((h >> 24) >= thr ? 8u : 0u);
 }
-// 4 consecutive columns starting at an EVEN col (two hashes)
+// multiplier (0 or 256 / (256 - thr)) for element (row, col)
+__device__ __forceinline__ float drop_mult(const DropCtx& d, uint32_t row, uint32_t col) {
+  const uint32_t h = drop_mix(d.seed, d.stream, row, col >> 2);
+  return (((h >> ((col & 3u) * 8u)) & 0xFFu) >= d.thr) ? d.scale : 0.f;
+}
+// 4 consecutive columns starting at a col that is a MULTIPLE OF 4 (one hash)
 __device__ __forceinline__ void drop_mult4(const DropCtx& d, uint32_t row, uint32_t col, float (&m)[4]) {
-  const uint32_t h0 = drop_mix(d.seed, d.stream, row, col >> 1), h1 = drop_mix(d.seed, d.stream, row, (col >> 1) + 1);
-  m[0] = ((h0 & 0xFFFFu) >= d.thr) ? d.scale : 0.f;
-  m[1] = ((h0 >> 16) >= d.thr) ? d.scale : 0.f;
-  m[2] = ((h1 & 0xFFFFu) >= d.thr) ? d.scale : 0.f;
-  m[3] = ((h1 >> 16) >= d.thr) ? d.scale : 0.f;
+  const uint32_t h = drop_mix(d.seed, d.stream, row, col >> 2);
+  m[0] = ((h & 0xFFu) >= d.thr) ? d.scale : 0.f;
+  m[1] = (((h >> 8) & 0xFFu) >= d.thr) ? d.scale : 0.f;
+  m[2] = (((h >> 16) & 0xFFu) >= d.thr) ? d.scale : 0.f;
+  m[3] = ((h >> 24) >= d.thr) ? d.scale : 0.f;
 }
 
 // ---- wave64 reductions -------------------------------------------------------------------

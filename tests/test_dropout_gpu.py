@@ -66,7 +66,8 @@ def test_step_with_dropout_matches_oracle(dev, dtype, heads, hidden, p_len, full
     osim = ol.sim_block(oq, oc)
     ol_, _, ods = ol.kl_distill(osim, z.astype(np.float64))
     # (NOTE: "matches the oracle" here is a consistency check of the mask plumbing -- the oracle restates the product's own
-    # stateless hash; what is pinned to the REFERENCE's dropout semantics is the keep rate and the 1/(1-p) scaling)
+    # stateless hash; what is pinned to the REFERENCE's dropout semantics is the keep rate -- p realised in steps of 1/256 -- and the
+    # 1/keep-rate scaling)
     tol = 2e-5 if dtype == "fp32" else 1.5e-3 if dtype == "fp16" else 8e-2       # fp16 measured on MI355X: embeddings 0.9-1.8e-3, loss 0.4-1.4e-3
     print("dropout step %s: q err %.2e c err %.2e loss err %.2e" % (dtype, np.abs(q.detach().cpu().numpy() - oq).max(),
                                                                    np.abs(c.detach().cpu().numpy() - oc).max(), abs(loss.item() - ol_)))
@@ -107,7 +108,8 @@ def test_large_gemm_epilogue_dropout(dev):
            None, 0, None, 0, C.byref(d))
     r = lambda x: x.to(torch.float32).cpu().numpy().astype(np.float64)
     mult = ob.drop_multipliers(0.1, 777, 17, np.arange(M), np.arange(N))
-    assert abs((mult == 0).mean() - 0.1) < 0.003
+    # p = 0.1 is realised as 26/256 (one hash per four columns, 8-bit threshold); kept values carry 256/230, so E[mask] = 1
+    assert abs((mult == 0).mean() - 26.0 / 256.0) < 0.002 and abs(mult.mean() - 1.0) < 0.005 and abs(mult.max() - 256.0 / 230.0) < 1e-6
     ref = (r(dA) @ r(dB).T + bias) * mult + r(dres)
     err = np.abs(r(out) - ref)
     assert (err <= 2e-2 + 1.2e-2 * np.abs(ref)).all()

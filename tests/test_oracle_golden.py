@@ -261,3 +261,28 @@ def test_torch_cpu_restatement_matches_reference_goldens(golden_dir):
         for k in ("encoder.layer.3.intermediate.dense.weight", "embeddings.word_embeddings.weight", "encoder.layer.11.output.dense.bias"):
             got = float(T[k].grad.double().norm())
             assert abs(got - norms[pre + k]) <= 1e-3 * norms[pre + k] + 1e-7, (pre + k, got, norms[pre + k])
+
+
+def test_dropout_mask_definition_statistics():
+    """The stateless dropout mask the kernels and the oracle share (one 32-bit hash per four columns, bytes against an 8-bit
+    threshold): realised drop rate = round(256 p) / 256, E[multiplier] = 1 exactly by construction, the four byte lanes of a
+    hash behave alike, neighbouring columns / rows / streams are uncorrelated.  (The reference fixes only p = 0.1,
+    SimANS/model/models.py:70-72; its torch RNG stream cannot be replayed by a stateless GPU mask.)"""
+    from oracle import bert as ob
+    for p, thr in ((0.1, 26), (0.5, 128), (0.001, 1), (0.999, 255), (0.25, 64)):
+        t, sc = ob.drop_threshold(p)
+        assert t == thr and abs(sc * (256 - thr) / 256.0 - 1.0) < 1e-6
+    rows, cols = np.arange(3000), np.arange(512)
+    m = ob.drop_multipliers(0.1, 1234, 19, rows, cols)
+    keep = m > 0
+    n = keep.size
+    assert abs(keep.mean() - 230.0 / 256.0) < 4 * np.sqrt(0.09 / n) and abs(m.mean() - 1.0) < 4 * np.sqrt(0.09 / n) * 1.12
+    for lane in range(4):                                  # each byte lane of the hash
+        k = keep[:, lane::4]
+        assert abs(k.mean() - 230.0 / 256.0) < 5 * np.sqrt(0.09 / k.size)
+    d = keep.astype(np.float64) - keep.mean()
+    for a, b in ((d[:, :-1], d[:, 1:]), (d[:-1], d[1:]), (d[:, 0::4], d[:, 3::4])):       # column / row neighbours, lanes of one hash
+        assert abs((a * b).mean() / d.var()) < 5 / np.sqrt(a.size)
+    m2 = ob.drop_multipliers(0.1, 1234, 20, rows, cols)    # another stream (site / layer): an independent mask
+    assert abs(((m2 > 0) == keep).mean() - (0.8984375 ** 2 + 0.1015625 ** 2)) < 0.003
+    assert np.array_equal(ob.drop_multipliers(0.0, 1, 1, rows[:4], cols[:8]), np.ones((4, 8)))

@@ -20,4 +20,6 @@ run teacher_train_step --dtype fp16 --teacher-step --teacher-arch large --steps 
 run cfg5_doc_fp16 --dtype fp16 --student-arch large --qlen 128 --plen 512 --celen 512 --negs 7 --batch 16 --grad-ckpt --steps 2 --warmup 1
 run cfg5_doc_fp32 --dtype fp32 --student-arch large --qlen 128 --plen 512 --celen 512 --negs 7 --batch 16 --grad-ckpt --steps 2 --warmup 1
 run cfg4_prod_B8 --dtype fp16 --student-layers 6 --loss cekd --batch 8 --steps 10 --warmup 3
+# the recipe to the letter (train_MS_Pas_AR2.sh: fp32, gradient checkpointing, micro-batch 16 x 16, accumulation 2, ernie-large teacher)
+run recipe_of_record --dtype fp32 --grad-ckpt --batch 16 --accum 2 --teacher-arch large --steps 3 --warmup 1
 ls -la $O

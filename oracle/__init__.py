@@ -9,5 +9,5 @@ vectors; its arithmetic lives in third-party HuggingFace ``transformers`` /
 ``torch``.  The oracle is therefore pinned against *outputs of the reference
 itself run in the build container* (``oracle/make_golden.py`` imports
 ``/root/reference/SimANS/model/models.py`` etc. and commits the vectors under
-``tests/golden/``) -- see DESIGN.md "Oracle".
+``tests/golden/``) -- see DESIGN.md section 7 row (c).
 """

@@ -729,6 +729,52 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p3_kernel(
       const uint32_t io0 = HAS_IN ? (uint32_t)(lr * ldin + ec0) * 2 : 0, io1 = HAS_IN ? (uint32_t)((lr + 8) * ldin + ec1) * 2 : 0;
       bf16_t* const obase = HM_C ? C + ((long)(nw >> 6) * hmR + mw) * 64 : C + (long)mw * ldc + nw;          // uniform
       const bool store_pre = !(EPI == SIMX_EPI_GELU && ldin == 1);   // ldin == 1 on a GELU launch: SIMX_EPI_GELU_INFER
+#ifndef SIMX_P3_NOPIPE
+      // Plain epilogue (bias (+ dropout), no epilogue input), software-pipelined over the wave's two 2 KB sub-buffers: chunk
+      // i + 1 is packed and written while chunk i's two 16-B reads are in flight, and chunk i's global stores are issued
+      // while chunk i + 1's writes land -- one exposed LDS latency per chunk instead of two.  (LDS operations of a wave
+      // complete in order: lgkmcnt(4) after [read, read, 4 writes] = the reads are back.)  The dropout decision selects one of
+      // two copies of the loop: a branch between an asm read and the wait that names its registers makes hipcc copy them.
+      if (!HAS_IN && EPI == SIMX_EPI_NONE) {
+        auto run = [&](auto drop_c) {
+          constexpr bool DROPE = decltype(drop_c)::value;
+#define P3_PACK(I)                                                                                              \
+          do {                                                                                                  \
+            const uint32_t sb__ = ereg + (uint32_t)(((I) & 1) * 2048) + slot;                                  \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                     \
+              float vv[4] = {acc[I][j][0], acc[I][j][1], acc[I][j][2], acc[I][j][3]};                           \
+              if (DROPE) {                                                                                      \
+                float m4[4];                                                                                    \
+                drop_mult4(drop, (uint32_t)(mw + (I) * 16 + fr), (uint32_t)(nw + j * 16 + fg * 4), m4);         \
+                vv[0] *= m4[0]; vv[1] *= m4[1]; vv[2] *= m4[2]; vv[3] *= m4[3];                                 \
+              }                                                                                                 \
+              const uint2 o = make_uint2(H16<F>::pack2(vv[0], vv[1]), H16<F>::pack2(vv[2], vv[3]));             \
+              asm volatile("ds_write_b64 %0, %1" ::"v"(sb__ + (uint32_t)(((2 * j + (fg >> 1)) ^ sw) << 4)), "v"(o) : "memory"); \
+            }                                                                                                   \
+          } while (0)
+#define P3_CHUNK(I)                                                                                             \
+          do {                                                                                                  \
+            const uint32_t rd__ = ereg + (uint32_t)(((I) & 1) * 2048) + (uint32_t)(le * 16);                    \
+            u32x4 w0__, w1__;                                                                                   \
+            asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024"       \
+                         : "=&v"(w0__), "=&v"(w1__) : "v"(rd__) : "memory");                                    \
+            if ((I) < 7) {                                                                                      \
+              P3_PACK((I) + 1 < 8 ? (I) + 1 : 7);                                                               \
+              asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(w0__), "+v"(w1__)::"memory");                          \
+            } else {                                                                                            \
+              asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w0__), "+v"(w1__)::"memory");                          \
+            }                                                                                                   \
+            P_GST4(eo0, obase + (long)(I) * 16 * ldc, w0__);                                                    \
+            P_GST4(eo1, obase + (long)(I) * 16 * ldc, w1__);                                                    \
+          } while (0)
+          P3_PACK(0);
+          P3_CHUNK(0); P3_CHUNK(1); P3_CHUNK(2); P3_CHUNK(3); P3_CHUNK(4); P3_CHUNK(5); P3_CHUNK(6); P3_CHUNK(7);
+#undef P3_CHUNK
+#undef P3_PACK
+        };
+        if (drop.thr) run(std::true_type{}); else run(std::false_type{});
+      } else
+#endif
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const uint32_t sub = ereg + (uint32_t)((EPI == SIMX_EPI_GELU ? 0 : (i & 1)) * 2048);

@@ -19,7 +19,7 @@ def golden_dir():
 
 GOLDEN_DIR = golden_dir()
 
-# bf16 tolerances = 3x the errors MEASURED on MI355X with this fixture (tests print them; DESIGN.md "bf16 parity").  Measured,
+# bf16 tolerances = 3x the errors MEASURED on MI355X with this fixture (tests print them; docs/history.md "bf16 parity").  Measured,
 # [CLS]-only / full last layer: embeddings max |err| 0.070 / 0.085 (values up to 4.4), student logits 1.65 / 1.57 on a scale
 # of 28 (5.9 %), teacher logits 0.044, loss 0.0064 / 0.0009, gradient norms median 0.87 % / 0.78 % and max 4.6 % / 3.8 % over
 # 396 tensors, cosine of the [:8,:64] slices of the dense-layer weight gradients min 0.85-0.89 (a query-tower FFN slice: ~150

@@ -1,4 +1,4 @@
-"""`launch.py --fold-accumulation`: the micro-batches of an optimizer step run as ONE batch.  The claim behind it:
+"""`launch.py --fold-accumulation` (docs/history.md 6.7): the micro-batches of an optimizer step run as ONE batch.  The claim behind it:
 the MS-Pas recipe's loss is a mean of per-query terms (co_training_marco_train.py:198-217: every query scores its OWN 1 + N
 passages, no in-batch negatives), so  sum_k grad(loss_k / accum)  over the micro-batches equals the gradient of the folded batch.
 Checked here on the engine itself, dropout off, fp32 arithmetic: two towers, KL-distillation loss, 4 queries x (1 + 3) passages as

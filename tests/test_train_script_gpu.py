@@ -247,7 +247,7 @@ def test_gpu_sampler_matches_host_collate_and_law(dev, tmp_path):
         np.add.at(cnt_dev, tab.ravel(), 1)
     # host side of the same law: the reference's rounds (weights, N with-replacement draws, dedupe, remove, repeat) with the
     # surplus of the last round dropped in DRAW order -- the device rule; the reference drops it in CPython set order, a
-    # pid-hash-dependent subset (the documented deviation, SURVEY App. B / DESIGN.md 8), so its frequencies are not comparable
+    # pid-hash-dependent subset (the documented deviation, SURVEY App. B / DESIGN.md section 8), so its frequencies are not comparable
     import math
     cnt_host = np.zeros(C)
     rng = random.Random(1)

@@ -11,5 +11,5 @@ hipcc $FLAGS "$@" -c simxns_amd/csrc/gemm.hip -o $d/gemm.o
 OBJS="$d/gemm.o"
 for f in gemm_x3 gemm_xp attention attention_f32 attention_x3 layernorm loss sampler optim encoder collate retrieval det; do OBJS="$OBJS simxns_amd/csrc/$f.o"; done
 hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $d/libsimx_hip.so
-hipcc -O2 tools/kbench.cpp -Iinclude -L$d -lsimx_hip -Wl,-rpath,'$ORIGIN' -o $d/kbench
+hipcc -O2 tools/kbench.cpp -Iinclude -L$d -lsimx_hip -ldl -Wl,-rpath,'$ORIGIN' -o $d/kbench
 echo "built $d"

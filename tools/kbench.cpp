@@ -6,6 +6,7 @@
 #include <cstring>
 #include <vector>
 #include <string>
+#include <dlfcn.h>
 #include "simx.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 #define SX(x) do { int r = (x); if (r) { printf("simx error %d: %s (line %d)\n", r, simx_last_error(), __LINE__); exit(1);} } while (0)
@@ -28,6 +29,27 @@ template <typename F> static double timeit(F f, int iters) {
   f(); f(); CK(hipDeviceSynchronize());
   CK(hipEventRecord(a, 0)); for (int i = 0; i < iters; ++i) f(); CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
   float ms; CK(hipEventElapsedTime(&ms, a, b)); return ms / iters;
+}
+// KB_TS=1 on a tools/p3_timeline.py build: cycles per tile of the persistent NT kernel's phases (waves 0 and 5 of one workgroup,
+// tiles 2..13 of the last launch): main loop, epilogue, epilogue end -> first stage boundary of the next tile, tile period
+static void print_timeline() {
+  if (!getenv("KB_TS")) return;
+  typedef int (*fn_t)(unsigned long long*);
+  fn_t fn = (fn_t)dlsym(RTLD_DEFAULT, "simx_debug_p3_ts");
+  if (!fn) { printf("  (no simx_debug_p3_ts in this build)\n"); return; }
+  unsigned long long ts[2 * 16 * 4];
+  CK(hipDeviceSynchronize());
+  if (fn(ts)) return;
+  for (int w = 0; w < 2; ++w) {
+    double main_ = 0, epi = 0, gap = 0, per = 0; int n = 0;
+    for (int t = 2; t < 13; ++t) {
+      const unsigned long long* a = ts + (w * 16 + t) * 4; const unsigned long long* b = a + 4;
+      if (!a[0] || !b[0] || b[0] < a[0]) continue;
+      main_ += (double)(a[1] - a[0]); epi += (double)(a[2] - a[1]); gap += (double)(a[3] - a[2]); per += (double)(b[0] - a[0]); ++n;
+    }
+    if (n) printf("  timeline wave %d: main loop %.0f  epilogue %.0f  epilogue-end -> next tile's first boundary %.0f  tile period %.0f cycles (%d tiles)\n",
+                  w ? 5 : 0, main_ / n, epi / n, gap / n, per / n, n);
+  }
 }
 int main(int argc, char** argv) {
   if (getenv("KB_F16")) g_dt = SIMX_F16;
@@ -129,6 +151,7 @@ int main(int argc, char** argv) {
     ++idx; if (oi >= 0 && idx != oi) continue;
     double ms = timeit([&] { SX(simx_gemm_nt(0, g_dt, T, s.N, s.K, A, s.K + pad, W, s.K, C, s.N, s.epi == 2 ? nullptr : bias, s.res ? A2 : nullptr, s.N, s.epi, s.epi == 2 ? A2 : nullptr, s.N, s.epi == 1 ? C2 : nullptr, s.N)); }, iters);
     double fl = 2.0 * T * s.N * s.K; tot += ms; totf += fl;
+    print_timeline();
     if (base) printf("gemm_nt %-36s %8.3f ms  %7.1f TF/s\n", s.name, ms, fl / ms / 1e9);
     else printf("gemm_nt %-10.10s N=%-5d K=%-5d epi %d res %d %8.3f ms  %7.1f TF/s\n", s.name, s.N, s.K, s.epi, s.res, ms, fl / ms / 1e9);
   }

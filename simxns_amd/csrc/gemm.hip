@@ -562,6 +562,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p3_kernel(
   const int ec0 = ((lane & 7) ^ (lane >> 4)) << 3, ec1 = ((lane & 7) ^ (4 + (lane >> 4))) << 3;   // element column of the lane's 16-B chunk, rows lr / 8+lr
   const uint32_t bmask = bias ? 0xFFFFFFFFu : 0u;
   constexpr bool HM_A = (HMF & 1) != 0, HM_C = (HMF & 2) != 0, HM_I = (HMF & 4) != 0;
+  // DEEP_IN: the epilogue's input tensor (residual / stored GELU') is fetched FOUR 16-row chunks ahead instead of one.  The wave's
+  // 4 KB slice of the freed A slot holds two 2 KB chunk buffers; the other two are the wave's 4 KB slice of the B slot the tile's
+  // last stage frees -- the bytes wave w's own share of the next tile's B(1) load will overwrite -- so that load is issued AFTER
+  // the epilogue (weights: L2 hits, one stage of slack) instead of at the last stage boundary.  One chunk ahead (round 4) the
+  // epilogue waited out a memory latency per chunk: 12-13k cycles per tile against 3.3k without an input (tools/p3_timeline.py).
+#ifdef SIMX_P3_NODEEP
+  constexpr bool DEEP_IN = false;
+#else
+  constexpr bool DEEP_IN = HAS_IN;
+#endif
   const int hmR = ldc2;                           // rows of a plane (ldc2 is free: a plane-blocked C2 has pitch 64)
   if (HM_A) lda = 64;                             // row pitch inside a plane; the stage's k offset selects the plane (P3_AK)
   if (HM_I) ldin = 64;
@@ -660,12 +670,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p3_kernel(
       const uint32_t io0__ = (uint32_t)(lr__ * ldin + (((lb__ & 7) ^ (lb__ >> 4)) << 3)) * 2;  \
       const uint32_t io1__ = (uint32_t)((lr__ + 8) * ldin + (((lb__ & 7) ^ (4 + (lb__ >> 4))) << 3)) * 2; \
       P_DMA16(io0__, ibase, ereg); P_DMA16(io1__, ibase, ereg + 1024u);                        \
+      if (DEEP_IN) {                     /* chunks 1-3: second half of the A slice, then this wave's slice of the freed B slot */ \
+        const uint32_t breg__ = ldsB + (uint32_t)(bc * 32768 + wave * 4096);                   \
+        P_DMA16(io0__, ibase + (long)32 * ldin, ereg + 2048u); P_DMA16(io1__, ibase + (long)32 * ldin, ereg + 3072u); \
+        P_DMA16(io0__, ibase + (long)64 * ldin, breg__); P_DMA16(io1__, ibase + (long)64 * ldin, breg__ + 1024u); \
+        P_DMA16(io0__, ibase + (long)96 * ldin, breg__ + 2048u); P_DMA16(io1__, ibase + (long)96 * ldin, breg__ + 3072u); \
+      }                                                                                        \
     }                                                                                          \
     /* next tile's stage 1 of B; its stage 2 of A goes into the slot this tile's epilogue borrows -> issued after it */ \
     pb_g = reinterpret_cast<const char*>(B + (long)(n0n + wave * 32) * ldb + 64);              \
     pb_slot = ldsB + (uint32_t)(bc * 32768 + wave * 4096);                                     \
-    pb_pend = true;                                                                            \
-    P_DMA16(offB0, pb_g, pb_slot);                                                             \
+    if (!DEEP_IN) {                                                                            \
+      pb_pend = true;                                                                          \
+      P_DMA16(offB0, pb_g, pb_slot);                                                           \
+    }                                                                                          \
   } while (0)
 
   for (;;) {
@@ -717,7 +735,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p3_kernel(
     // ---- epilogue, 8 chunks of 16 rows (= accumulator row-block i), per wave, no barrier
     // (the bias registers are pinned here, BEFORE any branch: a branch between an asm load and its pin makes hipcc
     // copy the in-flight registers and the copies read garbage)
-    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(bq0), "+v"(bq1), "+v"(bq2), "+v"(bq3) : "n"(HAS_IN ? 6 : 4) : "memory");
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(bq0), "+v"(bq1), "+v"(bq2), "+v"(bq3) : "n"(DEEP_IN ? 8 : HAS_IN ? 6 : 4) : "memory");
     if (C != nullptr) {                          // (nullptr: the main-loop-only measurement build, -DSIMX_MEASUREMENT_HOOKS)
       P_LANE(le);
       const int fr = le & 15, fg = le >> 4, lr = le >> 3;          // shadow the kernel-scope copies on purpose
@@ -775,10 +793,26 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p3_kernel(
         if (drop.thr) run(std::true_type{}); else run(std::false_type{});
       } else
 #endif
+      {
+      // DEEP_IN: the input of chunk i + 1 is read from its buffer while chunk i's output is on its way through its own
+      // (tn0..3: issued behind chunk i's four writes, waited for together with chunk i's two 16-B reads) -- two LDS waits per chunk
+      // instead of three.  Issue order of the wave's VMEM operations from the last stage boundary on: D0 D1 D2 D3 | S0 D4 | S1 D5 |
+      // S2 D6 | S3 D7 | S4 | S5 | S6 | S7 (Dk, Sk: 2 instructions each)
+      uint2 tn0 = make_uint2(0, 0), tn1 = tn0, tn2 = tn0, tn3 = tn0;
+      if (DEEP_IN) {                                     // chunk 0 (younger than D0: D1 D2 D3)
+        const uint32_t b0 = ereg + slot;
+        asm volatile("s_waitcnt vmcnt(6)\n\tds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(tn0), "=&v"(tn1), "=&v"(tn2), "=&v"(tn3)
+                     : "v"(b0 + (uint32_t)(((0 + (fg >> 1)) ^ sw) << 4)), "v"(b0 + (uint32_t)(((2 + (fg >> 1)) ^ sw) << 4)),
+                       "v"(b0 + (uint32_t)(((4 + (fg >> 1)) ^ sw) << 4)), "v"(b0 + (uint32_t)(((6 + (fg >> 1)) ^ sw) << 4)) : "memory");
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const uint32_t sub = ereg + (uint32_t)((EPI == SIMX_EPI_GELU ? 0 : (i & 1)) * 2048);
-        if (HAS_IN) {
+        // DEEP_IN: chunk i lives (input, then output, in place) in buffer i % 4: two in the A slice, two in the B-slot slice
+        const uint32_t sub = DEEP_IN ? ((i & 2) ? pb_slot : ereg) + (uint32_t)((i & 1) * 2048)
+                                     : ereg + (uint32_t)((EPI == SIMX_EPI_GELU ? 0 : (i & 1)) * 2048);
+        if (DEEP_IN) {
+        } else if (HAS_IN) {
           if (i < 7) {
             const uint32_t nx = ereg + (uint32_t)(((i + 1) & 1) * 2048);
             const char* ib = ibase + (long)(i + 1) * 32 * ldin;
@@ -792,7 +826,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p3_kernel(
         uint2 t0, t1, t2, t3;
         const uint32_t ad0 = sub + slot + (uint32_t)(((0 + (fg >> 1)) ^ sw) << 4), ad1 = sub + slot + (uint32_t)(((2 + (fg >> 1)) ^ sw) << 4);
         const uint32_t ad2 = sub + slot + (uint32_t)(((4 + (fg >> 1)) ^ sw) << 4), ad3 = sub + slot + (uint32_t)(((6 + (fg >> 1)) ^ sw) << 4);
-        if (HAS_IN) {
+        if (DEEP_IN) {
+          t0 = tn0; t1 = tn1; t2 = tn2; t3 = tn3;
+        } else if (HAS_IN) {
           asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\ts_waitcnt lgkmcnt(0)"
                        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(ad0), "v"(ad1), "v"(ad2), "v"(ad3) : "memory");
         }
@@ -836,11 +872,28 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p3_kernel(
         }
         const uint32_t rd = sub + (uint32_t)(le * 16);
         u32x4 w0, w1;
+        if (DEEP_IN && i < 7) {
+          // wait for D(i+1) (younger than it here: 4, 6, 8, 8, 8, 6, 4 operations for i = 0..6), request its four 8-B pieces,
+          // lgkmcnt(4) = this chunk's four writes have landed, read them back as two 16-B rows, wait for everything
+          const uint32_t bn = (((i + 1) & 2) ? pb_slot : ereg) + (uint32_t)(((i + 1) & 1) * 2048) + slot;
+          asm volatile("s_waitcnt vmcnt(%12)\n\tds_read_b64 %0, %6\n\tds_read_b64 %1, %7\n\tds_read_b64 %2, %8\n\tds_read_b64 %3, %9\n\t"
+                       "s_waitcnt lgkmcnt(4)\n\tds_read_b128 %4, %10\n\tds_read_b128 %5, %10 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(tn0), "=&v"(tn1), "=&v"(tn2), "=&v"(tn3), "=&v"(w0), "=&v"(w1)
+                       : "v"(bn + (uint32_t)(((0 + (fg >> 1)) ^ sw) << 4)), "v"(bn + (uint32_t)(((2 + (fg >> 1)) ^ sw) << 4)),
+                         "v"(bn + (uint32_t)(((4 + (fg >> 1)) ^ sw) << 4)), "v"(bn + (uint32_t)(((6 + (fg >> 1)) ^ sw) << 4)), "v"(rd),
+                         "n"(0), "n"(i == 0 || i == 6 ? 4 : i == 1 || i == 5 ? 6 : 8)
+                       : "memory");
+        } else
         asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
                      : "=&v"(w0), "=&v"(w1) : "v"(rd) : "memory");
         if (store_pre) {                                 // (inference GELU: the pre-activation has no reader)
           P_GST4(eo0, obase + (long)i * 16 * ldc, w0);
           P_GST4(eo1, obase + (long)i * 16 * ldc, w1);
+        }
+        if (DEEP_IN && i < 4) {                          // the buffer is drained (w0, w1 are back): chunk i + 4 into it
+          const char* ib = ibase + (long)(i + 4) * 32 * ldin;
+          P_DMA16(io0, ib, sub);
+          P_DMA16(io1, ib, sub + 1024u);
         }
         if (EPI == SIMX_EPI_GELU) {
           u32x4 w2, w3;
@@ -852,6 +905,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p3_kernel(
           P_GST4((uint32_t)((lr + 8) * ld2 + ec1) * 2, gbase, w3);
         }
       }
+      }
+    }
+    if (DEEP_IN) {       // the borrowed B-slot slice is free again: next tile's stage 1 of B (ahead of A(2): the vmcnt(4) rule)
+      P_DMA16(offB0, pb_g, pb_slot); P_DMA16(offB1, pb_g + (long)8 * ldb * 2, pb_slot + 1024u);
+      P_DMA16(offB0, pb_g + (long)16 * ldb * 2, pb_slot + 2048u); P_DMA16(offB1, pb_g + (long)24 * ldb * 2, pb_slot + 3072u);
     }
     // the borrowed A slot is free again (this wave's slice only ever holds this wave's rows): next tile's stage 2
     if (has_next) {                                // issued by the next tile's first four MFMA rows (same order: after B(1))

@@ -794,6 +794,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p3_kernel(
       } else
 #endif
       {
+      // (the training / inference decision of the GELU launch -- is gelu'(u) stored? -- selects one of two copies of the loop: as a
+      // runtime test it put a branch into every 16 x 16 sub-tile of the GELU arithmetic and the scheduler could not interleave
+      // the transcendental chains of neighbouring sub-tiles)
+      const int ld2 = HM_C ? 64 : ldc2;
+      const uint32_t go0 = (uint32_t)(lr * ld2 + ec0) * 2, go1 = (uint32_t)((lr + 8) * ld2 + ec1) * 2;     // the gelu(u) output's lane offsets
+      auto body = [&, go0, go1](auto pre_c) {
+      constexpr bool SP = decltype(pre_c)::value;
       // DEEP_IN: the input of chunk i + 1 is read from its buffer while chunk i's output is on its way through its own
       // (tn0..3: issued behind chunk i's four writes, waited for together with chunk i's two 16-B reads) -- two LDS waits per chunk
       // instead of three.  Issue order of the wave's VMEM operations from the last stage boundary on: D0 D1 D2 D3 | S0 D4 | S1 D5 |
@@ -850,7 +857,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p3_kernel(
           }
           if (EPI == SIMX_EPI_GELU) {             // C2 = gelu(u); C = gelu'(u) (skipped on the inference form: no backward)
             float g[4];
-            if (store_pre) {
+            if (SP) {
 #pragma unroll
               for (int e = 0; e < 4; e += 2) {
                 f32p_t gp, dp;
@@ -886,7 +893,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p3_kernel(
         } else
         asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
                      : "=&v"(w0), "=&v"(w1) : "v"(rd) : "memory");
-        if (store_pre) {                                 // (inference GELU: the pre-activation has no reader)
+        if (SP) {                                 // (inference GELU: the pre-activation has no reader)
           P_GST4(eo0, obase + (long)i * 16 * ldc, w0);
           P_GST4(eo1, obase + (long)i * 16 * ldc, w1);
         }
@@ -899,12 +906,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p3_kernel(
           u32x4 w2, w3;
           asm volatile("ds_read_b128 %0, %2 offset:2048\n\tds_read_b128 %1, %2 offset:3072\n\ts_waitcnt lgkmcnt(0)"
                        : "=&v"(w2), "=&v"(w3) : "v"(rd) : "memory");
-          const int ld2 = HM_C ? 64 : ldc2;
           bf16_t* const gbase = HM_C ? C2 + ((long)(nw >> 6) * hmR + mw + i * 16) * 64 : C2 + (long)(mw + i * 16) * ldc2 + nw;   // uniform
-          P_GST4((uint32_t)(lr * ld2 + ec0) * 2, gbase, w2);
-          P_GST4((uint32_t)((lr + 8) * ld2 + ec1) * 2, gbase, w3);
+          P_GST4(go0, gbase, w2);
+          P_GST4(go1, gbase, w3);
         }
       }
+      };
+      if (store_pre) body(std::true_type{}); else body(std::false_type{});
       }
     }
     if (DEEP_IN) {       // the borrowed B-slot slice is free again: next tile's stage 1 of B (ahead of A(2): the vmcnt(4) rule)

@@ -15,8 +15,6 @@ cd /tmp; export TMPDIR=/tmp
 # exclusive -- the same conditions as bench.py's own roofline pass, which the averages must agree with.
 export SIMX_OVERLAP_TOWERS=0
 CMD="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-realistic --no-parity"
-SIMX_OVERLAP_TOWERS=1 timeout 900 python $R/bench.py --steps 5 --warmup 2 > $O/bench_line.json 2> $O/bench.err
-cp $R/gpurun_out/bench_full.json $O/bench.json       # the full record (side-line kernel tables); bench_line.json = the stdout line the driver parses
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- $CMD > $O/stats.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- $CMD > $O/pmc_fetch.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- $CMD > $O/pmc_write.log 2>&1
@@ -32,4 +30,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fp32_stat
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fp32_pmc_fetch -o p -- python $R/bench.py --dtype fp32 --side --steps 2 --warmup 1 --no-prof > $O/fp32_pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/fp32_pmc_write -o p -- python $R/bench.py --dtype fp32 --side --steps 2 --warmup 1 --no-prof > $O/fp32_pmc_write.log 2>&1
 cd $R && python tools/traffic.py $tag $commit
+# the bench line LAST, so that the counters it quotes (roofline.traffic, mfma_busy_pmc) are the ones just taken at this tree
+SIMX_OVERLAP_TOWERS=1 timeout 900 python $R/bench.py --steps 5 --warmup 2 > $O/bench_line.json 2> $O/bench.err
+cp $R/gpurun_out/bench_full.json $O/bench.json       # the full record (side-line kernel tables); bench_line.json = the stdout line the driver parses
 ls -la $O

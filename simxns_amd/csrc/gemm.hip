@@ -1656,8 +1656,12 @@ static void tn_plan(int M, int N, int K, int* splits, int* k_per_split) {
   const bool v2 = tn_use_v2(M, N, K);
   const int tiles = v2 ? cdiv(M, 256) * cdiv(N, 256) : cdiv(M, 128) * cdiv(N, 128);
   // whole rounds of the chip: v2 runs one workgroup per CU (256 per round), v1 two.  Rounding the split count UP
-  // (513 workgroups for wqkv/wo, 540 for w1/w2) left a third, almost empty round; round DOWN to fill exactly two.
-  int s = (v2 ? 512 : 1024) / tiles;
+  // (513 workgroups for wqkv/wo, 540 for w1/w2) left a third, almost empty round; rounds 2-4 filled exactly TWO rounds; ONE
+  // round (half the splits: each workgroup pays its prologue, its 256 KB slab epilogue and its share of the slab pass once
+  // for twice the tokens) measures better at every size -- 262144 tokens 3.54 -> 3.37 ms over the four wgrad shapes, 32768
+  // tokens 0.61 -> 0.52, 16384 tokens 0.41 -> 0.32 (tools/kbench, profiles/r05_experiments/09).  SIMX_TN_ROUNDS=2: the old rule.
+  static const char* rounds_env = getenv("SIMX_TN_ROUNDS");
+  int s = (v2 ? (rounds_env && rounds_env[0] == '2' ? 512 : 256) : 1024) / tiles;
   const int max_s = cdiv(K, 512);          // at least 8 k-tiles per split
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;

@@ -1121,7 +1121,8 @@ extern "C" int simx_gemm_nt_planes_cs(simx_stream_t stream, int fmt, int epilogu
 
 static void xp_tn_plan(int M, int N, int K, int* splits, int* kps) {
   const int tiles = cdiv(M, 256) * cdiv(N, 256);
-  int sp = 512 / tiles;                            // whole rounds of the chip (one workgroup per CU), as tn_plan (csrc/gemm.hip)
+  static const char* rounds_env = getenv("SIMX_TN_ROUNDS");
+  int sp = (rounds_env && rounds_env[0] == '2' ? 512 : 256) / tiles;      // ONE whole round of the chip (one workgroup per CU), as tn_plan (csrc/gemm.hip): 32768 tokens 1.60 -> 1.48 ms
   const int max_s = cdiv(K, 512);
   if (sp > max_s) sp = max_s;
   if (sp < 1) sp = 1;

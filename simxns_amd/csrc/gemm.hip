@@ -1827,12 +1827,19 @@ extern "C" int simx_colsum_gs(simx_stream_t stream, int dtype, int T, int N, con
   return SIMX_OK;
 }
 
+int simx_transpose_cast_group(hipStream_t s, int out_dtype, const SimxCastGroup* g);
 extern "C" int simx_transpose_cast(simx_stream_t stream, int out_dtype, const float* w, int rows, int cols, void* out,
                                    void* outT) {
-  SIMX_PROF(SIMX_K_CAST, stream, (double)rows * cols * 8);
   SIMX_REQUIRE(rows > 0 && cols > 0 && w, SIMX_ERR_BAD_SHAPE, "transpose_cast: bad shape");
-  dim3 grid(cdiv(cols, 32), cdiv(rows, 32));
   SIMX_REQUIRE(simx_dtype_ok(out_dtype), SIMX_ERR_BAD_DTYPE, "transpose_cast: dtype %d", out_dtype);
+  if (simx_is16(out_dtype) && rows % 64 == 0 && cols % 64 == 0) {      // the grouped path's 64 x 64-tile kernel, one job
+    SimxCastGroup g;
+    g.n = 1;
+    g.job[0] = SimxCastJob{w, out, outT, rows, cols, 0, 0};
+    return simx_transpose_cast_group((hipStream_t)stream, out_dtype, &g);
+  }
+  SIMX_PROF(SIMX_K_CAST, stream, (double)rows * cols * 8);
+  dim3 grid(cdiv(cols, 32), cdiv(rows, 32));
   SIMX_DISPATCH3(out_dtype, TT, hipLaunchKernelGGL((cast_weight_kernel<TT>), grid, dim3(256), 0, (hipStream_t)stream, w, rows, cols, (TT*)out,
                                                    (TT*)outT));
   SIMX_CHECK_LAUNCH("cast_weight");
@@ -1865,19 +1872,69 @@ __global__ __launch_bounds__(256) void cast_weight_group_kernel(SimxCastGroup g)
       if (r < j.rows && c < j.cols) Elem<TO>::st(ot + (long)c * j.rows + r, tile[tx][i]);
     }
 }
+// the same job list on 64 x 64 tiles with 16-byte accesses on all three streams (16-bit outputs, rows % 64 == 0 and cols % 64 == 0:
+// every dense weight of the BERT geometries; csrc/gemm_xp.hip split_weight_group64_kernel is the fp32 engine's twin): a thread owns
+// 8 consecutive columns of a row in the first phase and 8 consecutive rows of a column in the second (LDS reads at stride 65
+// words: the lanes of a wave cover 8 columns x 8 row groups = 64 distinct banks)
+template <typename TO>
+__global__ __launch_bounds__(256) void cast_weight_group64_kernel(SimxCastGroup g) {
+  int ji = 0;
+  while (ji + 1 < g.n && (int)blockIdx.x >= g.job[ji].tile_end) ++ji;
+  const SimxCastJob j = g.job[ji];
+  const int t = (int)blockIdx.x - (ji ? g.job[ji - 1].tile_end : 0), tc = j.cols >> 6;
+  __shared__ float tile[64][65];
+  const int c0 = (t % tc) * 64, r0 = (t / tc) * 64;
+  bf16_t* o = reinterpret_cast<bf16_t*>(j.out);
+  bf16_t* ot = reinterpret_cast<bf16_t*>(j.outT);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int idx = (int)threadIdx.x + k * 256;            // 64 rows x 8 column groups
+    const int r = idx >> 3, cg = (idx & 7) * 8;
+    const long off = (long)(r0 + r) * j.cols + c0 + cg;
+    const float4 a = *reinterpret_cast<const float4*>(j.w + off), b = *reinterpret_cast<const float4*>(j.w + off + 4);
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) tile[r][cg + e] = v[e];
+    if (o) *reinterpret_cast<uint4*>(o + off) = make_uint4(H16<TO>::pack2(v[0], v[1]), H16<TO>::pack2(v[2], v[3]), H16<TO>::pack2(v[4], v[5]), H16<TO>::pack2(v[6], v[7]));
+  }
+  __syncthreads();
+  if (ot) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int idx = (int)threadIdx.x + k * 256;          // 64 columns x 8 row groups
+      const int c = idx >> 3, rg = (idx & 7) * 8;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = tile[rg + e][c];
+      *reinterpret_cast<uint4*>(ot + (long)(c0 + c) * j.rows + r0 + rg) =
+          make_uint4(H16<TO>::pack2(v[0], v[1]), H16<TO>::pack2(v[2], v[3]), H16<TO>::pack2(v[4], v[5]), H16<TO>::pack2(v[6], v[7]));
+    }
+  }
+}
 int simx_transpose_cast_group(hipStream_t s, int out_dtype, const SimxCastGroup* g) {
   SIMX_REQUIRE(g && g->n > 0 && g->n <= SIMX_CAST_GROUP_MAX, SIMX_ERR_BAD_SHAPE, "transpose_cast_group: bad job count");
   SIMX_REQUIRE(simx_dtype_ok(out_dtype), SIMX_ERR_BAD_DTYPE, "transpose_cast_group: dtype %d", out_dtype);
   double bytes = 0;
   SimxCastGroup gg = *g;
   int tiles = 0;
+  bool wide = simx_is16(out_dtype);               // every job on whole 64 x 64 tiles with 16-byte-aligned streams
   for (int i = 0; i < gg.n; ++i) {
-    SIMX_REQUIRE(gg.job[i].rows > 0 && gg.job[i].cols > 0 && gg.job[i].w, SIMX_ERR_BAD_SHAPE, "transpose_cast_group: bad job %d", i);
-    tiles += cdiv(gg.job[i].rows, 32) * cdiv(gg.job[i].cols, 32);
+    const SimxCastJob& jb = gg.job[i];
+    SIMX_REQUIRE(jb.rows > 0 && jb.cols > 0 && jb.w, SIMX_ERR_BAD_SHAPE, "transpose_cast_group: bad job %d", i);
+    wide = wide && jb.rows % 64 == 0 && jb.cols % 64 == 0 && aligned16(jb.w) && aligned16(jb.out) && aligned16(jb.outT);
+  }
+  const int ts = wide ? 64 : 32;
+  for (int i = 0; i < gg.n; ++i) {
+    tiles += cdiv(gg.job[i].rows, ts) * cdiv(gg.job[i].cols, ts);
     gg.job[i].tile_end = tiles;
     bytes += (double)gg.job[i].rows * gg.job[i].cols * 8;
   }
   SIMX_PROF(SIMX_K_CAST, s, bytes);
+  if (wide) {
+    SIMX_DISPATCH16(out_dtype, TT, hipLaunchKernelGGL((cast_weight_group64_kernel<TT>), dim3(tiles), dim3(256), 0, s, gg));
+    SIMX_CHECK_LAUNCH("cast_weight_group64");
+    return SIMX_OK;
+  }
   SIMX_DISPATCH3(out_dtype, TT, hipLaunchKernelGGL((cast_weight_group_kernel<TT>), dim3(tiles), dim3(256), 0, s, gg));
   SIMX_CHECK_LAUNCH("cast_weight_group");
   return SIMX_OK;

@@ -295,6 +295,15 @@ def test_colsum_and_cast(dev):
     ot = torch.empty(36, 100, device=dev, dtype=torch.bfloat16)
     lib.call("simx_cast_weight", lib.stream_ptr(), lib.ptr(dw), 100, 36, lib.ptr(o), lib.ptr(ot))
     assert torch.equal(o, dw.to(torch.bfloat16)) and torch.equal(ot, dw.to(torch.bfloat16).t().contiguous())
+    # multiples of 64: the 64 x 64-tile kernel with 16-byte accesses (what simx_bert_cast_weights runs for the BERT geometries)
+    for rows, cols, dt, tdt in ((768, 3072, 1, torch.bfloat16), (2304, 768, 2, torch.float16), (64, 128, 2, torch.float16)):
+        dw = to_dev(rnd((rows, cols), 3), dev)
+        o = torch.full((rows, cols), -1.0, device=dev, dtype=tdt)
+        ot = torch.full((cols, rows), -1.0, device=dev, dtype=tdt)
+        lib.call("simx_transpose_cast", lib.stream_ptr(), dt, lib.ptr(dw), rows, cols, lib.ptr(o), lib.ptr(ot))
+        assert torch.equal(o, dw.to(tdt)) and torch.equal(ot, dw.to(tdt).t().contiguous())
+        lib.call("simx_transpose_cast", lib.stream_ptr(), dt, lib.ptr(dw), rows, cols, None, lib.ptr(ot))      # either output may be absent
+        torch.cuda.synchronize()
 
 
 # ------------------------------------------------------------------------------------------ LayerNorm family

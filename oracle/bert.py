@@ -69,7 +69,9 @@ def drop_threshold(p):
     probability is realised in steps of 1/256 -- thr = round(256 p), 26/256 for p = 0.1 -- and kept values are scaled by the
     reciprocal of the REALISED keep rate, 256 / (256 - thr): E[multiplier] = 1 exactly (common.h make_drop)."""
     thr = int(np.float32(p) * np.float32(256.0) + np.float32(0.5))
-    thr = min(255, max(1, thr))
+    if np.float32(p) >= np.float32(1.0):
+        return 256, 0.0                                                         # p >= 1: everything dropped, like torch (no 256 / 0)
+    thr = min(255, thr) if np.float32(p) >= np.float32(1.0 / 512.0) else 0      # p < 1/512: no dropout (never clamped UP to 1/256)
     return thr, float(np.float32(256.0) / np.float32(256 - thr))
 
 

@@ -196,11 +196,14 @@ __device__ __forceinline__ void st4(bf16_t* p, const float (&v)[4]) {
 struct DropCtx { uint32_t thr; float scale; uint32_t seed; uint32_t stream; };   // thr == 0: disabled
 static inline DropCtx make_drop(const simx_dropout* d) {
   DropCtx c = {0u, 1.0f, 0u, 0u};
-  if (d && d->p > 0.f) {
+  // p is never clamped into the representable range: 0 < p < 1/512 runs as NO dropout (thr = 0, the nearest realisable rate) and
+  // p >= 1 drops everything like torch (thr = 256: no byte passes; scale 0 instead of 256 / 0).  In between the rate is
+  // round(256 p) / 256, at most 255/256.
+  if (d && d->p >= 1.0f / 512.0f) {
     uint32_t t = (uint32_t)(d->p * 256.0f + 0.5f);
-    t = t < 1u ? 1u : (t > 255u ? 255u : t);
+    t = d->p >= 1.0f ? 256u : (t > 255u ? 255u : t);
     c.thr = t;
-    c.scale = 256.0f / (float)(256u - t);
+    c.scale = t >= 256u ? 0.f : 256.0f / (float)(256u - t);
     c.seed = d->seed;
     c.stream = d->stream;
   }

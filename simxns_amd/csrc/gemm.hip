@@ -572,6 +572,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p3_kernel(
 #else
   constexpr bool DEEP_IN = HAS_IN;
 #endif
+  // (the counted vmcnt immediates of the DEEP_IN epilogue assume two stores per chunk and one input stream: EPI NONE / DGELU)
+  static_assert(!(DEEP_IN && EPI == SIMX_EPI_GELU), "DEEP_IN epilogue: the vmcnt schedule has no room for the GELU pair's second store");
   const int hmR = ldc2;                           // rows of a plane (ldc2 is free: a plane-blocked C2 has pitch 64)
   if (HM_A) lda = 64;                             // row pitch inside a plane; the stage's k offset selects the plane (P3_AK)
   if (HM_I) ldin = 64;
@@ -916,6 +918,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p3_kernel(
       }
     }
     if (DEEP_IN) {       // the borrowed B-slot slice is free again: next tile's stage 1 of B (ahead of A(2): the vmcnt(4) rule)
+      if (C == nullptr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (measurement build only: the input chunks requested at the last boundary were never consumed)
       P_DMA16(offB0, pb_g, pb_slot); P_DMA16(offB1, pb_g + (long)8 * ldb * 2, pb_slot + 1024u);
       P_DMA16(offB0, pb_g + (long)16 * ldb * 2, pb_slot + 2048u); P_DMA16(offB1, pb_g + (long)24 * ldb * 2, pb_slot + 3072u);
     }
@@ -1660,7 +1663,7 @@ static void tn_plan(int M, int N, int K, int* splits, int* k_per_split) {
   // round (half the splits: each workgroup pays its prologue, its 256 KB slab epilogue and its share of the slab pass once
   // for twice the tokens) measures better at every size -- 262144 tokens 3.54 -> 3.37 ms over the four wgrad shapes, 32768
   // tokens 0.61 -> 0.52, 16384 tokens 0.41 -> 0.32 (tools/kbench, profiles/r05_experiments/09).  SIMX_TN_ROUNDS=2: the old rule.
-  static const char* rounds_env = getenv("SIMX_TN_ROUNDS");
+  const char* rounds_env = getenv("SIMX_TN_ROUNDS");       // (read per call: tests/test_fullsize_gpu.py covers both rules in one process)
   int s = (v2 ? (rounds_env && rounds_env[0] == '2' ? 512 : 256) : 1024) / tiles;
   const int max_s = cdiv(K, 512);          // at least 8 k-tiles per split
   if (s > max_s) s = max_s;
@@ -1833,7 +1836,7 @@ extern "C" int simx_transpose_cast(simx_stream_t stream, int out_dtype, const fl
   SIMX_REQUIRE(rows > 0 && cols > 0 && w, SIMX_ERR_BAD_SHAPE, "transpose_cast: bad shape");
   SIMX_REQUIRE(simx_dtype_ok(out_dtype), SIMX_ERR_BAD_DTYPE, "transpose_cast: dtype %d", out_dtype);
   if (simx_is16(out_dtype) && rows % 64 == 0 && cols % 64 == 0) {      // the grouped path's 64 x 64-tile kernel, one job
-    SimxCastGroup g;
+    SimxCastGroup g{};
     g.n = 1;
     g.job[0] = SimxCastJob{w, out, outT, rows, cols, 0, 0};
     return simx_transpose_cast_group((hipStream_t)stream, out_dtype, &g);

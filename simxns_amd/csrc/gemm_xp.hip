@@ -1121,7 +1121,7 @@ extern "C" int simx_gemm_nt_planes_cs(simx_stream_t stream, int fmt, int epilogu
 
 static void xp_tn_plan(int M, int N, int K, int* splits, int* kps) {
   const int tiles = cdiv(M, 256) * cdiv(N, 256);
-  static const char* rounds_env = getenv("SIMX_TN_ROUNDS");
+  const char* rounds_env = getenv("SIMX_TN_ROUNDS");       // (read per call, as tn_plan)
   int sp = (rounds_env && rounds_env[0] == '2' ? 512 : 256) / tiles;      // ONE whole round of the chip (one workgroup per CU), as tn_plan (csrc/gemm.hip): 32768 tokens 1.60 -> 1.48 ms
   const int max_s = cdiv(K, 512);
   if (sp > max_s) sp = max_s;
@@ -1181,7 +1181,7 @@ extern "C" int simx_gemm_tn_planes(simx_stream_t stream, int M, int N, int K, co
 
 // planes of a [rows, cols] tensor.  src_fmt: SIMX_F32 (src = f32 matrix, src_ps ignored) or the format of a source plane pair
 extern "C" int simx_split_weight(simx_stream_t stream, const float* W, int rows, int cols, void* planes_f16, void* planesT_bf16, float* WT) {
-  SimxSplitGroup g;
+  SimxSplitGroup g{};
   g.n = 1;
   g.job[0] = SimxSplitJob{W, planes_f16, planesT_bf16, WT, rows, cols, 0, 0};
   return simx_split_weight_group((hipStream_t)stream, &g);

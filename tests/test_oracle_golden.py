@@ -269,9 +269,13 @@ def test_dropout_mask_definition_statistics():
     hash behave alike, neighbouring columns / rows / streams are uncorrelated.  (The reference fixes only p = 0.1,
     SimANS/model/models.py:70-72; its torch RNG stream cannot be replayed by a stateless GPU mask.)"""
     from oracle import bert as ob
-    for p, thr in ((0.1, 26), (0.5, 128), (0.001, 1), (0.999, 255), (0.25, 64)):
+    for p, thr in ((0.1, 26), (0.5, 128), (0.002, 1), (0.999, 255), (0.25, 64)):
         t, sc = ob.drop_threshold(p)
         assert t == thr and abs(sc * (256 - thr) / 256.0 - 1.0) < 1e-6
+    # outside the realisable range nothing is clamped INTO it: below 1/512 no dropout, p >= 1 drops everything (torch's p = 1)
+    assert ob.drop_threshold(0.001) == (0, 1.0) and ob.drop_threshold(1.0) == (256, 0.0)
+    assert np.array_equal(ob.drop_multipliers(0.001, 7, 3, np.arange(8), np.arange(16)), np.ones((8, 16)))
+    assert not ob.drop_multipliers(1.0, 7, 3, np.arange(8), np.arange(16)).any()
     rows, cols = np.arange(3000), np.arange(512)
     m = ob.drop_multipliers(0.1, 1234, 19, rows, cols)
     keep = m > 0

@@ -9,6 +9,7 @@ commit=${2:-unknown}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/$tag
 mkdir -p $O
+rm -f $O/bench.json $O/bench_line.json        # never let an earlier run's line sit next to fresh counters
 cd /tmp; export TMPDIR=/tmp
 # The profiled command is the bench job with the towers on one stream (SIMX_OVERLAP_TOWERS=0) and without the
 # realistic-length side measurement, so that every launch of a kernel is the headline workload's and its duration is
@@ -33,4 +34,9 @@ cd $R && python tools/traffic.py $tag $commit
 # the bench line LAST, so that the counters it quotes (roofline.traffic, mfma_busy_pmc) are the ones just taken at this tree
 SIMX_OVERLAP_TOWERS=1 timeout 900 python $R/bench.py --steps 5 --warmup 2 > $O/bench_line.json 2> $O/bench.err
 cp $R/gpurun_out/bench_full.json $O/bench.json       # the full record (side-line kernel tables); bench_line.json = the stdout line the driver parses
+# (tools/traffic.py ran BEFORE the bench and found neither file: copy them into profiles/ now, next to the counters they quote)
+mkdir -p $R/profiles
+cp $O/bench.json $R/profiles/${tag}_bench.json
+cp $O/bench_line.json $R/profiles/${tag}_bench_line.json
+mkdir -p $O/profiles && cp $R/profiles/${tag}_* $O/profiles/      # profiles/ of the box comes back through gpurun_out/
 ls -la $O

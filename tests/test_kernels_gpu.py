@@ -564,3 +564,50 @@ def test_adamw_clip(dev):
     lib.call("simx_adamw_step", lib.stream_ptr(), lib.ptr(dp), lib.ptr(dg), lib.ptr(dm), lib.ptr(dv), n, 1e-3, 0.9, 0.999, 1e-8, 0.0, 4,
              None, 0.0, 0.5, 1)
     assert float(dg.abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------ p5: epilogue under the next tile's main loop
+@pytest.mark.parametrize("fmt", ["f16", True])
+@pytest.mark.parametrize("M,N,K,with_bias,hm", [(65536, 768, 768, True, False), (49152, 2304, 768, True, True), (49152, 2304, 768, False, False),
+                                                (65536, 768, 3072, True, False), (65536, 768, 576, True, False), (262144, 768, 768, True, False)])
+def test_gemm_nt_p5_bit_identical_to_p3(dev, fmt, M, N, K, with_bias, hm):
+    """csrc/gemm_p5.hip (one wave per SIMD, accumulators in AGPRs, the finished tile parked in registers and drained through LDS
+    inside the next tile's main loop) against gemm_nt_p3_kernel on the same operands: same k order, bias as the accumulators'
+    initial value, one rounding -> the outputs must be EQUAL, and both equal the float64 product within the output rounding.
+    Shapes: 3 to 36 tiles per workgroup, 8 / 12 / 48 stages per tile, row-major and head-major (QKV projection) outputs."""
+    import os
+    lib = L()
+    A, B = rnd((M, K), 11, 0.5), rnd((N, K), 12, 0.5)
+    bias = rnd((N,), 13, 0.5) if with_bias else None
+    dA, dB = to_dev(A, dev, fmt), to_dev(B, dev, fmt)
+    dbias = to_dev(bias, dev) if with_bias else None
+    outs = {}
+    old = os.environ.get("SIMX_P5")
+    try:
+        for mode in ("0", "1"):
+            os.environ["SIMX_P5"] = mode
+            dC = torch.full((M, N), float("nan"), device=dev, dtype=tdt(fmt))
+            if hm:
+                lib.call("simx_gemm_nt_hm", lib.stream_ptr(), code(fmt), M, N, K, lib.ptr(dA), K, lib.ptr(dB), K, lib.ptr(dC), 64, lib.ptr(dbias),
+                         None, 0, None, 0, M)
+            else:
+                lib.call("simx_gemm_nt", lib.stream_ptr(), code(fmt), M, N, K, lib.ptr(dA), K, lib.ptr(dB), K, lib.ptr(dC), N,
+                         lib.ptr(dbias), None, N, 0, None, N, None, N)
+            torch.cuda.synchronize()
+            outs[mode] = dC
+    finally:
+        if old is None:
+            os.environ.pop("SIMX_P5", None)
+        else:
+            os.environ["SIMX_P5"] = old
+    assert torch.isfinite(outs["1"].float()).all(), "p5 left output elements unwritten"
+    assert torch.equal(outs["0"], outs["1"]), "p5 differs from p3: %d elements, worst %.3e" % (
+        int((outs["0"] != outs["1"]).sum()), float((outs["0"].float() - outs["1"].float()).abs().max()))
+    rows = np.r_[0:256, M // 2:M // 2 + 256, M - 256:M]                 # three 256-row tiles against float64
+    acc = rounded(A[rows], fmt) @ rounded(B, fmt).T + (bias.astype(np.float64) if with_bias else 0.0)
+    got = outs["1"]
+    if hm:                                                              # [N/64][M][64] -> [M, N]
+        got = got.view(N // 64, M, 64).permute(1, 0, 2).reshape(M, N)
+    t = dict(TOL[fmt])
+    t["atol"] *= max(1.0, math.sqrt(K) * 0.25)
+    assert_close(back(got[torch.from_numpy(rows).to(dev)]), acc, what="gemm_nt p5 vs float64", **t)

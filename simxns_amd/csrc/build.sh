@@ -8,7 +8,7 @@ OUT=../libsimx_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -mllvm -amdgpu-mfma-vgpr-form -Rpass-analysis=kernel-resource-usage"
 OBJS=""
 PIDS=""
-for f in gemm gemm_p5 gemm_x3 gemm_xp attention attention_f32 attention_x3 layernorm loss sampler optim encoder collate retrieval det; do
+for f in gemm gemm_p5 gemm_tn5 gemm_x3 gemm_xp attention attention_f32 attention_x3 layernorm loss sampler optim encoder collate retrieval det; do
   if [ ! -f $f.o ] || [ ! -f $f.res ] || [ $f.hip -nt $f.o ] || [ common.h -nt $f.o ] || [ prof.h -nt $f.o ] || [ p3.h -nt $f.o ] || [ ../../include/simx.h -nt $f.o ]; then
     echo "hipcc $f.hip"
     ( hipcc $FLAGS -c $f.hip -o $f.o 2> $f.res.tmp || { grep -v "kernel-resource-usage" $f.res.tmp | head -60 >&2; rm -f $f.o; exit 1; }

@@ -1704,6 +1704,8 @@ extern "C" size_t simx_gemm_tn_workspace_bytes(int M, int N, int K) {
   return m2 > x3 ? m2 : x3;                     // (the dtype is not an argument: enough for any of them)
 }
 
+int simx_launch_tn5(hipStream_t s, int dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, float* slabs,
+                    int splits, int kps, float* dbias, int a_hm_rows, const float* gs);
 static int gemm_tn_impl(simx_stream_t stream, int dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, float* C,
                         int ldc, int accumulate, void* ws, size_t ws_bytes, float* dbias, int a_hm_rows, const float* gs);
 extern "C" int simx_gemm_tn(simx_stream_t stream, int dtype, int M, int N, int K, const void* A, int lda,
@@ -1785,6 +1787,20 @@ static int gemm_tn_impl(simx_stream_t stream, int dtype, int M, int N, int K, co
     const size_t need2 = (size_t)splits * M * N * sizeof(float);
     SIMX_REQUIRE(ws && ws_bytes >= need2, SIMX_ERR_WORKSPACE, "gemm_tn: workspace %zu < %zu", ws_bytes, need2);
     SIMX_REQUIRE(aligned16(ws), SIMX_ERR_WORKSPACE, "gemm_tn: workspace not 16-B aligned");
+    // csrc/gemm_tn5.hip: one wave per SIMD, AGPR accumulators, 96 KB in flight -- full tiles, whole stages, not the ordered mode.
+    // SIMX_TN5=0 keeps gemm_tn2_kernel (A/B measurements; read per call: the kernel test compares the two in one process).
+    {
+      const char* e5 = getenv("SIMX_TN5");
+      if (!(e5 && e5[0] == '0') && !dparts &&
+          simx_launch_tn5(s, dtype, M, N, K, A, lda, B, ldb, (float*)ws, splits, kps, dbias, a_hm_rows, gs) == SIMX_OK) {
+        const long tot4 = (long)M * N / 4;
+        int rb = (int)((tot4 + 255) / 256);
+        if (rb > 2048) rb = 2048;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(rb), dim3(256), 0, s, (const float*)ws, (long)M * N, splits, M, N, C, ldc, accumulate, gs);
+        SIMX_CHECK_LAUNCH("slab_reduce");
+        return SIMX_OK;
+      }
+    }
     SIMX_DISPATCH16(dtype, FF, hipLaunchKernelGGL(gemm_tn2_kernel<FF>, dim3(t_mn * splits), dim3(512), TN2_LDS, s, M, N, K, (const bf16_t*)A, lda,
                                                   (const bf16_t*)B, ldb, (float*)ws, (long)M * N, N, t_n, t_mn, kps, 0, dbias, a_hm_rows, gs, 0, dparts));
     SIMX_CHECK_LAUNCH("gemm_tn2");

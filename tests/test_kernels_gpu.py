@@ -611,3 +611,46 @@ def test_gemm_nt_p5_bit_identical_to_p3(dev, fmt, M, N, K, with_bias, hm):
     t = dict(TOL[fmt])
     t["atol"] *= max(1.0, math.sqrt(K) * 0.25)
     assert_close(back(got[torch.from_numpy(rows).to(dev)]), acc, what="gemm_nt p5 vs float64", **t)
+
+
+# ------------------------------------------------------------------------------------------ tn5: the one-wave-per-SIMD wgrad kernel
+@pytest.mark.parametrize("fmt", ["f16", True])
+@pytest.mark.parametrize("M,N,K", [(768, 768, 16384), (2304, 768, 32768), (768, 3072, 65536), (3072, 768, 24576), (256, 256, 4096)])
+def test_gemm_tn5_vs_float64_and_tn2(dev, fmt, M, N, K):
+    """csrc/gemm_tn5.hip (4 waves, 128 x 128 wave tiles, AGPR accumulators, 3 + 2 slot ring, fused bias gradient) through
+    simx_gemm_tn_bias against the float64 product of the same 16-bit operands, and against gemm_tn2_kernel (SIMX_TN5=0) on the
+    same split plan: the two differ only in the order of f32 additions inside a token slice."""
+    import os
+    lib = L()
+    g = torch.Generator(device=dev)
+    g.manual_seed(99 + M + K)
+    A = (torch.randn(K, M, device=dev, generator=g) * 0.5).to(tdt(fmt))
+    B = (torch.randn(K, N, device=dev, generator=g) * 0.5).to(tdt(fmt))
+    C0 = torch.randn(M, N, device=dev, generator=g)
+    db0 = torch.randn(M, device=dev, generator=g)
+    wsb = int(lib.load().simx_gemm_tn_workspace_bytes(M, N, K))
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+    outs = {}
+    old = os.environ.get("SIMX_TN5")
+    try:
+        for mode in ("0", "1"):
+            os.environ["SIMX_TN5"] = mode
+            dC, db = C0.clone(), db0.clone()
+            lib.call("simx_gemm_tn_bias", lib.stream_ptr(), code(fmt), M, N, K, lib.ptr(A), M, lib.ptr(B), N, lib.ptr(dC), N, 1, lib.ptr(ws), wsb,
+                     lib.ptr(db))
+            torch.cuda.synchronize()
+            outs[mode] = (dC, db)
+    finally:
+        if old is None:
+            os.environ.pop("SIMX_TN5", None)
+        else:
+            os.environ["SIMX_TN5"] = old
+    Ad, Bd = A.double(), B.double()
+    ref = (Ad.t() @ Bd + C0.double()).cpu().numpy()                       # (float64 on the device: a checker, not the product path)
+    col = (Ad.sum(0) + db0.double()).cpu().numpy()
+    for mode in ("0", "1"):
+        got, gb = back(outs[mode][0]), back(outs[mode][1])
+        assert_close(got, ref, rtol=2e-5, atol=2e-5 * math.sqrt(K), what="gemm_tn (SIMX_TN5=%s)" % mode)
+        assert_close(gb, col, rtol=1e-5, atol=2e-5 * math.sqrt(K), what="fused bias gradient (SIMX_TN5=%s)" % mode)
+    d = float((outs["0"][0] - outs["1"][0]).abs().max())
+    assert d <= 1e-5 * math.sqrt(K), "tn5 vs tn2: %.3e" % d

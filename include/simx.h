@@ -55,6 +55,11 @@ enum { SIMX_F32 = 0, SIMX_BF16 = 1, SIMX_F16 = 2,
        SIMX_F32_SPLIT_H = 3, SIMX_F32_SPLIT_B = 4 };
 
 int simx_version(void);
+/* CUs the persistent kernels (gemm_nt_p3 / p5 / xp: one workgroup per CU with a static share of the tiles; the wgrad plans: one round
+ * of the chip) may fill; 0 = all.  The data-parallel step sets ncu - (CUs of the RCCL ring) while the gradient all-reduce overlaps the
+ * backward (DDP of SimANS/co_training/co_training_marco_train.py:107-114): a workgroup that finds no free CU starts only when a
+ * resident one has finished its whole share and the launch takes up to twice as long (profiles/r06_cu_steal.json). */
+int simx_set_compute_cus(int n);
 const char* simx_last_error(void);
 
 /* ------------------------------------------------------------------ GEMMs

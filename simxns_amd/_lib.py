@@ -45,6 +45,7 @@ _cfgp, _lpp, _dp = C.POINTER(BertCfg), C.POINTER(LossParams), C.POINTER(Dropout)
 # name -> (restype, argtypes); every symbol of include/simx.h
 SIGNATURES = {
     "simx_version": (_i, []),
+    "simx_set_compute_cus": (_i, [_i]),
     "simx_last_error": (C.c_char_p, []),
     "simx_gemm_nt": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _i, _i, _p, _i, _p, _i]),
     "simx_gemm_nt_ex": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _i, _i, _p, _i, _p, _i, _dp]),

@@ -17,6 +17,7 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 // ---- error plumbing (api.cpp) ---------------------------------------------------------
 void simx_set_error(const char* fmt, ...);
+int simx_compute_cus(int device_cus);      // CUs the persistent kernels may fill (simx_set_compute_cus / SIMX_COMPUTE_CUS; encoder.hip)
 // SIMX_DETERMINISTIC=1 (det.hip): ordered reductions instead of f32 atomics
 bool simx_det();
 float* simx_det_ws(hipStream_t st, size_t bytes);                       // per-stream scratch, NULL (+ error text) on failure

@@ -25,6 +25,25 @@ void simx_set_error(const char* fmt, ...) {
 extern "C" const char* simx_last_error(void) { return g_err; }
 extern "C" int simx_version(void) { return 100; }
 
+// ---- compute-CU budget of the persistent kernels (include/simx.h simx_set_compute_cus) --------------------------------
+// The persistent GEMMs launch one workgroup per CU (each needs a whole CU's 160 KB of LDS) and give every workgroup a STATIC share
+// of the tile list; the wgrad plans fill exactly one round of the chip.  When another kernel holds k CUs for the whole launch -- an
+// RCCL ring during the overlapped backward -- k of those workgroups only start when a resident one has finished its WHOLE share:
+// the launch takes up to twice as long (tools/cu_steal_bench, profiles/r06_cu_steal.json).  With a budget of ncu - k the launches
+// fit beside the communication kernel and lose k / ncu instead.  0 = every CU (default; SIMX_COMPUTE_CUS overrides at first use).
+static int g_compute_cus = -1;
+extern "C" int simx_set_compute_cus(int n) {
+  SIMX_REQUIRE(n >= 0, SIMX_ERR_BAD_SHAPE, "simx_set_compute_cus: %d", n);
+  g_compute_cus = n;
+  return SIMX_OK;
+}
+int simx_compute_cus(int device_cus) {
+  if (g_compute_cus < 0) { const char* e = getenv("SIMX_COMPUTE_CUS"); g_compute_cus = e ? atoi(e) : 0; if (g_compute_cus < 0) g_compute_cus = 0; }
+  int n = g_compute_cus > 0 && g_compute_cus < device_cus ? g_compute_cus : device_cus;
+  n -= n % 8;                                   // whole XCD rows: xcd_remap assumes block b -> XCD b % 8
+  return n < 8 ? 8 : n;
+}
+
 extern "C" int simx_transpose_cast(simx_stream_t stream, int out_dtype, const float* w, int rows, int cols, void* out, void* outT);
 
 // ------------------------------------------------------------------------------------------ layouts

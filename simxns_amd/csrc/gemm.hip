@@ -1555,9 +1555,10 @@ extern "C" int simx_gemm_nt_ex(simx_stream_t stream, int dtype, int M, int N, in
     if (!force_v1 && !force_v5 && nwg3 >= 192 && M % 256 == 0 && N % 256 == 0 && K >= 256 && ldc % 8 == 0 &&
         (!residual || ldr % 8 == 0) && (!aux || ldaux % 8 == 0) && (!C2 || ldc2 % 8 == 0) &&
         !(epilogue == SIMX_EPI_DGELU && residual) && !(epilogue == SIMX_EPI_GELU && residual)) {
-      const int grid = nwg3 < gd->ncu ? nwg3 : gd->ncu;
+      const int ncu = simx_compute_cus(gd->ncu);
+      const int grid = nwg3 < ncu ? nwg3 : ncu;
       if (epilogue == SIMX_EPI_NONE && !residual && !drop.thr && p5_enabled(K) &&
-          simx_launch_nt_p5(s, dtype, M, N, K, A, lda, B, ldb, C, ldc, bias, 0, gd->ncu) == SIMX_OK) {
+          simx_launch_nt_p5(s, dtype, M, N, K, A, lda, B, ldb, C, ldc, bias, 0, ncu) == SIMX_OK) {
         simx_prof_retag(SIMX_K_GEMM_NT_P3);
         return SIMX_OK;
       }
@@ -1648,8 +1649,9 @@ extern "C" int simx_gemm_nt_pb(simx_stream_t stream, int dtype, int M, int N, in
                   (!in || pi || (ldin % 8 == 0 && ldin >= N)) && (!C2 || pc || (ldc2 % 8 == 0 && ldc2 >= N));
   SIMX_REQUIRE(ok, SIMX_ERR_UNSUPPORTED, "gemm_nt_pb: shape %d x %d x %d (planes of %d rows) is outside the persistent kernel's rules", M, N, K, rows);
   const DropCtx drop = make_drop(epilogue == SIMX_EPI_NONE ? dropd : nullptr);
-  const int grid = nwg3 < gd->ncu ? nwg3 : gd->ncu;
-  if (flags == 2 && !drop.thr && p5_enabled(K) && simx_launch_nt_p5(s, dtype, M, N, K, A, lda, B, ldb, C, 64, bias, rows, gd->ncu) == SIMX_OK) {
+  const int ncu = simx_compute_cus(gd->ncu);
+  const int grid = nwg3 < ncu ? nwg3 : ncu;
+  if (flags == 2 && !drop.thr && p5_enabled(K) && simx_launch_nt_p5(s, dtype, M, N, K, A, lda, B, ldb, C, 64, bias, rows, ncu) == SIMX_OK) {
     simx_prof_retag(SIMX_K_GEMM_NT_P3);
     return SIMX_OK;
   }
@@ -1685,7 +1687,8 @@ static void tn_plan(int M, int N, int K, int* splits, int* k_per_split) {
   // for twice the tokens) measures better at every size -- 262144 tokens 3.54 -> 3.37 ms over the four wgrad shapes, 32768
   // tokens 0.61 -> 0.52, 16384 tokens 0.41 -> 0.32 (tools/kbench, profiles/r05_experiments/09).  SIMX_TN_ROUNDS=2: the old rule.
   const char* rounds_env = getenv("SIMX_TN_ROUNDS");       // (read per call: tests/test_fullsize_gpu.py covers both rules in one process)
-  int s = (v2 ? (rounds_env && rounds_env[0] == '2' ? 512 : 256) : 1024) / tiles;
+  const int round = simx_compute_cus(256);      // one workgroup per CU the launch may fill (256 unless a compute-CU budget is set)
+  int s = (v2 ? (rounds_env && rounds_env[0] == '2' ? 2 * round : round) : 1024) / tiles;
   const int max_s = cdiv(K, 512);          // at least 8 k-tiles per split
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;

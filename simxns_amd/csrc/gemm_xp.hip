@@ -1079,7 +1079,8 @@ extern "C" int simx_gemm_nt_planes_cs(simx_stream_t stream, int fmt, int epilogu
   const XpDevice* gd = xp_device();
   SIMX_REQUIRE(gd != nullptr, SIMX_ERR_HIP, "gemm_nt_planes: cannot query / configure the current device");
   const int tn = N / 256, nt = (M / 256) * tn;
-  const int grid = nt < gd->ncu ? nt : gd->ncu;
+  const int ncu_c = simx_compute_cus(gd->ncu);
+  const int grid = nt < ncu_c ? nt : ncu_c;
   const DropCtx drop = make_drop(epilogue == SIMX_EPI_NONE ? dropd : nullptr);
   // SIMX_NT_XP=k3 pins the tripled-K stream (six tile loads per k block; A/B measurements); the ring form needs lda == ldb
   static const bool k3 = [] { const char* e = getenv("SIMX_NT_XP"); return e && e[0] == 'k'; }();
@@ -1122,7 +1123,8 @@ extern "C" int simx_gemm_nt_planes_cs(simx_stream_t stream, int fmt, int epilogu
 static void xp_tn_plan(int M, int N, int K, int* splits, int* kps) {
   const int tiles = cdiv(M, 256) * cdiv(N, 256);
   const char* rounds_env = getenv("SIMX_TN_ROUNDS");       // (read per call, as tn_plan)
-  int sp = (rounds_env && rounds_env[0] == '2' ? 512 : 256) / tiles;      // ONE whole round of the chip (one workgroup per CU), as tn_plan (csrc/gemm.hip): 32768 tokens 1.60 -> 1.48 ms
+  const int round = simx_compute_cus(256);
+  int sp = (rounds_env && rounds_env[0] == '2' ? 2 * round : round) / tiles;      // ONE whole round of the chip (one workgroup per CU), as tn_plan (csrc/gemm.hip): 32768 tokens 1.60 -> 1.48 ms
   const int max_s = cdiv(K, 512);
   if (sp > max_s) sp = max_s;
   if (sp < 1) sp = 1;

@@ -654,3 +654,34 @@ def test_gemm_tn5_vs_float64_and_tn2(dev, fmt, M, N, K):
         assert_close(gb, col, rtol=1e-5, atol=2e-5 * math.sqrt(K), what="fused bias gradient (SIMX_TN5=%s)" % mode)
     d = float((outs["0"][0] - outs["1"][0]).abs().max())
     assert d <= 1e-5 * math.sqrt(K), "tn5 vs tn2: %.3e" % d
+
+
+def test_compute_cu_budget_changes_the_partition_not_the_result(dev):
+    """simx_set_compute_cus (the budget the data-parallel step can give the persistent kernels while an RCCL ring holds CUs,
+    profiles/r06_cu_steal.json): 240 instead of 256 workgroups walk the same tiles -- p3 / p5 outputs are EQUAL, the wgrad (another
+    split plan: one round of 240) agrees within f32 summation order."""
+    lib = L()
+    M, N, K = 65536, 768, 768
+    A, B, bias = rnd((M, K), 21, 0.5), rnd((N, K), 22, 0.5), rnd((N,), 23, 0.5)
+    dA, dB, db = to_dev(A, dev, "f16"), to_dev(B, dev, "f16"), to_dev(bias, dev)
+    X = to_dev(rnd((M, 3072), 24, 0.5), dev, "f16")
+    W2 = to_dev(rnd((N, 3072), 25, 0.5), dev, "f16")
+    outs = {}
+    try:
+        for budget in (0, 240):
+            lib.call("simx_set_compute_cus", budget)
+            c1 = torch.empty(M, N, device=dev, dtype=torch.float16)
+            c2 = torch.empty(M, N, device=dev, dtype=torch.float16)
+            lib.call("simx_gemm_nt", lib.stream_ptr(), 2, M, N, K, lib.ptr(dA), K, lib.ptr(dB), K, lib.ptr(c1), N, lib.ptr(db), None, N, 0, None, N, None, N)
+            lib.call("simx_gemm_nt", lib.stream_ptr(), 2, M, N, 3072, lib.ptr(X), 3072, lib.ptr(W2), 3072, lib.ptr(c2), N, lib.ptr(db), None, N, 0, None, N, None, N)
+            wsb = int(lib.load().simx_gemm_tn_workspace_bytes(N, K, M))
+            ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+            g = torch.zeros(N, K, device=dev)
+            lib.call("simx_gemm_tn", lib.stream_ptr(), 2, N, K, M, lib.ptr(c1), N, lib.ptr(dA), K, lib.ptr(g), K, 0, lib.ptr(ws), wsb)
+            torch.cuda.synchronize()
+            outs[budget] = (c1, c2, g)
+    finally:
+        lib.call("simx_set_compute_cus", 0)
+    assert torch.equal(outs[0][0], outs[240][0]) and torch.equal(outs[0][1], outs[240][1])
+    d = float((outs[0][2] - outs[240][2]).abs().max())
+    assert d <= 1e-5 * math.sqrt(M) * float(outs[0][2].abs().max()) / 100 + 1e-2, d

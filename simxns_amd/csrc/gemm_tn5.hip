@@ -24,8 +24,8 @@
 //   * fused bias gradient (column sums of A over the tokens) on 1 / (2 tiles_n) of the stages per wave, v_dot2_f32_f16 against
 //     (1, 1) for fp16, in the gaps behind the row block's own MFMAs.
 //   * epilogue: the f32 slab tile goes out straight from the AGPRs (global_store_dwordx4 takes AGPR data): no VALU.
-// Rules: full 256 x 256 tiles, every split a whole number of 64-token stages (K % 64 == 0), >= 2 splits (slab path), not the
-// deterministic mode (gemm_tn2 keeps those).  Same sums as tn2 up to the order of the f32 additions inside a slice.
+// Rules: full 256 x 256 tiles, >= 2 splits (slab path) of >= 4 stages, not the deterministic mode (gemm_tn2 keeps those); a ragged
+// token count (K % 64 != 0) ends the last split with one clamped, zero-padded stage behind the main loop.  Same sums as tn2 up to the order of the f32 additions inside a slice.
 #include <type_traits>
 #include "common.h"
 #include "prof.h"
@@ -81,7 +81,8 @@ __global__ __launch_bounds__(256) void gemm_tn5_kernel(
   const int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
   const int kb = split * k_per_split;
   const int ke = min(K, kb + k_per_split);
-  const int nst = (ke - kb) / 64;                                   // whole stages (launch rule)
+  const int nst = (ke - kb) / 64;                                   // whole stages; `tail` more tokens (last split of a ragged K) follow
+  const int tail = (ke - kb) - nst * 64;
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
   const uint32_t ldsB = lds0 + 98304u;
   // fused bias gradient: the column sums of A over this workgroup's tokens are shared out stage by stage over the tiles_n
@@ -223,6 +224,46 @@ __global__ __launch_bounds__(256) void gemm_tn5_kernel(
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the trailing (dummy) stage loads land before the LDS is released
 
+  // ---- ragged end of the token range (K % 64 != 0: the last split only): the last `tail` tokens as one more stage, loaded HERE with
+  // clamped rows (the caller's buffers end at row K), rows >= tail zeroed in LDS (both operands: 0 x NaN would still be NaN), then
+  // two plain k-steps.  One exposed memory latency in the workgroups of the last split; nothing in the main loop.
+  if (tail) {
+    asm volatile("s_barrier" ::: "memory");                         // every wave is done with the ring
+    {
+      const char* gA = reinterpret_cast<const char*>(A + (long)(kb + nst * 64) * lda_e);
+      const char* gB = reinterpret_cast<const char*>(B + (long)(kb + nst * 64) * ldb);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int kr = wave * 16 + 2 * j + (lane >> 5);             // LDS row (its swizzle term is kr & 7); source row clamped into the range
+        const int rk = kr < tail ? kr : tail - 1;
+        const int p16 = lane & 31;
+        const int col = (((p16 >> 1) ^ (kr & 7)) << 4) + (p16 & 1) * 8;
+        P_DMA16(((uint32_t)(rk * lda_e) + tn2_acol(m0 + col, hm_a)) * 2, gA, lds0 + (uint32_t)(wave * 8192 + j * 1024));
+        P_DMA16((uint32_t)(rk * ldb + n0 + col) * 2, gB, ldsB + (uint32_t)(wave * 8192 + j * 1024));
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int idx = tid; idx < 64 * 64; idx += 256) {
+      const int kr = idx >> 6, c16 = idx & 63;
+      if (kr >= tail) *reinterpret_cast<uint4*>(smem + (c16 >> 5) * 98304 + kr * 512 + (c16 & 31) * 16) = make_uint4(0, 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const bool do_bias = dbias != nullptr && (nst % bias_mod) == bias_slot;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const uint32_t ta = lds0 + (uint32_t)(wr * 256 + ks * 16384), tb = ldsB + (uint32_t)(wc * 256 + ks * 16384);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { fa[0][i] = t5_frag((V ^ (uint32_t)(i << 5)) + ta); fb[0][i] = t5_frag((V ^ (uint32_t)(i << 5)) + tb); }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t5_mfma<F>(acc[i][j], fb[0][j], fa[0][i]);
+        if (do_bias) bsum[i] = t5_sum8<F>(fa[0][i], bsum[i]);
+      }
+    }
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");               // (the stores below read the AGPRs the last MFMAs write)
+  }
+
   // ---- epilogue: the f32 tile straight from the AGPRs (block (i, j): row 16i + fs, columns 16j + 4fg .. +3 = 16 B per lane)
   {
     float* o = out + (long)split * slab_stride + (long)(m0 + wr * 128) * ldo + n0 + wc * 128;
@@ -257,7 +298,7 @@ static bool t5_attr_done[SIMX_MAX_DEVICES];
 // when the shape is outside the rules above, so that the caller falls through to gemm_tn2_kernel.
 int simx_launch_tn5(hipStream_t s, int dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, float* slabs,
                     int splits, int kps, float* dbias, int a_hm_rows, const float* gs) {
-  if (!(simx_is16(dtype) && M % 256 == 0 && N % 256 == 0 && K % 64 == 0 && kps % 64 == 0 && splits >= 2 && kps >= 256 &&
+  if (!(simx_is16(dtype) && M % 256 == 0 && N % 256 == 0 && kps % 64 == 0 && splits >= 2 && kps >= 256 &&
         K - (splits - 1) * (long)kps >= 256))
     return SIMX_ERR_UNSUPPORTED;
   int dev = 0;

@@ -615,7 +615,8 @@ def test_gemm_nt_p5_bit_identical_to_p3(dev, fmt, M, N, K, with_bias, hm):
 
 # ------------------------------------------------------------------------------------------ tn5: the one-wave-per-SIMD wgrad kernel
 @pytest.mark.parametrize("fmt", ["f16", True])
-@pytest.mark.parametrize("M,N,K", [(768, 768, 16384), (2304, 768, 32768), (768, 3072, 65536), (3072, 768, 24576), (256, 256, 4096)])
+@pytest.mark.parametrize("M,N,K", [(768, 768, 16384), (2304, 768, 32768), (768, 3072, 65536), (3072, 768, 24576), (256, 256, 4096),
+                                   (768, 768, 16421), (3072, 768, 24576 + 63), (768, 3072, 40000 + 1), (2304, 768, 20000 + 32)])   # ragged token counts
 def test_gemm_tn5_vs_float64_and_tn2(dev, fmt, M, N, K):
     """csrc/gemm_tn5.hip (4 waves, 128 x 128 wave tiles, AGPR accumulators, 3 + 2 slot ring, fused bias gradient) through
     simx_gemm_tn_bias against the float64 product of the same 16-bit operands, and against gemm_tn2_kernel (SIMX_TN5=0) on the

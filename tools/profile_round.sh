@@ -25,12 +25,14 @@ timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCL
 timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_active -o p -- $CMD > $O/pmc_active.log 2>&1
 # the fp32 engine (the arithmetic every shipped recipe selects) as a first-class measurement: its own un-profiled line
 # (10 timed steps) and a kernel-trace summary of the same command
-timeout 600 python $R/bench.py --dtype fp32 --side --steps 10 --warmup 2 > $O/fp32_bench.json 2> $O/fp32_bench.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fp32_stats -o s -- python $R/bench.py --dtype fp32 --side --steps 3 --warmup 1 > $O/fp32_stats.log 2>&1
 # HBM traffic of the fp32 engine's dominant kernel (gemm_nt_xp_kernel): the same two separate PMC passes
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fp32_pmc_fetch -o p -- python $R/bench.py --dtype fp32 --side --steps 2 --warmup 1 --no-prof > $O/fp32_pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/fp32_pmc_write -o p -- python $R/bench.py --dtype fp32 --side --steps 2 --warmup 1 --no-prof > $O/fp32_pmc_write.log 2>&1
 cd $R && python tools/traffic.py $tag $commit
+# the fp32 engine's own line AFTER its counters exist (it quotes profiles/<tag>_fp32_traffic.json; r05's record quoted r04's)
+timeout 600 python $R/bench.py --dtype fp32 --side --steps 10 --warmup 2 > $O/fp32_bench.json 2> $O/fp32_bench.err
+cp $O/fp32_bench.json $R/profiles/${tag}_fp32_bench.json
 # the bench line LAST, so that the counters it quotes (roofline.traffic, mfma_busy_pmc) are the ones just taken at this tree
 SIMX_OVERLAP_TOWERS=1 timeout 900 python $R/bench.py --steps 5 --warmup 2 > $O/bench_line.json 2> $O/bench.err
 cp $R/gpurun_out/bench_full.json $O/bench.json       # the full record (side-line kernel tables); bench_line.json = the stdout line the driver parses

@@ -45,23 +45,22 @@ __device__ __forceinline__ bf16x8 t5_frag(uint32_t addr) {
   const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tn_lds4_t)(uintptr_t)(addr + 8192u));
   return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
-// sum of the 8 values of a fragment (f32)
+// c + the two values of pair E (0..3 / 4..7: elements 2E, 2E+1) of a fragment, in f32
 template <typename F>
-__device__ __forceinline__ float t5_sum8(const bf16x8& f, float c) {
+__device__ __forceinline__ float t5_sum2(const bf16x8& f, int e, float c) {
   if constexpr (std::is_same<F, f16_t>::value) {
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     typedef short s2 __attribute__((ext_vector_type(2)));
     const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
-    c = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, (s2){f[0], f[1]}), one, c, false);
-    c = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, (s2){f[2], f[3]}), one, c, false);
-    c = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, (s2){f[4], f[5]}), one, c, false);
-    c = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, (s2){f[6], f[7]}), one, c, false);
-    return c;
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, (s2){f[2 * e], f[2 * e + 1]}), one, c, false);
   } else {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) c += H16<F>::one(f[e]);
-    return c;
+    return c + H16<F>::one(f[2 * e]) + H16<F>::one(f[2 * e + 1]);
   }
+}
+template <typename F>
+__device__ __forceinline__ float t5_sum8(const bf16x8& f, float c) {
+  c = t5_sum2<F>(f, 0, c); c = t5_sum2<F>(f, 1, c); c = t5_sum2<F>(f, 2, c);
+  return t5_sum2<F>(f, 3, c);
 }
 
 template <typename F>
@@ -131,7 +130,13 @@ __global__ __launch_bounds__(256) void gemm_tn5_kernel(
   uint32_t oA = lds0 + (uint32_t)(wr * 256), oB = ldsB + (uint32_t)(wc * 256);     // slots of the stage being consumed (+ the wave's columns)
   const uint32_t oA0 = oA, oBsum = 2u * oB + 32768u;
 
-  bf16x8 fa[2][8], fb[2][8];
+// a fragment's two transpose reads go out in two consecutive gaps (address + rows 0-15, then rows 16-31 through the immediate
+// offset): two instructions per gap at most, so that the s_waitcnt hipcc puts in front of an MFMA still fits the gap's three slots
+#define T5_RDLO(ARR, NXT, Q, BASE) do { ra__ = (V ^ (uint32_t)((Q) << 5)) + (BASE); ARR##lo[NXT][Q] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tn_lds4_t)(uintptr_t)ra__); } while (0)
+#define T5_RDHI(ARR, NXT, Q) ARR##hi[NXT][Q] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tn_lds4_t)(uintptr_t)(ra__ + 8192u))
+#define T5_FR(ARR, S, Q) ((bf16x8){ARR##lo[S][Q][0], ARR##lo[S][Q][1], ARR##lo[S][Q][2], ARR##lo[S][Q][3], ARR##hi[S][Q][0], ARR##hi[S][Q][1], ARR##hi[S][Q][2], ARR##hi[S][Q][3]})
+  bf16x4 falo[2][8], fahi[2][8], fblo[2][8], fbhi[2][8];          // fragment halves (token rows 0-15 / 16-31 of the k-step)
+  uint32_t ra__ = 0;
   f32x4 acc[8][8];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
@@ -139,88 +144,100 @@ __global__ __launch_bounds__(256) void gemm_tn5_kernel(
     for (int j = 0; j < 8; ++j) { acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; asm volatile("" : "+a"(acc[i][j])); }
   float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { fb[0][i] = t5_frag((V ^ (uint32_t)(i << 5)) + oB); }
+  for (int i = 0; i < 8; ++i) { T5_RDLO(fb, 0, i, oB); T5_RDHI(fb, 0, i); }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { fa[0][i] = t5_frag((V ^ (uint32_t)(i << 5)) + oA); }
+  for (int i = 0; i < 8; ++i) { T5_RDLO(fa, 0, i, oA); T5_RDHI(fa, 0, i); }
 
   // ---- one k-step: 64 MFMAs on fragment set CUR, the 16 fragments of the NEXT k-step read into set NXT behind every third
   // MFMA (B first: the next k-step's first row block needs all of B and A[0]); G(g): the gap's other work (DMA pieces, request
   // bookkeeping, bias sums).  `na`, `nb`: LDS base of the next k-step's A / B fragments.
-#define T5_RDB(NXT, Q) fb[NXT][Q] = t5_frag((V ^ (uint32_t)((Q) << 5)) + nb__)
-#define T5_RDA(NXT, Q) fa[NXT][Q] = t5_frag((V ^ (uint32_t)((Q) << 5)) + na__)
+#ifdef T5_UNSPLIT_READS        /* tools/build_variant.sh experiment: both reads of a fragment in one gap (three instructions) */
 #define T5_RD(NXT, G)                                                                                          \
   do {                                                                                                         \
-    if ((G) % 3 == 1 && (G) / 3 < 8) T5_RDB(NXT, ((G) / 3) & 7);                                               \
-    else if ((G) % 3 == 1 && (G) / 3 < 16) T5_RDA(NXT, ((G) / 3) & 7);                                         \
+    if ((G) % 3 == 1 && (G) / 3 < 8) { T5_RDLO(fb, NXT, ((G) / 3) & 7, nb__); T5_RDHI(fb, NXT, ((G) / 3) & 7); }  \
+    else if ((G) % 3 == 1 && (G) / 3 < 16) { T5_RDLO(fa, NXT, ((G) / 3) & 7, na__); T5_RDHI(fa, NXT, ((G) / 3) & 7); } \
   } while (0)
-#define T5_BS(CUR, I, G) do { if (do_bias && ((G) & 7) == 6) bsum[I] = t5_sum8<F>(fa[CUR][I], bsum[I]); } while (0)
-#define T5_M(CUR, NXT, I, J, X)                                                                                \
+#else
+#define T5_RD(NXT, G)                                                                                          \
   do {                                                                                                         \
-    T5_SB; t5_mfma<F>(acc[I][J], fb[CUR][J], fa[CUR][I]); T5_SB;                                               \
-    T5_RD(NXT, (I) * 8 + (J)); T5_BS(CUR, I, (I) * 8 + (J)); X;                                                \
+    if ((G) % 3 == 1 && (G) / 3 < 8) T5_RDLO(fb, NXT, ((G) / 3) & 7, nb__);                                    \
+    else if ((G) % 3 == 2 && (G) / 3 < 8) T5_RDHI(fb, NXT, ((G) / 3) & 7);                                     \
+    else if ((G) % 3 == 1 && (G) / 3 < 16) T5_RDLO(fa, NXT, ((G) / 3) & 7, na__);                              \
+    else if ((G) % 3 == 2 && (G) / 3 < 16) T5_RDHI(fa, NXT, ((G) / 3) & 7);                                    \
+  } while (0)
+#endif
+// (a bias-gradient stage adds the row block's A fragment to its column sums behind the block's fifth MFMA)
+#define T5_BS(BS, CUR, I, J) do { if ((BS) && (J) == 4 && do_bias) { asm volatile("" ::: "memory"); bsum[I] = t5_sum8<F>(T5_FR(fa, CUR, I), bsum[I]); } } while (0)
+#define T5_M(BS, CUR, NXT, I, J, X)                                                                            \
+  do {                                                                                                         \
+    T5_SB; t5_mfma<F>(acc[I][J], T5_FR(fb, CUR, J), T5_FR(fa, CUR, I)); T5_SB;                                               \
+    T5_RD(NXT, (I) * 8 + (J)); T5_BS(BS, CUR, I, J); X;                                                        \
   } while (0)
 #define T5_NOP_ (void)0
-#define T5_ROW(CUR, NXT, I, X0, X1, X2, X3, X4, X5, X6, X7)                                                    \
+#define T5_ROW(BS, CUR, NXT, I, X0, X1, X2, X3, X4, X5, X6, X7)                                                \
   do {                                                                                                         \
-    T5_M(CUR, NXT, I, 0, X0); T5_M(CUR, NXT, I, 1, X1); T5_M(CUR, NXT, I, 2, X2); T5_M(CUR, NXT, I, 3, X3);    \
-    T5_M(CUR, NXT, I, 4, X4); T5_M(CUR, NXT, I, 5, X5); T5_M(CUR, NXT, I, 6, X6); T5_M(CUR, NXT, I, 7, X7);    \
+    T5_M(BS, CUR, NXT, I, 0, X0); T5_M(BS, CUR, NXT, I, 1, X1); T5_M(BS, CUR, NXT, I, 2, X2); T5_M(BS, CUR, NXT, I, 3, X3); \
+    T5_M(BS, CUR, NXT, I, 4, X4); T5_M(BS, CUR, NXT, I, 5, X5); T5_M(BS, CUR, NXT, I, 6, X6); T5_M(BS, CUR, NXT, I, 7, X7); \
   } while (0)
   // k-step 0 of a stage (set 0 -> reads set 1 = the stage's own second half; the pending A request goes out)
-#define T5_KS0()                                                                                               \
+#define T5_KS0(BS)                                                                                             \
   do {                                                                                                         \
     const uint32_t na__ = oA + 16384u, nb__ = oB + 16384u;                                                     \
-    T5_ROW(0, 1, 0, T5_NOP_, T5_NOP_, T5_REQ_A(), T5_PIECE_A(0), T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);          \
-    T5_ROW(0, 1, 1, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_A(1), T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);             \
-    T5_ROW(0, 1, 2, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_A(2), T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);             \
-    T5_ROW(0, 1, 3, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_A(3), T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);             \
-    T5_ROW(0, 1, 4, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_A(4), T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);             \
-    T5_ROW(0, 1, 5, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_A(5), T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);             \
-    T5_ROW(0, 1, 6, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_A(6), T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);             \
-    T5_ROW(0, 1, 7, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_A(7), T5_NOP_, T5_DONE_A(), T5_NOP_, T5_NOP_);         \
+    T5_ROW(BS, 0, 1, 0, T5_NOP_, T5_NOP_, T5_REQ_A(), T5_PIECE_A(0), T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);          \
+    T5_ROW(BS, 0, 1, 1, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_A(1), T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);             \
+    T5_ROW(BS, 0, 1, 2, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_A(2), T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);             \
+    T5_ROW(BS, 0, 1, 3, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_A(3), T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);             \
+    T5_ROW(BS, 0, 1, 4, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_A(4), T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);             \
+    T5_ROW(BS, 0, 1, 5, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_A(5), T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);             \
+    T5_ROW(BS, 0, 1, 6, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_A(6), T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);             \
+    T5_ROW(BS, 0, 1, 7, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_A(7), T5_NOP_, T5_DONE_A(), T5_NOP_, T5_NOP_);         \
   } while (0)
   // where the eight B pieces of a request go (tools/build_variant.sh -DT5_B_WHOLE_KSTEP: over the whole k-step like A; default: its
   // first half -- B(g+2) is needed one stage later and comes from HBM like A)
 #ifdef T5_B_WHOLE_KSTEP
-#define T5_KS1_ROWS()                                                                                          \
+#define T5_KS1_ROWS(BS)                                                                                        \
   do {                                                                                                         \
-    T5_ROW(1, 0, 0, T5_NOP_, T5_NOP_, T5_REQ_B(), T5_PIECE_B(0), T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);          \
-    T5_ROW(1, 0, 1, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_B(1), T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);             \
-    T5_ROW(1, 0, 2, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_B(2), T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);             \
-    T5_ROW(1, 0, 3, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_B(3), T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);             \
-    T5_ROW(1, 0, 4, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_B(4), T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);             \
-    T5_ROW(1, 0, 5, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_B(5), T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);             \
-    T5_ROW(1, 0, 6, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_B(6), T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);             \
-    T5_ROW(1, 0, 7, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_B(7), T5_NOP_, T5_DONE_B(), T5_NOP_, T5_NOP_);         \
+    T5_ROW(BS, 1, 0, 0, T5_NOP_, T5_NOP_, T5_REQ_B(), T5_PIECE_B(0), T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);          \
+    T5_ROW(BS, 1, 0, 1, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_B(1), T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);             \
+    T5_ROW(BS, 1, 0, 2, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_B(2), T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);             \
+    T5_ROW(BS, 1, 0, 3, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_B(3), T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);             \
+    T5_ROW(BS, 1, 0, 4, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_B(4), T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);             \
+    T5_ROW(BS, 1, 0, 5, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_B(5), T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);             \
+    T5_ROW(BS, 1, 0, 6, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_B(6), T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);             \
+    T5_ROW(BS, 1, 0, 7, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_B(7), T5_NOP_, T5_DONE_B(), T5_NOP_, T5_NOP_);         \
   } while (0)
 #else
-#define T5_KS1_ROWS()                                                                                          \
+#define T5_KS1_ROWS(BS)                                                                                        \
   do {                                                                                                         \
-    T5_ROW(1, 0, 0, T5_NOP_, T5_NOP_, T5_REQ_B(), T5_PIECE_B(0), T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_B(1));    \
-    T5_ROW(1, 0, 1, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_B(2), T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_B(3));       \
-    T5_ROW(1, 0, 2, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_B(4), T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_B(5));       \
-    T5_ROW(1, 0, 3, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_B(6), T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_B(7));       \
-    T5_ROW(1, 0, 4, T5_NOP_, T5_NOP_, T5_NOP_, T5_DONE_B(), T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);               \
-    T5_ROW(1, 0, 5, T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);                   \
-    T5_ROW(1, 0, 6, T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);                   \
-    T5_ROW(1, 0, 7, T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);                   \
+    T5_ROW(BS, 1, 0, 0, T5_NOP_, T5_NOP_, T5_REQ_B(), T5_PIECE_B(0), T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_B(1));    \
+    T5_ROW(BS, 1, 0, 1, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_B(2), T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_B(3));       \
+    T5_ROW(BS, 1, 0, 2, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_B(4), T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_B(5));       \
+    T5_ROW(BS, 1, 0, 3, T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_B(6), T5_NOP_, T5_NOP_, T5_NOP_, T5_PIECE_B(7));       \
+    T5_ROW(BS, 1, 0, 4, T5_NOP_, T5_NOP_, T5_NOP_, T5_DONE_B(), T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);               \
+    T5_ROW(BS, 1, 0, 5, T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);                   \
+    T5_ROW(BS, 1, 0, 6, T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);                   \
+    T5_ROW(BS, 1, 0, 7, T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_, T5_NOP_);                   \
   } while (0)
 #endif
   // k-step 1: the stage barrier first (every fragment of the stage is in registers, stage g+1 has landed), B(g+2) in the first
   // half, reads of stage g+1's first k-step into set 0
-#define T5_KS1()                                                                                               \
+#define T5_KS1(BS)                                                                                             \
   do {                                                                                                         \
     asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");                                   \
     const uint32_t oAn__ = oA + 32768u >= ldsB ? oA - 65536u : oA + 32768u;                                     \
     const uint32_t na__ = oAn__, nb__ = oBsum - oB;                                                            \
-    T5_KS1_ROWS();                                                                                             \
+    T5_KS1_ROWS(BS);                                                                                           \
     oA = oAn__; oB = oBsum - oB;                                                                               \
   } while (0)
 
   (void)oA0;
   for (int st = 0; st < nst; ++st) {
+    // (the bias sums sit behind a REAL branch -- the empty asm keeps hipcc from turning `if (do_bias)` into selects, which made
+    // every stage pay 64 v_dot2 + 16 v_cndmask in gaps that hold three instructions for free; two copies of the stage body, one
+    // branch per stage, made the allocator merge the accumulators of the two paths through VGPRs: 250-850 spilled registers)
     const bool do_bias = dbias != nullptr && (st % bias_mod) == bias_slot;
-    T5_KS0();
-    T5_KS1();
+    T5_KS0(true);
+    T5_KS1(true);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the trailing (dummy) stage loads land before the LDS is released
 
@@ -253,12 +270,12 @@ __global__ __launch_bounds__(256) void gemm_tn5_kernel(
     for (int ks = 0; ks < 2; ++ks) {
       const uint32_t ta = lds0 + (uint32_t)(wr * 256 + ks * 16384), tb = ldsB + (uint32_t)(wc * 256 + ks * 16384);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { fa[0][i] = t5_frag((V ^ (uint32_t)(i << 5)) + ta); fb[0][i] = t5_frag((V ^ (uint32_t)(i << 5)) + tb); }
+      for (int i = 0; i < 8; ++i) { T5_RDLO(fa, 0, i, ta); T5_RDHI(fa, 0, i); T5_RDLO(fb, 0, i, tb); T5_RDHI(fb, 0, i); }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) t5_mfma<F>(acc[i][j], fb[0][j], fa[0][i]);
-        if (do_bias) bsum[i] = t5_sum8<F>(fa[0][i], bsum[i]);
+        for (int j = 0; j < 8; ++j) t5_mfma<F>(acc[i][j], T5_FR(fb, 0, j), T5_FR(fa, 0, i));
+        if (do_bias) bsum[i] = t5_sum8<F>(T5_FR(fa, 0, i), bsum[i]);
       }
     }
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");               // (the stores below read the AGPRs the last MFMAs write)

@@ -586,8 +586,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p3_kernel(
 #define P_LANE(L) int L = lane; asm volatile("" : "+v"(L))
 
   int v = blockIdx.x;
-  int tile = xcd_remap(v, ntiles);
-  int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
+  // Tile order.  Default: the XCD-aware row-major order -- the tiles_n N-tiles of an M-panel run at the same time on neighbouring CUs of
+  // one XCD and each fetches the A panel itself (traffic 1.43x algorithmic).  -DSIMX_P3_PANEL_ORDER (tools/build_variant.sh, the
+  // refetch-vs-clock A/B of DESIGN.md section 5): a workgroup walks all N-tiles of ITS M-panels one after the other, so the panel comes
+  // from HBM once and from the L2 tiles_n - 1 times (needs tiles_m % gridDim.x == 0: M = 262144 or 327680 on 256 CUs).
+#ifdef SIMX_P3_PANEL_ORDER
+#define P3_TILE(V, M0, N0) do { const int k__ = (V) / (int)gridDim.x, w__ = (V) % (int)gridDim.x; \
+                                M0 = (w__ + (k__ / tiles_n) * (int)gridDim.x) * 256; N0 = (k__ % tiles_n) * 256; } while (0)
+#else
+#define P3_TILE(V, M0, N0) do { const int t__ = xcd_remap(V, ntiles); M0 = (t__ / tiles_n) * 256; N0 = (t__ % tiles_n) * 256; } while (0)
+#endif
+  int m0, n0;
+  P3_TILE(v, m0, n0);
   p3_half(B, ldb, n0, 0, ldsB, wave, offB0, offB1);
   p3_half(A, lda, m0, P3_AK(0), lds0, wave, offA0, offA1);
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -692,7 +702,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p3_kernel(
     const int vn = v + (int)gridDim.x;
     const bool has_next = vn < ntiles;
     int m0n = m0, n0n = n0;                       // past the end: re-fetch this tile (harmless, keeps the loop branch-free)
-    if (has_next) { const int tn_ = xcd_remap(vn, ntiles); m0n = (tn_ / tiles_n) * 256; n0n = (tn_ % tiles_n) * 256; }
+    if (has_next) P3_TILE(vn, m0n, n0n);
     const int mw = m0 + wr * 128, nw = n0 + wc * 64;
     const float* bptr = bias ? bias + n0n + wc * 64 : reinterpret_cast<const float*>(A);   // uniform
     const char* ibase = !HAS_IN ? nullptr : reinterpret_cast<const char*>(HM_I ? in + ((long)(nw >> 6) * hmR + mw) * 64 : in + (long)mw * ldin + nw);   // uniform
@@ -934,6 +944,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_p3_kernel(
     v = vn; m0 = m0n; n0 = n0n; a0 = ac == 2 ? 0 : ac + 1; b0 = bc ^ 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (dummy) stage loads must land before the LDS is released
+#undef P3_TILE
 #undef P_LANE
 #undef P3_HA
 #undef P3_HAX

@@ -14,30 +14,40 @@
 //   * 256 threads = 4 waves (2 x 2), one per SIMD, wave tile 128 x 128 = 8 x 8 blocks of v_mfma_f32_16x16x32: 256 accumulator
 //     registers in AGPRs (inline-asm MFMA with a tied "+a" operand), which leaves the 256 architectural VGPRs for 18 fragment
 //     quads (p4's E-step / O-step scheme: the streaming operand's register is refilled with the NEXT k-step's resident fragment
-//     as soon as its MFMAs are issued) and for ONE FINISHED TILE packed to 16 bits (`pk`: 8 x 8 x 8 B per lane = 128 VGPRs).
-//   * operand stream exactly as p3: 64-deep stages HBM -> LDS by global_load_lds (SGPR base + lane offset), XOR-swizzled 128-B
-//     rows, three 32 KB A slots + two B slots = all 160 KB, running ACROSS tiles, one barrier per stage (in the O-step, after
-//     the second row block: every fragment of the stage is in registers by then):  s_waitcnt vmcnt(8)  ("all but the eight
-//     A(g+2) pieces" = stage g+1 has landed: vmcnt completes in order), s_barrier, then B(g+2) x 8, A(g+3) x 8 spread over the
-//     next 13 MFMA groups.
+//     as soon as its MFMAs are issued) and for the FINISHED TILE packed to 16 bits (`pk`: 8 B per lane and block; seven of the
+//     eight row blocks = 112 VGPRs stay parked, row block 0 leaves in the k-step that rounds it).  229 VGPRs, no spill.
+//   * operand stream exactly as p3: 64-deep stages HBM -> LDS by global_load_lds, XOR-swizzled 128-B rows, three 32 KB A slots +
+//     two B slots = all 160 KB, running ACROSS tiles, one barrier per stage (in the O-step, after the second row block: every
+//     fragment of the stage is in registers by then):  s_waitcnt vmcnt(8)  ("all but the eight A(g+2) pieces" = stage g+1 has
+//     landed: vmcnt completes in order), s_barrier, then B(g+2) x 8 and A(g+3) x 8.  A request keeps one base pointer; a piece is
+//     two instructions (its lane offset lives in one of eight VGPRs shared by A and B: lda == ldb; M0 carries the LDS address).
+//   * THE ISSUE RULE.  A wave issues at most one instruction per four cycles and is alone on its SIMD; an MFMA 16x16x32 keeps the
+//     pipe busy 16 cycles, so ~3 other instructions fit behind each one for free and every further one is matrix-pipe idle time.
+//     Every fragment read, DMA piece, drain instruction and address computation therefore sits in a GAP behind one particular
+//     MFMA (P5_ECOLG / P5_OROWG take eight gap statements), never as a block between groups (profiles/r06_experiments/01_p5.md:
+//     the same instructions as blocks cost 8 %, one instruction too many on the 16 DMA gaps of a stage 2.4 %).
 //   * a tile's life:
-//       E-step of stage 0 : the accumulators START as the bias -- srcC of the first MFMA of every block is the block's bias
-//                           quad (one ds_bpermute_b32 per value from two VGPRs that hold the wave's 128 bias columns), written
-//                           with "=a": no initialisation pass;
-//       stages 0..7       : also DRAIN tile t-1, one 16-row unit per stage: right after the stage barrier the wave's own 8 KB
-//                           slice of the A slot that barrier freed is dead until the wave's own share of A(g+3) overwrites it
-//                           (p3's epilogue borrows the same bytes), so the unit goes pk -> 8 x ds_write_b64 (swizzled) ->
-//                           4 x ds_read_b128 (16 B per lane = full 128-B lines) -> 4 x global_store_dwordx4 (nt) and the A
-//                           pieces are issued behind the stores;
+//       stages 0..6       : also DRAIN tile t-1, one 16-row unit per stage (units 1..7): right after the stage barrier the wave's
+//                           own 8 KB slice of the A slot that barrier freed is dead until the wave's own share of A(g+3) overwrites
+//                           it (p3's epilogue borrows the same bytes), so the unit goes pk -> 8 x ds_write_b64 (swizzled) ->
+//                           4 x ds_read_b128 (16 B per lane = full 128-B lines) -> 4 x global_store_dwordx4 (nt), in gaps, and
+//                           the A pieces are issued behind the stores;
 //       stage nst-2       : requests the NEXT tile's bias columns (two dwords per lane, ahead of the A pieces: the vmcnt(8)
 //                           rule at the next barrier covers them);
-//       O-step of stage nst-1 : row block i is final after its eight MFMAs -> read from the AGPRs, rounded, packed into pk
-//                           between the MFMAs of row block i + 1 (the only exposed epilogue work: ~6 VALU per block).
-//     The last tile of a workgroup is drained in the open.
+//       O-step of stage nst-1 : writes those columns as a 512-B table into the last KB of the slice; row block i is final after
+//                           its eight MFMAs -> in the gaps of row block i + 1 each of its blocks is read from the AGPRs, rounded
+//                           into pk and RE-INITIALISED for the next tile by one ds_read_b128 of its bias quad straight into the
+//                           AGPRs (an MFMA's srcC and vdst share one AGPR / VGPR select bit on gfx90a+, so "vdst in AGPRs, srcC = a
+//                           VGPR bias quad" does not encode; 4 x v_accvgpr_write per block is issue time).  Row block 0 is drained
+//                           here.  These ~7 instructions per gap (instead of 3) and the last row block's rounding are the only
+//                           exposed epilogue work: ~1.3k cycles per tile against p3's 3.3k.
+//     The last tile's parked row blocks are drained in the open.
 //   Results are bit-identical to gemm_nt_p3_kernel (same k order, bias as the initial accumulator value, one rounding).
 //
-// Built in so far: EPI_NONE with bias, no epilogue input, no dropout; row-major C or plane-blocked C (HMC: the head-major
-// q / k / v output of the QKV projection).  K >= 640, full 256 x 256 tiles.
+// Built in: EPI_NONE with bias, no epilogue input, no dropout; row-major C or plane-blocked C (HMC: the head-major q / k / v
+// output of the QKV projection); K >= 576, lda == ldb, full 256 x 256 tiles.  Measured (profiles/r06_experiments/01_p5.md): 4 % faster
+// than p3 at K = 3072 (0.877 vs 0.914 ms at M = 262144, 1410 TFLOP/s), a tie at K = 768 -- the dispatcher (csrc/gemm.hip) routes
+// plain, dropout-free launches with K >= 1536 here.  Why the GELU pair and the input-tensor epilogues are not here: DESIGN.md 5.
 #include <type_traits>
 #include "common.h"
 #include "prof.h"
@@ -45,7 +55,6 @@
 
 #define P5_LDS (5 * 32768)
 #define P5_SB __builtin_amdgcn_sched_barrier(0)
-#define P5_IC(X) std::integral_constant<int, (X)>{}
 
 // MFMA as inline asm with the accumulator TIED in an AGPR (with the builtin hipcc renames accumulators between the unrolled
 // stage bodies and moves them through VGPRs, which costs the registers the parked tile needs).  volatile: program order among
@@ -195,7 +204,6 @@ __global__ __launch_bounds__(256) void gemm_nt_p5_kernel(
   // ---- E-step of the stage.  FIRST: a tile's first k-step -- the accumulators were re-initialised to the bias by the previous
   // O-step's LDS reads (P5_INITRD), which must have landed.  Column block 0 reads in k-step 0's B fragments 1..7 and the O-step's
   // spare; block J refills b[J-1] with k-step 1's fragment and issues piece J + 2 of the pending A request.
-#define P5_EF(F_, I, J) (void)0
 #define P5_EW(F_, N_) P5_IF(F_, asm volatile("s_waitcnt lgkmcnt(" #N_ ")" ::: "memory"))
 #define P5_ESTEP(FIRST)                                                                                                        \
   do {                                                                                                                         \
@@ -205,15 +213,15 @@ __global__ __launch_bounds__(256) void gemm_nt_p5_kernel(
     const char* sb1__ = smem + (vq0 ^ 64u);                                                                                    \
     P5_EW(FIRST, 0);                            /* (the accumulators' re-initialisation reads of the last O-step have landed) */ \
     a[7] = P5_LDF(sa0__ + 7 * 2048);            /* (the previous O-step's last refill: its row block 7 has just been issued) */ \
-    P5_ECOLG(0, bx, b[1] = P5_LDF(sb0__ + 1 * 2048), b[2] = P5_LDF(sb0__ + 2 * 2048); P5_EF(FIRST, 1, 4), b[3] = P5_LDF(sb0__ + 3 * 2048); P5_EF(FIRST, 2, 4), \
-             b[4] = P5_LDF(sb0__ + 4 * 2048); P5_EF(FIRST, 3, 4), b[5] = P5_LDF(sb0__ + 5 * 2048); P5_EF(FIRST, 4, 4), b[6] = P5_LDF(sb0__ + 6 * 2048); P5_EF(FIRST, 5, 4), \
-             b[7] = P5_LDF(sb0__ + 7 * 2048); P5_EF(FIRST, 6, 4), ax = P5_LDF(sa1__); P5_EF(FIRST, 7, 4));                     \
-    P5_ECOLG(1, b[1], b[0] = P5_LDF(sb1__ + 0 * 2048), P5_EF(FIRST, 1, 5), P5_EF(FIRST, 2, 5), P5_PIECE_A(3); P5_EF(FIRST, 3, 5), P5_EF(FIRST, 4, 5), \
-             P5_EF(FIRST, 5, 5), P5_EF(FIRST, 6, 5), P5_EF(FIRST, 7, 5));                                                      \
-    P5_ECOLG(2, b[2], b[1] = P5_LDF(sb1__ + 1 * 2048), P5_EF(FIRST, 1, 6), P5_EF(FIRST, 2, 6), P5_PIECE_A(4); P5_EF(FIRST, 3, 6), P5_EF(FIRST, 4, 6), \
-             P5_EF(FIRST, 5, 6), P5_EF(FIRST, 6, 6), P5_EF(FIRST, 7, 6));                                                      \
-    P5_ECOLG(3, b[3], b[2] = P5_LDF(sb1__ + 2 * 2048), P5_EF(FIRST, 1, 7), P5_EF(FIRST, 2, 7), P5_PIECE_A(5); P5_EF(FIRST, 3, 7), P5_EF(FIRST, 4, 7), \
-             P5_EF(FIRST, 5, 7), P5_EF(FIRST, 6, 7), P5_EF(FIRST, 7, 7));                                                      \
+    P5_ECOLG(0, bx, b[1] = P5_LDF(sb0__ + 1 * 2048), b[2] = P5_LDF(sb0__ + 2 * 2048), b[3] = P5_LDF(sb0__ + 3 * 2048), \
+             b[4] = P5_LDF(sb0__ + 4 * 2048), b[5] = P5_LDF(sb0__ + 5 * 2048), b[6] = P5_LDF(sb0__ + 6 * 2048), \
+             b[7] = P5_LDF(sb0__ + 7 * 2048), ax = P5_LDF(sa1__));                     \
+    P5_ECOLG(1, b[1], b[0] = P5_LDF(sb1__ + 0 * 2048), P5_NOP_, P5_NOP_, P5_PIECE_A(3), P5_NOP_, \
+             P5_NOP_, P5_NOP_, P5_NOP_);                                                      \
+    P5_ECOLG(2, b[2], b[1] = P5_LDF(sb1__ + 1 * 2048), P5_NOP_, P5_NOP_, P5_PIECE_A(4), P5_NOP_, \
+             P5_NOP_, P5_NOP_, P5_NOP_);                                                      \
+    P5_ECOLG(3, b[3], b[2] = P5_LDF(sb1__ + 2 * 2048), P5_NOP_, P5_NOP_, P5_PIECE_A(5), P5_NOP_, \
+             P5_NOP_, P5_NOP_, P5_NOP_);                                                      \
     P5_ECOLG(4, b[4], b[3] = P5_LDF(sb1__ + 3 * 2048), P5_NOP_, P5_NOP_, P5_PIECE_A(6), P5_NOP_, P5_NOP_, P5_NOP_, P5_NOP_);   \
     P5_ECOLG(5, b[5], b[4] = P5_LDF(sb1__ + 4 * 2048), P5_NOP_, P5_NOP_, P5_PIECE_A(7), P5_NOP_, P5_NOP_, P5_NOP_, P5_NOP_);   \
     P5_ECOLG(6, b[6], b[5] = P5_LDF(sb1__ + 5 * 2048), P5_NOP_, P5_NOP_, P5_DONE_A(), P5_NOP_, P5_NOP_, P5_NOP_, P5_NOP_);     \

@@ -147,8 +147,10 @@ SIGNATURES = {
     "simx_prof_end": (_i, [_p, _p, _p]),
     "simx_prof_kernel_count": (_i, []),
 }
+# "gemm_nt_p3" = the persistent NT launches (gemm_nt_p3_kernel and gemm_nt_p5_kernel); "gemm_tn5_tn2" = the large wgrad launches (gemm_tn5_kernel or
+# gemm_tn2_kernel + the slab pass; records taken before round 6's last commit call this slot "gemm_tn2")
 PROF_NAMES = ["gemm_nt", "gemm_tn", "mha_fwd", "mha_bwd", "ln_fwd", "ln_bwd", "embed_fwd", "embed_bwd", "colsum", "cast",
-              "loss", "sampler", "adamw", "other", "collate", "topk", "gemm_nt_p3", "gemm_tn2", "gemm_nt_xp", "gemm_tn_xp"]
+              "loss", "sampler", "adamw", "other", "collate", "topk", "gemm_nt_p3", "gemm_tn5_tn2", "gemm_nt_xp", "gemm_tn_xp"]
 
 _lib = None
 

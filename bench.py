@@ -219,6 +219,9 @@ def main():
     zero_col = torch.zeros(B, 1, dtype=torch.long, device=dev)
     nll = None
     step_no = [0]
+    fwd_cus = [int(v) for v in os.environ.get("SIMX_FWD_CUS", "0").split(",")]       # "n" or "teacher,student"
+    fwd_cus = fwd_cus * 2 if len(fwd_cus) == 1 else fwd_cus
+    fwd_cus = fwd_cus if fwd_cus[0] or fwd_cus[1] else None
     teacher_stream = torch.cuda.Stream(device=dev) if os.environ.get("SIMX_TEACHER_STREAM", "1") == "1" else None
 
     def micro_step(mi):
@@ -227,6 +230,8 @@ def main():
         sel = torch.cat([zero_col, neg.long() + 1], dim=1)                         # [B,1+N] rows of the query's pool
         batch = ops.assemble_batch(pool["q"], pool["p"], q_rows, (row_base + sel).to(torch.int32), 1 + N, pad_id=0, sep_id=102, ce_len=CL)
         q_ids, q_mask, c_ids, c_mask, _ = batch["student"]
+        if fwd_cus:                       # experiment (profiles/r06_experiments/04): the forward's persistent GEMMs on fwd_cus CUs each,
+            L.call("simx_set_compute_cus", fwd_cus[0])  # so that the teacher's and the passage tower's launches fit side by side
         if args.teacher_step:
             z = teacher(batch["teacher"][0], batch["teacher"][1])
             loss, _ = ops.teacher_ce_loss(z, args.accum)
@@ -242,6 +247,8 @@ def main():
             teacher_stream.wait_stream(cur)
             with torch.cuda.stream(teacher_stream), torch.no_grad():
                 z = teacher(batch["teacher"][0], batch["teacher"][1])
+            if fwd_cus:
+                L.call("simx_set_compute_cus", fwd_cus[1])
             q, c = bi(q_ids, q_mask, c_ids, c_mask)
             cur.wait_stream(teacher_stream)
             z.record_stream(cur)
@@ -257,6 +264,8 @@ def main():
         if args.inbatch:
             from simxns_amd import parallel
             loss = loss + 0.2 * parallel.inbatch_nll_allgather(q, c, 1 + N)
+        if fwd_cus:
+            L.call("simx_set_compute_cus", 0)
         loss.backward()
         return loss
 

@@ -235,8 +235,11 @@ def test_rccl_one_rank_drives_the_whole_dp_path(dev, tmp_path, dtype):
     assert p.returncode == 0 and "rccl one-rank ok" in out, out
 
 
-def test_bench_two_ranks_share_one_gpu(dev):
-    """`bench.py --gpus 2` end to end (the command the driver's SCALE run launches at N = 2, 4, 8): self-spawned ranks, rendezvous on
+@pytest.mark.parametrize("launcher", ["self", "torch.distributed.run"])
+def test_bench_two_ranks_share_one_gpu(dev, launcher):
+    """`bench.py --gpus 2` end to end, both ways it is launched: `python bench.py --gpus 2` (self-spawned ranks) and the driver's
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2`
+    (the SCALE run at N = 2, 4, 8).  Rendezvous on
     127.0.0.1, sharded queries, overlapped gradient all-reduce with the default bf16 payload, replica check after the first step,
     barrier + max-over-ranks timing, ONE JSON line from rank 0 with a `comm` block.  SIMX_BENCH_SHARE_GPU=1 puts both ranks on
     cuda:0 over gloo (a 1-GPU box cannot host two RCCL ranks): the control flow is what is checked here, never a number."""
@@ -246,8 +249,17 @@ def test_bench_two_ranks_share_one_gpu(dev):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SIMX_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("SIMX_GRAD_PAYLOAD", None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8",
-                        "--no-cpu-baseline", "--no-realistic", "--no-parity", "--no-fp32-side"],
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable]
+    if launcher != "self":
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    r = subprocess.run(cmd + [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8",
+                              "--no-cpu-baseline", "--no-realistic", "--no-parity", "--no-fp32-side"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

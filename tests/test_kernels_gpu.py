@@ -571,7 +571,8 @@ def test_adamw_clip(dev):
 @pytest.mark.parametrize("M,N,K,with_bias,hm", [(65536, 768, 768, True, False), (49152, 2304, 768, True, True), (49152, 2304, 768, False, False),
                                                 (65536, 768, 3072, True, False), (65536, 768, 576, True, False), (262144, 768, 768, True, False),
                                                 (12800, 1024, 768, True, False),      # 200 tiles: fewer than CUs, one tile per workgroup (tail drain only)
-                                                (49152, 1536, 1536, False, True)])    # 1152 tiles on 256 workgroups: 4 or 5 tiles each
+                                                (49152, 1536, 1536, False, True),     # 1152 tiles on 256 workgroups: 4 or 5 tiles each
+                                                (327680, 768, 3072, True, False)])    # the launch the headline routes to p5: the teacher's FFN-out, 2048 x 160 tokens
 def test_gemm_nt_p5_bit_identical_to_p3(dev, fmt, M, N, K, with_bias, hm):
     """csrc/gemm_p5.hip (one wave per SIMD, accumulators in AGPRs, the finished tile parked in registers and drained through LDS
     inside the next tile's main loop) against gemm_nt_p3_kernel on the same operands: same k order, bias as the accumulators'
